@@ -1,0 +1,290 @@
+"""Oracle networks: plain PyTorch-CPU restatements of the reference's U-Net family.
+
+TEST INFRASTRUCTURE -- see oracle/__init__.py.  Each class keeps the reference's
+constructor signature, forward semantics and ``state_dict`` key names so that
+closed-form weights (oracle/fill.py) land on the same tensors on both sides.
+
+Follows (reference file:line):
+  * UNet3D      -- models/three_d/unet3d.py:10-48 (ctor), :50-71 (forward), :73-104 (block)
+  * VNet        -- models/three_d/vnet3d.py:21-31, :41-58, :61-80, :83-104, :107-121, :124-157
+  * ResUNet     -- models/three_d/residual_unet3d.py:11-80 (ctor), :82-107 (factories), :109-204 (forward)
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+
+# --------------------------------------------------------------------------- U-Net
+def _double_conv(tag, cin, cout):
+    """(Conv3d k3 p1 bias -> BatchNorm3d -> ReLU) x 2, keys '<tag>conv1' ... '<tag>relu2'
+    (unet3d.py:73-104)."""
+    mods = OrderedDict()
+    for i, c_in in ((1, cin), (2, cout)):
+        mods[f"{tag}conv{i}"] = nn.Conv3d(c_in, cout, kernel_size=3, padding=1, bias=True)
+        mods[f"{tag}norm{i}"] = nn.BatchNorm3d(cout)
+        mods[f"{tag}relu{i}"] = nn.ReLU(inplace=True)
+    return nn.Sequential(mods)
+
+
+class UNet3D(nn.Module):
+    """3D U-Net (unet3d.py:10-71): 4 encoder levels + bottleneck + 4 decoder levels,
+    MaxPool3d(2,2) down, ConvTranspose3d k2s2 up, channel concat (up first, skip
+    second), 1x1x1 head."""
+
+    def __init__(self, in_channels=1, out_channels=3, init_features=64):
+        super().__init__()
+        f = init_features
+        widths = [f, 2 * f, 4 * f, 8 * f]
+        prev = in_channels
+        for lvl, w in enumerate(widths, start=1):
+            setattr(self, f"encoder{lvl}", _double_conv(f"enc{lvl}", prev, w))
+            setattr(self, f"pool{lvl}", nn.MaxPool3d(kernel_size=2, stride=2))
+            prev = w
+        self.bottleneck = _double_conv("bottleneck", prev, 16 * f)
+        prev = 16 * f
+        for lvl in (4, 3, 2, 1):
+            w = widths[lvl - 1]
+            setattr(self, f"upconv{lvl}", nn.ConvTranspose3d(prev, w, kernel_size=2, stride=2))
+            setattr(self, f"decoder{lvl}", _double_conv(f"dec{lvl}", 2 * w, w))
+            prev = w
+        self.conv = nn.Conv3d(f, out_channels, kernel_size=1)
+
+    def forward(self, x):
+        skips = []
+        h = x
+        for lvl in (1, 2, 3, 4):
+            h = getattr(self, f"encoder{lvl}")(h)
+            skips.append(h)
+            h = getattr(self, f"pool{lvl}")(h)
+        h = self.bottleneck(h)
+        for lvl in (4, 3, 2, 1):
+            h = getattr(self, f"upconv{lvl}")(h)
+            h = torch.cat((h, skips[lvl - 1]), dim=1)
+            h = getattr(self, f"decoder{lvl}")(h)
+        return self.conv(h)
+
+
+# --------------------------------------------------------------------------- V-Net
+def _act(elu, nchan):
+    # vnet3d.py:14-18 -- ELU(alpha=1, inplace) at the defaults, PReLU otherwise
+    return nn.ELU(inplace=True) if elu else nn.PReLU(nchan)
+
+
+class LUConv(nn.Module):
+    """conv k5 p2 -> BN -> act (vnet3d.py:21-31)."""
+
+    def __init__(self, nchan, elu):
+        super().__init__()
+        self.relu1 = _act(elu, nchan)
+        self.conv1 = nn.Conv3d(nchan, nchan, kernel_size=5, padding=2)
+        self.bn1 = nn.BatchNorm3d(nchan)
+
+    def forward(self, x):
+        return self.relu1(self.bn1(self.conv1(x)))
+
+
+def _n_conv(nchan, depth, elu):
+    return nn.Sequential(*[LUConv(nchan, elu) for _ in range(depth)])
+
+
+class InputTransition(nn.Module):
+    """conv k5 -> BN -> + x repeated to 16 channels -> act (vnet3d.py:41-58)."""
+
+    def __init__(self, in_channels, elu):
+        super().__init__()
+        self.num_features = 16
+        self.in_channels = in_channels
+        self.conv1 = nn.Conv3d(in_channels, 16, kernel_size=5, padding=2)
+        self.bn1 = nn.BatchNorm3d(16)
+        self.relu1 = _act(elu, 16)
+
+    def forward(self, x):
+        y = self.bn1(self.conv1(x))
+        rep = int(self.num_features / self.in_channels)
+        return self.relu1(y + x.repeat(1, rep, 1, 1, 1))
+
+
+class DownTransition(nn.Module):
+    """conv k2 s2 -> BN -> act -> nConvs x LUConv -> + down -> act (vnet3d.py:61-80)."""
+
+    def __init__(self, inChans, nConvs, elu, dropout=False):
+        super().__init__()
+        out = 2 * inChans
+        self.down_conv = nn.Conv3d(inChans, out, kernel_size=2, stride=2)
+        self.bn1 = nn.BatchNorm3d(out)
+        self.relu1 = _act(elu, out)
+        self.relu2 = _act(elu, out)
+        self.do1 = nn.Dropout3d() if dropout else nn.Identity()
+        self.ops = _n_conv(out, nConvs, elu)
+
+    def forward(self, x):
+        down = self.relu1(self.bn1(self.down_conv(x)))
+        y = self.ops(self.do1(down))
+        return self.relu2(y + down)
+
+
+class UpTransition(nn.Module):
+    """Dropout3d(skip) -> ConvT k2 s2 -> BN -> act -> cat -> LUConvs -> + cat -> act
+    (vnet3d.py:83-104).  ``do2`` (p=0.5) is always active in train mode."""
+
+    def __init__(self, inChans, outChans, nConvs, elu, dropout=False):
+        super().__init__()
+        half = outChans // 2
+        self.up_conv = nn.ConvTranspose3d(inChans, half, kernel_size=2, stride=2)
+        self.bn1 = nn.BatchNorm3d(half)
+        self.do1 = nn.Dropout3d() if dropout else nn.Identity()
+        self.do2 = nn.Dropout3d()
+        self.relu1 = _act(elu, half)
+        self.relu2 = _act(elu, outChans)
+        self.ops = _n_conv(outChans, nConvs, elu)
+
+    def forward(self, x, skipx):
+        skip = self.do2(skipx)
+        up = self.relu1(self.bn1(self.up_conv(self.do1(x))))
+        cat = torch.cat((up, skip), 1)
+        return self.relu2(self.ops(cat) + cat)
+
+
+class OutputTransition(nn.Module):
+    """conv k5 -> BN -> act -> conv k1 (vnet3d.py:107-121)."""
+
+    def __init__(self, in_channels, classes, elu):
+        super().__init__()
+        self.classes = classes
+        self.conv1 = nn.Conv3d(in_channels, classes, kernel_size=5, padding=2)
+        self.bn1 = nn.BatchNorm3d(classes)
+        self.conv2 = nn.Conv3d(classes, classes, kernel_size=1)
+        self.relu1 = _act(elu, classes)
+
+    def forward(self, x):
+        return self.conv2(self.relu1(self.bn1(self.conv1(x))))
+
+
+class VNet(nn.Module):
+    """V-Net (vnet3d.py:124-157)."""
+
+    def __init__(self, elu=True, in_channels=1, classes=2):
+        super().__init__()
+        self.classes = classes
+        self.in_channels = in_channels
+        self.in_tr = InputTransition(in_channels, elu=elu)
+        self.down_tr32 = DownTransition(16, 1, elu)
+        self.down_tr64 = DownTransition(32, 2, elu)
+        self.down_tr128 = DownTransition(64, 3, elu, dropout=False)
+        self.down_tr256 = DownTransition(128, 2, elu, dropout=False)
+        self.up_tr256 = UpTransition(256, 256, 2, elu, dropout=False)
+        self.up_tr128 = UpTransition(256, 128, 2, elu, dropout=False)
+        self.up_tr64 = UpTransition(128, 64, 1, elu)
+        self.up_tr32 = UpTransition(64, 32, 1, elu)
+        self.out_tr = OutputTransition(32, classes, elu)
+
+    def forward(self, x):
+        o16 = self.in_tr(x)
+        o32 = self.down_tr32(o16)
+        o64 = self.down_tr64(o32)
+        o128 = self.down_tr128(o64)
+        o256 = self.down_tr256(o128)
+        h = self.up_tr256(o256, o128)
+        h = self.up_tr128(h, o64)
+        h = self.up_tr64(h, o32)
+        h = self.up_tr32(h, o16)
+        return self.out_tr(h)
+
+
+# --------------------------------------------------------------------------- Residual U-Net
+def _c3(cin, cout, stride=1):
+    return nn.Conv3d(cin, cout, kernel_size=3, stride=stride, padding=1, bias=False)
+
+
+def _c1(cin, cout):
+    return nn.Conv3d(cin, cout, kernel_size=1, stride=1, padding=0, bias=False)
+
+
+class ResUNet(nn.Module):
+    """Isensee-style residual U-Net; the reference class is called ``UNet``
+    (residual_unet3d.py:5).  Conv3d bias=False everywhere, InstanceNorm3d without
+    affine, LeakyReLU(0.01), Dropout3d(0.6), nearest x2 upsampling, deep supervision.
+    ``norm_lrelu_conv_c{2..5}`` are applied twice with shared weights (:126,128 ...)."""
+
+    def __init__(self, in_channels, n_classes, base_n_filter=8):
+        super().__init__()
+        self.in_channels, self.n_classes, self.base_n_filter = in_channels, n_classes, base_n_filter
+        b = base_n_filter
+        self.lrelu = nn.LeakyReLU()
+        self.dropout3d = nn.Dropout3d(p=0.6)
+        self.upsacle = nn.Upsample(scale_factor=2, mode="nearest")
+        self.softmax = nn.Softmax(dim=1)
+
+        self.conv3d_c1_1 = _c3(in_channels, b)
+        self.conv3d_c1_2 = _c3(b, b)
+        self.lrelu_conv_c1 = nn.Sequential(nn.LeakyReLU(), _c3(b, b))
+        self.inorm3d_c1 = nn.InstanceNorm3d(b)
+        for lvl, mult in ((2, 2), (3, 4), (4, 8), (5, 16)):
+            w = b * mult
+            setattr(self, f"conv3d_c{lvl}", _c3(w // 2, w, stride=2))
+            setattr(self, f"norm_lrelu_conv_c{lvl}", self._nlc(w, w))
+            if lvl < 5:
+                setattr(self, f"inorm3d_c{lvl}", nn.InstanceNorm3d(w))
+        self.norm_lrelu_upscale_conv_norm_lrelu_l0 = self._nlucnl(b * 16, b * 8)
+        self.conv3d_l0 = _c1(b * 8, b * 8)
+        self.inorm3d_l0 = nn.InstanceNorm3d(b * 8)
+        for lvl, mult in ((1, 16), (2, 8), (3, 4)):
+            w = b * mult
+            setattr(self, f"conv_norm_lrelu_l{lvl}", self._cnl(w, w))
+            setattr(self, f"conv3d_l{lvl}", _c1(w, w // 2))
+            setattr(self, f"norm_lrelu_upscale_conv_norm_lrelu_l{lvl}", self._nlucnl(w // 2, w // 4))
+        self.conv_norm_lrelu_l4 = self._cnl(b * 2, b * 2)
+        self.conv3d_l4 = _c1(b * 2, n_classes)
+        self.ds2_1x1_conv3d = _c1(b * 8, n_classes)
+        self.ds3_1x1_conv3d = _c1(b * 4, n_classes)
+        self.sigmoid = nn.Sigmoid()
+
+    @staticmethod
+    def _cnl(cin, cout):            # residual_unet3d.py:82-86
+        return nn.Sequential(_c3(cin, cout), nn.InstanceNorm3d(cout), nn.LeakyReLU())
+
+    @staticmethod
+    def _nlc(cin, cout):            # :88-92
+        return nn.Sequential(nn.InstanceNorm3d(cin), nn.LeakyReLU(), _c3(cin, cout))
+
+    @staticmethod
+    def _nlucnl(cin, cout):         # :99-107
+        return nn.Sequential(nn.InstanceNorm3d(cin), nn.LeakyReLU(),
+                             nn.Upsample(scale_factor=2, mode="nearest"),
+                             _c3(cin, cout), nn.InstanceNorm3d(cout), nn.LeakyReLU())
+
+    def forward(self, x):
+        # level 1 context (:110-121): note inorm is applied to the *pre*-lrelu sum
+        h = self.conv3d_c1_1(x)
+        res = h
+        h = self.conv3d_c1_2(self.lrelu(h))
+        h = self.lrelu_conv_c1(self.dropout3d(h))
+        h = h + res
+        ctx = [self.lrelu(h)]
+        h = self.lrelu(self.inorm3d_c1(h))
+        # levels 2..5 (:123-168)
+        for lvl in (2, 3, 4, 5):
+            h = getattr(self, f"conv3d_c{lvl}")(h)
+            res = h
+            blk = getattr(self, f"norm_lrelu_conv_c{lvl}")
+            h = blk(self.dropout3d(blk(h)))
+            h = h + res
+            if lvl < 5:
+                h = self.lrelu(getattr(self, f"inorm3d_c{lvl}")(h))
+                ctx.append(h)
+        h = self.norm_lrelu_upscale_conv_norm_lrelu_l0(h)
+        h = self.lrelu(self.inorm3d_l0(self.conv3d_l0(h)))
+        # localisation (:174-194)
+        ds = {}
+        for lvl in (1, 2, 3):
+            h = torch.cat([h, ctx[4 - lvl]], dim=1)
+            h = getattr(self, f"conv_norm_lrelu_l{lvl}")(h)
+            ds[lvl] = h
+            h = getattr(self, f"conv3d_l{lvl}")(h)
+            h = getattr(self, f"norm_lrelu_upscale_conv_norm_lrelu_l{lvl}")(h)
+        h = torch.cat([h, ctx[0]], dim=1)
+        out_pred = self.conv3d_l4(self.conv_norm_lrelu_l4(h))
+        # deep supervision (:196-202)
+        s = self.upsacle(self.ds2_1x1_conv3d(ds[2])) + self.ds3_1x1_conv3d(ds[3])
+        return out_pred + self.upsacle(s)

@@ -1,0 +1,85 @@
+"""The oracle (oracle/) must reproduce the fixtures captured from the reference
+modules (tests/golden/make_golden.py).  Same torch build => same ATen CPU kernels, so
+the tolerance is tight; it is not zero only because thread count may differ."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import losses as ol
+from oracle.fill import fill_module_, make_class_labels, make_input, make_labels
+from oracle.metric import metric as oracle_metric
+from oracle.nets import UNet3D
+from oracle.step import train_step, two_channel_gt
+
+TOL = 2e-5
+
+
+def _sample(t, k=4096):
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // k)
+    return f[::step][:k].numpy()
+
+
+def test_unet3d_train_step_matches_reference_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "unet3d_f8_32.npz"))
+    m = fill_module_(UNet3D(in_channels=1, out_channels=2, init_features=8)).train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    x = make_input((2, 1, 32, 32, 32))
+    gt = make_labels((2, 1, 32, 32, 32))
+    grads = {}
+    # capture grads before the optimizer step clears nothing (Adam keeps .grad)
+    pred, mask, loss, (jac, dice) = train_step(m, opt, x, gt)
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    assert np.abs(pred.detach().numpy() - g["pred"]).max() < TOL
+    # masks: identical wherever the reference logit margin exceeds the tolerance
+    margin = np.abs(g["pred"][:, 0] - g["pred"][:, 1])[:, None]
+    same = mask.numpy().astype(np.uint8) == g["mask"]
+    assert same[margin > 2 * TOL].all()
+    params = dict(m.named_parameters())
+    for k in g.files:
+        if k.startswith("grad/"):
+            ref = g[k]
+            got = _sample(params[k[5:]].grad)
+            assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), k
+        elif k.startswith("post/"):
+            assert np.abs(_sample(params[k[5:]]) - g[k]).max() < 2e-4, k   # Adam step = +-lr
+        elif k.startswith("buf/"):
+            assert np.abs(dict(m.named_buffers())[k[4:]].numpy() - g[k]).max() < 1e-5, k
+    # Dice of the oracle metric on the fixture's own mask
+    gt2 = two_channel_gt(gt)
+    j2, d2 = oracle_metric(gt2.argmax(1, keepdim=True), torch.from_numpy(g["mask"].astype(np.int64)))
+    assert abs(d2 - dice) < 1e-4 and abs(j2 - jac) < 1e-4
+    m.eval()
+    with torch.no_grad():
+        pe = m(x).numpy()
+    assert np.abs(pe - g["pred_eval"]).max() < 5e-4  # after one Adam step; params differ by <=2e-4 tolerance
+
+
+def test_losses_match_reference_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "losses.npz"))
+    shp = (2, 4, 8, 12, 10)
+    logits = make_input(shp, freq=0.37, phase=0.3) * 2.0
+    labels = make_class_labels((2, 8, 12, 10), 4)
+    onehot = ol.make_one_hot(labels.unsqueeze(1), 4)
+    assert np.array_equal(onehot.sum(dim=(0, 2, 3, 4)).numpy(), g["onehot_sum"])
+
+    def check(fn, key):
+        lg = logits.clone().requires_grad_(True)
+        l = fn(lg)
+        l.backward()
+        assert abs(l.item() - float(g[key])) < 1e-6, key
+        assert np.abs(lg.grad.numpy() - g[key + "_grad"]).max() < 1e-8 + 1e-5 * np.abs(g[key + "_grad"]).max(), key
+
+    check(lambda z: ol.cross_entropy_3d(z, labels), "ce")
+    check(lambda z: ol.bce_with_logits(z, onehot), "bce")
+    check(lambda z: ol.dice_loss(z, onehot), "dice")
+    check(lambda z: ol.dice_loss_multiclass(z, labels, 4, softmax=True), "dicess")
+    check(lambda z: ol.dice_loss_multiclass(z, labels, 4, weight=[0.1, 0.2, 0.3, 0.4]), "dicess_w")
+    pr = torch.sigmoid(logits[:, 1])
+    for red in ("mean", "sum", "none"):
+        got = ol.binary_dice_loss(pr, onehot[:, 1], reduction=red).numpy()
+        assert np.abs(got - g["bdl_" + red]).max() < 1e-6
+    with pytest.raises(Exception):
+        ol.binary_dice_loss(pr, onehot[:, 1], reduction="bogus")
