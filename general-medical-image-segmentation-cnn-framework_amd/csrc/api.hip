@@ -1,0 +1,113 @@
+// api.hip -- error state, version, layout helpers of the C-ABI.
+#include "common.h"
+#include <string.h>
+
+namespace seg {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// [N,C,S] -> [N,S,ld] (channel-last) through a 32x33 LDS tile so both sides stay coalesced
+__global__ __launch_bounds__(256) void ncs_to_nsc_kernel(const float* __restrict__ src, float* __restrict__ dst, int ld,
+                                                          int C, long long S) {
+    __shared__ float tile[32][33];
+    const long long s0 = (long long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const long long n = blockIdx.z;
+    const int tx = threadIdx.x % 32, ty = threadIdx.x / 32;   // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        int c = c0 + j; long long s = s0 + tx;
+        tile[j][tx] = (c < C && s < S) ? src[(n * C + c) * S + s] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        long long s = s0 + j; int c = c0 + tx;
+        if (c < C && s < S) dst[(n * S + s) * ld + c] = tile[tx][j];
+    }
+}
+__global__ __launch_bounds__(256) void nsc_to_ncs_kernel(const float* __restrict__ src, int ld, float* __restrict__ dst,
+                                                          int C, long long S) {
+    __shared__ float tile[32][33];
+    const long long s0 = (long long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const long long n = blockIdx.z;
+    const int tx = threadIdx.x % 32, ty = threadIdx.x / 32;
+    for (int j = ty; j < 32; j += 8) {
+        long long s = s0 + j; int c = c0 + tx;
+        tile[j][tx] = (c < C && s < S) ? src[(n * S + s) * ld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        int c = c0 + j; long long s = s0 + tx;
+        if (c < C && s < S) dst[(n * C + c) * S + s] = tile[tx][j];
+    }
+}
+
+template <bool ADD>
+__global__ __launch_bounds__(256) void rows_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd,
+                                                    long long rows, int C) {
+    const bool v = (C % 4 == 0) && (lds % 4 == 0) && (ldd % 4 == 0);
+    const int cw = v ? C / 4 : C;
+    const long long total = rows * cw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long r = i / cw;
+        int c = (int)(i % cw);
+        if (v) {
+            float4 a = *reinterpret_cast<const float4*>(src + r * lds + c * 4);
+            float4* d = reinterpret_cast<float4*>(dst + r * ldd + c * 4);
+            if (ADD) { float4 b = *d; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+            *d = a;
+        } else {
+            float a = src[r * lds + c];
+            if (ADD) a += dst[r * ldd + c];
+            dst[r * ldd + c] = a;
+        }
+    }
+}
+}  // namespace seg
+
+using namespace seg;
+
+extern "C" {
+
+const char* mi355seg_last_error(void) { return g_err; }
+int mi355seg_version(void) { return 100; }
+
+int mi355seg_ncdhw_to_ndhwc_f32(const float* src, float* dst, int lddst, long long N, int C, long long S, void* stream) {
+    SEG_CHECK_ARG(src && dst && N > 0 && C > 0 && S > 0 && lddst >= C && N < 65536, "ncdhw_to_ndhwc: bad arguments");
+    dim3 grid((unsigned)((S + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N);
+    hipLaunchKernelGGL(ncs_to_nsc_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, lddst, C, S);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_ndhwc_to_ncdhw_f32(const float* src, int ldsrc, float* dst, long long N, int C, long long S, void* stream) {
+    SEG_CHECK_ARG(src && dst && N > 0 && C > 0 && S > 0 && ldsrc >= C && N < 65536, "ndhwc_to_ncdhw: bad arguments");
+    dim3 grid((unsigned)((S + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N);
+    hipLaunchKernelGGL(nsc_to_ncs_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ldsrc, dst, C, S);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+static int rows_grid(long long total) {
+    long long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+int mi355seg_copy_rows_f32(const float* src, int ldsrc, float* dst, int lddst, long long rows, int C, void* stream) {
+    SEG_CHECK_ARG(src && dst && rows > 0 && C > 0 && ldsrc >= C && lddst >= C, "copy_rows: bad arguments");
+    hipLaunchKernelGGL((rows_kernel<false>), dim3(rows_grid(rows * C / 4 + 1)), dim3(256), 0, (hipStream_t)stream, src, ldsrc,
+                       dst, lddst, rows, C);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_add_rows_f32(const float* src, int ldsrc, float* dst, int lddst, long long rows, int C, void* stream) {
+    SEG_CHECK_ARG(src && dst && rows > 0 && C > 0 && ldsrc >= C && lddst >= C, "add_rows: bad arguments");
+    hipLaunchKernelGGL((rows_kernel<true>), dim3(rows_grid(rows * C / 4 + 1)), dim3(256), 0, (hipStream_t)stream, src, ldsrc,
+                       dst, lddst, rows, C);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,332 @@
+// conv_generic.hip -- shape-generic direct Conv3d kernels (any cubic k / stride / pad)
+// on NDHWC fp32.  These are the correctness path for every configuration and the
+// production path for the shapes the MFMA implicit-GEMM kernels (conv_mfma.hip) do not
+// cover (k5, k2s2, strided k3, k16s16, tiny channel counts).  Lanes of a wavefront map
+// to consecutive output channels of one voxel, so activation reads are wave-broadcasts
+// and packed-weight reads are fully coalesced.
+#include "common.h"
+#include "internal.h"
+
+namespace seg {
+
+// w (Cout,Cin,T) -> wp[T][Cin][Cout]   (forward / wgrad-friendly)
+__global__ void pack_w_fwd_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int T) {
+    long long total = (long long)Cout * Cin * T;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int co = (int)(i % Cout);
+        long long r = i / Cout;
+        int ci = (int)(r % Cin);
+        int t = (int)(r / Cin);
+        wp[i] = w[((long long)co * Cin + ci) * T + t];
+    }
+}
+// w (Cout,Cin,T) -> wd[T][Cout][Cin]   (dgrad: lanes over Cin); flip != 0 reverses the tap order
+__global__ void pack_w_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wd, int Cout, int Cin, int T, int flip) {
+    long long total = (long long)Cout * Cin * T;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int ci = (int)(i % Cin);
+        long long r = i / Cin;
+        int co = (int)(r % Cout);
+        int t = (int)(r / Cout);
+        int ts = flip ? (T - 1 - t) : t;
+        wd[i] = w[((long long)co * Cin + ci) * T + ts];
+    }
+}
+
+void pack_w_fwd(const float* w, float* wp, int Cout, int Cin, int T, hipStream_t st) {
+    long long total = (long long)Cout * Cin * T;
+    int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_w_fwd_kernel, dim3(grid), dim3(256), 0, st, w, wp, Cout, Cin, T);
+}
+void pack_w_dgrad(const float* w, float* wd, int Cout, int Cin, int T, int flip, hipStream_t st) {
+    long long total = (long long)Cout * Cin * T;
+    int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_w_dgrad_kernel, dim3(grid), dim3(256), 0, st, w, wd, Cout, Cin, T, flip);
+}
+
+struct ConvGeom {
+    int N, D, H, W, Cin, Cout, k, stride, pad, Do, Ho, Wo;
+};
+
+// ---------------------------------------------------------------- forward
+// one thread per (output voxel, cout); VOX_PER_THREAD voxels along W share weight loads.
+__global__ __launch_bounds__(256) void conv_fwd_generic_kernel(const float* __restrict__ x, int ldx,
+        const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int ldy, ConvGeom g) {
+    const long long nvox = (long long)g.N * g.Do * g.Ho * g.Wo;
+    const long long total = nvox * g.Cout;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int co = (int)(i % g.Cout);
+        long long v = i / g.Cout;
+        int ow = (int)(v % g.Wo); long long r = v / g.Wo;
+        int oh = (int)(r % g.Ho); r /= g.Ho;
+        int od = (int)(r % g.Do); int n = (int)(r / g.Do);
+        float acc = bias ? bias[co] : 0.f;
+        const int id0 = od * g.stride - g.pad, ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
+        for (int kd = 0; kd < g.k; ++kd) {
+            int id = id0 + kd;
+            if ((unsigned)id >= (unsigned)g.D) continue;
+            for (int kh = 0; kh < g.k; ++kh) {
+                int ih = ih0 + kh;
+                if ((unsigned)ih >= (unsigned)g.H) continue;
+                for (int kw = 0; kw < g.k; ++kw) {
+                    int iw = iw0 + kw;
+                    if ((unsigned)iw >= (unsigned)g.W) continue;
+                    const float* xp = x + ((((long long)n * g.D + id) * g.H + ih) * g.W + iw) * ldx;
+                    const float* wq = wp + ((long long)((kd * g.k + kh) * g.k + kw) * g.Cin) * g.Cout + co;
+                    int ci = 0;
+                    for (; ci + 4 <= g.Cin; ci += 4) {
+                        acc = fmaf(xp[ci], wq[(long long)ci * g.Cout], acc);
+                        acc = fmaf(xp[ci + 1], wq[(long long)(ci + 1) * g.Cout], acc);
+                        acc = fmaf(xp[ci + 2], wq[(long long)(ci + 2) * g.Cout], acc);
+                        acc = fmaf(xp[ci + 3], wq[(long long)(ci + 3) * g.Cout], acc);
+                    }
+                    for (; ci < g.Cin; ++ci) acc = fmaf(xp[ci], wq[(long long)ci * g.Cout], acc);
+                }
+            }
+        }
+        y[v * ldy + co] = acc;
+    }
+}
+
+// ---------------------------------------------------------------- dgrad
+// one thread per (input voxel, cin): dx = sum_{tap, co} dy[(i + pad - tap)/stride, co] * w[co, ci, tap]
+__global__ __launch_bounds__(256) void conv_dgrad_generic_kernel(const float* __restrict__ dy, int lddy,
+        const float* __restrict__ wd, float* __restrict__ dx, int lddx, ConvGeom g) {
+    const long long nvox = (long long)g.N * g.D * g.H * g.W;
+    const long long total = nvox * g.Cin;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int ci = (int)(i % g.Cin);
+        long long v = i / g.Cin;
+        int iw = (int)(v % g.W); long long r = v / g.W;
+        int ih = (int)(r % g.H); r /= g.H;
+        int id = (int)(r % g.D); int n = (int)(r / g.D);
+        float acc = 0.f;
+        for (int kd = 0; kd < g.k; ++kd) {
+            int td = id + g.pad - kd;
+            if (td < 0 || td % g.stride) continue;
+            int od = td / g.stride;
+            if (od >= g.Do) continue;
+            for (int kh = 0; kh < g.k; ++kh) {
+                int th = ih + g.pad - kh;
+                if (th < 0 || th % g.stride) continue;
+                int oh = th / g.stride;
+                if (oh >= g.Ho) continue;
+                for (int kw = 0; kw < g.k; ++kw) {
+                    int tw = iw + g.pad - kw;
+                    if (tw < 0 || tw % g.stride) continue;
+                    int ow = tw / g.stride;
+                    if (ow >= g.Wo) continue;
+                    const float* dp = dy + ((((long long)n * g.Do + od) * g.Ho + oh) * g.Wo + ow) * lddy;
+                    const float* wq = wd + ((long long)((kd * g.k + kh) * g.k + kw) * g.Cout) * g.Cin + ci;
+                    int co = 0;
+                    for (; co + 4 <= g.Cout; co += 4) {
+                        acc = fmaf(dp[co], wq[(long long)co * g.Cin], acc);
+                        acc = fmaf(dp[co + 1], wq[(long long)(co + 1) * g.Cin], acc);
+                        acc = fmaf(dp[co + 2], wq[(long long)(co + 2) * g.Cin], acc);
+                        acc = fmaf(dp[co + 3], wq[(long long)(co + 3) * g.Cin], acc);
+                    }
+                    for (; co < g.Cout; ++co) acc = fmaf(dp[co], wq[(long long)co * g.Cin], acc);
+                }
+            }
+        }
+        dx[v * lddx + ci] = acc;
+    }
+}
+
+// ---------------------------------------------------------------- wgrad
+// grid = (pair blocks, taps, splits).  Thread = one (ci, co) pair; it walks the output
+// voxels of its split.  partial[split][tap][ci][co].
+__global__ __launch_bounds__(256) void conv_wgrad_generic_kernel(const float* __restrict__ dy, int lddy,
+        const float* __restrict__ x, int ldx, float* __restrict__ part, ConvGeom g, long long vox_per_split) {
+    const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    const int npair = g.Cin * g.Cout;
+    const int tap = blockIdx.y;
+    const int split = blockIdx.z;
+    const int kw = tap % g.k, kh = (tap / g.k) % g.k, kd = tap / (g.k * g.k);
+    const long long nvox = (long long)g.N * g.Do * g.Ho * g.Wo;
+    long long v0 = (long long)split * vox_per_split;
+    long long v1 = v0 + vox_per_split; if (v1 > nvox) v1 = nvox;
+    if (pair >= npair) return;
+    const int co = pair % g.Cout, ci = pair / g.Cout;
+    float acc = 0.f;
+    for (long long v = v0; v < v1; ++v) {
+        int ow = (int)(v % g.Wo); long long r = v / g.Wo;
+        int oh = (int)(r % g.Ho); r /= g.Ho;
+        int od = (int)(r % g.Do); int n = (int)(r / g.Do);
+        int id = od * g.stride - g.pad + kd, ih = oh * g.stride - g.pad + kh, iw = ow * g.stride - g.pad + kw;
+        if ((unsigned)id >= (unsigned)g.D || (unsigned)ih >= (unsigned)g.H || (unsigned)iw >= (unsigned)g.W) continue;
+        acc = fmaf(dy[v * lddy + co], x[((((long long)n * g.D + id) * g.H + ih) * g.W + iw) * ldx + ci], acc);
+    }
+    part[(((long long)split * gridDim.y + tap) * g.Cin + ci) * g.Cout + co] = acc;
+}
+
+// dw[co][ci][tap] (+)= sum_split part[split][tap][ci][co]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits, int T, int Cin,
+                                    int Cout, int accumulate) {
+    long long total = (long long)T * Cin * Cout;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int co = (int)(i % Cout);
+        long long r = i / Cout;
+        int ci = (int)(r % Cin);
+        int t = (int)(r / Cin);
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += part[(long long)k * total + i];
+        long long o = ((long long)co * Cin + ci) * T + t;
+        dw[o] = accumulate ? dw[o] + s : s;
+    }
+}
+
+void wgrad_reduce(const float* part, float* dw, int splits, int T, int Cin, int Cout, int accumulate, hipStream_t st) {
+    long long total = (long long)T * Cin * Cout;
+    int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, part, dw, splits, T, Cin, Cout, accumulate);
+}
+
+static int generic_splits(const ConvGeom& g) {
+    const int T = g.k * g.k * g.k;
+    const long long nvox = (long long)g.N * g.Do * g.Ho * g.Wo;
+    int pairblocks = cdiv((long long)g.Cin * g.Cout, 256);
+    long long want = 4096 / ((long long)pairblocks * T) + 1;
+    long long maxs = nvox / 64 + 1;
+    if (want > maxs) want = maxs;
+    if (want > 128) want = 128;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+size_t conv_generic_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
+    ConvGeom g{N, D, H, W, Cin, Cout, k, stride, pad, (D + 2 * pad - k) / stride + 1, (H + 2 * pad - k) / stride + 1,
+               (W + 2 * pad - k) / stride + 1};
+    const size_t T = (size_t)k * k * k;
+    size_t wbytes = align_up(T * Cin * Cout * sizeof(float), 256);
+    size_t part = align_up((size_t)generic_splits(g) * T * Cin * Cout * sizeof(float), 256);
+    size_t red = colsum_ws_bytes(Cout);
+    return wbytes + (part > red ? part : red) + 1024;
+}
+
+static int ew_blocks(long long total) {
+    long long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+int conv_fwd_generic(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, const ConvGeom& g,
+                     double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int T = g.k * g.k * g.k;
+    Carver cv(ws);
+    float* wp = cv.take<float>((size_t)T * g.Cin * g.Cout);
+    size_t off = cv.used();
+    SEG_CHECK_WS(off + ((ssum || ssq) ? colsum_ws_bytes(g.Cout) : 0), ws_bytes);
+    pack_w_fwd(w, wp, g.Cout, g.Cin, T, st);
+    SEG_CHECK_LAUNCH();
+    long long total = (long long)g.N * g.Do * g.Ho * g.Wo * g.Cout;
+    hipLaunchKernelGGL(conv_fwd_generic_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, x, ldx, wp, bias, y, ldy, g);
+    SEG_CHECK_LAUNCH();
+    if (ssum || ssq)
+        return channel_sums(y, ldy, (long long)g.N * g.Do * g.Ho * g.Wo, g.Cout, ssum, ssq, nullptr, 0, (char*)ws + off,
+                            ws_bytes - off, st);
+    return MI355SEG_OK;
+}
+
+int conv_dgrad_generic(const float* dy, int lddy, const float* w, float* dx, int lddx, const ConvGeom& g, void* ws,
+                       size_t ws_bytes, hipStream_t st) {
+    const int T = g.k * g.k * g.k;
+    Carver cv(ws);
+    float* wd = cv.take<float>((size_t)T * g.Cin * g.Cout);
+    SEG_CHECK_WS(cv.used(), ws_bytes);
+    pack_w_dgrad(w, wd, g.Cout, g.Cin, T, 0, st);
+    SEG_CHECK_LAUNCH();
+    long long total = (long long)g.N * g.D * g.H * g.W * g.Cin;
+    hipLaunchKernelGGL(conv_dgrad_generic_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, dy, lddy, wd, dx, lddx, g);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+int conv_wgrad_generic(const float* dy, int lddy, const float* x, int ldx, float* dw, const ConvGeom& g, int accumulate,
+                       void* ws, size_t ws_bytes, hipStream_t st) {
+    const int T = g.k * g.k * g.k;
+    const int splits = generic_splits(g);
+    Carver cv(ws);
+    float* part = cv.take<float>((size_t)splits * T * g.Cin * g.Cout);
+    SEG_CHECK_WS(cv.used(), ws_bytes);
+    const long long nvox = (long long)g.N * g.Do * g.Ho * g.Wo;
+    long long vps = (nvox + splits - 1) / splits;
+    dim3 grid(cdiv((long long)g.Cin * g.Cout, 256), T, splits);
+    hipLaunchKernelGGL(conv_wgrad_generic_kernel, grid, dim3(256), 0, st, dy, lddy, x, ldx, part, g, vps);
+    SEG_CHECK_LAUNCH();
+    wgrad_reduce(part, dw, splits, T, g.Cin, g.Cout, accumulate, st);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+static int check_geom(ConvGeom* g, const char* who) {
+    SEG_CHECK_ARG(g->N > 0 && g->D > 0 && g->H > 0 && g->W > 0 && g->Cin > 0 && g->Cout > 0, "%s: non-positive extent", who);
+    SEG_CHECK_ARG(g->k >= 1 && g->k <= 16 && g->stride >= 1 && g->pad >= 0, "%s: bad k/stride/pad %d/%d/%d", who, g->k,
+                  g->stride, g->pad);
+    SEG_CHECK_ARG(g->D + 2 * g->pad >= g->k && g->H + 2 * g->pad >= g->k && g->W + 2 * g->pad >= g->k,
+                  "%s: kernel larger than padded input", who);
+    g->Do = (g->D + 2 * g->pad - g->k) / g->stride + 1;
+    g->Ho = (g->H + 2 * g->pad - g->k) / g->stride + 1;
+    g->Wo = (g->W + 2 * g->pad - g->k) / g->stride + 1;
+    return MI355SEG_OK;
+}
+
+}  // namespace seg
+
+using namespace seg;
+
+extern "C" {
+
+size_t mi355seg_conv3d_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
+    size_t a = conv_generic_ws_bytes(N, D, H, W, Cin, Cout, k, stride, pad);
+    size_t b = conv_mfma_ws_bytes(N, D, H, W, Cin, Cout, k, stride, pad);
+    return a > b ? a : b;
+}
+
+int mi355seg_conv3d_fwd_f32(const float* x, int ldx, const float* w, const float* bias,
+                            float* y, int ldy, int N, int D, int H, int W, int Cin, int Cout,
+                            int k, int stride, int pad, double* stats_sum, double* stats_sq,
+                            void* ws, size_t ws_bytes, void* stream) {
+    ConvGeom g{N, D, H, W, Cin, Cout, k, stride, pad, 0, 0, 0};
+    int rc = check_geom(&g, "conv3d_fwd");
+    if (rc) return rc;
+    SEG_CHECK_ARG(x && w && y && ldx >= Cin && ldy >= Cout, "conv3d_fwd: null pointer or pitch < channels");
+    SEG_CHECK_ARG((stats_sum == nullptr) == (stats_sq == nullptr), "conv3d_fwd: stats_sum/stats_sq must come together");
+    hipStream_t st = (hipStream_t)stream;
+    if (conv_mfma_supported(N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy))
+        return conv_fwd_mfma(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, /*dgrad=*/0, stats_sum, stats_sq, ws, ws_bytes, st);
+    return conv_fwd_generic(x, ldx, w, bias, y, ldy, g, stats_sum, stats_sq, ws, ws_bytes, st);
+}
+
+int mi355seg_conv3d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
+                              int N, int D, int H, int W, int Cin, int Cout,
+                              int k, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
+    ConvGeom g{N, D, H, W, Cin, Cout, k, stride, pad, 0, 0, 0};
+    int rc = check_geom(&g, "conv3d_dgrad");
+    if (rc) return rc;
+    SEG_CHECK_ARG(dy && w && dx && lddy >= Cout && lddx >= Cin, "conv3d_dgrad: null pointer or pitch < channels");
+    hipStream_t st = (hipStream_t)stream;
+    // k3 s1 p1: dgrad is the same convolution with flipped taps and Cin<->Cout swapped
+    if (conv_mfma_supported(N, D, H, W, Cout, Cin, k, stride, pad, lddy, lddx))
+        return conv_fwd_mfma(dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cout, Cin, /*dgrad=*/1, nullptr, nullptr, ws, ws_bytes, st);
+    return conv_dgrad_generic(dy, lddy, w, dx, lddx, g, ws, ws_bytes, st);
+}
+
+int mi355seg_conv3d_wgrad_f32(const float* dy, int lddy, const float* x, int ldx,
+                              float* dw, float* db, int N, int D, int H, int W, int Cin, int Cout,
+                              int k, int stride, int pad, int accumulate,
+                              void* ws, size_t ws_bytes, void* stream) {
+    ConvGeom g{N, D, H, W, Cin, Cout, k, stride, pad, 0, 0, 0};
+    int rc = check_geom(&g, "conv3d_wgrad");
+    if (rc) return rc;
+    SEG_CHECK_ARG(dy && x && dw && lddy >= Cout && ldx >= Cin, "conv3d_wgrad: null pointer or pitch < channels");
+    hipStream_t st = (hipStream_t)stream;
+    if (db) {
+        rc = channel_sums(dy, lddy, (long long)N * g.Do * g.Ho * g.Wo, Cout, nullptr, nullptr, db, accumulate, ws, ws_bytes, st);
+        if (rc) return rc;
+    }
+    if (wgrad_mfma_supported(N, D, H, W, Cin, Cout, k, stride, pad, ldx, lddy))
+        return conv_wgrad_mfma(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, st);
+    return conv_wgrad_generic(dy, lddy, x, ldx, dw, g, accumulate, ws, ws_bytes, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,187 @@
+// convt.hip -- ConvTranspose3d(kernel_size=2, stride=2) forward / dgrad / wgrad, NDHWC fp32.
+// kernel == stride => the 8 taps write disjoint output voxels: the op is a GEMM
+// [voxels, Cin] x [Cin, 8*Cout] whose columns are scattered to the 2x2x2 children.
+// Reference: nn.ConvTranspose3d unet3d.py:29-43, vnet3d.py:86, unetr.py:11.
+// Weight layout (PyTorch): (Cin, Cout, 2, 2, 2).
+#include "common.h"
+#include "internal.h"
+
+namespace seg {
+
+// w (Cin,Cout,8) -> wp[8][Cin][Cout]  and  wd[8][Cout][Cin]
+__global__ void convt_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, float* __restrict__ wd, int Cin, int Cout) {
+    long long total = (long long)Cin * Cout * 8;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int t = (int)(i % 8); long long r = i / 8;
+        int co = (int)(r % Cout); int ci = (int)(r / Cout);
+        float v = w[i];
+        if (wp) wp[((long long)t * Cin + ci) * Cout + co] = v;
+        if (wd) wd[((long long)t * Cout + co) * Cin + ci] = v;
+    }
+}
+
+// thread per (output voxel, cout)
+__global__ __launch_bounds__(256) void convt_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ wp,
+        const float* __restrict__ bias, float* __restrict__ y, int ldy, int N, int D, int H, int W, int Cin, int Cout) {
+    const int D2 = 2 * D, H2 = 2 * H, W2 = 2 * W;
+    const long long total = (long long)N * D2 * H2 * W2 * Cout;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int co = (int)(i % Cout); long long v = i / Cout;
+        int ow = (int)(v % W2); long long r = v / W2;
+        int oh = (int)(r % H2); r /= H2;
+        int od = (int)(r % D2); int n = (int)(r / D2);
+        int t = ((od & 1) << 2) | ((oh & 1) << 1) | (ow & 1);
+        const float* xp = x + ((((long long)n * D + (od >> 1)) * H + (oh >> 1)) * W + (ow >> 1)) * ldx;
+        const float* wq = wp + (long long)t * Cin * Cout + co;
+        float acc = bias ? bias[co] : 0.f;
+        int ci = 0;
+        for (; ci + 4 <= Cin; ci += 4) {
+            acc = fmaf(xp[ci], wq[(long long)ci * Cout], acc);
+            acc = fmaf(xp[ci + 1], wq[(long long)(ci + 1) * Cout], acc);
+            acc = fmaf(xp[ci + 2], wq[(long long)(ci + 2) * Cout], acc);
+            acc = fmaf(xp[ci + 3], wq[(long long)(ci + 3) * Cout], acc);
+        }
+        for (; ci < Cin; ++ci) acc = fmaf(xp[ci], wq[(long long)ci * Cout], acc);
+        y[v * ldy + co] = acc;
+    }
+}
+
+// thread per (input voxel, cin): dx = sum_{t,co} dy[child t, co] * w[ci][co][t]
+__global__ __launch_bounds__(256) void convt_dgrad_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ wd,
+        float* __restrict__ dx, int lddx, int N, int D, int H, int W, int Cin, int Cout) {
+    const int H2 = 2 * H, W2 = 2 * W, D2 = 2 * D;
+    const long long total = (long long)N * D * H * W * Cin;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int ci = (int)(i % Cin); long long v = i / Cin;
+        int iw = (int)(v % W); long long r = v / W;
+        int ih = (int)(r % H); r /= H;
+        int id = (int)(r % D); int n = (int)(r / D);
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float* dp = dy + ((((long long)n * D2 + 2 * id + (t >> 2)) * H2 + 2 * ih + ((t >> 1) & 1)) * W2 + 2 * iw + (t & 1)) * lddy;
+            const float* wq = wd + (long long)t * Cout * Cin + ci;
+            for (int co = 0; co < Cout; ++co) acc = fmaf(dp[co], wq[(long long)co * Cin], acc);
+        }
+        dx[v * lddx + ci] = acc;
+    }
+}
+
+// grid = (pair blocks, 8 taps, splits); thread = (ci, co); partial[split][t][ci][co]
+__global__ __launch_bounds__(256) void convt_wgrad_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
+        float* __restrict__ part, int N, int D, int H, int W, int Cin, int Cout, long long vps) {
+    const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.y, split = blockIdx.z;
+    const long long nvox = (long long)N * D * H * W;
+    long long v0 = (long long)split * vps, v1 = v0 + vps;
+    if (v1 > nvox) v1 = nvox;
+    if (pair >= Cin * Cout) return;
+    const int co = pair % Cout, ci = pair / Cout;
+    const int H2 = 2 * H, W2 = 2 * W, D2 = 2 * D;
+    float acc = 0.f;
+    for (long long v = v0; v < v1; ++v) {
+        int iw = (int)(v % W); long long r = v / W;
+        int ih = (int)(r % H); r /= H;
+        int id = (int)(r % D); int n = (int)(r / D);
+        long long ov = (((long long)n * D2 + 2 * id + (t >> 2)) * H2 + 2 * ih + ((t >> 1) & 1)) * W2 + 2 * iw + (t & 1);
+        acc = fmaf(x[v * ldx + ci], dy[ov * lddy + co], acc);
+    }
+    part[(((long long)split * 8 + t) * Cin + ci) * Cout + co] = acc;
+}
+
+// dw[ci][co][t] = sum_split part[split][t][ci][co]
+__global__ void convt_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits, int Cin, int Cout) {
+    long long total = (long long)8 * Cin * Cout;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int co = (int)(i % Cout); long long r = i / Cout;
+        int ci = (int)(r % Cin); int t = (int)(r / Cin);
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += part[(long long)k * total + i];
+        dw[((long long)ci * Cout + co) * 8 + t] = s;
+    }
+}
+
+static int convt_splits(long long nvox, int Cin, int Cout) {
+    int pairblocks = cdiv((long long)Cin * Cout, 256);
+    long long want = 4096 / ((long long)pairblocks * 8) + 1;
+    long long maxs = nvox / 64 + 1;
+    if (want > maxs) want = maxs;
+    if (want > 128) want = 128;
+    return (int)(want < 1 ? 1 : want);
+}
+static int tgrid(long long total) {
+    long long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+}  // namespace seg
+
+using namespace seg;
+
+extern "C" {
+
+size_t mi355seg_convt3d_k2s2_ws_bytes(int N, int D, int H, int W, int Cin, int Cout) {
+    size_t wb = align_up((size_t)8 * Cin * Cout * sizeof(float), 256);
+    size_t part = align_up((size_t)convt_splits((long long)N * D * H * W, Cin, Cout) * 8 * Cin * Cout * sizeof(float), 256);
+    size_t red = colsum_ws_bytes(Cout);
+    return wb + (part > red ? part : red) + 1024;
+}
+
+int mi355seg_convt3d_k2s2_fwd_f32(const float* x, int ldx, const float* w, const float* bias,
+                                  float* y, int ldy, int N, int D, int H, int W, int Cin, int Cout,
+                                  void* ws, size_t ws_bytes, void* stream) {
+    SEG_CHECK_ARG(x && w && y && N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ldx >= Cin && ldy >= Cout,
+                  "convt3d_k2s2_fwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    Carver cv(ws);
+    float* wp = cv.take<float>((size_t)8 * Cin * Cout);
+    SEG_CHECK_WS(cv.used(), ws_bytes);
+    hipLaunchKernelGGL(convt_pack_kernel, dim3(tgrid((long long)8 * Cin * Cout)), dim3(256), 0, st, w, wp, (float*)nullptr, Cin, Cout);
+    SEG_CHECK_LAUNCH();
+    long long total = (long long)N * D * H * W * 8 * Cout;
+    hipLaunchKernelGGL(convt_fwd_kernel, dim3(tgrid(total)), dim3(256), 0, st, x, ldx, wp, bias, y, ldy, N, D, H, W, Cin, Cout);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+int mi355seg_convt3d_k2s2_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
+                                    int N, int D, int H, int W, int Cin, int Cout,
+                                    void* ws, size_t ws_bytes, void* stream) {
+    SEG_CHECK_ARG(dy && w && dx && N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && lddy >= Cout && lddx >= Cin,
+                  "convt3d_k2s2_dgrad: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    Carver cv(ws);
+    float* wd = cv.take<float>((size_t)8 * Cin * Cout);
+    SEG_CHECK_WS(cv.used(), ws_bytes);
+    hipLaunchKernelGGL(convt_pack_kernel, dim3(tgrid((long long)8 * Cin * Cout)), dim3(256), 0, st, w, (float*)nullptr, wd, Cin, Cout);
+    SEG_CHECK_LAUNCH();
+    long long total = (long long)N * D * H * W * Cin;
+    hipLaunchKernelGGL(convt_dgrad_kernel, dim3(tgrid(total)), dim3(256), 0, st, dy, lddy, wd, dx, lddx, N, D, H, W, Cin, Cout);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+int mi355seg_convt3d_k2s2_wgrad_f32(const float* dy, int lddy, const float* x, int ldx,
+                                    float* dw, float* db, int N, int D, int H, int W, int Cin, int Cout,
+                                    void* ws, size_t ws_bytes, void* stream) {
+    SEG_CHECK_ARG(dy && x && dw && N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && lddy >= Cout && ldx >= Cin,
+                  "convt3d_k2s2_wgrad: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const long long nvox = (long long)N * D * H * W;
+    if (db) {
+        int rc = channel_sums(dy, lddy, nvox * 8, Cout, nullptr, nullptr, db, 0, ws, ws_bytes, st);
+        if (rc) return rc;
+    }
+    const int splits = convt_splits(nvox, Cin, Cout);
+    Carver cv(ws);
+    float* part = cv.take<float>((size_t)splits * 8 * Cin * Cout);
+    SEG_CHECK_WS(cv.used(), ws_bytes);
+    long long vps = (nvox + splits - 1) / splits;
+    dim3 grid(cdiv((long long)Cin * Cout, 256), 8, splits);
+    hipLaunchKernelGGL(convt_wgrad_kernel, grid, dim3(256), 0, st, dy, lddy, x, ldx, part, N, D, H, W, Cin, Cout, vps);
+    SEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(convt_wgrad_reduce_kernel, dim3(tgrid((long long)8 * Cin * Cout)), dim3(256), 0, st, part, dw, splits, Cin, Cout);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+}  // extern "C"

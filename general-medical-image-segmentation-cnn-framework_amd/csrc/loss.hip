@@ -1,0 +1,272 @@
+// loss.hip -- BCE-with-logits, channel argmax, integer Dice counters and the sum-type
+// reductions of the library Dice losses.  All are single-pass streaming reductions:
+// 16 B/lane loads, wavefront shuffle (DPP) sums, one LDS hop across the block's 4 waves,
+// per-block partials and a fixed-order fp64 / int64 finalise -- deterministic, no atomics.
+//
+// Reference: nn.BCEWithLogitsLoss train.py:115,209 (== Binary_Loss, loss_function.py:19-41);
+// pred.argmax(dim=1, keepdim=True) train.py:204; metric() utils/metric.py:20-75;
+// DiceLoss / BinaryDiceLoss / DiceLossss loss_function.py:61-185.
+#include "common.h"
+
+namespace seg {
+
+constexpr int kLossThreads = 256;
+constexpr int kLossMaxBlocks = 2048;
+
+static int loss_grid(long long items) {
+    long long b = (items + kLossThreads - 1) / kLossThreads;
+    return (int)(b < 1 ? 1 : (b > kLossMaxBlocks ? kLossMaxBlocks : b));
+}
+
+// block-wide sum of NV doubles; result valid in thread 0
+template <int NV, typename T>
+__device__ __forceinline__ void block_sum(T (&v)[NV], T* sh) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = wave_sum(v[j]);
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) sh[wid * NV + j] = v[j];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x >> 6;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            T s = sh[j];
+            for (int w = 1; w < nw; ++w) s += sh[w * NV + j];
+            v[j] = s;
+        }
+    }
+}
+
+__device__ __forceinline__ float bce_term(float x, float t) {
+    // max(x,0) - x*t + log1p(exp(-|x|))
+    return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+}
+
+__global__ __launch_bounds__(kLossThreads) void bce_fwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                                long long numel, double* __restrict__ part) {
+    __shared__ double sh[4];
+    double acc[1] = {0.0};
+    const long long n4 = numel / 4;
+    float local = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 a = reinterpret_cast<const float4*>(x)[i];
+        float4 b = reinterpret_cast<const float4*>(t)[i];
+        local = bce_term(a.x, b.x) + bce_term(a.y, b.y) + bce_term(a.z, b.z) + bce_term(a.w, b.w);
+        acc[0] += (double)local;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (numel & 3)) {
+        long long i = n4 * 4 + threadIdx.x;
+        acc[0] += (double)bce_term(x[i], t[i]);
+    }
+    block_sum<1>(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc[0];
+}
+
+__global__ void bce_finalize_kernel(const double* __restrict__ part, int nblk, double numel, float* __restrict__ loss) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nblk; ++i) s += part[i];
+        loss[0] = (float)(s / numel);
+    }
+}
+
+__global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                       const float* __restrict__ gscale, long long numel, float* __restrict__ dx) {
+    const float sc = gscale[0] / (float)numel;
+    const long long n4 = numel / 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 a = reinterpret_cast<const float4*>(x)[i];
+        float4 b = reinterpret_cast<const float4*>(t)[i];
+        float4 o;
+        o.x = (1.f / (1.f + expf(-a.x)) - b.x) * sc;
+        o.y = (1.f / (1.f + expf(-a.y)) - b.y) * sc;
+        o.z = (1.f / (1.f + expf(-a.z)) - b.z) * sc;
+        o.w = (1.f / (1.f + expf(-a.w)) - b.w) * sc;
+        reinterpret_cast<float4*>(dx)[i] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (numel & 3)) {
+        long long i = n4 * 4 + threadIdx.x;
+        dx[i] = (1.f / (1.f + expf(-x[i])) - t[i]) * sc;
+    }
+}
+
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ x, long long N, int K, long long S,
+                                                      int64_t* __restrict__ mask) {
+    const long long total = N * S;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long n = i / S, s = i % S;
+        const float* p = x + n * K * S + s;
+        float best = p[0]; int bi = 0;
+        for (int k = 1; k < K; ++k) { float v = p[(long long)k * S]; if (v > best) { best = v; bi = k; } }
+        mask[i] = bi;
+    }
+}
+
+__global__ __launch_bounds__(kLossThreads) void dice_counts_kernel(const int64_t* __restrict__ gt, const int64_t* __restrict__ pr,
+                                                                    long long numel, long long* __restrict__ part) {
+    __shared__ long long sh[16];
+    long long acc[4] = {0, 0, 0, 0};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (long long)gridDim.x * blockDim.x) {
+        long long g = gt[i], p = pr[i];
+        acc[0] += g; acc[1] += p;
+        acc[2] += ((g & p) != 0); acc[3] += ((g | p) != 0);
+    }
+    block_sum<4>(acc, sh);
+    if (threadIdx.x == 0) for (int j = 0; j < 4; ++j) part[(long long)blockIdx.x * 4 + j] = acc[j];
+}
+
+__global__ void counts_finalize_kernel(const long long* __restrict__ part, int nblk, int64_t* __restrict__ counts) {
+    int j = threadIdx.x;
+    if (j < 4 && blockIdx.x == 0) {
+        long long s = 0;
+        for (int i = 0; i < nblk; ++i) s += part[(long long)i * 4 + j];
+        counts[j] = s;
+    }
+}
+
+// one pass over logits + one-hot targets: BCE sum, argmax(pred), argmax(gt), Dice counters
+__global__ __launch_bounds__(kLossThreads) void bce_argmax_dice_kernel(const float* __restrict__ x, const float* __restrict__ t,
+        long long N, int K, long long S, int64_t* __restrict__ mask, double* __restrict__ lpart, long long* __restrict__ cpart) {
+    __shared__ double shd[4];
+    __shared__ long long shc[16];
+    double lacc[1] = {0.0};
+    long long acc[4] = {0, 0, 0, 0};
+    const long long total = N * S;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long n = i / S, s = i % S;
+        const float* px = x + n * K * S + s;
+        const float* pt = t + n * K * S + s;
+        float bx = px[0], bt = pt[0]; int ix = 0, it = 0;
+        float l = bce_term(bx, bt);
+        for (int k = 1; k < K; ++k) {
+            float vx = px[(long long)k * S], vt = pt[(long long)k * S];
+            l += bce_term(vx, vt);
+            if (vx > bx) { bx = vx; ix = k; }
+            if (vt > bt) { bt = vt; it = k; }
+        }
+        lacc[0] += (double)l;
+        mask[i] = ix;
+        acc[0] += it; acc[1] += ix;
+        acc[2] += ((it & ix) != 0); acc[3] += ((it | ix) != 0);
+    }
+    block_sum<1>(lacc, shd);
+    block_sum<4>(acc, shc);
+    if (threadIdx.x == 0) {
+        lpart[blockIdx.x] = lacc[0];
+        for (int j = 0; j < 4; ++j) cpart[(long long)blockIdx.x * 4 + j] = acc[j];
+    }
+}
+
+__global__ __launch_bounds__(kLossThreads) void dice_sums_kernel(const float* __restrict__ x, const float* __restrict__ t,
+        long long numel, int apply_sigmoid, double* __restrict__ part) {
+    __shared__ double sh[20];
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (long long)gridDim.x * blockDim.x) {
+        float a = x[i], b = t[i];
+        if (apply_sigmoid) a = 1.f / (1.f + expf(-a));
+        acc[0] += (double)(a * b); acc[1] += (double)a; acc[2] += (double)b;
+        acc[3] += (double)(a * a); acc[4] += (double)(b * b);
+    }
+    block_sum<5>(acc, sh);
+    if (threadIdx.x == 0) for (int j = 0; j < 5; ++j) part[(long long)blockIdx.x * 5 + j] = acc[j];
+}
+__global__ void sums_finalize5_kernel(const double* __restrict__ part, int nblk, double* __restrict__ out) {
+    int j = threadIdx.x;
+    if (j < 5 && blockIdx.x == 0) {
+        double s = 0;
+        for (int i = 0; i < nblk; ++i) s += part[(long long)i * 5 + j];
+        out[j] = s;
+    }
+}
+
+}  // namespace seg
+
+using namespace seg;
+
+extern "C" {
+
+size_t mi355seg_loss_ws_bytes(long long numel) {
+    (void)numel;
+    return (size_t)kLossMaxBlocks * (8 * sizeof(double)) + 1024;
+}
+
+int mi355seg_bce_logits_fwd_f32(const float* logits, const float* target, long long numel,
+                                float* loss, void* ws, size_t ws_bytes, void* stream) {
+    SEG_CHECK_ARG(logits && target && loss && numel > 0, "bce_logits_fwd: bad arguments");
+    SEG_CHECK_ARG(((uintptr_t)logits % 16) == 0 && ((uintptr_t)target % 16) == 0, "bce_logits_fwd: pointers must be 16-byte aligned");
+    int nblk = loss_grid(numel / 4 + 1);
+    SEG_CHECK_WS((size_t)nblk * sizeof(double), ws_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(nblk), dim3(kLossThreads), 0, st, logits, target, numel, (double*)ws);
+    SEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nblk, (double)numel, loss);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+int mi355seg_bce_logits_bwd_f32(const float* logits, const float* target, const float* gscale,
+                                long long numel, float* dlogits, void* stream) {
+    SEG_CHECK_ARG(logits && target && gscale && dlogits && numel > 0, "bce_logits_bwd: bad arguments");
+    SEG_CHECK_ARG(((uintptr_t)logits % 16) == 0 && ((uintptr_t)target % 16) == 0 && ((uintptr_t)dlogits % 16) == 0,
+                  "bce_logits_bwd: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3(loss_grid(numel / 4 + 1) * 2), dim3(256), 0, (hipStream_t)stream, logits, target,
+                       gscale, numel, dlogits);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+int mi355seg_argmax_ch_f32(const float* logits, long long N, int K, long long S, int64_t* mask, void* stream) {
+    SEG_CHECK_ARG(logits && mask && N > 0 && K > 0 && S > 0, "argmax_ch: bad arguments");
+    hipLaunchKernelGGL(argmax_kernel, dim3(loss_grid(N * S) * 2), dim3(256), 0, (hipStream_t)stream, logits, N, K, S, mask);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+int mi355seg_dice_counts_i64(const int64_t* gt, const int64_t* pred, long long numel,
+                             int64_t* counts, void* ws, size_t ws_bytes, void* stream) {
+    SEG_CHECK_ARG(gt && pred && counts && numel > 0, "dice_counts: bad arguments");
+    int nblk = loss_grid(numel);
+    SEG_CHECK_WS((size_t)nblk * 4 * sizeof(long long), ws_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(dice_counts_kernel, dim3(nblk), dim3(kLossThreads), 0, st, gt, pred, numel, (long long*)ws);
+    SEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(counts_finalize_kernel, dim3(1), dim3(64), 0, st, (const long long*)ws, nblk, counts);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+int mi355seg_bce_argmax_dice_f32(const float* logits, const float* target, long long N, int K, long long S,
+                                 float* loss, int64_t* mask, int64_t* counts,
+                                 void* ws, size_t ws_bytes, void* stream) {
+    SEG_CHECK_ARG(logits && target && loss && mask && counts && N > 0 && K > 0 && S > 0, "bce_argmax_dice: bad arguments");
+    int nblk = loss_grid(N * S);
+    SEG_CHECK_WS((size_t)nblk * 5 * sizeof(double), ws_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    double* lpart = (double*)ws;
+    long long* cpart = (long long*)((char*)ws + (size_t)nblk * sizeof(double));
+    hipLaunchKernelGGL(bce_argmax_dice_kernel, dim3(nblk), dim3(kLossThreads), 0, st, logits, target, N, K, S, mask, lpart, cpart);
+    SEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(64), 0, st, lpart, nblk, (double)(N * K * S), loss);
+    SEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(counts_finalize_kernel, dim3(1), dim3(64), 0, st, cpart, nblk, counts);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+int mi355seg_dice_sums_f32(const float* x, const float* t, long long numel, int apply_sigmoid,
+                           double* out5, void* ws, size_t ws_bytes, void* stream) {
+    SEG_CHECK_ARG(x && t && out5 && numel > 0, "dice_sums: bad arguments");
+    int nblk = loss_grid(numel);
+    SEG_CHECK_WS((size_t)nblk * 5 * sizeof(double), ws_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(dice_sums_kernel, dim3(nblk), dim3(kLossThreads), 0, st, x, t, numel, apply_sigmoid, (double*)ws);
+    SEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sums_finalize5_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nblk, out5);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+}  // extern "C"

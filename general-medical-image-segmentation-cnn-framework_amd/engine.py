@@ -1,0 +1,43 @@
+"""Train-step engine: the reference's per-iteration glue (train.py:187-221) on the GPU.
+
+zero_grad -> 2-channel gt -> forward -> argmax -> BCE -> backward -> optimizer.step ->
+Dice, with the Dice counters reduced on the device (four int64 cross PCIe instead of the
+reference's two full int64 volumes, train.py:221).  Optimizer stays torch.optim (north_star:
+"autograd/optimizer plumbing stays Python")."""
+import torch
+
+from . import functional as F
+from .utils.metric import metric_from_counts
+
+
+def two_channel_gt(gt):
+    """train.py:190-193: gt_back = (gt == 0); gt = cat([gt_back, gt], dim=1) as float."""
+    gt = gt.to(torch.float32)
+    return torch.cat([(gt == 0).to(torch.float32), gt], dim=1)
+
+
+def train_step(model, optimizer, x, gt, criterion=None, sync_metric=True, grad_hook=None):
+    """One iteration.  ``gt`` is the single-channel label volume [N,1,D,H,W].
+    ``grad_hook`` (if given) runs between backward and optimizer.step -- the data-parallel
+    gradient all-reduce plugs in there.  Returns a dict with pred, mask, loss and, when
+    ``sync_metric``, python floats jaccard/dice (one tiny D2H copy); otherwise the raw
+    int64[4] counters stay on the device under 'counts'."""
+    optimizer.zero_grad(set_to_none=True)
+    gt2 = two_channel_gt(gt)
+    pred = model(x.to(torch.float32))
+    if criterion is None:
+        loss = F.bce_with_logits(pred, gt2)
+    else:
+        loss = criterion(pred, gt2)
+    with torch.no_grad():
+        mask = F.argmax_channels(pred)
+        gt_lab = F.argmax_channels(gt2)
+        counts = F.dice_counts(gt_lab, mask)
+    loss.backward()
+    if grad_hook is not None:
+        grad_hook(model)
+    optimizer.step()
+    out = {"pred": pred, "mask": mask, "loss": loss.detach(), "counts": counts}
+    if sync_metric:
+        out["jaccard"], out["dice"] = metric_from_counts(counts.cpu().tolist())
+    return out

@@ -1,0 +1,424 @@
+"""torch.autograd wrappers over the C-ABI (libmi355seg.so).
+
+PyTorch is plumbing here: device memory (caching allocator), the current HIP stream and
+the autograd graph.  Every numeric kernel is a hand-written gfx950 kernel behind
+include/mi355seg.h; nothing in this file computes with torch ops on the hot path.
+
+Activations inside the package are channel-last: a 5-D fp32 tensor of logical shape
+[N, D, H, W, C] whose last stride is 1 and whose voxel pitch (stride of W) may exceed C
+(a channel slice of a wider concat buffer).
+"""
+import torch
+from torch.autograd import Function
+
+from ._lib import lib, Mi355SegError
+
+ACT_NONE, ACT_RELU, ACT_ELU, ACT_LRELU = 0, 1, 2, 3
+
+_WS = {}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def workspace(nbytes, device):
+    """Per-device scratch buffer, grown on demand.  Stream-ordered reuse: all kernels of
+    one process run on the current stream, so consecutive ops may share it."""
+    buf = _WS.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[device] = buf
+    return buf
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise Mi355SegError(f"{what}: expected a tensor on an MI355X (cuda/HIP) device, got {t.device}; "
+                            "there is no CPU fallback in this package")
+    if t.dtype != torch.float32:
+        raise Mi355SegError(f"{what}: expected float32, got {t.dtype}")
+
+
+def cl_view(t, what="tensor"):
+    """Return (tensor, ld) with tensor laid out NDHWC (last stride 1, dense in N,D,H,W with
+    voxel pitch ld >= C).  Copies only if the given tensor does not already satisfy that."""
+    _require_cuda(t, what)
+    if t.dim() != 5:
+        raise Mi355SegError(f"{what}: expected 5-D [N,D,H,W,C], got shape {tuple(t.shape)}")
+    N, D, H, W, C = t.shape
+    s = t.stride()
+    ld = s[3]
+    ok = (C == 1 or s[4] == 1) and ld >= C and W > 1
+    ok = ok and (H == 1 or s[2] == W * ld) and (D == 1 or s[1] == H * W * ld) and (N == 1 or s[0] == D * H * W * ld)
+    ok = ok and t.data_ptr() % 16 == 0          # the float4 paths assume a 16-byte aligned base
+    if not ok:
+        t = t.contiguous()
+        ld = C
+    return t, ld
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def to_channels_last(x):
+    """[N,C,D,H,W] -> [N,D,H,W,C] (free view when C == 1)."""
+    return _ToNDHWC.apply(x)
+
+
+def to_channels_first(x):
+    """[N,D,H,W,C] -> [N,C,D,H,W] contiguous (free view when C == 1)."""
+    return _ToNCDHW.apply(x)
+
+
+class _ToNDHWC(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_cuda(x, "to_channels_last")
+        N, C, D, H, W = x.shape
+        x = x.contiguous()
+        if C == 1:
+            return x.view(N, D, H, W, 1)
+        y = torch.empty((N, D, H, W, C), dtype=x.dtype, device=x.device)
+        lib().call("mi355seg_ncdhw_to_ndhwc_f32", _p(x), _p(y), C, N, C, D * H * W, _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return _ToNCDHW.apply(g)
+
+
+class _ToNCDHW(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x, ld = cl_view(x, "to_channels_first")
+        N, D, H, W, C = x.shape
+        if C == 1 and ld == 1:
+            return x.view(N, 1, D, H, W)
+        y = torch.empty((N, C, D, H, W), dtype=x.dtype, device=x.device)
+        lib().call("mi355seg_ndhwc_to_ncdhw_f32", _p(x), ld, _p(y), N, C, D * H * W, _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return _ToNDHWC.apply(g)
+
+
+# ----------------------------------------------------------------------------- conv
+class _Conv3d(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad):
+        x, ldx = cl_view(x, "conv3d input")
+        N, D, H, W, Cin = x.shape
+        Cout, Cin_w, k = w.shape[0], w.shape[1], w.shape[2]
+        if Cin_w != Cin or w.shape[3] != k or w.shape[4] != k:
+            raise Mi355SegError(f"conv3d: weight {tuple(w.shape)} does not match input channels {Cin} / cubic kernel")
+        w = w.contiguous()
+        Do, Ho, Wo = [(e + 2 * pad - k) // stride + 1 for e in (D, H, W)]
+        y = torch.empty((N, Do, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+        L = lib()
+        nb = L.query("mi355seg_conv3d_ws_bytes", N, D, H, W, Cin, Cout, k, stride, pad)
+        ws = workspace(nb, x.device)
+        L.call("mi355seg_conv3d_fwd_f32", _p(x), ldx, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
+               None, None, _p(ws), ws.numel(), _stream())
+        ctx.save_for_backward(x, w)
+        ctx.geom = (N, D, H, W, Cin, Cout, k, stride, pad, ldx, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        N, D, H, W, Cin, Cout, k, stride, pad, ldx, has_b = ctx.geom
+        dy, lddy = cl_view(dy, "conv3d grad")
+        L = lib()
+        nb = L.query("mi355seg_conv3d_ws_bytes", N, D, H, W, Cin, Cout, k, stride, pad)
+        ws = workspace(nb, x.device)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((N, D, H, W, Cin), dtype=x.dtype, device=x.device)
+            L.call("mi355seg_conv3d_dgrad_f32", _p(dy), lddy, _p(w), _p(dx), Cin, N, D, H, W, Cin, Cout, k, stride, pad,
+                   _p(ws), ws.numel(), _stream())
+        if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
+            dw = torch.empty_like(w)
+            db = torch.empty(Cout, dtype=x.dtype, device=x.device) if has_b else None
+            L.call("mi355seg_conv3d_wgrad_f32", _p(dy), lddy, _p(x), ldx, _p(dw), _p(db), N, D, H, W, Cin, Cout, k, stride, pad,
+                   0, _p(ws), ws.numel(), _stream())
+        return dx, dw, db, None, None
+
+
+def conv3d(x, weight, bias=None, stride=1, padding=0):
+    """nn.Conv3d on a channel-last tensor (cubic kernel, isotropic stride/padding)."""
+    return _Conv3d.apply(x, weight, bias, int(stride), int(padding))
+
+
+class _ConvT3dK2S2(Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, ldx = cl_view(x, "conv_transpose3d input")
+        N, D, H, W, Cin = x.shape
+        if tuple(w.shape[2:]) != (2, 2, 2) or w.shape[0] != Cin:
+            raise Mi355SegError(f"conv_transpose3d_k2s2: weight {tuple(w.shape)} must be (Cin={Cin}, Cout, 2, 2, 2)")
+        Cout = w.shape[1]
+        w = w.contiguous()
+        y = torch.empty((N, 2 * D, 2 * H, 2 * W, Cout), dtype=x.dtype, device=x.device)
+        L = lib()
+        ws = workspace(L.query("mi355seg_convt3d_k2s2_ws_bytes", N, D, H, W, Cin, Cout), x.device)
+        L.call("mi355seg_convt3d_k2s2_fwd_f32", _p(x), ldx, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout,
+               _p(ws), ws.numel(), _stream())
+        ctx.save_for_backward(x, w)
+        ctx.geom = (N, D, H, W, Cin, Cout, ldx, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        N, D, H, W, Cin, Cout, ldx, has_b = ctx.geom
+        dy, lddy = cl_view(dy, "conv_transpose3d grad")
+        L = lib()
+        ws = workspace(L.query("mi355seg_convt3d_k2s2_ws_bytes", N, D, H, W, Cin, Cout), x.device)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((N, D, H, W, Cin), dtype=x.dtype, device=x.device)
+            L.call("mi355seg_convt3d_k2s2_dgrad_f32", _p(dy), lddy, _p(w), _p(dx), Cin, N, D, H, W, Cin, Cout,
+                   _p(ws), ws.numel(), _stream())
+        if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
+            dw = torch.empty_like(w)
+            db = torch.empty(Cout, dtype=x.dtype, device=x.device) if has_b else None
+            L.call("mi355seg_convt3d_k2s2_wgrad_f32", _p(dy), lddy, _p(x), ldx, _p(dw), _p(db), N, D, H, W, Cin, Cout,
+                   _p(ws), ws.numel(), _stream())
+        return dx, dw, db
+
+
+def conv_transpose3d_k2s2(x, weight, bias=None):
+    """nn.ConvTranspose3d(kernel_size=2, stride=2) on a channel-last tensor."""
+    return _ConvT3dK2S2.apply(x, weight, bias)
+
+
+# ----------------------------------------------------------------------------- norm + activation
+class _NormAct(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, running_mean, running_var, training, momentum, eps, act, slope, instance):
+        x, ldx = cl_view(x, "norm input")
+        N, D, H, W, C = x.shape
+        groups = N if instance else 1
+        rows = D * H * W * (1 if instance else N)
+        L = lib()
+        dev = x.device
+        ws = workspace(L.query("mi355seg_norm_ws_bytes", rows, groups, C), dev)
+        if res is not None:
+            res, ldres = cl_view(res, "norm residual")
+        else:
+            ldres = 0
+        if training or instance:
+            mean = torch.empty(groups * C, dtype=torch.float32, device=dev)
+            rstd = torch.empty(groups * C, dtype=torch.float32, device=dev)
+            upd = training and (running_mean is not None) and not instance
+            L.call("mi355seg_norm_stats_f32", _p(x), ldx, rows, groups, C, eps, _p(mean), _p(rstd),
+                   _p(running_mean) if upd else None, _p(running_var) if upd else None, momentum,
+                   _p(ws), ws.numel(), _stream())
+        else:
+            mean = running_mean
+            rstd = torch.empty(C, dtype=torch.float32, device=dev)
+            L.call("mi355seg_rstd_from_var_f32", _p(running_var), eps, _p(rstd), C, _stream())
+        y = torch.empty((N, D, H, W, C), dtype=x.dtype, device=dev)
+        L.call("mi355seg_norm_act_fwd_f32", _p(x), ldx, _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), ldres,
+               _p(y), C, rows, groups, C, act, slope, _stream())
+        ctx.save_for_backward(x, mean, rstd, gamma, beta, res)
+        ctx.cfg = (ldx, ldres, rows, groups, C, act, slope, bool(training or instance))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gamma, beta, res = ctx.saved_tensors
+        ldx, ldres, rows, groups, C, act, slope, batch_stats = ctx.cfg
+        if not batch_stats:
+            raise Mi355SegError("backward through eval-mode BatchNorm (running statistics) is not supported")
+        dy, lddy = cl_view(dy, "norm grad")
+        L = lib()
+        dev = x.device
+        ws = workspace(L.query("mi355seg_norm_ws_bytes", rows, groups, C), dev)
+        dx = torch.empty(x.shape, dtype=x.dtype, device=dev)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev) if gamma is not None else None
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev) if gamma is not None else None
+        dres = torch.empty(x.shape, dtype=x.dtype, device=dev) if res is not None else None
+        L.call("mi355seg_norm_act_bwd_f32", _p(dy), lddy, _p(x), ldx, _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), ldres,
+               _p(dx), C, _p(dgamma), _p(dbeta), _p(dres), C, rows, groups, C, act, slope, _p(ws), ws.numel(), _stream())
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5,
+                   act=ACT_NONE, slope=0.01, residual=None):
+    """act(BatchNorm3d(x) [+ residual]); training mode updates running stats in place."""
+    return _NormAct.apply(x, gamma, beta, residual, running_mean, running_var, bool(training), float(momentum),
+                          float(eps), int(act), float(slope), False)
+
+
+def instance_norm_act(x, eps=1e-5, act=ACT_NONE, slope=0.01):
+    """act(InstanceNorm3d(x)) with affine=False, track_running_stats=False."""
+    return _NormAct.apply(x, None, None, None, None, None, True, 0.0, float(eps), int(act), float(slope), True)
+
+
+class _Act(Function):
+    @staticmethod
+    def forward(ctx, x, res, act, slope):
+        x, ldx = cl_view(x, "activation input")
+        N, D, H, W, C = x.shape
+        if res is not None:
+            res, ldres = cl_view(res, "activation residual")
+        else:
+            ldres = 0
+        y = torch.empty((N, D, H, W, C), dtype=x.dtype, device=x.device)
+        rows = N * D * H * W
+        lib().call("mi355seg_act_fwd_f32", _p(x), ldx, _p(res), ldres, _p(y), C, rows, C, act, slope, _stream())
+        ctx.save_for_backward(x, res)
+        ctx.cfg = (ldx, ldres, rows, C, act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, res = ctx.saved_tensors
+        ldx, ldres, rows, C, act, slope = ctx.cfg
+        dy, lddy = cl_view(dy, "activation grad")
+        dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        lib().call("mi355seg_act_bwd_f32", _p(dy), lddy, _p(x), ldx, _p(res), ldres, _p(dx), C, rows, C, act, slope, _stream())
+        return dx, (dx if res is not None else None), None, None
+
+
+def activation(x, act, slope=0.01, residual=None):
+    """act(x [+ residual]) for ReLU / ELU / LeakyReLU."""
+    return _Act.apply(x, residual, int(act), float(slope))
+
+
+# ----------------------------------------------------------------------------- pool / upsample
+class _MaxPool2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x, ldx = cl_view(x, "max_pool3d input")
+        N, D, H, W, C = x.shape
+        y = torch.empty((N, D // 2, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
+        idx = torch.empty((N, D // 2, H // 2, W // 2, C), dtype=torch.uint8, device=x.device)
+        lib().call("mi355seg_maxpool2_fwd_f32", _p(x), ldx, _p(y), C, _p(idx), N, D, H, W, C, _stream())
+        ctx.save_for_backward(idx)
+        ctx.geom = (N, D, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        N, D, H, W, C = ctx.geom
+        dy, lddy = cl_view(dy, "max_pool3d grad")
+        dx = torch.empty((N, D, H, W, C), dtype=dy.dtype, device=dy.device)
+        lib().call("mi355seg_maxpool2_bwd_f32", _p(dy), lddy, _p(idx), _p(dx), C, N, D, H, W, C, _stream())
+        return dx
+
+
+def max_pool3d_2x(x):
+    """nn.MaxPool3d(kernel_size=2, stride=2)."""
+    return _MaxPool2.apply(x)
+
+
+class _Upsample2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x, ldx = cl_view(x, "upsample input")
+        N, D, H, W, C = x.shape
+        y = torch.empty((N, 2 * D, 2 * H, 2 * W, C), dtype=x.dtype, device=x.device)
+        lib().call("mi355seg_upsample2_fwd_f32", _p(x), ldx, _p(y), C, N, D, H, W, C, _stream())
+        ctx.geom = (N, D, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, D, H, W, C = ctx.geom
+        dy, lddy = cl_view(dy, "upsample grad")
+        dx = torch.empty((N, D, H, W, C), dtype=dy.dtype, device=dy.device)
+        lib().call("mi355seg_upsample2_bwd_f32", _p(dy), lddy, _p(dx), C, N, D, H, W, C, _stream())
+        return dx
+
+
+def upsample_nearest_2x(x):
+    """nn.Upsample(scale_factor=2, mode='nearest')."""
+    return _Upsample2.apply(x)
+
+
+# ----------------------------------------------------------------------------- losses / metric kernels
+class _BCEWithLogits(Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        _require_cuda(logits, "bce_with_logits input")
+        logits = logits.contiguous()
+        target = target.contiguous().to(torch.float32)
+        if logits.shape != target.shape:
+            raise ValueError(f"Target size ({tuple(target.shape)}) must be the same as input size ({tuple(logits.shape)})")
+        L = lib()
+        ws = workspace(L.query("mi355seg_loss_ws_bytes", logits.numel()), logits.device)
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        L.call("mi355seg_bce_logits_fwd_f32", _p(logits), _p(target), logits.numel(), _p(loss), _p(ws), ws.numel(), _stream())
+        ctx.save_for_backward(logits, target)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target = ctx.saved_tensors
+        g = g.contiguous().to(torch.float32)
+        d = torch.empty_like(logits)
+        lib().call("mi355seg_bce_logits_bwd_f32", _p(logits), _p(target), _p(g), logits.numel(), _p(d), _stream())
+        return d, None
+
+
+def bce_with_logits(logits, target):
+    """nn.BCEWithLogitsLoss() (mean reduction)."""
+    return _BCEWithLogits.apply(logits, target)
+
+
+def argmax_channels(logits):
+    """pred.argmax(dim=1, keepdim=True) on an NCDHW tensor -> int64 [N,1,D,H,W]."""
+    _require_cuda(logits, "argmax input")
+    logits = logits.contiguous()
+    N, K = logits.shape[0], logits.shape[1]
+    S = logits[0, 0].numel()
+    mask = torch.empty((N, 1) + tuple(logits.shape[2:]), dtype=torch.int64, device=logits.device)
+    lib().call("mi355seg_argmax_ch_f32", _p(logits), N, K, S, _p(mask), _stream())
+    return mask
+
+
+def dice_counts(gt, pred):
+    """Integer counters of utils/metric.py on two int64 device tensors -> int64[4]
+    (sum gt, sum pred, nnz(gt & pred), nnz(gt | pred))."""
+    if not gt.is_cuda or gt.dtype != torch.int64 or pred.dtype != torch.int64:
+        raise Mi355SegError("dice_counts: expected int64 tensors on the GPU")
+    gt, pred = gt.contiguous(), pred.contiguous()
+    L = lib()
+    ws = workspace(L.query("mi355seg_loss_ws_bytes", gt.numel()), gt.device)
+    out = torch.empty(4, dtype=torch.int64, device=gt.device)
+    L.call("mi355seg_dice_counts_i64", _p(gt), _p(pred), gt.numel(), _p(out), _p(ws), ws.numel(), _stream())
+    return out
+
+
+def bce_argmax_dice(logits, target):
+    """Fused tail of the train step: (loss, mask int64 [N,1,...], counts int64[4]).
+    Forward only (use bce_with_logits for the differentiable loss)."""
+    _require_cuda(logits, "bce_argmax_dice input")
+    logits, target = logits.contiguous(), target.contiguous().to(torch.float32)
+    N, K = logits.shape[0], logits.shape[1]
+    S = logits[0, 0].numel()
+    L = lib()
+    ws = workspace(L.query("mi355seg_loss_ws_bytes", logits.numel()), logits.device)
+    loss = torch.empty((), dtype=torch.float32, device=logits.device)
+    mask = torch.empty((N, 1) + tuple(logits.shape[2:]), dtype=torch.int64, device=logits.device)
+    counts = torch.empty(4, dtype=torch.int64, device=logits.device)
+    L.call("mi355seg_bce_argmax_dice_f32", _p(logits), _p(target), N, K, S, _p(loss), _p(mask), _p(counts),
+           _p(ws), ws.numel(), _stream())
+    return loss, mask, counts
+
+
+def dice_sums(x, t, apply_sigmoid=False):
+    """(sum a*b, sum a, sum b, sum a*a, sum b*b) as float64[5], a = sigmoid(x) if asked."""
+    _require_cuda(x, "dice_sums input")
+    x, t = x.contiguous(), t.contiguous().to(torch.float32)
+    L = lib()
+    ws = workspace(L.query("mi355seg_loss_ws_bytes", x.numel()), x.device)
+    out = torch.empty(5, dtype=torch.float64, device=x.device)
+    L.call("mi355seg_dice_sums_f32", _p(x), _p(t), x.numel(), int(bool(apply_sigmoid)), _p(out), _p(ws), ws.numel(), _stream())
+    return out

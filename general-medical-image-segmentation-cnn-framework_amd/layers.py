@@ -1,0 +1,103 @@
+"""Leaf modules of the drop-in models.  Each subclasses the torch.nn module it replaces
+purely for parameter registration / initialisation / ``state_dict`` naming (so the
+reference's ``weights_init_normal`` and checkpoints keep working) and routes ``forward``
+to the HIP kernels on channel-last [N,D,H,W,C] tensors."""
+import torch
+import torch.nn as nn
+
+from . import functional as F
+
+_ACT_OF = {nn.ReLU: (F.ACT_RELU, 0.0), nn.ELU: (F.ACT_ELU, 1.0), nn.LeakyReLU: (F.ACT_LRELU, 0.01)}
+
+
+def _iso(v, what):
+    if isinstance(v, (tuple, list)):
+        if len(set(v)) != 1:
+            raise NotImplementedError(f"{what} must be isotropic, got {v}")
+        return int(v[0])
+    return int(v)
+
+
+class Conv3d(nn.Conv3d):
+    """nn.Conv3d (cubic kernel, isotropic stride/padding, dilation 1, groups 1)."""
+
+    def forward(self, x):
+        if self.groups != 1 or _iso(self.dilation, "dilation") != 1 or self.padding_mode != "zeros":
+            raise NotImplementedError("Conv3d: only groups=1, dilation=1, zero padding are implemented")
+        return F.conv3d(x, self.weight, self.bias, _iso(self.stride, "stride"), _iso(self.padding, "padding"))
+
+
+class ConvTranspose3d(nn.ConvTranspose3d):
+    """nn.ConvTranspose3d(kernel_size=2, stride=2) -- the only form the U-Net family uses."""
+
+    def forward(self, x):
+        if _iso(self.kernel_size, "kernel_size") != 2 or _iso(self.stride, "stride") != 2 or \
+                _iso(self.padding, "padding") != 0 or _iso(self.output_padding, "output_padding") != 0:
+            raise NotImplementedError("ConvTranspose3d: only kernel_size=2, stride=2, padding=0 is implemented")
+        return F.conv_transpose3d_k2s2(x, self.weight, self.bias)
+
+
+class BatchNorm3d(nn.BatchNorm3d):
+    """nn.BatchNorm3d; ``forward_act`` fuses the following activation (and an optional
+    residual add in front of it) into the normalisation kernel."""
+
+    def forward_act(self, x, act=F.ACT_NONE, slope=0.01, residual=None):
+        if self.momentum is None:
+            raise NotImplementedError("BatchNorm3d: cumulative moving average (momentum=None) is not implemented")
+        training = self.training or (self.running_mean is None)
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        return F.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, training,
+                                self.momentum, self.eps, act, slope, residual)
+
+    def forward(self, x):
+        return self.forward_act(x)
+
+
+class InstanceNorm3d(nn.InstanceNorm3d):
+    def forward_act(self, x, act=F.ACT_NONE, slope=0.01):
+        if self.affine or self.track_running_stats:
+            raise NotImplementedError("InstanceNorm3d: only affine=False, track_running_stats=False is implemented")
+        return F.instance_norm_act(x, self.eps, act, slope)
+
+    def forward(self, x):
+        return self.forward_act(x)
+
+
+class MaxPool3d(nn.MaxPool3d):
+    def forward(self, x):
+        if _iso(self.kernel_size, "kernel_size") != 2 or _iso(self.stride, "stride") != 2 or _iso(self.padding, "padding") != 0:
+            raise NotImplementedError("MaxPool3d: only kernel_size=2, stride=2 is implemented")
+        return F.max_pool3d_2x(x)
+
+
+class Upsample(nn.Upsample):
+    def forward(self, x):
+        if self.mode != "nearest" or float(self.scale_factor) != 2.0:
+            raise NotImplementedError("Upsample: only scale_factor=2, mode='nearest' is implemented")
+        return F.upsample_nearest_2x(x)
+
+
+class ReLU(nn.ReLU):
+    def forward(self, x):
+        return F.activation(x, F.ACT_RELU)
+
+
+class ELU(nn.ELU):
+    def forward(self, x):
+        if self.alpha != 1.0:
+            raise NotImplementedError("ELU: only alpha=1 is implemented")
+        return F.activation(x, F.ACT_ELU)
+
+
+class LeakyReLU(nn.LeakyReLU):
+    def forward(self, x):
+        return F.activation(x, F.ACT_LRELU, self.negative_slope)
+
+
+def act_code(m):
+    """(code, slope) of an activation module."""
+    for cls, (code, _) in _ACT_OF.items():
+        if isinstance(m, cls):
+            return code, (m.negative_slope if isinstance(m, nn.LeakyReLU) else 0.0)
+    raise NotImplementedError(f"no fused form for activation {type(m).__name__}")

@@ -1,0 +1,197 @@
+/*
+ * mi355seg.h -- C-ABI of libmi355seg.so: the MI355X (gfx950) hot path for 3D
+ * segmentation training (U-Net family forward/backward + loss/Dice reductions).
+ *
+ * The reference (QingYunA/General-Medical-Image-Segmentation-CNN-Framework) has no
+ * FFI: its seam for this path is torch.nn leaf modules.  Each entry point below names
+ * the reference call it replaces (file:line under /root/reference) -- that is what a
+ * ctypes binding on the reference side would bind.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host;
+ *   - activations are NDHWC fp32: element (n,d,h,w,c) of a tensor with channel pitch
+ *     `ld` lives at ((((n*D+d)*H+h)*W+w)*ld + c); ld >= C lets a producer write into a
+ *     channel slice of a wider (concat) buffer;
+ *   - weights keep the PyTorch logical layouts: Conv3d (Cout,Cin,kD,kH,kW),
+ *     ConvTranspose3d (Cin,Cout,kD,kH,kW), contiguous;
+ *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered, nothing
+ *     synchronises, allocates or frees; scratch comes from the caller (`ws`);
+ *   - return value: 0 on success, a negative MI355SEG_E* code otherwise;
+ *     mi355seg_last_error() returns a static message for the calling thread.
+ */
+#ifndef MI355SEG_H
+#define MI355SEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355SEG_OK 0
+#define MI355SEG_EINVAL (-1)   /* bad shape / unsupported argument combination */
+#define MI355SEG_EWORKSPACE (-2) /* workspace too small */
+#define MI355SEG_EHIP (-3)     /* a HIP launch failed */
+
+/* activation codes for the norm/activation entry points */
+#define MI355SEG_ACT_NONE 0
+#define MI355SEG_ACT_RELU 1   /* nn.ReLU            (unet3d.py:89,101)            */
+#define MI355SEG_ACT_ELU 2    /* nn.ELU(alpha=1)    (vnet3d.py:14-18)             */
+#define MI355SEG_ACT_LRELU 3  /* nn.LeakyReLU(slope) (residual_unet3d.py:17)      */
+
+const char* mi355seg_last_error(void);
+int mi355seg_version(void);
+
+/* ------------------------------------------------------------------ Conv3d
+ * Replaces nn.Conv3d forward/backward (ATen convolution / convolution_backward):
+ * unet3d.py:80-98 (k3 s1 p1), :46-48 (k1 head); vnet3d.py:25,47,111 (k5 p2), :65 (k2 s2);
+ * residual_unet3d.py:22-79 (k3 s1/s2 p1, k1, bias=False); unetr.py:134 (k16 s16).
+ * Cubic kernel k, isotropic stride/pad.  Output extent Do = (D + 2*pad - k)/stride + 1.
+ */
+size_t mi355seg_conv3d_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad);
+
+/* y = conv(x, w) + bias.  bias may be NULL.  If stats_sum/stats_sq are non-NULL they
+ * receive, per output channel, sum(y) and sum(y*y) over all N*Do*Ho*Wo voxels as
+ * doubles (the BatchNorm batch statistics, fused into the conv epilogue). */
+int mi355seg_conv3d_fwd_f32(const float* x, int ldx, const float* w, const float* bias,
+                            float* y, int ldy, int N, int D, int H, int W, int Cin, int Cout,
+                            int k, int stride, int pad, double* stats_sum, double* stats_sq,
+                            void* ws, size_t ws_bytes, void* stream);
+
+/* dx = conv_backward_input(dy, w).  D,H,W are the INPUT extents (of x/dx). */
+int mi355seg_conv3d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
+                              int N, int D, int H, int W, int Cin, int Cout,
+                              int k, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
+
+/* dw (Cout,Cin,k,k,k) and db (Cout, may be NULL) = conv_backward_weight(dy, x).
+ * Deterministic (two-stage reduction, no atomics).  accumulate!=0 adds into dw/db
+ * (weight sharing, residual_unet3d.py:126,128). */
+int mi355seg_conv3d_wgrad_f32(const float* dy, int lddy, const float* x, int ldx,
+                              float* dw, float* db, int N, int D, int H, int W, int Cin, int Cout,
+                              int k, int stride, int pad, int accumulate,
+                              void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ ConvTranspose3d k2 s2
+ * Replaces nn.ConvTranspose3d(kernel_size=2, stride=2): unet3d.py:29-43, vnet3d.py:86,
+ * unetr.py:11.  x is [N,D,H,W,Cin]; y is [N,2D,2H,2W,Cout]; w is (Cin,Cout,2,2,2).
+ */
+size_t mi355seg_convt3d_k2s2_ws_bytes(int N, int D, int H, int W, int Cin, int Cout);
+int mi355seg_convt3d_k2s2_fwd_f32(const float* x, int ldx, const float* w, const float* bias,
+                                  float* y, int ldy, int N, int D, int H, int W, int Cin, int Cout,
+                                  void* ws, size_t ws_bytes, void* stream);
+int mi355seg_convt3d_k2s2_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
+                                    int N, int D, int H, int W, int Cin, int Cout,
+                                    void* ws, size_t ws_bytes, void* stream);
+int mi355seg_convt3d_k2s2_wgrad_f32(const float* dy, int lddy, const float* x, int ldx,
+                                    float* dw, float* db, int N, int D, int H, int W, int Cin, int Cout,
+                                    void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ Batch / Instance norm
+ * Replaces nn.BatchNorm3d in training mode (native_batch_norm, unet3d.py:88,100;
+ * vnet3d.py:27,49,66,88,112) and nn.InstanceNorm3d (residual_unet3d.py:27..106), fused
+ * with the activation that follows it and an optional residual add in front of the
+ * activation (vnet3d.py:57-58,79,103).
+ * rows = voxels per statistics group, groups = 1 (BatchNorm: rows = N*D*H*W) or N
+ * (InstanceNorm: rows = D*H*W).  mean/rstd are [groups*C] floats.
+ */
+size_t mi355seg_norm_ws_bytes(long long rows, int groups, int C);
+
+/* Batch statistics of x: mean and rstd = 1/sqrt(var_biased + eps).  If running_mean /
+ * running_var are non-NULL (groups must be 1) they are updated in place with
+ * `momentum`, running_var with the UNBIASED variance (PyTorch semantics). */
+int mi355seg_norm_stats_f32(const float* x, int ldx, long long rows, int groups, int C, float eps,
+                            float* mean, float* rstd, float* running_mean, float* running_var,
+                            float momentum, void* ws, size_t ws_bytes, void* stream);
+
+/* Same, but from per-channel sum / sum-of-squares (as produced by the conv epilogue). */
+int mi355seg_norm_stats_from_sums_f32(const double* sum, const double* sq, long long rows, int C, float eps,
+                                      float* mean, float* rstd, float* running_mean, float* running_var,
+                                      float momentum, void* stream);
+
+/* y = act( (x-mean)*rstd*gamma + beta  [+ res] ).  gamma/beta/res may be NULL. */
+int mi355seg_norm_act_fwd_f32(const float* x, int ldx, const float* mean, const float* rstd,
+                              const float* gamma, const float* beta, const float* res, int ldres,
+                              float* y, int ldy, long long rows, int groups, int C,
+                              int act, float slope, void* stream);
+
+/* Backward of the above.  Inputs: dy (grad of the activation output), x (the norm
+ * input).  Outputs: dx; dgamma/dbeta [C] (NULL when the norm has no affine); dres (grad
+ * of the residual = grad at the activation input; NULL if no residual). */
+int mi355seg_norm_act_bwd_f32(const float* dy, int lddy, const float* x, int ldx,
+                              const float* mean, const float* rstd, const float* gamma, const float* beta,
+                              const float* res, int ldres,
+                              float* dx, int lddx, float* dgamma, float* dbeta, float* dres, int lddres,
+                              long long rows, int groups, int C, int act, float slope,
+                              void* ws, size_t ws_bytes, void* stream);
+
+/* Eval-mode BatchNorm (running stats) is norm_act_fwd with mean=running_mean and
+ * rstd = 1/sqrt(running_var+eps) computed by: */
+int mi355seg_rstd_from_var_f32(const float* var, float eps, float* rstd, int C, void* stream);
+
+/* Stand-alone activation (residual_unet3d.py:112,116 LeakyReLU; vnet ELU): y = act(x [+ res]) */
+int mi355seg_act_fwd_f32(const float* x, int ldx, const float* res, int ldres, float* y, int ldy,
+                         long long rows, int C, int act, float slope, void* stream);
+/* dx = dy * act'(x [+ res]) */
+int mi355seg_act_bwd_f32(const float* dy, int lddy, const float* x, int ldx, const float* res, int ldres,
+                         float* dx, int lddx, long long rows, int C, int act, float slope, void* stream);
+
+/* ------------------------------------------------------------------ Pool / upsample
+ * nn.MaxPool3d(2,2) (unet3d.py:19-25): y [N,D/2,H/2,W/2,C]; idx = 3-bit argmax code
+ * (dz*4+dy*2+dx of the first maximum in PyTorch scan order) per output element. */
+int mi355seg_maxpool2_fwd_f32(const float* x, int ldx, float* y, int ldy, uint8_t* idx,
+                              int N, int D, int H, int W, int C, void* stream);
+int mi355seg_maxpool2_bwd_f32(const float* dy, int lddy, const uint8_t* idx, float* dx, int lddx,
+                              int N, int D, int H, int W, int C, void* stream);
+/* nn.Upsample(scale_factor=2, mode='nearest') (residual_unet3d.py:19,103) */
+int mi355seg_upsample2_fwd_f32(const float* x, int ldx, float* y, int ldy,
+                               int N, int D, int H, int W, int C, void* stream);
+int mi355seg_upsample2_bwd_f32(const float* dy, int lddy, float* dx, int lddx,
+                               int N, int D, int H, int W, int C, void* stream);
+
+/* ------------------------------------------------------------------ Loss / argmax / Dice
+ * All take NCDHW-contiguous logits/targets [N,K,S] (S = D*H*W), as train.py hands them.
+ */
+size_t mi355seg_loss_ws_bytes(long long numel);
+
+/* nn.BCEWithLogitsLoss() mean (train.py:115,209; loss_function.py:19-41):
+ * loss[0] = mean( max(x,0) - x*t + log1p(exp(-|x|)) ). */
+int mi355seg_bce_logits_fwd_f32(const float* logits, const float* target, long long numel,
+                                float* loss, void* ws, size_t ws_bytes, void* stream);
+/* dlogits = (sigmoid(x) - t) * gscale[0] / numel   (gscale = upstream grad, device scalar) */
+int mi355seg_bce_logits_bwd_f32(const float* logits, const float* target, const float* gscale,
+                                long long numel, float* dlogits, void* stream);
+
+/* pred.argmax(dim=1, keepdim=True) (train.py:204, predict.py:139): first max wins; int64 out [N,1,S] */
+int mi355seg_argmax_ch_f32(const float* logits, long long N, int K, long long S, int64_t* mask, void* stream);
+
+/* Integer counters of utils/metric.py:34-43 on two int64 label volumes:
+ * counts[0]=sum(gt) counts[1]=sum(pred) counts[2]=nnz(gt&pred) counts[3]=nnz(gt|pred). */
+int mi355seg_dice_counts_i64(const int64_t* gt, const int64_t* pred, long long numel,
+                             int64_t* counts, void* ws, size_t ws_bytes, void* stream);
+
+/* Fused train-step tail (train.py:204,209,221 in one pass over the logits):
+ * BCE mean loss, argmax mask (int64), gt.argmax and the four Dice counters.
+ * target is the K-channel float one-hot [N,K,S]. */
+int mi355seg_bce_argmax_dice_f32(const float* logits, const float* target, long long N, int K, long long S,
+                                 float* loss, int64_t* mask, int64_t* counts,
+                                 void* ws, size_t ws_bytes, void* stream);
+
+/* Sum-type reductions for the library losses (loss_function.py:61-185):
+ * out[0]=sum(a*b) out[1]=sum(a) out[2]=sum(b) out[3]=sum(a*a) out[4]=sum(b*b), a = sigmoid(x) if
+ * apply_sigmoid else x.  Deterministic wavefront-shuffle + two-stage reduce. */
+int mi355seg_dice_sums_f32(const float* x, const float* t, long long numel, int apply_sigmoid,
+                           double* out5, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ Layout helpers */
+int mi355seg_ncdhw_to_ndhwc_f32(const float* src, float* dst, int lddst, long long N, int C, long long S, void* stream);
+int mi355seg_ndhwc_to_ncdhw_f32(const float* src, int ldsrc, float* dst, long long N, int C, long long S, void* stream);
+/* strided channel-slice copy: dst[r, 0:C] = src[r, 0:C] */
+int mi355seg_copy_rows_f32(const float* src, int ldsrc, float* dst, int lddst, long long rows, int C, void* stream);
+/* dst[r, 0:C] += src[r, 0:C] */
+int mi355seg_add_rows_f32(const float* src, int ldsrc, float* dst, int lddst, long long rows, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355SEG_H */

@@ -1,0 +1,273 @@
+"""GPU parity tests: every HIP entry point (called through the C-ABI via the package's
+autograd wrappers) against the CPU oracle arithmetic (ATen CPU ops == the reference's
+arithmetic) on the same seeded inputs.  Tolerance: 1e-4 absolute on O(1) outputs
+(north_star: "logits/Dice within 1e-4 fp32"), bit-exact for integer work."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def seg():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import mi355seg
+    mi355seg.lib()          # raises if the HIP library is missing -- no fallback
+    return mi355seg
+
+
+def cl(x):   # NCDHW cpu -> channel-last gpu
+    return x.permute(0, 2, 3, 4, 1).contiguous().cuda()
+
+
+def cf(y):   # channel-last gpu -> NCDHW cpu
+    return y.detach().cpu().permute(0, 4, 1, 2, 3).contiguous()
+
+
+def rel_err(a, b):
+    return float((a - b).abs().max() / max(1e-12, float(b.abs().max())))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+CONV_CASES = [
+    # N, D, H, W, Cin, Cout, k, s, p
+    (2, 8, 8, 8, 1, 8, 3, 1, 1),
+    (1, 6, 10, 12, 8, 16, 3, 1, 1),
+    (2, 16, 16, 16, 32, 32, 3, 1, 1),
+    (1, 8, 8, 32, 32, 64, 3, 1, 1),
+    (1, 16, 16, 16, 64, 32, 3, 1, 1),
+    (2, 8, 8, 8, 128, 128, 3, 1, 1),
+    (1, 4, 4, 4, 256, 512, 3, 1, 1),
+    (1, 32, 32, 32, 32, 32, 3, 1, 1),
+    (1, 8, 8, 8, 16, 16, 5, 1, 2),
+    (2, 8, 8, 8, 8, 16, 2, 2, 0),
+    (1, 8, 12, 8, 16, 32, 3, 2, 1),
+    (2, 8, 8, 8, 16, 4, 1, 1, 0),
+    (1, 16, 16, 16, 1, 8, 16, 16, 0),
+    (1, 7, 9, 11, 3, 5, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3d_fwd_bwd(seg, case):
+    N, D, H, W, Cin, Cout, k, s, p = case
+    F = seg.functional
+    x = rnd(N, Cin, D, H, W, seed=1)
+    w = rnd(Cout, Cin, k, k, k, seed=2, scale=(2.0 / (Cin * k ** 3)) ** 0.5)
+    b = rnd(Cout, seed=3, scale=0.1)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = TF.conv3d(xr, wr, br, stride=s, padding=p)
+    g = rnd(*yr.shape, seed=4)
+    yr.backward(g)
+
+    xg, wg, bg = cl(x).requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    yg = F.conv3d(xg, wg, bg, s, p)
+    yg.backward(cl(g))
+    assert (cf(yg) - yr.detach()).abs().max() < TOL
+    assert rel_err(cf(xg.grad), xr.grad) < TOL
+    assert rel_err(wg.grad.cpu(), wr.grad) < TOL
+    assert rel_err(bg.grad.cpu(), br.grad) < TOL
+
+
+def test_conv3d_channel_slices_and_no_bias(seg):
+    """Inputs / grads that are channel slices of wider buffers (pitch > C), bias=None."""
+    F = seg.functional
+    N, D, H, W, Cin, Cout = 1, 8, 8, 8, 32, 32
+    big = rnd(N, 2 * Cin, D, H, W, seed=5)
+    w = rnd(Cout, Cin, 3, 3, 3, seed=6, scale=0.05)
+    xr = big[:, Cin:].clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = TF.conv3d(xr, wr, None, padding=1)
+    gbig = rnd(N, 2 * Cout, D, H, W, seed=7)
+    yr.backward(gbig[:, :Cout])
+    bigg = cl(big)
+    xg = bigg[..., Cin:].detach().requires_grad_(True)        # strided view, pitch 2*Cin
+    wg = w.cuda().requires_grad_(True)
+    yg = F.conv3d(xg, wg, None, 1, 1)
+    yg.backward(cl(gbig)[..., :Cout])
+    assert (cf(yg) - yr.detach()).abs().max() < TOL
+    assert rel_err(cf(xg.grad), xr.grad) < TOL
+    assert rel_err(wg.grad.cpu(), wr.grad) < TOL
+
+
+@pytest.mark.parametrize("case", [(2, 4, 4, 4, 16, 8), (1, 8, 8, 8, 64, 32), (1, 3, 5, 4, 6, 10), (2, 2, 2, 2, 512, 256)])
+def test_conv_transpose3d_k2s2(seg, case):
+    N, D, H, W, Cin, Cout = case
+    F = seg.functional
+    x = rnd(N, Cin, D, H, W, seed=1)
+    w = rnd(Cin, Cout, 2, 2, 2, seed=2, scale=(2.0 / (Cin * 8)) ** 0.5)
+    b = rnd(Cout, seed=3, scale=0.1)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = TF.conv_transpose3d(xr, wr, br, stride=2)
+    g = rnd(*yr.shape, seed=4)
+    yr.backward(g)
+    xg, wg, bg = cl(x).requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    yg = F.conv_transpose3d_k2s2(xg, wg, bg)
+    yg.backward(cl(g))
+    assert (cf(yg) - yr.detach()).abs().max() < TOL
+    assert rel_err(cf(xg.grad), xr.grad) < TOL
+    assert rel_err(wg.grad.cpu(), wr.grad) < TOL
+    assert rel_err(bg.grad.cpu(), br.grad) < TOL
+
+
+@pytest.mark.parametrize("C,act", [(32, "relu"), (16, "elu"), (2, "elu"), (64, "none"), (6, "relu")])
+def test_batchnorm_act_train(seg, C, act):
+    F = seg.functional
+    N, D, H, W = 2, 8, 6, 10
+    x = rnd(N, C, D, H, W, seed=1) * 2.0 + 0.5
+    gamma, beta = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    rm, rv = 0.05 * rnd(C, seed=4), 1 + 0.1 * rnd(C, seed=5).abs()
+    res = rnd(N, C, D, H, W, seed=6) if act == "elu" else None
+    actf = {"relu": torch.relu, "elu": TF.elu, "none": lambda z: z}[act]
+    code = {"relu": F.ACT_RELU, "elu": F.ACT_ELU, "none": F.ACT_NONE}[act]
+
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if res is not None else None
+    rm_r, rv_r = rm.clone(), rv.clone()
+    z = TF.batch_norm(xr, rm_r, rv_r, gr, br, training=True, momentum=0.1, eps=1e-5)
+    yr = actf(z + rr if rr is not None else z)
+    g = rnd(*yr.shape, seed=7)
+    yr.backward(g)
+
+    xg, gg, bg = cl(x).requires_grad_(True), gamma.cuda().requires_grad_(True), beta.cuda().requires_grad_(True)
+    rg = cl(res).requires_grad_(True) if res is not None else None
+    rm_g, rv_g = rm.cuda(), rv.cuda()
+    yg = F.batch_norm_act(xg, gg, bg, rm_g, rv_g, True, 0.1, 1e-5, code, 0.01, rg)
+    yg.backward(cl(g))
+    assert (cf(yg) - yr.detach()).abs().max() < TOL
+    assert (rm_g.cpu() - rm_r).abs().max() < 1e-6 and (rv_g.cpu() - rv_r).abs().max() < 1e-5
+    assert rel_err(cf(xg.grad), xr.grad) < 2e-4
+    assert rel_err(gg.grad.cpu(), gr.grad) < TOL and rel_err(bg.grad.cpu(), br.grad) < TOL
+    if res is not None:
+        assert rel_err(cf(rg.grad), rr.grad) < TOL
+
+
+def test_batchnorm_eval_and_instancenorm(seg):
+    F = seg.functional
+    N, C, D, H, W = 2, 16, 4, 6, 8
+    x = rnd(N, C, D, H, W, seed=1) * 1.5 - 0.3
+    gamma, beta = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    rm, rv = 0.05 * rnd(C, seed=4), 1 + 0.1 * rnd(C, seed=5).abs()
+    yr = torch.relu(TF.batch_norm(x, rm, rv, gamma, beta, training=False, eps=1e-5))
+    yg = F.batch_norm_act(cl(x), gamma.cuda(), beta.cuda(), rm.cuda(), rv.cuda(), False, 0.1, 1e-5, F.ACT_RELU)
+    assert (cf(yg) - yr).abs().max() < TOL
+    # InstanceNorm3d (no affine) + LeakyReLU, forward/backward
+    xr = x.clone().requires_grad_(True)
+    yr = TF.leaky_relu(TF.instance_norm(xr, eps=1e-5), 0.01)
+    g = rnd(*yr.shape, seed=6)
+    yr.backward(g)
+    xg = cl(x).requires_grad_(True)
+    yg = F.instance_norm_act(xg, 1e-5, F.ACT_LRELU, 0.01)
+    yg.backward(cl(g))
+    assert (cf(yg) - yr.detach()).abs().max() < TOL
+    assert rel_err(cf(xg.grad), xr.grad) < 2e-4
+
+
+@pytest.mark.parametrize("act", ["relu", "elu", "lrelu"])
+def test_activation(seg, act):
+    F = seg.functional
+    x = rnd(2, 8, 4, 4, 6, seed=1)
+    res = rnd(2, 8, 4, 4, 6, seed=2)
+    fn = {"relu": torch.relu, "elu": TF.elu, "lrelu": lambda z: TF.leaky_relu(z, 0.01)}[act]
+    code = {"relu": F.ACT_RELU, "elu": F.ACT_ELU, "lrelu": F.ACT_LRELU}[act]
+    xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    yr = fn(xr + rr)
+    g = rnd(*yr.shape, seed=3)
+    yr.backward(g)
+    xg, rg = cl(x).requires_grad_(True), cl(res).requires_grad_(True)
+    yg = F.activation(xg, code, 0.01, rg)
+    yg.backward(cl(g))
+    assert (cf(yg) - yr.detach()).abs().max() < 1e-6
+    assert (cf(xg.grad) - xr.grad).abs().max() < 1e-6 and (cf(rg.grad) - rr.grad).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("C", [32, 3])
+def test_maxpool_and_upsample(seg, C):
+    F = seg.functional
+    x = rnd(2, C, 8, 6, 10, seed=1)
+    x[0, 0, :2, :2, :2] = 1.0          # exact ties: the first maximum in scan order must win
+    xr = x.clone().requires_grad_(True)
+    yr = TF.max_pool3d(xr, 2, 2)
+    g = rnd(*yr.shape, seed=2)
+    yr.backward(g)
+    xg = cl(x).requires_grad_(True)
+    yg = F.max_pool3d_2x(xg)
+    yg.backward(cl(g))
+    assert torch.equal(cf(yg), yr.detach())
+    assert torch.equal(cf(xg.grad), xr.grad)
+    xr = x.clone().requires_grad_(True)
+    yr = TF.interpolate(xr, scale_factor=2, mode="nearest")
+    g = rnd(*yr.shape, seed=3)
+    yr.backward(g)
+    xg = cl(x).requires_grad_(True)
+    yg = F.upsample_nearest_2x(xg)
+    yg.backward(cl(g))
+    assert torch.equal(cf(yg), yr.detach())
+    assert (cf(xg.grad) - xr.grad).abs().max() < 1e-5
+
+
+def test_layout_roundtrip(seg):
+    F = seg.functional
+    x = rnd(2, 5, 4, 6, 7, seed=1)
+    y = F.to_channels_last(x.cuda())
+    assert torch.equal(y.cpu(), x.permute(0, 2, 3, 4, 1).contiguous())
+    assert torch.equal(F.to_channels_first(y).cpu(), x)
+
+
+def test_bce_argmax_dice(seg):
+    from oracle.metric import confusion_counts, metric as ometric
+    F = seg.functional
+    N, K, D, H, W = 2, 2, 8, 10, 12
+    logits = rnd(N, K, D, H, W, seed=1) * 3
+    logits[0, :, 0, 0, :4] = 0.25                         # exact ties -> class 0 must win
+    lab = (rnd(N, 1, D, H, W, seed=2) > 0.8).float()
+    tgt = torch.cat([1 - lab, lab], 1)
+    lr = logits.clone().requires_grad_(True)
+    loss_r = TF.binary_cross_entropy_with_logits(lr, tgt)
+    (loss_r * 1.7).backward()
+    lg = logits.cuda().requires_grad_(True)
+    loss_g = F.bce_with_logits(lg, tgt.cuda())
+    (loss_g * 1.7).backward()
+    assert abs(loss_g.item() - loss_r.item()) < 1e-6
+    assert (lg.grad.cpu() - lr.grad).abs().max() < 1e-9 + 1e-5 * lr.grad.abs().max()
+    mask_r = logits.argmax(1, keepdim=True)
+    mask_g = F.argmax_channels(logits.cuda())
+    assert torch.equal(mask_g.cpu(), mask_r)
+    gt_r = tgt.argmax(1, keepdim=True)
+    cnt = F.dice_counts(gt_r.cuda(), mask_g).cpu().tolist()
+    c = confusion_counts(gt_r.numpy(), mask_r.numpy())
+    assert cnt == [c["gdth_sum"], c["pred_sum"], c["intersection_sum"], c["union_sum"]]
+    loss_f, mask_f, cnt_f = F.bce_argmax_dice(logits.cuda(), tgt.cuda())
+    assert abs(loss_f.item() - loss_r.item()) < 1e-6
+    assert torch.equal(mask_f.cpu(), mask_r) and cnt_f.cpu().tolist() == cnt
+    from mi355seg.utils.metric import metric
+    j, d = metric(gt_r.cuda(), mask_g)
+    jo, do = ometric(gt_r, mask_r)
+    assert abs(j - jo) < 1e-12 and abs(d - do) < 1e-12
+    # multi-class labels: bitwise & / | quirk of utils/metric.py:40-41
+    a = torch.randint(0, 4, (2, 1, 4, 4, 4), generator=torch.Generator().manual_seed(3))
+    b = torch.randint(0, 4, (2, 1, 4, 4, 4), generator=torch.Generator().manual_seed(4))
+    assert metric(a.cuda(), b.cuda()) == ometric(a, b)
+    s = F.dice_sums(logits.cuda(), tgt.cuda(), apply_sigmoid=True).cpu()
+    pr = torch.sigmoid(logits.double())
+    ref = torch.stack([(pr * tgt).sum(), pr.sum(), tgt.double().sum(), (pr * pr).sum(), (tgt * tgt).double().sum()])
+    assert ((s - ref).abs() / ref.abs().clamp_min(1)).max() < 1e-6
+
+
+def test_missing_library_fails_loudly(seg, monkeypatch):
+    import importlib
+    L = importlib.import_module(seg.__name__ + "._lib")
+    monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libmi355seg.so")
+    with pytest.raises(L.Mi355SegError):
+        L._Lib()
+    with pytest.raises(L.Mi355SegError):
+        seg.functional.conv3d(torch.zeros(1, 2, 2, 2, 1), torch.zeros(1, 1, 3, 3, 3), None, 1, 1)   # CPU tensor

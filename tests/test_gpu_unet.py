@@ -1,0 +1,89 @@
+"""GPU parity of the whole drop-in 3D U-Net train step (train.py:187-221) against
+(a) the golden fixture captured from the reference modules and (b) the CPU oracle run
+here on the same closed-form weights/inputs.  fp32: logits and Dice within 1e-4, argmax
+masks identical wherever the reference logit margin exceeds the tolerance."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.fill import fill_module_, make_input, make_labels
+from oracle.metric import metric as oracle_metric
+from oracle.step import two_channel_gt
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _sample(t, k=4096):
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // k)
+    return f[::step][:k].cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def seg():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import mi355seg
+    mi355seg.lib()
+    return mi355seg
+
+
+def test_unet3d_train_step_vs_reference_fixture(seg, golden_dir):
+    from mi355seg.models.three_d.unet3d import UNet3D
+    from mi355seg.engine import train_step
+    g = np.load(os.path.join(golden_dir, "unet3d_f8_32.npz"))
+    m = fill_module_(UNet3D(in_channels=1, out_channels=2, init_features=8)).cuda().train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    x = make_input((2, 1, 32, 32, 32)).cuda()
+    gt = make_labels((2, 1, 32, 32, 32)).cuda()
+    out = train_step(m, opt, x, gt)
+    pred = out["pred"].detach().cpu().numpy()
+    assert abs(out["loss"].item() - float(g["loss"])) < 1e-5
+    assert np.abs(pred - g["pred"]).max() < TOL
+    margin = np.abs(g["pred"][:, 0] - g["pred"][:, 1])[:, None]
+    same = out["mask"].cpu().numpy().astype(np.uint8) == g["mask"]
+    excluded = int((margin <= 2 * TOL).sum())
+    assert same[margin > 2 * TOL].all(), "argmax mask differs where the reference margin is decisive"
+    assert excluded < 0.001 * margin.size
+    # Dice from the device counters vs the oracle metric on the reference mask
+    gt2 = two_channel_gt(gt.cpu())
+    jo, do = oracle_metric(gt2.argmax(1, keepdim=True), torch.from_numpy(g["mask"].astype(np.int64)))
+    assert abs(out["dice"] - do) < TOL and abs(out["jaccard"] - jo) < TOL
+    params = dict(m.named_parameters())
+    for k in g.files:
+        if k.startswith("grad/"):
+            ref = g[k]
+            got = _sample(params[k[5:]].grad)
+            assert np.abs(got - ref).max() <= 2e-4 * max(1e-3, np.abs(ref).max()), k
+        elif k.startswith("buf/"):
+            assert np.abs(dict(m.named_buffers())[k[4:]].cpu().numpy() - g[k]).max() < 1e-5, k
+    gn = np.array([float(p.grad.double().norm()) for p in m.parameters()])
+    assert np.abs(gn - g["gradnorm"]).max() <= 2e-4 * g["gradnorm"].max()
+    for k, b in m.named_buffers():
+        if k.endswith("num_batches_tracked"):
+            assert int(b) == 1
+    m.eval()
+    with torch.no_grad():
+        pe = m(x).cpu().numpy()
+    assert np.abs(pe - g["pred_eval"]).max() < 1e-3      # after one Adam step (sign-sensitive +-lr updates)
+
+
+def test_unet3d_matches_oracle_other_shape(seg):
+    """Non-cubic volume, batch 1, 3 input channels, 3 classes, width 4."""
+    from mi355seg.models.three_d.unet3d import UNet3D
+    from oracle.nets import UNet3D as OracleUNet
+    a = fill_module_(OracleUNet(3, 3, 4)).train()
+    b = fill_module_(UNet3D(3, 3, 4)).cuda().train()
+    x = make_input((1, 3, 16, 32, 48), freq=0.013)
+    ya = a(x)
+    ya.square().mean().backward()
+    yb = b(x.cuda())
+    yb.square().mean().backward()
+    assert (yb.detach().cpu() - ya.detach()).abs().max() < TOL
+    ga = dict(a.named_parameters())
+    for k, p in b.named_parameters():
+        ref = ga[k].grad
+        assert (p.grad.cpu() - ref).abs().max() <= 2e-4 * max(1e-4, float(ref.abs().max())), k
