@@ -11,6 +11,32 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- per-family HIP-event timing ----
+bool g_prof_on = false;
+namespace {
+struct ProfRec { hipEvent_t a, b; int family; double flops, bytes; };
+constexpr int kProfMax = 1 << 16;
+ProfRec* g_recs = nullptr;
+int g_nrec = 0, g_nevents = 0;
+}
+void prof_begin(int family, double flops, double bytes, hipStream_t st) {
+    if (!g_recs) g_recs = new ProfRec[kProfMax];
+    if (g_nrec >= kProfMax) return;
+    if (g_nrec >= g_nevents) {
+        hipEventCreate(&g_recs[g_nrec].a);
+        hipEventCreate(&g_recs[g_nrec].b);
+        g_nevents = g_nrec + 1;
+    }
+    ProfRec& r = g_recs[g_nrec];
+    r.family = family; r.flops = flops; r.bytes = bytes;
+    hipEventRecord(r.a, st);
+}
+void prof_end(hipStream_t st) {
+    if (!g_recs || g_nrec >= kProfMax) return;
+    hipEventRecord(g_recs[g_nrec].b, st);
+    ++g_nrec;
+}
+
 // [N,C,S] -> [N,S,ld] (channel-last) through a 32x33 LDS tile so both sides stay coalesced
 __global__ __launch_bounds__(256) void ncs_to_nsc_kernel(const float* __restrict__ src, float* __restrict__ dst, int ld,
                                                           int C, long long S) {
@@ -76,6 +102,21 @@ extern "C" {
 
 const char* mi355seg_last_error(void) { return g_err; }
 int mi355seg_version(void) { return 100; }
+
+int mi355seg_prof_enable(int on) { g_prof_on = on != 0; return MI355SEG_OK; }
+int mi355seg_prof_reset(void) { g_nrec = 0; return MI355SEG_OK; }
+int mi355seg_prof_read(double* out, int n) {
+    SEG_CHECK_ARG(out && n >= 4 * MI355SEG_PROF_FAMILIES, "prof_read: need room for %d doubles", 4 * MI355SEG_PROF_FAMILIES);
+    for (int i = 0; i < 4 * MI355SEG_PROF_FAMILIES; ++i) out[i] = 0.0;
+    for (int i = 0; i < g_nrec; ++i) {
+        float ms = 0.f;
+        hipEventSynchronize(g_recs[i].b);
+        if (hipEventElapsedTime(&ms, g_recs[i].a, g_recs[i].b) != hipSuccess) continue;
+        int f = g_recs[i].family;
+        out[4 * f] += 1.0; out[4 * f + 1] += (double)ms; out[4 * f + 2] += g_recs[i].flops; out[4 * f + 3] += g_recs[i].bytes;
+    }
+    return MI355SEG_OK;
+}
 
 int mi355seg_ncdhw_to_ndhwc_f32(const float* src, float* dst, int lddst, long long N, int C, long long S, void* stream) {
     SEG_CHECK_ARG(src && dst && N > 0 && C > 0 && S > 0 && lddst >= C && N < 65536, "ncdhw_to_ndhwc: bad arguments");

@@ -55,6 +55,17 @@ struct Carver {
 
 constexpr int kWave = 64;
 
+// ---- optional per-family kernel timing (api.hip) ----
+enum ProfFamily { PF_IGEMM = 0, PF_WGRAD = 1, PF_GENERIC = 2, PF_CONVT = 3, PF_NORM = 4, PF_POOL = 5, PF_LOSS = 6, PF_DIRECT = 7 };
+extern bool g_prof_on;
+void prof_begin(int family, double flops, double bytes, hipStream_t st);
+void prof_end(hipStream_t st);
+struct ProfScope {
+    hipStream_t st; bool on;
+    ProfScope(int family, double flops, double bytes, hipStream_t s) : st(s), on(g_prof_on) { if (on) prof_begin(family, flops, bytes, s); }
+    ~ProfScope() { if (on) prof_end(st); }
+};
+
 // Sum across the 64 lanes of a wavefront (result valid in every lane).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

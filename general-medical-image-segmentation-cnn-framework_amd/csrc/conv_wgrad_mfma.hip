@@ -1,0 +1,222 @@
+// conv_wgrad_mfma.hip -- weight gradient of Conv3d k3 s1 p1 on the fp32 matrix cores.
+//
+//   dW[tap][ci][co] = sum over voxels v of  x[v + tap][ci] * dy[v][co]
+//
+// i.e. 27 GEMMs (one per tap) with M = Cin, N = Cout and K = all output voxels.  A
+// workgroup (4 waves, one per SIMD, up to 512 registers each) owns one 32(ci) x 32(co)
+// block pair and a strip of 256-voxel spatial tiles; its 27 tap-tiles are dealt to the
+// four waves (7/7/7/6), so the whole 27 x 32 x 32 slab stays in accumulators while the
+// workgroup walks its strip.  Per tile the x halo (32 channels) and the dy tile live in
+// LDS; both MFMA operands are conflict-free ds_read_b32 (lanes = 32 consecutive channels
+// of one voxel) and the dy fragment of a k-step is shared by the wave's 7 MFMAs.  The
+// next tile is prefetched into registers during the MFMAs (issue early / write late).
+// Each workgroup writes its slab once; a fixed-order second stage sums the strips and
+// emits the PyTorch (Cout,Cin,3,3,3) layout -> bitwise reproducible, no atomics.
+#include "common.h"
+#include "internal.h"
+
+namespace seg {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <int BX>
+struct WTile {
+    static constexpr int TY = BX == 8 ? 8 : 4;
+    static constexpr int LINES = 256 / BX;
+    static constexpr int TZ = LINES / TY;
+    static constexpr int HX = BX + 2, HY = TY + 2, HZ = TZ + 2;
+    static constexpr int NVOX = HX * HY * HZ;
+    static constexpr int XPIECES = NVOX * 8;              // 16-byte pieces of the x halo (32 ch)
+    static constexpr int XITER = (XPIECES + 255) / 256;
+    static constexpr int DYITER = 256 * 8 / 256;          // dy tile: 256 voxels x 32 ch
+    static constexpr int X_FLOATS = NVOX * 32;
+    static constexpr int LDS_BYTES = (X_FLOATS + 256 * 32) * 4;
+};
+
+struct WgradArgs {
+    const float* x; const float* dy; float* part;
+    int ldx, lddy, N, D, H, W, Cin, Cout;
+    int ntx, nty, ntz, ntiles, nstrips, npairs, ncob;
+};
+
+template <int BX>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgradArgs a) {
+    using T = WTile<BX>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xs = lds;
+    float* ds = lds + T::X_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, i = lane & 31;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int pair = t % a.npairs, strip = t / a.npairs;
+    const int cib = pair / a.ncob, cob = pair % a.ncob;
+    const int ci0 = cib * 32, co0 = cob * 32;
+
+    // the (up to) 7 taps of this wave: wave, wave+4, ... ; the 7th of wave 3 is a clamped dummy
+    int abase[7];
+#pragma unroll
+    for (int tt = 0; tt < 7; ++tt) {
+        int tap = wave + 4 * tt;
+        if (tap > 26) tap = 26;
+        const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+        abase[tt] = (((dz * T::HY + dy) * T::HX + dx) + h) * 32 + i;
+    }
+    const int bbase = h * 32 + i;
+
+    f32x16 acc[7];
+#pragma unroll
+    for (int tt = 0; tt < 7; ++tt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[tt][v] = 0.f;
+
+    f32x4 sx[T::XITER], sd[T::DYITER];
+    auto load_stage = [&](int tile) {
+        int mt = tile;
+        const int txi = mt % a.ntx; mt /= a.ntx;
+        const int tyi = mt % a.nty; mt /= a.nty;
+        const int tzi = mt % a.ntz;
+        const int n = mt / a.ntz;
+        const int x0 = txi * BX, y0 = tyi * T::TY, z0 = tzi * T::TZ;
+#pragma unroll
+        for (int it = 0; it < T::XITER; ++it) {
+            const int p = it * 256 + tid;
+            const int vox = p >> 3, part = p & 7;
+            const int hz = vox / (T::HY * T::HX), rem = vox % (T::HY * T::HX);
+            const int hy = rem / T::HX, hx = rem % T::HX;
+            const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            const bool ok = (p < T::XPIECES) && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4*>(a.x + ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.ldx + ci0 + part * 4);
+            sx[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < T::DYITER; ++it) {
+            const int p = it * 256 + tid;
+            const int vox = p >> 3, part = p & 7;
+            const int line = vox / BX, xx = vox % BX;
+            const int gz = z0 + line / T::TY, gy = y0 + line % T::TY, gx = x0 + xx;
+            sd[it] = *reinterpret_cast<const f32x4*>(a.dy + ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.lddy + co0 + part * 4);
+        }
+    };
+    auto write_stage = [&]() {
+#pragma unroll
+        for (int it = 0; it < T::XITER; ++it) {
+            const int p = it * 256 + tid;
+            if (p < T::XPIECES) *reinterpret_cast<f32x4*>(xs + p * 4) = sx[it];
+        }
+#pragma unroll
+        for (int it = 0; it < T::DYITER; ++it) *reinterpret_cast<f32x4*>(ds + (it * 256 + tid) * 4) = sd[it];
+    };
+
+    int tile = strip;
+    if (tile < a.ntiles) load_stage(tile);
+    for (; tile < a.ntiles; tile += a.nstrips) {
+        __syncthreads();
+        write_stage();
+        __syncthreads();
+        if (tile + a.nstrips < a.ntiles) load_stage(tile + a.nstrips);
+#pragma unroll 2
+        for (int line = 0; line < T::LINES; ++line) {
+            const int lbase = (((line / T::TY) * T::HY + (line % T::TY)) * T::HX) * 32;
+            const float* xl = xs + lbase;
+            const float* dl = ds + line * BX * 32 + bbase;
+#pragma unroll
+            for (int xp = 0; xp < BX / 2; ++xp) {
+                const float b = dl[xp * 64];
+#pragma unroll
+                for (int tt = 0; tt < 7; ++tt) {
+                    const float av = xl[abase[tt] + xp * 64];
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[tt], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // slab store: part[strip][tap][ci][co]; rows of the 32x32 tile = ci, lanes (cols) = co
+#pragma unroll
+    for (int tt = 0; tt < 7; ++tt) {
+        const int tap = wave + 4 * tt;
+        if (tap > 26) break;
+        float* dst = a.part + (((long long)strip * 27 + tap) * a.Cin + ci0) * a.Cout + co0 + i;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int r = (v & 3) + 8 * (v >> 2) + 4 * h;
+            dst[(long long)r * a.Cout] = acc[tt][v];
+        }
+    }
+}
+
+struct WgradPlan { int BX, ntx, nty, ntz, ntiles, nstrips, npairs; };
+
+static bool wgrad_plan(int N, int D, int H, int W, int Cin, int Cout, WgradPlan* p) {
+    if (Cin % 32 || Cout % 32) return false;
+    int BX = (W % 32 == 0) ? 32 : (W % 16 == 0) ? 16 : (W % 8 == 0) ? 8 : 0;
+    if (!BX) return false;
+    const int TY = BX == 8 ? 8 : 4, TZ = (256 / BX) / TY;
+    if (H % TY || D % TZ) return false;
+    p->BX = BX; p->ntx = W / BX; p->nty = H / TY; p->ntz = D / TZ;
+    p->ntiles = N * p->ntz * p->nty * p->ntx;
+    p->npairs = (Cin / 32) * (Cout / 32);
+    int want = (512 + p->npairs - 1) / p->npairs;
+    long long cap = (long long)(160u << 20) / ((long long)27 * Cin * Cout * 4);   // keep the slab workspace <= 160 MB
+    if (cap < 1) cap = 1;
+    if (want > cap) want = (int)cap;
+    if (want > p->ntiles) want = p->ntiles;
+    if (want < 1) want = 1;
+    p->nstrips = want;
+    return true;
+}
+
+bool wgrad_mfma_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int lddy) {
+    if (k != 3 || stride != 1 || pad != 1 || (ldx % 4) || (lddy % 4)) return false;
+    WgradPlan p;
+    return wgrad_plan(N, D, H, W, Cin, Cout, &p);
+}
+
+size_t wgrad_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout) {
+    WgradPlan p;
+    if (!wgrad_plan(N, D, H, W, Cin, Cout, &p)) return 0;
+    return align_up((size_t)p.nstrips * 27 * Cin * Cout * sizeof(float), 256) + 1024;
+}
+
+template <int BX>
+static void launch_wgrad(const WgradArgs& a, int nwg, hipStream_t st) {
+    using T = WTile<BX>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv_wgrad_kernel<BX>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_kernel<BX>), dim3(nwg), dim3(256), T::LDS_BYTES, st, a);
+}
+
+int conv_wgrad_mfma(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin,
+                    int Cout, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+    WgradPlan p;
+    SEG_CHECK_ARG(wgrad_plan(N, D, H, W, Cin, Cout, &p), "conv_wgrad_mfma: unsupported shape");
+    SEG_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, "conv_wgrad_mfma: pointers must be 16-byte aligned");
+    Carver cv(ws);
+    float* part = cv.take<float>((size_t)p.nstrips * 27 * Cin * Cout);
+    SEG_CHECK_WS(cv.used(), ws_bytes);
+    WgradArgs a{x, dy, part, ldx, lddy, N, D, H, W, Cin, Cout, p.ntx, p.nty, p.ntz, p.ntiles, p.nstrips, p.npairs, Cout / 32};
+    const int nwg = p.nstrips * p.npairs;
+    const double vox = (double)N * D * H * W;
+    {
+        ProfScope ps(PF_WGRAD, 2.0 * vox * 27.0 * Cin * Cout, 4.0 * (vox * (Cin + Cout) + 27.0 * Cin * Cout), st);
+        if (p.BX == 32) launch_wgrad<32>(a, nwg, st);
+        else if (p.BX == 16) launch_wgrad<16>(a, nwg, st);
+        else launch_wgrad<8>(a, nwg, st);
+        SEG_CHECK_LAUNCH();
+    }
+    wgrad_reduce(part, dw, p.nstrips, 27, Cin, Cout, accumulate, st);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+}  // namespace seg

@@ -21,6 +21,7 @@ bool conv_mfma_supported(int N, int D, int H, int W, int Cin, int Cout, int k, i
 // seen from this call's Cin/Cout; taps are flipped while packing.
 int conv_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W,
                   int Cin, int Cout, int dgrad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st);
+size_t wgrad_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout);
 bool wgrad_mfma_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int lddy);
 int conv_wgrad_mfma(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin,
                     int Cout, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);

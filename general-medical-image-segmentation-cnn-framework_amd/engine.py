@@ -41,3 +41,38 @@ def train_step(model, optimizer, x, gt, criterion=None, sync_metric=True, grad_h
     if sync_metric:
         out["jaccard"], out["dice"] = metric_from_counts(counts.cpu().tolist())
     return out
+
+
+def weights_init_normal(init_type):
+    """The reference's init policy (train.py:33-61) for ``model.apply(...)``: Conv*/Linear
+    weights by ``init_type``, their biases zeroed; only classes named *BatchNorm2d* get the
+    norm branch, so BatchNorm3d keeps its default (1, 0)."""
+    from torch.nn import init
+
+    def init_func(m):
+        name = type(m).__name__
+        if "BatchNorm2d" in name:
+            if getattr(m, "weight", None) is not None:
+                init.normal_(m.weight.data, 1.0, 0.02)
+            if getattr(m, "bias", None) is not None:
+                init.constant_(m.bias.data, 0.0)
+            return
+        if not (hasattr(m, "weight") and ("Conv" in name or "Linear" in name)):
+            return
+        table = {
+            "normal": lambda w: init.normal_(w, 0.0, 0.02),
+            "xavier": lambda w: init.xavier_normal_(w, gain=0.02),
+            "xavier_uniform": lambda w: init.xavier_uniform_(w, gain=1.0),
+            "kaiming": lambda w: init.kaiming_normal_(w, a=0, mode="fan_in"),
+            "orthogonal": lambda w: init.orthogonal_(w, gain=0.02),
+        }
+        if init_type == "none":
+            m.reset_parameters()
+        elif init_type in table:
+            table[init_type](m.weight.data)
+        else:
+            raise NotImplementedError("initialization method [%s] is not implemented" % init_type)
+        if getattr(m, "bias", None) is not None:
+            init.constant_(m.bias.data, 0.0)
+
+    return init_func

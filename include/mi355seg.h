@@ -183,6 +183,19 @@ int mi355seg_bce_argmax_dice_f32(const float* logits, const float* target, long 
 int mi355seg_dice_sums_f32(const float* x, const float* t, long long numel, int apply_sigmoid,
                            double* out5, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------ In-library kernel timing
+ * Optional HIP-event timing of the kernel families, on the stream each kernel is launched
+ * on (used by bench.py for the live roofline numbers; off by default, zero cost when off).
+ * Families: 0 conv implicit-GEMM (fwd+dgrad), 1 conv wgrad MFMA, 2 conv generic, 3 convT,
+ * 4 norm/act, 5 pool/upsample, 6 loss/metric, 7 stem/head direct conv.
+ * prof_read synchronises the recorded events and returns, per family f:
+ *   out[4*f+0] = launches, out[4*f+1] = total milliseconds,
+ *   out[4*f+2] = total algorithmic FLOPs, out[4*f+3] = total algorithmic bytes. */
+#define MI355SEG_PROF_FAMILIES 8
+int mi355seg_prof_enable(int on);
+int mi355seg_prof_reset(void);
+int mi355seg_prof_read(double* out_host, int n_doubles);
+
 /* ------------------------------------------------------------------ Layout helpers */
 int mi355seg_ncdhw_to_ndhwc_f32(const float* src, float* dst, int lddst, long long N, int C, long long S, void* stream);
 int mi355seg_ndhwc_to_ncdhw_f32(const float* src, int ldsrc, float* dst, long long N, int C, long long S, void* stream);

@@ -48,6 +48,10 @@ CONV_CASES = [
     (2, 8, 8, 8, 128, 128, 3, 1, 1),
     (1, 4, 4, 4, 256, 512, 3, 1, 1),
     (1, 32, 32, 32, 32, 32, 3, 1, 1),
+    (1, 32, 64, 64, 32, 64, 3, 1, 1),      # MFMA tile BX=32, MB=2, NBW=2
+    (1, 64, 64, 16, 16, 128, 3, 1, 1),     # BX=16, MB=2
+    (1, 64, 64, 8, 16, 256, 3, 1, 1),      # BX=8, MB=2
+    (2, 16, 16, 16, 48, 96, 3, 1, 1),      # 3 chunks, NBW=1
     (1, 8, 8, 8, 16, 16, 5, 1, 2),
     (2, 8, 8, 8, 8, 16, 2, 2, 0),
     (1, 8, 12, 8, 16, 32, 3, 2, 1),
@@ -76,6 +80,26 @@ def test_conv3d_fwd_bwd(seg, case):
     assert rel_err(cf(xg.grad), xr.grad) < TOL
     assert rel_err(wg.grad.cpu(), wr.grad) < TOL
     assert rel_err(bg.grad.cpu(), br.grad) < TOL
+
+
+def test_conv3d_fused_batch_statistics(seg):
+    """conv epilogue statistics (sum, sum of squares per output channel) == those of y."""
+    import ctypes
+    F = seg.functional
+    L = seg.lib()
+    for (N, D, H, W, Cin, Cout) in [(2, 16, 16, 32, 32, 64), (1, 8, 8, 8, 4, 8)]:
+        x = cl(rnd(N, Cin, D, H, W, seed=1))
+        w = rnd(Cout, Cin, 3, 3, 3, seed=2, scale=0.1).cuda()
+        b = rnd(Cout, seed=3).cuda()
+        y = torch.empty(N, D, H, W, Cout, device="cuda")
+        ssum = torch.zeros(Cout, dtype=torch.float64, device="cuda")
+        ssq = torch.zeros(Cout, dtype=torch.float64, device="cuda")
+        ws = F.workspace(L.query("mi355seg_conv3d_ws_bytes", N, D, H, W, Cin, Cout, 3, 1, 1), x.device)
+        L.call("mi355seg_conv3d_fwd_f32", x.data_ptr(), Cin, w.data_ptr(), b.data_ptr(), y.data_ptr(), Cout, N, D, H, W, Cin, Cout,
+               3, 1, 1, ssum.data_ptr(), ssq.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+        yd = y.double().reshape(-1, Cout)
+        assert ((ssum - yd.sum(0)).abs() / yd.abs().sum(0)).max() < 1e-6
+        assert ((ssq - (yd * yd).sum(0)).abs() / (yd * yd).sum(0)).max() < 1e-6
 
 
 def test_conv3d_channel_slices_and_no_bias(seg):

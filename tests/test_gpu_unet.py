@@ -84,6 +84,7 @@ def test_unet3d_matches_oracle_other_shape(seg):
     yb.square().mean().backward()
     assert (yb.detach().cpu() - ya.detach()).abs().max() < TOL
     ga = dict(a.named_parameters())
+    gmax = max(float(q.grad.abs().max()) for q in ga.values())
     for k, p in b.named_parameters():
-        ref = ga[k].grad
-        assert (p.grad.cpu() - ref).abs().max() <= 2e-4 * max(1e-4, float(ref.abs().max())), k
+        ref = ga[k].grad      # conv biases in front of a BatchNorm have an exactly-zero true gradient
+        assert (p.grad.cpu() - ref).abs().max() <= 2e-4 * float(ref.abs().max()) + 1e-6 * gmax, k
