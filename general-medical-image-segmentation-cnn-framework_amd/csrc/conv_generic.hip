@@ -219,7 +219,10 @@ int conv_fwd_generic(const float* x, int ldx, const float* w, const float* bias,
     pack_w_fwd(w, wp, g.Cout, g.Cin, T, st);
     SEG_CHECK_LAUNCH();
     long long total = (long long)g.N * g.Do * g.Ho * g.Wo * g.Cout;
-    hipLaunchKernelGGL(conv_fwd_generic_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, x, ldx, wp, bias, y, ldy, g);
+    {
+        ProfScope ps(PF_GENERIC, 2.0 * total * T * g.Cin, 0.0, st);
+        hipLaunchKernelGGL(conv_fwd_generic_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, x, ldx, wp, bias, y, ldy, g);
+    }
     SEG_CHECK_LAUNCH();
     if (ssum || ssq)
         return channel_sums(y, ldy, (long long)g.N * g.Do * g.Ho * g.Wo, g.Cout, ssum, ssq, nullptr, 0, (char*)ws + off,
@@ -236,7 +239,10 @@ int conv_dgrad_generic(const float* dy, int lddy, const float* w, float* dx, int
     pack_w_dgrad(w, wd, g.Cout, g.Cin, T, 0, st);
     SEG_CHECK_LAUNCH();
     long long total = (long long)g.N * g.D * g.H * g.W * g.Cin;
-    hipLaunchKernelGGL(conv_dgrad_generic_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, dy, lddy, wd, dx, lddx, g);
+    {
+        ProfScope ps(PF_GENERIC, 2.0 * total * T * g.Cout, 0.0, st);
+        hipLaunchKernelGGL(conv_dgrad_generic_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, dy, lddy, wd, dx, lddx, g);
+    }
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
@@ -251,7 +257,10 @@ int conv_wgrad_generic(const float* dy, int lddy, const float* x, int ldx, float
     const long long nvox = (long long)g.N * g.Do * g.Ho * g.Wo;
     long long vps = (nvox + splits - 1) / splits;
     dim3 grid(cdiv((long long)g.Cin * g.Cout, 256), T, splits);
-    hipLaunchKernelGGL(conv_wgrad_generic_kernel, grid, dim3(256), 0, st, dy, lddy, x, ldx, part, g, vps);
+    {
+        ProfScope ps(PF_GENERIC, 2.0 * nvox * T * g.Cin * g.Cout, 0.0, st);
+        hipLaunchKernelGGL(conv_wgrad_generic_kernel, grid, dim3(256), 0, st, dy, lddy, x, ldx, part, g, vps);
+    }
     SEG_CHECK_LAUNCH();
     wgrad_reduce(part, dw, splits, T, g.Cin, g.Cout, accumulate, st);
     SEG_CHECK_LAUNCH();
@@ -279,7 +288,9 @@ extern "C" {
 size_t mi355seg_conv3d_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
     size_t a = conv_generic_ws_bytes(N, D, H, W, Cin, Cout, k, stride, pad);
     size_t b = conv_mfma_ws_bytes(N, D, H, W, Cin, Cout, k, stride, pad);
-    return a > b ? a : b;
+    size_t c = (stem_supported(Cin, Cout, k, stride, pad, 4) || head_supported(Cin, Cout, k, stride, pad, 4)) ? small_ws_bytes(Cin, Cout, k) : 0;
+    if (b > a) a = b;
+    return a > c ? a : c;
 }
 
 int mi355seg_conv3d_fwd_f32(const float* x, int ldx, const float* w, const float* bias,
@@ -293,7 +304,14 @@ int mi355seg_conv3d_fwd_f32(const float* x, int ldx, const float* w, const float
     SEG_CHECK_ARG((stats_sum == nullptr) == (stats_sq == nullptr), "conv3d_fwd: stats_sum/stats_sq must come together");
     hipStream_t st = (hipStream_t)stream;
     if (conv_mfma_supported(N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy))
-        return conv_fwd_mfma(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, /*dgrad=*/0, stats_sum, stats_sq, ws, ws_bytes, st);
+        return conv_fwd_mfma(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, /*dgrad=*/0, stats_sum, stats_sq, ws, ws_bytes, st);
+    if (stem_supported(Cin, Cout, k, stride, pad, ldy))
+        return stem_fwd(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, stats_sum, stats_sq, ws, ws_bytes, st);
+    if (head_supported(Cin, Cout, k, stride, pad, ldx)) {
+        rc = head_fwd(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, st);
+        if (rc || !stats_sum) return rc;
+        return channel_sums(y, ldy, (long long)N * D * H * W, Cout, stats_sum, stats_sq, nullptr, 0, ws, ws_bytes, st);
+    }
     return conv_fwd_generic(x, ldx, w, bias, y, ldy, g, stats_sum, stats_sq, ws, ws_bytes, st);
 }
 
@@ -307,7 +325,9 @@ int mi355seg_conv3d_dgrad_f32(const float* dy, int lddy, const float* w, float* 
     hipStream_t st = (hipStream_t)stream;
     // k3 s1 p1: dgrad is the same convolution with flipped taps and Cin<->Cout swapped
     if (conv_mfma_supported(N, D, H, W, Cout, Cin, k, stride, pad, lddy, lddx))
-        return conv_fwd_mfma(dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cout, Cin, /*dgrad=*/1, nullptr, nullptr, ws, ws_bytes, st);
+        return conv_fwd_mfma(dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cout, Cin, k, /*dgrad=*/1, nullptr, nullptr, ws, ws_bytes, st);
+    if (head_supported(Cin, Cout, k, stride, pad, lddx))
+        return head_dgrad(dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, st);
     return conv_dgrad_generic(dy, lddy, w, dx, lddx, g, ws, ws_bytes, st);
 }
 
@@ -324,8 +344,20 @@ int mi355seg_conv3d_wgrad_f32(const float* dy, int lddy, const float* x, int ldx
         rc = channel_sums(dy, lddy, (long long)N * g.Do * g.Ho * g.Wo, Cout, nullptr, nullptr, db, accumulate, ws, ws_bytes, st);
         if (rc) return rc;
     }
-    if (wgrad_mfma_supported(N, D, H, W, Cin, Cout, k, stride, pad, ldx, lddy))
+    if (k == 3 && wgrad_mfma_supported(N, D, H, W, Cin, Cout, k, stride, pad, ldx, lddy))
         return conv_wgrad_mfma(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, st);
+    if (k == 1 && stride == 1 && pad == 0 && pw_wgrad_supported((long long)N * D * H * W, Cin, Cout, 1, ldx, lddy)) {
+        float* part; int nstrips;
+        rc = pw_wgrad_mfma(dy, lddy, x, ldx, N, D, H, W, Cin, Cout, 1, &part, &nstrips, ws, ws_bytes, st);
+        if (rc) return rc;
+        wgrad_reduce(part, dw, nstrips, 1, Cin, Cout, accumulate, st);
+        SEG_CHECK_LAUNCH();
+        return MI355SEG_OK;
+    }
+    if (stem_supported(Cin, Cout, k, stride, pad, lddy))
+        return stem_wgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, st);
+    if (head_supported(Cin, Cout, k, stride, pad, ldx))
+        return head_wgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, st);
     return conv_wgrad_generic(dy, lddy, x, ldx, dw, g, accumulate, ws, ws_bytes, st);
 }
 

@@ -29,13 +29,15 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int CK = 16;          // input channels per LDS chunk
 constexpr int PITCH = CK + 4;   // floats per halo voxel in LDS (odd number of 16-B slots)
 
-template <int BX, int MB>
+template <int KS, int BX, int MB>
 struct Tile {
+    static constexpr int HALO = KS / 2;
+    static constexpr int NTAP = KS * KS * KS;
     static constexpr int LPB = 32 / BX;           // x-lines per 32-voxel M-block
     static constexpr int LINES = 4 * MB * LPB;    // x-lines per workgroup tile
     static constexpr int TY = 4;
     static constexpr int TZ = LINES / TY;
-    static constexpr int HX = BX + 2, HY = TY + 2, HZ = TZ + 2;
+    static constexpr int HX = BX + 2 * HALO, HY = TY + 2 * HALO, HZ = TZ + 2 * HALO;
     static constexpr int NVOX = HX * HY * HZ;
     static constexpr int NPIECE = NVOX * (CK / 4);            // 16-byte pieces per chunk
     static constexpr int NITER = (NPIECE + 255) / 256;
@@ -43,38 +45,54 @@ struct Tile {
     static_assert(LINES % TY == 0, "tile lines must fill whole y-rows");
 };
 
+// The M space is always the "base grid" (N, D, H, W).  in_mul / out_mul = 2 turn the same kernel into
+// ConvTranspose3d k2 s2: forward scatters N-tile (tap, cout-tile) to child voxel 2*v + tap of the
+// (2D,2H,2W) output; dgrad gathers K-chunk (tap, cout-chunk) from child voxel 2*v + tap of the input.
 struct IgemmArgs {
     const float* x; const float* wq; const float* bias; float* y; float* spart;
-    int ldx, ldy, N, D, H, W, Cin, Cout;
+    int ldx, ldy, N, D, H, W, Cout;
     int ntx, nty, ntz, nN;
+    int nchunks;        // total K chunks of 16 channels (taps of a ConvT dgrad included)
+    int cpt;            // chunks per input tap  (== nchunks when in_mul == 1)
+    int nNpt;           // N-tiles per output tap (== nN when out_mul == 1)
+    int in_mul, out_mul;
 };
 
 // ---------------------------------------------------------------- weight packing
-// wq[nt][chunk][tap][kk][h][j][s]  =  W[co = nt*NT + j][ci = chunk*16 + kk*8 + h*4 + s][tap]
-__global__ void pack_wq_kernel(const float* __restrict__ w, float* __restrict__ wq, int Cin, int Cout, int NT, int dgrad) {
-    const long long total = (long long)Cin * Cout * 27;
+// wq[nt][chunk][tap][kk][h][j][s]  =  B[k = (chunk, tap, kk, h, s)][n = nt*NT + j]  with
+//   mode 0 (conv fwd):     B = W[co = n][ci = chunk*16 + kk*8 + h*4 + s][tap]            W: (Cout, Cin, T)
+//   mode 1 (conv dgrad):   B = W[ci_f = n .. swapped roles, taps reversed]              W: (Cin_k, Cout_k, T)
+//   mode 2 (convT fwd):    n = (tapn, co): B = Wt[ci][co][tapn]                          Wt: (Cin, Cout, 8), T = 1
+//   mode 3 (convT dgrad):  chunk = (tapk, cc): B = Wt[ci = n][co = cc*16 + ..][tapk]     Wt: (Cin_f, Cout_f, 8), T = 1
+__global__ void pack_wq_kernel(const float* __restrict__ w, float* __restrict__ wq, int K, int Nn, int T, int NT, int mode, int aux) {
+    const long long total = (long long)K * Nn * T;        // K = channels in the GEMM K dim (taps of mode 3 included)
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         long long r = idx;
         int s = (int)(r % 4); r /= 4;
         int j = (int)(r % NT); r /= NT;
         int h = (int)(r % 2); r /= 2;
         int kk = (int)(r % (CK / 8)); r /= (CK / 8);
-        int tap = (int)(r % 27); r /= 27;
-        int chunk = (int)(r % (Cin / CK)); r /= (Cin / CK);
+        int tap = (int)(r % T); r /= T;
+        int chunk = (int)(r % (K / CK)); r /= (K / CK);
         int nt = (int)r;
-        int co = nt * NT + j, ci = chunk * CK + kk * 8 + h * 4 + s;
-        float v = dgrad ? w[((long long)ci * Cout + co) * 27 + (26 - tap)] : w[((long long)co * Cin + ci) * 27 + tap];
+        int n = nt * NT + j, k = chunk * CK + kk * 8 + h * 4 + s;
+        float v;
+        if (mode == 0) v = w[((long long)n * K + k) * T + tap];
+        else if (mode == 1) v = w[((long long)k * Nn + n) * T + (T - 1 - tap)];
+        else if (mode == 2) { int cout = aux; int tapn = n / cout, co = n % cout; v = w[((long long)k * cout + co) * 8 + tapn]; }
+        else { int cout = aux; int tapk = k / cout, co = k % cout; v = w[((long long)n * cout + co) * 8 + tapk]; }
         wq[idx] = v;
     }
 }
 
 // ---------------------------------------------------------------- the kernel
-template <int BX, int MB, int NBW>
+template <int KS, int BX, int MB, int NBW>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
-    using T = Tile<BX, MB>;
+    using T = Tile<KS, BX, MB>;
     constexpr int NT = 32 * NBW;
+    constexpr int NTAP = T::NTAP;
     constexpr int STEP_FLOATS = 2 * NT * 4;                 // packed weights consumed per (tap, kk) step
-    constexpr int CHUNK_FLOATS = 27 * (CK / 8) * STEP_FLOATS;
+    constexpr int CHUNK_FLOATS = NTAP * (CK / 8) * STEP_FLOATS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -92,7 +110,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
     const int tzi = mt % a.ntz;
     const int n = mt / a.ntz;
     const int x0 = txi * BX, y0 = tyi * T::TY, z0 = tzi * T::TZ;
-    const int n0 = ntile * NT;
+    const int tapn = ntile / a.nNpt;                          // output child (ConvT fwd), else 0
+    const int n0 = (ntile % a.nNpt) * NT;
+    const int Di = a.D * a.in_mul, Hi = a.H * a.in_mul, Wi = a.W * a.in_mul;
 
     f32x16 acc[MB][NBW];
 #pragma unroll
@@ -111,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
         abase[mb] = (((line / T::TY) * T::HY + (line % T::TY)) * T::HX + xx) * PITCH + 4 * h;
     }
 
-    const int nchunks = a.Cin / CK;
+    const int nchunks = a.nchunks;
     const float* wlane = a.wq + (long long)ntile * nchunks * CHUNK_FLOATS + (h * NT + i) * 4;
 
     // ---- halo staging: global -> registers (issue early) -> LDS (write late)
@@ -123,11 +143,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
             const int vox = p >> 2, part = p & 3;
             const int hz = vox / (T::HY * T::HX), rem = vox % (T::HY * T::HX);
             const int hy = rem / T::HX, hx = rem % T::HX;
-            const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-            const bool ok = (p < T::NPIECE) && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            const int tapk = chunk / a.cpt, cch = chunk - tapk * a.cpt;     // input child (ConvT dgrad), else 0
+            const int gz = (z0 - T::HALO + hz) * a.in_mul + ((tapk >> 2) & 1);
+            const int gy = (y0 - T::HALO + hy) * a.in_mul + ((tapk >> 1) & 1);
+            const int gx = (x0 - T::HALO + hx) * a.in_mul + (tapk & 1);
+            const bool ok = (p < T::NPIECE) && (unsigned)gz < (unsigned)Di && (unsigned)gy < (unsigned)Hi && (unsigned)gx < (unsigned)Wi;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (ok) {
-                const long long off = ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.ldx + chunk * CK + part * 4;
+                const long long off = ((((long long)n * Di + gz) * Hi + gy) * Wi + gx) * a.ldx + cch * CK + part * 4;
                 v = *reinterpret_cast<const f32x4*>(a.x + off);
             }
             stage[it] = v;
@@ -153,13 +176,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) bcur[nb] = *reinterpret_cast<const f32x4*>(wp + nb * 128);
 #pragma unroll
-        for (int tap = 0; tap < 27; ++tap) {
-            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+        for (int tap = 0; tap < NTAP; ++tap) {
+            const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
             const int tapoff = ((dz * T::HY + dy) * T::HX + dx) * PITCH;
 #pragma unroll
             for (int kk = 0; kk < CK / 8; ++kk) {
                 const int step = tap * (CK / 8) + kk;
-                if (step + 1 < 27 * (CK / 8)) {
+                if (step + 1 < NTAP * (CK / 8)) {
 #pragma unroll
                     for (int nb = 0; nb < NBW; ++nb)
                         bnxt[nb] = *reinterpret_cast<const f32x4*>(wp + (step + 1) * STEP_FLOATS + nb * 128);
@@ -194,9 +217,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
             for (int v = 0; v < 16; ++v) {
                 const int r = (v & 3) + 8 * (v >> 2) + 4 * h;      // row of the 32x32 tile held in register v
                 const int line = m * T::LPB + r / BX, xx = r % BX;
-                const int gz = z0 + line / T::TY, gy = y0 + line % T::TY, gx = x0 + xx;
+                const int gz = (z0 + line / T::TY) * a.out_mul + ((tapn >> 2) & 1);
+                const int gy = (y0 + line % T::TY) * a.out_mul + ((tapn >> 1) & 1);
+                const int gx = (x0 + xx) * a.out_mul + (tapn & 1);
                 const float val = acc[mb][nb][v] + bv;
-                a.y[((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.ldy + col] = val;
+                a.y[((((long long)n * (a.D * a.out_mul) + gz) * (a.H * a.out_mul) + gy) * (a.W * a.out_mul) + gx) * a.ldy + col] = val;
                 s1 += val; s2 += val * val;
             }
         }
@@ -245,12 +270,13 @@ __global__ __launch_bounds__(256) void igemm_stats_finalize_kernel(const float* 
 // ---------------------------------------------------------------- host side
 struct IgemmPlan { int BX, MB, NBW, TZ, nM, nN, ntx, nty, ntz; };
 
-static bool igemm_plan(int N, int D, int H, int W, int Cin, int Cout, IgemmPlan* p) {
-    if (Cin % CK || Cout % 32 || H % 4) return false;
+// Kc = GEMM K channels per tap-chunk unit (multiple of 16), Nc = GEMM N per output tap (multiple of 32)
+static bool igemm_plan(int N, int D, int H, int W, int Kc, int Nc, int ntaps_out, IgemmPlan* p) {
+    if (Kc % CK || Nc % 32 || H % 4) return false;
     int BX = (W % 32 == 0) ? 32 : (W % 16 == 0) ? 16 : (W % 8 == 0) ? 8 : 0;
     if (!BX) return false;
-    const int NBW = (Cout % 64 == 0) ? 2 : 1;
-    const int nN = Cout / (32 * NBW);
+    const int NBW = (Nc % 64 == 0) ? 2 : 1;
+    const int nN = Nc / (32 * NBW) * ntaps_out;
     auto tiles = [&](int MB, int* tz) {
         int lines = 4 * MB * (32 / BX);
         *tz = lines / 4;
@@ -271,70 +297,117 @@ static bool igemm_plan(int N, int D, int H, int W, int Cin, int Cout, IgemmPlan*
 }
 
 bool conv_mfma_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int ldy) {
-    if (k != 3 || stride != 1 || pad != 1) return false;
+    if (!((k == 3 && pad == 1) || (k == 1 && pad == 0)) || stride != 1) return false;
     if (ldx % 4) return false;
     IgemmPlan p;
-    return igemm_plan(N, D, H, W, Cin, Cout, &p);
+    return igemm_plan(N, D, H, W, Cin, Cout, 1, &p);
 }
 
 size_t conv_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
-    if (k != 3 || stride != 1 || pad != 1) return 0;
+    if (!((k == 3 && pad == 1) || (k == 1 && pad == 0)) || stride != 1) return 0;
     size_t best = 0;
+    const size_t T = (size_t)k * k * k;
     // the same workspace must serve fwd (Cin->Cout) and dgrad (Cout->Cin)
     for (int pass = 0; pass < 2; ++pass) {
         int ci = pass ? Cout : Cin, co = pass ? Cin : Cout;
         IgemmPlan p;
-        if (!igemm_plan(N, D, H, W, ci, co, &p)) continue;
-        size_t need = align_up((size_t)27 * Cin * Cout * sizeof(float), 256) + align_up((size_t)p.nM * co * 2 * sizeof(float), 256) + 1024;
+        if (!igemm_plan(N, D, H, W, ci, co, 1, &p)) continue;
+        size_t need = align_up(T * Cin * Cout * sizeof(float), 256) + align_up((size_t)p.nM * co * 2 * sizeof(float), 256) + 1024;
         if (need > best) best = need;
     }
-    size_t wg = wgrad_mfma_ws_bytes(N, D, H, W, Cin, Cout);
+    size_t wg = k == 3 ? wgrad_mfma_ws_bytes(N, D, H, W, Cin, Cout) : pw_wgrad_ws_bytes((long long)N * D * H * W, Cin, Cout, 1);
     return best > wg ? best : wg;
 }
 
-template <int BX, int MB, int NBW>
+template <int KS, int BX, int MB, int NBW>
 static void launch_igemm(const IgemmArgs& a, int nwg, hipStream_t st) {
-    using T = Tile<BX, MB>;
+    using T = Tile<KS, BX, MB>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_igemm_kernel<BX, MB, NBW>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<KS, BX, MB, NBW>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<BX, MB, NBW>), dim3(nwg), dim3(256), T::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<KS, BX, MB, NBW>), dim3(nwg), dim3(256), T::LDS_BYTES, st, a);
 }
 
+template <int KS>
+static void dispatch_igemm(const IgemmPlan& p, const IgemmArgs& a, int nwg, hipStream_t st) {
+#define IGEMM_CASE(bx, mb, nbw) \
+    if (p.BX == bx && p.MB == mb && p.NBW == nbw) launch_igemm<KS, bx, mb, nbw>(a, nwg, st)
+    IGEMM_CASE(32, 2, 2); else IGEMM_CASE(32, 2, 1); else IGEMM_CASE(32, 1, 2); else IGEMM_CASE(32, 1, 1);
+    else IGEMM_CASE(16, 2, 2); else IGEMM_CASE(16, 2, 1); else IGEMM_CASE(16, 1, 2); else IGEMM_CASE(16, 1, 1);
+    else IGEMM_CASE(8, 2, 2); else IGEMM_CASE(8, 2, 1); else IGEMM_CASE(8, 1, 2); else IGEMM_CASE(8, 1, 1);
+#undef IGEMM_CASE
+}
+
+static int pack_grid(long long total) { return (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256); }
+
+// k == 3 (pad 1) or k == 1 (pad 0), stride 1
 int conv_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W,
-                  int Cin, int Cout, int dgrad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st) {
+                  int Cin, int Cout, int k, int dgrad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st) {
     IgemmPlan p;
-    SEG_CHECK_ARG(igemm_plan(N, D, H, W, Cin, Cout, &p), "conv_fwd_mfma: unsupported shape");
+    SEG_CHECK_ARG(igemm_plan(N, D, H, W, Cin, Cout, 1, &p), "conv_fwd_mfma: unsupported shape");
     SEG_CHECK_ARG(((uintptr_t)x % 16) == 0, "conv_fwd_mfma: input pointer must be 16-byte aligned");
+    const int T = k * k * k;
     Carver cv(ws);
-    float* wq = cv.take<float>((size_t)27 * Cin * Cout);
+    float* wq = cv.take<float>((size_t)T * Cin * Cout);
     float* spart = ssum ? cv.take<float>((size_t)p.nM * Cout * 2) : nullptr;
     SEG_CHECK_WS(cv.used(), ws_bytes);
-    {
-        long long total = (long long)27 * Cin * Cout;
-        int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-        hipLaunchKernelGGL(pack_wq_kernel, dim3(grid), dim3(256), 0, st, w, wq, Cin, Cout, 32 * p.NBW, dgrad);
-        SEG_CHECK_LAUNCH();
-    }
-    IgemmArgs a{x, wq, bias, y, spart, ldx, ldy, N, D, H, W, Cin, Cout, p.ntx, p.nty, p.ntz, p.nN};
+    hipLaunchKernelGGL(pack_wq_kernel, dim3(pack_grid((long long)T * Cin * Cout)), dim3(256), 0, st, w, wq, Cin, Cout, T, 32 * p.NBW, dgrad ? 1 : 0, 0);
+    SEG_CHECK_LAUNCH();
+    IgemmArgs a{x, wq, bias, y, spart, ldx, ldy, N, D, H, W, Cout, p.ntx, p.nty, p.ntz, p.nN, Cin / CK, Cin / CK, p.nN, 1, 1};
     const int nwg = p.nM * p.nN;
     const double vox = (double)N * D * H * W;
     {
-        ProfScope ps(PF_IGEMM, 2.0 * vox * 27.0 * Cin * Cout, 4.0 * (vox * (Cin + Cout) + 27.0 * Cin * Cout), st);
-#define IGEMM_CASE(bx, mb, nbw) \
-        if (p.BX == bx && p.MB == mb && p.NBW == nbw) launch_igemm<bx, mb, nbw>(a, nwg, st)
-        IGEMM_CASE(32, 2, 2); else IGEMM_CASE(32, 2, 1); else IGEMM_CASE(32, 1, 2); else IGEMM_CASE(32, 1, 1);
-        else IGEMM_CASE(16, 2, 2); else IGEMM_CASE(16, 2, 1); else IGEMM_CASE(16, 1, 2); else IGEMM_CASE(16, 1, 1);
-        else IGEMM_CASE(8, 2, 2); else IGEMM_CASE(8, 2, 1); else IGEMM_CASE(8, 1, 2); else IGEMM_CASE(8, 1, 1);
-#undef IGEMM_CASE
+        ProfScope ps(PF_IGEMM, 2.0 * vox * T * Cin * Cout, 4.0 * (vox * (Cin + Cout) + (double)T * Cin * Cout), st);
+        if (k == 3) dispatch_igemm<3>(p, a, nwg, st); else dispatch_igemm<1>(p, a, nwg, st);
         SEG_CHECK_LAUNCH();
     }
     if (ssum) {
         hipLaunchKernelGGL(igemm_stats_finalize_kernel, dim3(Cout), dim3(256), 0, st, spart, p.nM, Cout, ssum, ssq);
         SEG_CHECK_LAUNCH();
     }
+    return MI355SEG_OK;
+}
+
+// ---- ConvTranspose3d k2 s2 on the same kernel (KS = 1)
+bool convt_mfma_supported(int N, int D, int H, int W, int Cin, int Cout, int ldx, int ldy) {
+    IgemmPlan p;
+    return (ldx % 4) == 0 && (ldy % 4) == 0 && igemm_plan(N, D, H, W, Cin, Cout, 8, &p) && igemm_plan(N, D, H, W, Cout, Cin, 1, &p) && Cin % 32 == 0;
+}
+
+int convt_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W,
+                   int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t st) {
+    IgemmPlan p;
+    SEG_CHECK_ARG(igemm_plan(N, D, H, W, Cin, Cout, 8, &p), "convt_fwd_mfma: unsupported shape");
+    Carver cv(ws);
+    float* wq = cv.take<float>((size_t)8 * Cin * Cout);
+    SEG_CHECK_WS(cv.used(), ws_bytes);
+    hipLaunchKernelGGL(pack_wq_kernel, dim3(pack_grid((long long)8 * Cin * Cout)), dim3(256), 0, st, w, wq, Cin, 8 * Cout, 1, 32 * p.NBW, 2, Cout);
+    SEG_CHECK_LAUNCH();
+    IgemmArgs a{x, wq, bias, y, nullptr, ldx, ldy, N, D, H, W, Cout, p.ntx, p.nty, p.ntz, p.nN, Cin / CK, Cin / CK, p.nN / 8, 1, 2};
+    const double vox = (double)N * D * H * W;
+    ProfScope ps(PF_CONVT, 2.0 * vox * 8 * Cin * Cout, 4.0 * (vox * (Cin + 8.0 * Cout) + 8.0 * Cin * Cout), st);
+    dispatch_igemm<1>(p, a, p.nM * p.nN, st);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+// dx[N,D,H,W,Cin] from dy[N,2D,2H,2W,Cout]
+int convt_dgrad_mfma(const float* dy, int lddy, const float* w, float* dx, int lddx, int N, int D, int H, int W,
+                     int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t st) {
+    IgemmPlan p;
+    SEG_CHECK_ARG(igemm_plan(N, D, H, W, Cout, Cin, 1, &p), "convt_dgrad_mfma: unsupported shape");
+    Carver cv(ws);
+    float* wq = cv.take<float>((size_t)8 * Cin * Cout);
+    SEG_CHECK_WS(cv.used(), ws_bytes);
+    hipLaunchKernelGGL(pack_wq_kernel, dim3(pack_grid((long long)8 * Cin * Cout)), dim3(256), 0, st, w, wq, 8 * Cout, Cin, 1, 32 * p.NBW, 3, Cout);
+    SEG_CHECK_LAUNCH();
+    IgemmArgs a{dy, wq, nullptr, dx, nullptr, lddy, lddx, N, D, H, W, Cin, p.ntx, p.nty, p.ntz, p.nN, 8 * Cout / CK, Cout / CK, p.nN, 2, 1};
+    const double vox = (double)N * D * H * W;
+    ProfScope ps(PF_CONVT, 2.0 * vox * 8 * Cin * Cout, 4.0 * (vox * (Cin + 8.0 * Cout) + 8.0 * Cin * Cout), st);
+    dispatch_igemm<1>(p, a, p.nM * p.nN, st);
+    SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
 

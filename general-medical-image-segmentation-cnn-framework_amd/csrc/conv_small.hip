@@ -1,0 +1,318 @@
+// conv_small.hip -- the HBM-bound ends of the network as direct (non-GEMM) kernels:
+//   * stem:  Conv3d k3 s1 p1 with Cin <= 4   (unet3d.py enc1conv1 1->32; residual_unet3d.py conv3d_c1_1 4->32)
+//   * heads: Conv3d k1 with Cout <= 4        (unet3d.py `conv` 32->2; residual_unet3d.py conv3d_l4 / ds*_1x1)
+// Arithmetic intensity is 1-13 flop/B, so these are laid out for
+// bandwidth, not for MFMA: every lane moves 16 B, a wavefront's stores are one contiguous
+// 1 KiB run of NDHWC, weights sit in LDS / registers, per-channel reductions are register
+// sums -> DPP shuffles -> one LDS hop -> per-block partials -> fixed-order second stage.
+#include "common.h"
+#include "internal.h"
+
+namespace seg {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct SmallGeom { int N, D, H, W, Cin, Cout, ldx, ldy; };
+
+// ---------------------------------------------------------------- stem forward
+// thread = (voxel, output-channel quad); LPV = Cout/4 lanes per voxel
+template <int CIN>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+        const float* __restrict__ bias, float* __restrict__ y, float* __restrict__ spart, SmallGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float sw[];      // [27][CIN][Cout] then reduction scratch
+    const int Cout = g.Cout, LPV = Cout / 4;
+    for (int i = threadIdx.x; i < 27 * CIN * Cout; i += 256) {
+        int co = i % Cout, r = i / Cout, ci = r % CIN, tap = r / CIN;
+        sw[i] = w[((long long)co * CIN + ci) * 27 + tap];
+    }
+    __syncthreads();
+    const int cq = threadIdx.x % LPV, vl = threadIdx.x / LPV, VPB = 256 / LPV;
+    const long long nvox = (long long)g.N * g.D * g.H * g.W;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + cq * 4);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    for (long long v = (long long)blockIdx.x * VPB + vl; v < nvox; v += (long long)gridDim.x * VPB) {
+        int xw = (int)(v % g.W); long long r = v / g.W;
+        int yh = (int)(r % g.H); r /= g.H;
+        int zd = (int)(r % g.D); int n = (int)(r / g.D);
+        f32x4 acc = bv;
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+            const int iz = zd + dz, iy = yh + dy, ix = xw + dx;
+            if ((unsigned)iz < (unsigned)g.D && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W) {
+                const float* xp = x + ((((long long)n * g.D + iz) * g.H + iy) * g.W + ix) * g.ldx;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) {
+                    const float xv = xp[ci];
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(sw + (tap * CIN + ci) * Cout + cq * 4);
+                    acc += xv * wv;
+                }
+            }
+        }
+        *reinterpret_cast<f32x4*>(y + v * g.ldy + cq * 4) = acc;
+        s1 += acc; s2 += acc * acc;
+    }
+    if (spart) {          // per-channel sum / sum of squares of this block (BatchNorm statistics)
+        __syncthreads();
+        float* red = sw;  // reuse
+        for (int j = 0; j < 4; ++j) { red[(threadIdx.x * 2) * 4 + j] = s1[j]; red[(threadIdx.x * 2 + 1) * 4 + j] = s2[j]; }
+        __syncthreads();
+        if (threadIdx.x < Cout) {
+            const int c = threadIdx.x, q = c / 4, j = c % 4;
+            float a = 0.f, b = 0.f;
+            for (int k = 0; k < VPB; ++k) { a += red[((k * LPV + q) * 2) * 4 + j]; b += red[((k * LPV + q) * 2 + 1) * 4 + j]; }
+            spart[((long long)blockIdx.x * Cout + c) * 2] = a;
+            spart[((long long)blockIdx.x * Cout + c) * 2 + 1] = b;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- stem wgrad
+// grid = (blocks, CIN).  thread = (voxel, cout quad) keeps 27 x 4 accumulators:
+// acc[tap][j] += x[v + tap][ci] * dy[v][cq*4 + j].  part[blk][tap][ci][co].
+template <int DUMMY>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+        float* __restrict__ part, SmallGeom g, int lddy) {
+    extern __shared__ __attribute__((aligned(16))) float sred[];
+    const int Cout = g.Cout, LPV = Cout / 4, VPB = 256 / LPV;
+    const int cq = threadIdx.x % LPV, vl = threadIdx.x / LPV;
+    const int ci = blockIdx.y, CIN = gridDim.y;
+    const long long nvox = (long long)g.N * g.D * g.H * g.W;
+    f32x4 acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long long v = (long long)blockIdx.x * VPB + vl; v < nvox; v += (long long)gridDim.x * VPB) {
+        int xw = (int)(v % g.W); long long r = v / g.W;
+        int yh = (int)(r % g.H); r /= g.H;
+        int zd = (int)(r % g.D); int n = (int)(r / g.D);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + v * lddy + cq * 4);
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            const int dz = tap / 9 - 1, dyy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+            const int iz = zd + dz, iy = yh + dyy, ix = xw + dx;
+            float xv = 0.f;
+            if ((unsigned)iz < (unsigned)g.D && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+                xv = x[((((long long)n * g.D + iz) * g.H + iy) * g.W + ix) * g.ldx + ci];
+            acc[tap] += xv * d;
+        }
+    }
+    // reduce over the voxel lanes that share cq: DPP/shuffle inside the wave, LDS across the 4 waves
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = acc[t][j];
+            for (int o = 32; o >= LPV; o >>= 1) s += __shfl_xor(s, o, 64);
+            acc[t][j] = s;
+        }
+    }
+    if (lane < LPV) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t) *reinterpret_cast<f32x4*>(sred + ((wave * 27 + t) * LPV + lane) * 4) = acc[t];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 27 * Cout; i += 256) {
+        const int t = i / Cout, co = i % Cout;
+        float s = 0.f;
+        for (int w = 0; w < 4; ++w) s += sred[((w * 27 + t) * LPV + co / 4) * 4 + co % 4];
+        part[(((long long)blockIdx.x * 27 + t) * CIN + ci) * Cout + co] = s;
+    }
+}
+
+// ---------------------------------------------------------------- pointwise (k1) small-Cout head
+// thread = (voxel, input-channel quad); LPV = Cin/4 lanes per voxel (<= 64)
+template <int COUT>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+        const float* __restrict__ bias, float* __restrict__ y, SmallGeom g) {
+    const int LPV = g.Cin / 4, VPB = 256 / LPV;
+    const int c4 = threadIdx.x % LPV, vl = threadIdx.x / LPV;
+    const long long nvox = (long long)g.N * g.D * g.H * g.W;
+    f32x4 wr[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) wr[co] = *reinterpret_cast<const f32x4*>(w + (long long)co * g.Cin + c4 * 4);
+    for (long long v = (long long)blockIdx.x * VPB + vl; v < nvox; v += (long long)gridDim.x * VPB) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + v * g.ldx + c4 * 4);
+        float o[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            float s = xv[0] * wr[co][0] + xv[1] * wr[co][1] + xv[2] * wr[co][2] + xv[3] * wr[co][3];
+            for (int off = LPV >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            o[co] = s + (bias ? bias[co] : 0.f);
+        }
+        if (c4 == 0) {
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) y[v * g.ldy + co] = o[co];
+        }
+    }
+}
+
+template <int COUT>
+__global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ w,
+        float* __restrict__ dx, SmallGeom g) {
+    const int LPV = g.Cin / 4, VPB = 256 / LPV;
+    const int c4 = threadIdx.x % LPV, vl = threadIdx.x / LPV;
+    const long long nvox = (long long)g.N * g.D * g.H * g.W;
+    f32x4 wr[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) wr[co] = *reinterpret_cast<const f32x4*>(w + (long long)co * g.Cin + c4 * 4);
+    for (long long v = (long long)blockIdx.x * VPB + vl; v < nvox; v += (long long)gridDim.x * VPB) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc += dy[v * lddy + co] * wr[co];
+        *reinterpret_cast<f32x4*>(dx + v * g.ldx + c4 * 4) = acc;
+    }
+}
+
+// part[blk][0][ci][co] = sum over the block's voxels of x[v][ci] * dy[v][co]
+template <int COUT>
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int lddy,
+        float* __restrict__ part, SmallGeom g) {
+    __shared__ float sred[4 * 64 * COUT * 4];
+    const int LPV = g.Cin / 4, VPB = 256 / LPV;
+    const int c4 = threadIdx.x % LPV, vl = threadIdx.x / LPV;
+    const long long nvox = (long long)g.N * g.D * g.H * g.W;
+    f32x4 acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long long v = (long long)blockIdx.x * VPB + vl; v < nvox; v += (long long)gridDim.x * VPB) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + v * g.ldx + c4 * 4);
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] += dy[v * lddy + co] * xv;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = acc[co][j];
+            for (int o = 32; o >= LPV; o >>= 1) s += __shfl_xor(s, o, 64);
+            acc[co][j] = s;
+        }
+    // lanes [0, min(LPV,64)) of each wave hold that wave's totals (if LPV == 64 every lane is its own c4)
+    const int nl = LPV < 64 ? LPV : 64;
+    if (lane < nl) {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) *reinterpret_cast<f32x4*>(sred + ((wave * 64 + lane) * COUT + co) * 4) = acc[co];
+    }
+    __syncthreads();
+    // when LPV == 64 a wave covers exactly one voxel row of quads; waves then hold different voxels of the same quads
+    for (int i = threadIdx.x; i < g.Cin * COUT; i += 256) {
+        const int ci = i / COUT, co = i % COUT;
+        float s = 0.f;
+        for (int w = 0; w < 4; ++w) s += sred[((w * 64 + (ci / 4) % 64) * COUT + co) * 4 + ci % 4];
+        part[((long long)blockIdx.x * g.Cin + ci) * COUT + co] = s;
+    }
+}
+
+static int small_grid(long long nvox, int vpb) {
+    long long b = (nvox + vpb - 1) / vpb;
+    b = (b + 7) / 8;                       // >= 8 voxel rounds per block
+    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+bool stem_supported(int Cin, int Cout, int k, int stride, int pad, int ldy) {
+    const int lpv = Cout / 4;
+    return k == 3 && stride == 1 && pad == 1 && (Cin == 1 || Cin == 2 || Cin == 4) && Cout % 4 == 0 && Cout >= 4 && Cout <= 64 &&
+           (lpv & (lpv - 1)) == 0 && ldy % 4 == 0;
+}
+bool head_supported(int Cin, int Cout, int k, int stride, int pad, int ldx) {
+    const int lpv = Cin / 4;
+    return k == 1 && stride == 1 && pad == 0 && (Cout == 2 || Cout == 4) && Cin % 4 == 0 && Cin >= 4 && Cin <= 256 &&
+           (lpv & (lpv - 1)) == 0 && ldx % 4 == 0;
+}
+
+size_t small_ws_bytes(int Cin, int Cout, int k) {
+    size_t T = (size_t)k * k * k;
+    return align_up((size_t)1024 * T * Cin * Cout * sizeof(float), 256) + colsum_ws_bytes(Cout) + 1024;
+}
+
+int stem_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W, int Cin,
+             int Cout, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st) {
+    SmallGeom g{N, D, H, W, Cin, Cout, ldx, ldy};
+    const long long nvox = (long long)N * D * H * W;
+    const int vpb = 256 / (Cout / 4);
+    const int nblk = small_grid(nvox, vpb);
+    float* spart = nullptr;
+    if (ssum) {
+        SEG_CHECK_WS((size_t)nblk * Cout * 2 * sizeof(float), ws_bytes);
+        spart = (float*)ws;
+    }
+    size_t lds = (size_t)27 * Cin * Cout * 4;
+    if (lds < 256 * 8 * 4) lds = 256 * 8 * 4;
+    {
+        ProfScope ps(PF_DIRECT, 2.0 * nvox * 27.0 * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
+        if (Cin == 1) hipLaunchKernelGGL((stem_fwd_kernel<1>), dim3(nblk), dim3(256), lds, st, x, w, bias, y, spart, g);
+        else if (Cin == 2) hipLaunchKernelGGL((stem_fwd_kernel<2>), dim3(nblk), dim3(256), lds, st, x, w, bias, y, spart, g);
+        else hipLaunchKernelGGL((stem_fwd_kernel<4>), dim3(nblk), dim3(256), lds, st, x, w, bias, y, spart, g);
+        SEG_CHECK_LAUNCH();
+    }
+    if (ssum) return finalize_channel_partials(spart, nblk, Cout, ssum, ssq, st);
+    return MI355SEG_OK;
+}
+
+int stem_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
+               int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+    SmallGeom g{N, D, H, W, Cin, Cout, ldx, 0};
+    const long long nvox = (long long)N * D * H * W;
+    const int vpb = 256 / (Cout / 4);
+    int nblk = small_grid(nvox, vpb);
+    if (nblk > 512) nblk = 512;
+    SEG_CHECK_WS((size_t)nblk * 27 * Cin * Cout * sizeof(float), ws_bytes);
+    float* part = (float*)ws;
+    size_t lds = (size_t)4 * 27 * Cout * 4;
+    {
+        ProfScope ps(PF_DIRECT, 2.0 * nvox * 27.0 * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
+        hipLaunchKernelGGL((stem_wgrad_kernel<0>), dim3(nblk, Cin), dim3(256), lds, st, x, dy, part, g, lddy);
+        SEG_CHECK_LAUNCH();
+    }
+    wgrad_reduce(part, dw, nblk, 27, Cin, Cout, accumulate, st);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+int head_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W, int Cin,
+             int Cout, hipStream_t st) {
+    SmallGeom g{N, D, H, W, Cin, Cout, ldx, ldy};
+    const long long nvox = (long long)N * D * H * W;
+    const int nblk = small_grid(nvox, 256 / (Cin / 4)) * 2;
+    ProfScope ps(PF_DIRECT, 2.0 * nvox * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
+    if (Cout == 2) hipLaunchKernelGGL((head_fwd_kernel<2>), dim3(nblk), dim3(256), 0, st, x, w, bias, y, g);
+    else hipLaunchKernelGGL((head_fwd_kernel<4>), dim3(nblk), dim3(256), 0, st, x, w, bias, y, g);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+int head_dgrad(const float* dy, int lddy, const float* w, float* dx, int lddx, int N, int D, int H, int W, int Cin, int Cout,
+               hipStream_t st) {
+    SmallGeom g{N, D, H, W, Cin, Cout, lddx, 0};
+    const long long nvox = (long long)N * D * H * W;
+    const int nblk = small_grid(nvox, 256 / (Cin / 4)) * 2;
+    ProfScope ps(PF_DIRECT, 2.0 * nvox * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
+    if (Cout == 2) hipLaunchKernelGGL((head_dgrad_kernel<2>), dim3(nblk), dim3(256), 0, st, dy, lddy, w, dx, g);
+    else hipLaunchKernelGGL((head_dgrad_kernel<4>), dim3(nblk), dim3(256), 0, st, dy, lddy, w, dx, g);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+int head_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
+               int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+    SmallGeom g{N, D, H, W, Cin, Cout, ldx, 0};
+    const long long nvox = (long long)N * D * H * W;
+    int nblk = small_grid(nvox, 256 / (Cin / 4));
+    if (nblk > 512) nblk = 512;
+    SEG_CHECK_WS((size_t)nblk * Cin * Cout * sizeof(float), ws_bytes);
+    float* part = (float*)ws;
+    {
+        ProfScope ps(PF_DIRECT, 2.0 * nvox * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
+        if (Cout == 2) hipLaunchKernelGGL((head_wgrad_kernel<2>), dim3(nblk), dim3(256), 0, st, x, dy, lddy, part, g);
+        else hipLaunchKernelGGL((head_wgrad_kernel<4>), dim3(nblk), dim3(256), 0, st, x, dy, lddy, part, g);
+        SEG_CHECK_LAUNCH();
+    }
+    wgrad_reduce(part, dw, nblk, 1, Cin, Cout, accumulate, st);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+}  // namespace seg

@@ -123,6 +123,8 @@ size_t mi355seg_convt3d_k2s2_ws_bytes(int N, int D, int H, int W, int Cin, int C
     size_t wb = align_up((size_t)8 * Cin * Cout * sizeof(float), 256);
     size_t part = align_up((size_t)convt_splits((long long)N * D * H * W, Cin, Cout) * 8 * Cin * Cout * sizeof(float), 256);
     size_t red = colsum_ws_bytes(Cout);
+    size_t pw = pw_wgrad_ws_bytes((long long)N * D * H * W, Cin, Cout, 8);
+    if (pw > part) part = pw;
     return wb + (part > red ? part : red) + 1024;
 }
 
@@ -132,6 +134,8 @@ int mi355seg_convt3d_k2s2_fwd_f32(const float* x, int ldx, const float* w, const
     SEG_CHECK_ARG(x && w && y && N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ldx >= Cin && ldy >= Cout,
                   "convt3d_k2s2_fwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
+    if (convt_mfma_supported(N, D, H, W, Cin, Cout, ldx, ldy) && ((uintptr_t)x % 16) == 0)
+        return convt_fwd_mfma(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, ws, ws_bytes, st);
     Carver cv(ws);
     float* wp = cv.take<float>((size_t)8 * Cin * Cout);
     SEG_CHECK_WS(cv.used(), ws_bytes);
@@ -149,6 +153,8 @@ int mi355seg_convt3d_k2s2_dgrad_f32(const float* dy, int lddy, const float* w, f
     SEG_CHECK_ARG(dy && w && dx && N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && lddy >= Cout && lddx >= Cin,
                   "convt3d_k2s2_dgrad: bad arguments");
     hipStream_t st = (hipStream_t)stream;
+    if (convt_mfma_supported(N, D, H, W, Cin, Cout, lddx, lddy) && ((uintptr_t)dy % 16) == 0)
+        return convt_dgrad_mfma(dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, ws, ws_bytes, st);
     Carver cv(ws);
     float* wd = cv.take<float>((size_t)8 * Cin * Cout);
     SEG_CHECK_WS(cv.used(), ws_bytes);
@@ -170,6 +176,14 @@ int mi355seg_convt3d_k2s2_wgrad_f32(const float* dy, int lddy, const float* x, i
     if (db) {
         int rc = channel_sums(dy, lddy, nvox * 8, Cout, nullptr, nullptr, db, 0, ws, ws_bytes, st);
         if (rc) return rc;
+    }
+    if (pw_wgrad_supported(nvox, Cin, Cout, 8, ldx, lddy) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0) {
+        float* part; int nstrips;
+        int rc = pw_wgrad_mfma(dy, lddy, x, ldx, N, D, H, W, Cin, Cout, 8, &part, &nstrips, ws, ws_bytes, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(convt_wgrad_reduce_kernel, dim3(tgrid((long long)8 * Cin * Cout)), dim3(256), 0, st, part, dw, nstrips, Cin, Cout);
+        SEG_CHECK_LAUNCH();
+        return MI355SEG_OK;
     }
     const int splits = convt_splits(nvox, Cin, Cout);
     Carver cv(ws);

@@ -9,6 +9,23 @@ size_t colsum_ws_bytes(int C);
 int channel_sums(const float* x, int ldx, long long rows, int C, double* sum, double* sq, float* fsum, int accumulate,
                  void* ws, size_t ws_bytes, hipStream_t st);
 
+int finalize_channel_partials(const float* part, int nblk, int C, double* sum, double* sq, hipStream_t st);
+
+// conv_small.hip -- direct kernels for Cin<=4 stems and Cout<=4 pointwise heads
+bool stem_supported(int Cin, int Cout, int k, int stride, int pad, int ldy);
+bool head_supported(int Cin, int Cout, int k, int stride, int pad, int ldx);
+size_t small_ws_bytes(int Cin, int Cout, int k);
+int stem_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W, int Cin,
+             int Cout, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st);
+int stem_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
+               int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+int head_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W, int Cin,
+             int Cout, hipStream_t st);
+int head_dgrad(const float* dy, int lddy, const float* w, float* dx, int lddx, int N, int D, int H, int W, int Cin, int Cout,
+               hipStream_t st);
+int head_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
+               int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+
 // conv_generic.hip
 void pack_w_fwd(const float* w, float* wp, int Cout, int Cin, int T, hipStream_t st);
 void pack_w_dgrad(const float* w, float* wd, int Cout, int Cin, int T, int flip, hipStream_t st);
@@ -20,7 +37,17 @@ bool conv_mfma_supported(int N, int D, int H, int W, int Cin, int Cout, int k, i
 // dgrad != 0: `w` is still the (Cfwd_out=Cin_here ... ) torch weight of the FORWARD conv, i.e. shape (Cin, Cout, 27)
 // seen from this call's Cin/Cout; taps are flipped while packing.
 int conv_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W,
-                  int Cin, int Cout, int dgrad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st);
+                  int Cin, int Cout, int k, int dgrad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st);
+bool convt_mfma_supported(int N, int D, int H, int W, int Cin, int Cout, int ldx, int ldy);
+int convt_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W,
+                   int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t st);
+int convt_dgrad_mfma(const float* dy, int lddy, const float* w, float* dx, int lddx, int N, int D, int H, int W,
+                     int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t st);
+// conv_pw_wgrad.hip -- K = voxels GEMM wgrads (T = 1: Conv3d k1, T = 8: ConvTranspose3d k2 s2)
+size_t pw_wgrad_ws_bytes(long long nvox, int Cin, int Cout, int T);
+bool pw_wgrad_supported(long long nvox, int Cin, int Cout, int T, int ldx, int lddy);
+int pw_wgrad_mfma(const float* dy, int lddy, const float* x, int ldx, int N, int D, int H, int W, int Cin, int Cout, int T,
+                  float** part_out, int* nstrips_out, void* ws, size_t ws_bytes, hipStream_t st);
 size_t wgrad_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout);
 bool wgrad_mfma_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int lddy);
 int conv_wgrad_mfma(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin,

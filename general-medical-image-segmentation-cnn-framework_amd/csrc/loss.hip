@@ -65,12 +65,12 @@ __global__ __launch_bounds__(kLossThreads) void bce_fwd_kernel(const float* __re
     if (threadIdx.x == 0) part[blockIdx.x] = acc[0];
 }
 
-__global__ void bce_finalize_kernel(const double* __restrict__ part, int nblk, double numel, float* __restrict__ loss) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < nblk; ++i) s += part[i];
-        loss[0] = (float)(s / numel);
-    }
+__global__ __launch_bounds__(256) void bce_finalize_kernel(const double* __restrict__ part, int nblk, double numel, float* __restrict__ loss) {
+    __shared__ double sh[4];
+    double acc[1] = {0.0};
+    for (int i = threadIdx.x; i < nblk; i += 256) acc[0] += part[i];
+    block_sum<1>(acc, sh);
+    if (threadIdx.x == 0) loss[0] = (float)(acc[0] / numel);
 }
 
 __global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
@@ -118,13 +118,13 @@ __global__ __launch_bounds__(kLossThreads) void dice_counts_kernel(const int64_t
     if (threadIdx.x == 0) for (int j = 0; j < 4; ++j) part[(long long)blockIdx.x * 4 + j] = acc[j];
 }
 
-__global__ void counts_finalize_kernel(const long long* __restrict__ part, int nblk, int64_t* __restrict__ counts) {
-    int j = threadIdx.x;
-    if (j < 4 && blockIdx.x == 0) {
-        long long s = 0;
-        for (int i = 0; i < nblk; ++i) s += part[(long long)i * 4 + j];
-        counts[j] = s;
-    }
+__global__ __launch_bounds__(256) void counts_finalize_kernel(const long long* __restrict__ part, int nblk, int64_t* __restrict__ counts) {
+    __shared__ long long sh[16];
+    long long acc[4] = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i < nblk; i += 256)
+        for (int j = 0; j < 4; ++j) acc[j] += part[(long long)i * 4 + j];
+    block_sum<4>(acc, sh);
+    if (threadIdx.x == 0) for (int j = 0; j < 4; ++j) counts[j] = acc[j];
 }
 
 // one pass over logits + one-hot targets: BCE sum, argmax(pred), argmax(gt), Dice counters
@@ -173,13 +173,13 @@ __global__ __launch_bounds__(kLossThreads) void dice_sums_kernel(const float* __
     block_sum<5>(acc, sh);
     if (threadIdx.x == 0) for (int j = 0; j < 5; ++j) part[(long long)blockIdx.x * 5 + j] = acc[j];
 }
-__global__ void sums_finalize5_kernel(const double* __restrict__ part, int nblk, double* __restrict__ out) {
-    int j = threadIdx.x;
-    if (j < 5 && blockIdx.x == 0) {
-        double s = 0;
-        for (int i = 0; i < nblk; ++i) s += part[(long long)i * 5 + j];
-        out[j] = s;
-    }
+__global__ __launch_bounds__(256) void sums_finalize5_kernel(const double* __restrict__ part, int nblk, double* __restrict__ out) {
+    __shared__ double sh[20];
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < nblk; i += 256)
+        for (int j = 0; j < 5; ++j) acc[j] += part[(long long)i * 5 + j];
+    block_sum<5>(acc, sh);
+    if (threadIdx.x == 0) for (int j = 0; j < 5; ++j) out[j] = acc[j];
 }
 
 }  // namespace seg
@@ -202,7 +202,7 @@ int mi355seg_bce_logits_fwd_f32(const float* logits, const float* target, long l
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bce_fwd_kernel, dim3(nblk), dim3(kLossThreads), 0, st, logits, target, numel, (double*)ws);
     SEG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nblk, (double)numel, loss);
+    hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nblk, (double)numel, loss);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
@@ -233,7 +233,7 @@ int mi355seg_dice_counts_i64(const int64_t* gt, const int64_t* pred, long long n
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(dice_counts_kernel, dim3(nblk), dim3(kLossThreads), 0, st, gt, pred, numel, (long long*)ws);
     SEG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(counts_finalize_kernel, dim3(1), dim3(64), 0, st, (const long long*)ws, nblk, counts);
+    hipLaunchKernelGGL(counts_finalize_kernel, dim3(1), dim3(256), 0, st, (const long long*)ws, nblk, counts);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
@@ -249,9 +249,9 @@ int mi355seg_bce_argmax_dice_f32(const float* logits, const float* target, long 
     long long* cpart = (long long*)((char*)ws + (size_t)nblk * sizeof(double));
     hipLaunchKernelGGL(bce_argmax_dice_kernel, dim3(nblk), dim3(kLossThreads), 0, st, logits, target, N, K, S, mask, lpart, cpart);
     SEG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(64), 0, st, lpart, nblk, (double)(N * K * S), loss);
+    hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(256), 0, st, lpart, nblk, (double)(N * K * S), loss);
     SEG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(counts_finalize_kernel, dim3(1), dim3(64), 0, st, cpart, nblk, counts);
+    hipLaunchKernelGGL(counts_finalize_kernel, dim3(1), dim3(256), 0, st, cpart, nblk, counts);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
@@ -264,7 +264,7 @@ int mi355seg_dice_sums_f32(const float* x, const float* t, long long numel, int 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(dice_sums_kernel, dim3(nblk), dim3(kLossThreads), 0, st, x, t, numel, apply_sigmoid, (double*)ws);
     SEG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sums_finalize5_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nblk, out5);
+    hipLaunchKernelGGL(sums_finalize5_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nblk, out5);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }

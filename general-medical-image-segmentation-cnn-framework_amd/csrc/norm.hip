@@ -155,18 +155,20 @@ static int launch_colreduce2(const F& f, long long rows, int groups, int C, int 
     return MI355SEG_OK;
 }
 
-// finalise: one thread per (group, channel); fixed summation order, fp64.
-__global__ void stats_finalize_kernel(const float* __restrict__ part, int nblk, int C, int groups, double rows,
+// finalise: one wavefront per (group, channel); lanes stride over the per-block partials, fp64
+// shuffle reduction -> fixed summation order (deterministic).
+__global__ __launch_bounds__(64) void stats_finalize_kernel(const float* __restrict__ part, int nblk, int C, int groups, double rows,
                                       float eps, float* __restrict__ mean, float* __restrict__ rstd,
                                       float* __restrict__ rmean, float* __restrict__ rvar, float momentum) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= groups * C) return;
-    int g = i / C, c = i % C;
+    const int i = blockIdx.x;
+    const int g = i / C, c = i % C;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = threadIdx.x; b < nblk; b += 64) {
         const float* p = part + (((long long)g * nblk + b) * C + c) * 2;
         s += (double)p[0]; q += (double)p[1];
     }
+    s = wave_sum(s); q = wave_sum(q);
+    if (threadIdx.x != 0) return;
     double m = s / rows;
     double var = q / rows - m * m;
     if (var < 0.0) var = 0.0;
@@ -196,18 +198,19 @@ __global__ void stats_from_sums_kernel(const double* __restrict__ sum, const dou
     }
 }
 
-__global__ void bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, int groups,
+__global__ __launch_bounds__(64) void bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, int groups,
                                     float* __restrict__ s1, float* __restrict__ s2,
                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    // s1/s2: per (group, channel) sums of dz and dz*xhat.  dgamma/dbeta: summed over groups.
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= groups * C) return;
-    int g = i / C, c = i % C;
+    // s1/s2: per (group, channel) sums of dz and dz*xhat; one wavefront per (group, channel).
+    const int i = blockIdx.x;
+    const int g = i / C, c = i % C;
     double a = 0.0, b = 0.0;
-    for (int k = 0; k < nblk; ++k) {
+    for (int k = threadIdx.x; k < nblk; k += 64) {
         const float* p = part + (((long long)g * nblk + k) * C + c) * 2;
         a += (double)p[0]; b += (double)p[1];
     }
+    a = wave_sum(a); b = wave_sum(b);
+    if (threadIdx.x != 0) return;
     s1[i] = (float)a; s2[i] = (float)b;
     if (dgamma && groups == 1) { dgamma[c] = (float)b; dbeta[c] = (float)a; }
 }
@@ -357,21 +360,28 @@ struct SumF {
     }
 };
 
-__global__ void sums_finalize_kernel(const float* __restrict__ part, int nblk, int C, double* __restrict__ sum,
+__global__ __launch_bounds__(64) void sums_finalize_kernel(const float* __restrict__ part, int nblk, int C, double* __restrict__ sum,
                                      double* __restrict__ sq, float* __restrict__ fsum, int accumulate) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;
     double a = 0.0, b = 0.0;
-    for (int k = 0; k < nblk; ++k) {
+    for (int k = threadIdx.x; k < nblk; k += 64) {
         a += (double)part[((long long)k * C + c) * 2];
         b += (double)part[((long long)k * C + c) * 2 + 1];
     }
+    a = wave_sum(a); b = wave_sum(b);
+    if (threadIdx.x != 0) return;
     if (sum) sum[c] = a;
     if (sq) sq[c] = b;
     if (fsum) fsum[c] = accumulate ? fsum[c] + (float)a : (float)a;
 }
 
 size_t colsum_ws_bytes(int C) { return align_up((size_t)kMaxRedBlocks * C * 2 * sizeof(float), 256); }
+
+int finalize_channel_partials(const float* part, int nblk, int C, double* sum, double* sq, hipStream_t st) {
+    hipLaunchKernelGGL(sums_finalize_kernel, dim3(C), dim3(64), 0, st, part, nblk, C, sum, sq, (float*)nullptr, 0);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
 
 // exported to the other translation units
 int channel_sums(const float* x, int ldx, long long rows, int C, double* sum, double* sq, float* fsum, int accumulate,
@@ -382,7 +392,7 @@ int channel_sums(const float* x, int ldx, long long rows, int C, double* sum, do
     SumF f{x, ldx};
     int rc = launch_colreduce2(f, rows, 1, C, ldx, part, &p, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(sums_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, part, p.nblk, C, sum, sq, fsum, accumulate);
+    hipLaunchKernelGGL(sums_finalize_kernel, dim3(C), dim3(64), 0, st, part, p.nblk, C, sum, sq, fsum, accumulate);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
@@ -414,7 +424,7 @@ int mi355seg_norm_stats_f32(const float* x, int ldx, long long rows, int groups,
     StatsF f{x, ldx};
     int rc = launch_colreduce2(f, rows, groups, C, ldx, part, &p, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(cdiv((long long)groups * C, 128)), dim3(128), 0, st, part, p.nblk, C,
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(groups * C), dim3(64), 0, st, part, p.nblk, C,
                        groups, (double)rows, eps, mean, rstd, running_mean, running_var, momentum);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
@@ -471,7 +481,7 @@ int mi355seg_norm_act_bwd_f32(const float* dy, int lddy, const float* x, int ldx
     BwdF f{dy, lddy, x, ldx, mean, rstd, gamma, beta, res, ldres, act, slope};
     int rc = launch_colreduce2(f, rows, groups, C, ldmin, part, &p, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(bwd_finalize_kernel, dim3(cdiv((long long)groups * C, 128)), dim3(128), 0, st, part, p.nblk, C,
+    hipLaunchKernelGGL(bwd_finalize_kernel, dim3(groups * C), dim3(64), 0, st, part, p.nblk, C,
                        groups, s1, s2, dgamma, dbeta);
     SEG_CHECK_LAUNCH();
     bool v = vec_ok(C, {lddy, ldx, lddx, res ? ldres : 4, dres ? lddres : 4});

@@ -52,6 +52,11 @@ CONV_CASES = [
     (1, 64, 64, 16, 16, 128, 3, 1, 1),     # BX=16, MB=2
     (1, 64, 64, 8, 16, 256, 3, 1, 1),      # BX=8, MB=2
     (2, 16, 16, 16, 48, 96, 3, 1, 1),      # 3 chunks, NBW=1
+    (1, 8, 8, 16, 4, 32, 3, 1, 1),         # direct stem kernel, Cin=4
+    (2, 8, 8, 8, 32, 2, 1, 1, 0),          # direct head kernel, Cout=2
+    (1, 4, 4, 8, 256, 4, 1, 1, 0),         # direct head kernel, 64 lanes per voxel
+    (1, 16, 16, 32, 64, 32, 1, 1, 0),      # k1 on the MFMA igemm + MFMA pointwise wgrad
+    (2, 8, 8, 8, 32, 64, 1, 1, 0),
     (1, 8, 8, 8, 16, 16, 5, 1, 2),
     (2, 8, 8, 8, 8, 16, 2, 2, 0),
     (1, 8, 12, 8, 16, 32, 3, 2, 1),
@@ -123,7 +128,8 @@ def test_conv3d_channel_slices_and_no_bias(seg):
     assert rel_err(wg.grad.cpu(), wr.grad) < TOL
 
 
-@pytest.mark.parametrize("case", [(2, 4, 4, 4, 16, 8), (1, 8, 8, 8, 64, 32), (1, 3, 5, 4, 6, 10), (2, 2, 2, 2, 512, 256)])
+@pytest.mark.parametrize("case", [(2, 4, 4, 4, 16, 8), (1, 8, 8, 8, 64, 32), (1, 3, 5, 4, 6, 10), (2, 2, 2, 2, 512, 256),
+                                  (2, 8, 8, 8, 512, 256), (1, 16, 16, 16, 128, 64), (1, 16, 32, 32, 64, 32)])
 def test_conv_transpose3d_k2s2(seg, case):
     N, D, H, W, Cin, Cout = case
     F = seg.functional
