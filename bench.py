@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="1,1,128,128,128")
     ap.add_argument("--no-prof", action="store_true", help="skip the in-library HIP-event kernel timing")
+    ap.add_argument("--dump-launches", default=None, help="write per-launch (family, ms, GFLOP, TFLOP/s) of the LAST timed step to this file")
     args = ap.parse_args()
 
     import mi355seg
@@ -157,6 +158,17 @@ def main():
                 fam[nm] = {"launches_per_step": n / args.steps, "ms_per_step": tms / args.steps,
                            "tflops": fl / (tms * 1e-3) / 1e12 if tms > 0 else 0.0, "gbs": by / (tms * 1e-3) / 1e9 if tms > 0 else 0.0}
         res["kernel_families"] = fam
+        if args.dump_launches:
+            nmax = 65536
+            rec = (ctypes.c_double * (4 * nmax))()
+            nrec = ctypes.c_int(0)
+            L.call("mi355seg_prof_records", rec, nmax, ctypes.byref(nrec))
+            per = nrec.value // args.steps
+            with open(args.dump_launches, "w") as fh:
+                fh.write("family,ms,gflop,tflops,alg_gbytes,alg_gbs\n")
+                for r in range(nrec.value - per, nrec.value):
+                    f_, ms_, fl_, by_ = int(rec[4 * r]), rec[4 * r + 1], rec[4 * r + 2], rec[4 * r + 3]
+                    fh.write(f"{names[f_]},{ms_:.4f},{fl_ / 1e9:.2f},{fl_ / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0:.2f},{by_ / 1e9:.4f},{by_ / (ms_ * 1e-3) / 1e9 if ms_ > 0 else 0:.1f}\n")
         n, tms, fl, by = buf[0], buf[1], buf[2], buf[3]
         if n > 0 and tms > 0:
             ach = fl / (tms * 1e-3) / 1e12

@@ -105,6 +105,19 @@ int mi355seg_version(void) { return 100; }
 
 int mi355seg_prof_enable(int on) { g_prof_on = on != 0; return MI355SEG_OK; }
 int mi355seg_prof_reset(void) { g_nrec = 0; return MI355SEG_OK; }
+int mi355seg_prof_records(double* out, int max_records, int* n_host) {
+    SEG_CHECK_ARG(out && n_host && max_records >= 0, "prof_records: bad arguments");
+    int n = 0;
+    for (int i = 0; i < g_nrec && n < max_records; ++i) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(g_recs[i].b);
+        if (hipEventElapsedTime(&ms, g_recs[i].a, g_recs[i].b) != hipSuccess) continue;
+        out[4 * n] = g_recs[i].family; out[4 * n + 1] = ms; out[4 * n + 2] = g_recs[i].flops; out[4 * n + 3] = g_recs[i].bytes;
+        ++n;
+    }
+    *n_host = n;
+    return MI355SEG_OK;
+}
 int mi355seg_prof_read(double* out, int n) {
     SEG_CHECK_ARG(out && n >= 4 * MI355SEG_PROF_FAMILIES, "prof_read: need room for %d doubles", 4 * MI355SEG_PROF_FAMILIES);
     for (int i = 0; i < 4 * MI355SEG_PROF_FAMILIES; ++i) out[i] = 0.0;

@@ -195,6 +195,9 @@ int mi355seg_dice_sums_f32(const float* x, const float* t, long long numel, int 
 int mi355seg_prof_enable(int on);
 int mi355seg_prof_reset(void);
 int mi355seg_prof_read(double* out_host, int n_doubles);
+/* per-launch records: writes up to max_records rows of 4 doubles (family, ms, flops, bytes); returns the
+ * number of rows through *n_host (call after prof_read, which synchronises). */
+int mi355seg_prof_records(double* out_host, int max_records, int* n_host);
 
 /* ------------------------------------------------------------------ Layout helpers */
 int mi355seg_ncdhw_to_ndhwc_f32(const float* src, float* dst, int lddst, long long N, int C, long long S, void* stream);
