@@ -139,7 +139,7 @@ static bool pw_plan(long long nvox, int Cin, int Cout, int T, PwPlan* p) {
     if (nvox % V) return false;
     p->ntiles = (int)(nvox / V);
     p->npairs = (Cin / 32) * (Cout / 32);
-    int want = (1024 + p->npairs - 1) / p->npairs;
+    int want = (512 + p->npairs - 1) / p->npairs;
     long long cap = (long long)(64u << 20) / ((long long)T * Cin * Cout * 4);
     if (cap < 1) cap = 1;
     if (want > cap) want = (int)cap;

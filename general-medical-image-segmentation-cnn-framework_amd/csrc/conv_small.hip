@@ -121,6 +121,146 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------- Cin == 1 stem, LDS-tiled
+// The 1-channel NDHWC input is a plain 3-D volume: a (2+2) x (4+2) x (TX+2) halo tile sits in LDS,
+// every tap is a fixed LDS offset (no per-tap bounds / address arithmetic), and the 27 x 4 weights of
+// the lane's output-channel quad live in registers.  thread = (x position, channel quad); it walks the
+// tile's 8 x-lines.  TX = 256 / (Cout/4).
+constexpr int S1_TZ = 2, S1_TY = 4;
+
+__device__ __forceinline__ void s1_stage(float* tile, const float* __restrict__ x, int ldx, int n, int z0, int y0, int x0, int TX,
+                                         int D, int H, int W) {
+    const int HX = TX + 2, HY = S1_TY + 2, HZ = S1_TZ + 2;
+    for (int p = threadIdx.x; p < HX * HY * HZ; p += 256) {
+        const int hx = p % HX, r = p / HX, hy = r % HY, hz = r / HY;
+        const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        float v = 0.f;
+        if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+            v = x[((((long long)n * D + gz) * H + gy) * W + gx) * ldx];
+        tile[p] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void stem1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+        const float* __restrict__ bias, float* __restrict__ y, float* __restrict__ spart, SmallGeom g, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Cout = g.Cout, LPV = Cout / 4, TX = 256 / LPV, HX = TX + 2, HY = S1_TY + 2;
+    const int cq = threadIdx.x % LPV, xs = threadIdx.x / LPV;
+    f32x4 wr[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wr[t][j] = w[(long long)(cq * 4 + j) * 27 + t];
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + cq * 4);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    const int ntx = g.W / TX, nty = g.H / S1_TY, ntz = g.D / S1_TZ;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int mt = tile;
+        const int txi = mt % ntx; mt /= ntx;
+        const int tyi = mt % nty; mt /= nty;
+        const int tzi = mt % ntz; const int n = mt / ntz;
+        const int x0 = txi * TX, y0 = tyi * S1_TY, z0 = tzi * S1_TZ;
+        __syncthreads();
+        s1_stage(sm, x, g.ldx, n, z0, y0, x0, TX, g.D, g.H, g.W);
+        __syncthreads();
+#pragma unroll
+        for (int line = 0; line < S1_TZ * S1_TY; ++line) {
+            const int lz = line / S1_TY, ly = line % S1_TY;
+            const float* tp = sm + (lz * HY + ly) * HX + xs;
+            f32x4 acc = bv;
+#pragma unroll
+            for (int t = 0; t < 27; ++t) {
+                const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+                acc += tp[(dz * HY + dy) * HX + dx] * wr[t];
+            }
+            const long long v = (((long long)n * g.D + z0 + lz) * g.H + y0 + ly) * g.W + x0 + xs;
+            *reinterpret_cast<f32x4*>(y + v * g.ldy + cq * 4) = acc;
+            s1 += acc; s2 += acc * acc;
+        }
+    }
+    if (spart) {
+        __syncthreads();
+        float* red = sm;
+        for (int j = 0; j < 4; ++j) { red[(threadIdx.x * 2) * 4 + j] = s1[j]; red[(threadIdx.x * 2 + 1) * 4 + j] = s2[j]; }
+        __syncthreads();
+        if (threadIdx.x < Cout) {
+            const int c = threadIdx.x, q = c / 4, j = c % 4;
+            float a = 0.f, b = 0.f;
+            for (int k = 0; k < TX; ++k) { a += red[((k * LPV + q) * 2) * 4 + j]; b += red[((k * LPV + q) * 2 + 1) * 4 + j]; }
+            spart[((long long)blockIdx.x * Cout + c) * 2] = a;
+            spart[((long long)blockIdx.x * Cout + c) * 2 + 1] = b;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void stem1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+        float* __restrict__ part, SmallGeom g, int lddy, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Cout = g.Cout, LPV = Cout / 4, TX = 256 / LPV, HX = TX + 2, HY = S1_TY + 2;
+    const int cq = threadIdx.x % LPV, xs = threadIdx.x / LPV;
+    f32x4 acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ntx = g.W / TX, nty = g.H / S1_TY, ntz = g.D / S1_TZ;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int mt = tile;
+        const int txi = mt % ntx; mt /= ntx;
+        const int tyi = mt % nty; mt /= nty;
+        const int tzi = mt % ntz; const int n = mt / ntz;
+        const int x0 = txi * TX, y0 = tyi * S1_TY, z0 = tzi * S1_TZ;
+        __syncthreads();
+        s1_stage(sm, x, g.ldx, n, z0, y0, x0, TX, g.D, g.H, g.W);
+        __syncthreads();
+#pragma unroll
+        for (int line = 0; line < S1_TZ * S1_TY; ++line) {
+            const int lz = line / S1_TY, ly = line % S1_TY;
+            const float* tp = sm + (lz * HY + ly) * HX + xs;
+            const long long v = (((long long)n * g.D + z0 + lz) * g.H + y0 + ly) * g.W + x0 + xs;
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dy + v * lddy + cq * 4);
+#pragma unroll
+            for (int t = 0; t < 27; ++t) {
+                const int dz = t / 9, dyy = (t / 3) % 3, dx = t % 3;
+                acc[t] += tp[(dz * HY + dyy) * HX + dx] * d;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = acc[t][j];
+            for (int o = 32; o >= LPV; o >>= 1) s += __shfl_xor(s, o, 64);
+            acc[t][j] = s;
+        }
+    }
+    __syncthreads();
+    if (lane < LPV) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t) *reinterpret_cast<f32x4*>(sm + ((wave * 27 + t) * LPV + lane) * 4) = acc[t];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 27 * Cout; i += 256) {
+        const int t = i / Cout, co = i % Cout;
+        float s = 0.f;
+        for (int w = 0; w < 4; ++w) s += sm[((w * 27 + t) * LPV + co / 4) * 4 + co % 4];
+        part[((long long)blockIdx.x * 27 + t) * Cout + co] = s;
+    }
+}
+
+static bool stem1_tiled_ok(const SmallGeom& g) {
+    if (g.Cin != 1) return false;
+    const int TX = 256 / (g.Cout / 4);
+    return g.W % TX == 0 && g.H % S1_TY == 0 && g.D % S1_TZ == 0;
+}
+static size_t stem1_lds(int Cout) {
+    const int TX = 256 / (Cout / 4);
+    size_t a = (size_t)(TX + 2) * (S1_TY + 2) * (S1_TZ + 2) * 4, b = 256 * 8 * 4, c = (size_t)4 * 27 * Cout * 4;
+    size_t m = a > b ? a : b;
+    return m > c ? m : c;
+}
+
 // ---------------------------------------------------------------- pointwise (k1) small-Cout head
 // thread = (voxel, input-channel quad); LPV = Cin/4 lanes per voxel (<= 64)
 template <int COUT>
@@ -241,6 +381,18 @@ int stem_fwd(const float* x, int ldx, const float* w, const float* bias, float* 
     }
     size_t lds = (size_t)27 * Cin * Cout * 4;
     if (lds < 256 * 8 * 4) lds = 256 * 8 * 4;
+    if (stem1_tiled_ok(g)) {
+        const int ntiles = (int)(nvox / ((long long)S1_TZ * S1_TY * (256 / (Cout / 4))));   // tile = 2 x 4 x TX voxels
+        int nb = ntiles < 1024 ? ntiles : 1024;
+        if (ssum) { SEG_CHECK_WS((size_t)nb * Cout * 2 * sizeof(float), ws_bytes); }
+        {
+            ProfScope ps(PF_DIRECT, 2.0 * nvox * 27.0 * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
+            hipLaunchKernelGGL(stem1_fwd_kernel, dim3(nb), dim3(256), stem1_lds(Cout), st, x, w, bias, y, spart, g, ntiles);
+            SEG_CHECK_LAUNCH();
+        }
+        if (ssum) return finalize_channel_partials(spart, nb, Cout, ssum, ssq, st);
+        return MI355SEG_OK;
+    }
     {
         ProfScope ps(PF_DIRECT, 2.0 * nvox * 27.0 * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
         if (Cin == 1) hipLaunchKernelGGL((stem_fwd_kernel<1>), dim3(nblk), dim3(256), lds, st, x, w, bias, y, spart, g);
@@ -262,6 +414,18 @@ int stem_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, in
     SEG_CHECK_WS((size_t)nblk * 27 * Cin * Cout * sizeof(float), ws_bytes);
     float* part = (float*)ws;
     size_t lds = (size_t)4 * 27 * Cout * 4;
+    if (stem1_tiled_ok(g)) {
+        const int ntiles = (int)(nvox / ((long long)S1_TZ * S1_TY * (256 / (Cout / 4))));   // tile = 2 x 4 x TX voxels
+        int nb = ntiles < 512 ? ntiles : 512;
+        {
+            ProfScope ps(PF_DIRECT, 2.0 * nvox * 27.0 * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
+            hipLaunchKernelGGL(stem1_wgrad_kernel, dim3(nb), dim3(256), stem1_lds(Cout), st, x, dy, part, g, lddy, ntiles);
+            SEG_CHECK_LAUNCH();
+        }
+        wgrad_reduce(part, dw, nb, 27, Cin, Cout, accumulate, st);
+        SEG_CHECK_LAUNCH();
+        return MI355SEG_OK;
+    }
     {
         ProfScope ps(PF_DIRECT, 2.0 * nvox * 27.0 * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
         hipLaunchKernelGGL((stem_wgrad_kernel<0>), dim3(nblk, Cin), dim3(256), lds, st, x, dy, part, g, lddy);

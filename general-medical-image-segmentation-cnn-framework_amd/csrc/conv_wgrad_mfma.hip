@@ -163,7 +163,7 @@ static bool wgrad_plan(int N, int D, int H, int W, int Cin, int Cout, WgradPlan*
     p->BX = BX; p->ntx = W / BX; p->nty = H / TY; p->ntz = D / TZ;
     p->ntiles = N * p->ntz * p->nty * p->ntx;
     p->npairs = (Cin / 32) * (Cout / 32);
-    int want = (512 + p->npairs - 1) / p->npairs;
+    int want = (256 + p->npairs - 1) / p->npairs;      // one workgroup per CU (136 KB of LDS each)
     long long cap = (long long)(160u << 20) / ((long long)27 * Cin * Cout * 4);   // keep the slab workspace <= 160 MB
     if (cap < 1) cap = 1;
     if (want > cap) want = (int)cap;

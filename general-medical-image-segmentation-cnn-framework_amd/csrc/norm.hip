@@ -216,37 +216,49 @@ __global__ __launch_bounds__(64) void bwd_finalize_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------
-// elementwise kernels (grid-stride, float4 when possible)
+// elementwise kernels.  A thread owns one fixed channel quad (or channel) and walks rows:
+// per-channel constants are hoisted out of the loop, there is no per-element integer
+// division, and a wavefront touches 64 consecutive 16-byte pieces of the NDHWC stream.
+// grid = (row blocks, groups).
 // ---------------------------------------------------------------------------------------
+struct RowMap {
+    int lanes, rpi;     // threads across channels, rows per block iteration
+};
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const float* __restrict__ x, int ldx,
         const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
         const float* __restrict__ beta, const float* __restrict__ res, int ldres, float* __restrict__ y, int ldy,
-        long long rows, int groups, int C, int act, float slope) {
+        long long rows, int C, int lanes, int rpi, int act, float slope) {
+    constexpr int NJ = VEC ? 4 : 1;
+    const int g = blockIdx.y;
     const int cw = VEC ? C / 4 : C;
-    const long long total = rows * groups * cw;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        long long r = i / cw;
-        int cc = (int)(i % cw);
-        int g = (int)(r / rows);
-        if (VEC) {
-            int c = cc * 4;
-            float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
-            float4 rr = res ? *reinterpret_cast<const float4*>(res + r * ldres + c) : make_float4(0, 0, 0, 0);
-            float vin[4] = {v.x, v.y, v.z, v.w}, rin[4] = {rr.x, rr.y, rr.z, rr.w}, o[4];
+    const int rsub = threadIdx.x / lanes;
+    if (rsub >= rpi) return;
+    const long long rbase = (long long)g * rows;
+    for (int cc = threadIdx.x % lanes; cc < cw; cc += lanes) {
+        const int c = cc * NJ;
+        float al[NJ], be[NJ];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float al = rstd[g * C + c + j] * (gamma ? gamma[c + j] : 1.f);
-                float be = (beta ? beta[c + j] : 0.f) - mean[g * C + c + j] * al;
-                o[j] = act_apply(fmaf(vin[j], al, be) + rin[j], act, slope);
+        for (int j = 0; j < NJ; ++j) {
+            al[j] = rstd[g * C + c + j] * (gamma ? gamma[c + j] : 1.f);
+            be[j] = (beta ? beta[c + j] : 0.f) - mean[g * C + c + j] * al[j];
+        }
+        for (long long r = (long long)blockIdx.x * rpi + rsub; r < rows; r += (long long)gridDim.x * rpi) {
+            const long long row = rbase + r;
+            if (VEC) {
+                float4 v = *reinterpret_cast<const float4*>(x + row * ldx + c);
+                float4 rr = res ? *reinterpret_cast<const float4*>(res + row * ldres + c) : make_float4(0, 0, 0, 0);
+                float4 o;
+                o.x = act_apply(fmaf(v.x, al[0], be[0]) + rr.x, act, slope);
+                o.y = act_apply(fmaf(v.y, al[NJ > 1 ? 1 : 0], be[NJ > 1 ? 1 : 0]) + rr.y, act, slope);
+                o.z = act_apply(fmaf(v.z, al[NJ > 1 ? 2 : 0], be[NJ > 1 ? 2 : 0]) + rr.z, act, slope);
+                o.w = act_apply(fmaf(v.w, al[NJ > 1 ? 3 : 0], be[NJ > 1 ? 3 : 0]) + rr.w, act, slope);
+                *reinterpret_cast<float4*>(y + row * ldy + c) = o;
+            } else {
+                const float rv = res ? res[row * ldres + c] : 0.f;
+                y[row * ldy + c] = act_apply(fmaf(x[row * ldx + c], al[0], be[0]) + rv, act, slope);
             }
-            *reinterpret_cast<float4*>(y + r * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
-        } else {
-            int c = cc;
-            float al = rstd[g * C + c] * (gamma ? gamma[c] : 1.f);
-            float be = (beta ? beta[c] : 0.f) - mean[g * C + c] * al;
-            float rv = res ? res[r * ldres + c] : 0.f;
-            y[r * ldy + c] = act_apply(fmaf(x[r * ldx + c], al, be) + rv, act, slope);
         }
     }
 }
@@ -256,77 +268,87 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(const float* __
         const float* __restrict__ x, int ldx, const float* __restrict__ mean, const float* __restrict__ rstd,
         const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ res, int ldres,
         const float* __restrict__ s1, const float* __restrict__ s2, float* __restrict__ dx, int lddx,
-        float* __restrict__ dres, int lddres, long long rows, int groups, int C, int act, float slope) {
+        float* __restrict__ dres, int lddres, long long rows, int C, int lanes, int rpi, int act, float slope) {
+    constexpr int NJ = VEC ? 4 : 1;
+    const int g = blockIdx.y;
     const int cw = VEC ? C / 4 : C;
-    const long long total = rows * groups * cw;
+    const int rsub = threadIdx.x / lanes;
+    if (rsub >= rpi) return;
+    const long long rbase = (long long)g * rows;
     const float invM = 1.f / (float)rows;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        long long r = i / cw;
-        int cc = (int)(i % cw);
-        int g = (int)(r / rows);
-        const int nj = VEC ? 4 : 1;
-        int c = VEC ? cc * 4 : cc;
-        float dv[4], xv[4], rv[4] = {0, 0, 0, 0}, od[4], oz[4];
-        if (VEC) {
-            float4 d = *reinterpret_cast<const float4*>(dy + r * lddy + c);
-            float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
-            dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
-            xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
-            if (res) {
-                float4 q = *reinterpret_cast<const float4*>(res + r * ldres + c);
-                rv[0] = q.x; rv[1] = q.y; rv[2] = q.z; rv[3] = q.w;
-            }
-        } else {
-            dv[0] = dy[r * lddy + c]; xv[0] = x[r * ldx + c];
-            if (res) rv[0] = res[r * ldres + c];
-        }
+    for (int cc = threadIdx.x % lanes; cc < cw; cc += lanes) {
+        const int c = cc * NJ;
+        float m[NJ], rs[NJ], ga[NJ], be[NJ], k1[NJ], k2[NJ];
 #pragma unroll
-        for (int j = 0; j < nj; ++j) {
-            float m = mean[g * C + c + j], rs = rstd[g * C + c + j];
-            float ga = gamma ? gamma[c + j] : 1.f, be = beta ? beta[c + j] : 0.f;
-            float xh = (xv[j] - m) * rs;
-            float z = fmaf(xh, ga, be) + rv[j];
-            float dz = dv[j] * act_grad(z, act, slope);
-            oz[j] = dz;
-            od[j] = ga * rs * (dz - s1[g * C + c + j] * invM - xh * s2[g * C + c + j] * invM);
+        for (int j = 0; j < NJ; ++j) {
+            m[j] = mean[g * C + c + j]; rs[j] = rstd[g * C + c + j];
+            ga[j] = gamma ? gamma[c + j] : 1.f; be[j] = beta ? beta[c + j] : 0.f;
+            k1[j] = s1[g * C + c + j] * invM; k2[j] = s2[g * C + c + j] * invM;
         }
-        if (VEC) {
-            *reinterpret_cast<float4*>(dx + r * lddx + c) = make_float4(od[0], od[1], od[2], od[3]);
-            if (dres) *reinterpret_cast<float4*>(dres + r * lddres + c) = make_float4(oz[0], oz[1], oz[2], oz[3]);
-        } else {
-            dx[r * lddx + c] = od[0];
-            if (dres) dres[r * lddres + c] = oz[0];
+        for (long long r = (long long)blockIdx.x * rpi + rsub; r < rows; r += (long long)gridDim.x * rpi) {
+            const long long row = rbase + r;
+            float dv[NJ], xv[NJ], rv[NJ], od[NJ], oz[NJ];
+            if (VEC) {
+                float4 d = *reinterpret_cast<const float4*>(dy + row * lddy + c);
+                float4 v = *reinterpret_cast<const float4*>(x + row * ldx + c);
+                dv[0] = d.x; xv[0] = v.x;
+                if (NJ > 1) { dv[1] = d.y; dv[2] = d.z; dv[3] = d.w; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w; }
+                float4 q = res ? *reinterpret_cast<const float4*>(res + row * ldres + c) : make_float4(0, 0, 0, 0);
+                rv[0] = q.x;
+                if (NJ > 1) { rv[1] = q.y; rv[2] = q.z; rv[3] = q.w; }
+            } else {
+                dv[0] = dy[row * lddy + c]; xv[0] = x[row * ldx + c];
+                rv[0] = res ? res[row * ldres + c] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float xh = (xv[j] - m[j]) * rs[j];
+                const float z = fmaf(xh, ga[j], be[j]) + rv[j];
+                const float dz = dv[j] * act_grad(z, act, slope);
+                oz[j] = dz;
+                od[j] = ga[j] * rs[j] * (dz - k1[j] - xh * k2[j]);
+            }
+            if (VEC) {
+                *reinterpret_cast<float4*>(dx + row * lddx + c) = make_float4(od[0], od[NJ > 1 ? 1 : 0], od[NJ > 1 ? 2 : 0], od[NJ > 1 ? 3 : 0]);
+                if (dres) *reinterpret_cast<float4*>(dres + row * lddres + c) = make_float4(oz[0], oz[NJ > 1 ? 1 : 0], oz[NJ > 1 ? 2 : 0], oz[NJ > 1 ? 3 : 0]);
+            } else {
+                dx[row * lddx + c] = od[0];
+                if (dres) dres[row * lddres + c] = oz[0];
+            }
         }
     }
 }
 
 template <bool VEC, bool BWD>
 __global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
-        const float* __restrict__ res, int ldres, float* __restrict__ out, int ldo, long long rows, int C, int act, float slope) {
+        const float* __restrict__ res, int ldres, float* __restrict__ out, int ldo, long long rows, int C, int lanes, int rpi,
+        int act, float slope) {
     const int cw = VEC ? C / 4 : C;
-    const long long total = rows * cw;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        long long r = i / cw;
-        int c = (int)(i % cw) * (VEC ? 4 : 1);
-        if (VEC) {
-            float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
-            if (res) {
-                float4 q = *reinterpret_cast<const float4*>(res + r * ldres + c);
-                v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-            }
-            float4 o;
-            if (BWD) {
-                float4 d = *reinterpret_cast<const float4*>(dy + r * lddy + c);
-                o = make_float4(d.x * act_grad(v.x, act, slope), d.y * act_grad(v.y, act, slope),
-                                d.z * act_grad(v.z, act, slope), d.w * act_grad(v.w, act, slope));
+    const int rsub = threadIdx.x / lanes;
+    if (rsub >= rpi) return;
+    for (int cc = threadIdx.x % lanes; cc < cw; cc += lanes) {
+        const int c = cc * (VEC ? 4 : 1);
+        for (long long r = (long long)blockIdx.x * rpi + rsub; r < rows; r += (long long)gridDim.x * rpi) {
+            if (VEC) {
+                float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+                if (res) {
+                    float4 q = *reinterpret_cast<const float4*>(res + r * ldres + c);
+                    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+                }
+                float4 o;
+                if (BWD) {
+                    float4 d = *reinterpret_cast<const float4*>(dy + r * lddy + c);
+                    o = make_float4(d.x * act_grad(v.x, act, slope), d.y * act_grad(v.y, act, slope),
+                                    d.z * act_grad(v.z, act, slope), d.w * act_grad(v.w, act, slope));
+                } else {
+                    o = make_float4(act_apply(v.x, act, slope), act_apply(v.y, act, slope),
+                                    act_apply(v.z, act, slope), act_apply(v.w, act, slope));
+                }
+                *reinterpret_cast<float4*>(out + r * ldo + c) = o;
             } else {
-                o = make_float4(act_apply(v.x, act, slope), act_apply(v.y, act, slope),
-                                act_apply(v.z, act, slope), act_apply(v.w, act, slope));
+                float v = x[r * ldx + c] + (res ? res[r * ldres + c] : 0.f);
+                out[r * ldo + c] = BWD ? dy[r * lddy + c] * act_grad(v, act, slope) : act_apply(v, act, slope);
             }
-            *reinterpret_cast<float4*>(out + r * ldo + c) = o;
-        } else {
-            float v = x[r * ldx + c] + (res ? res[r * ldres + c] : 0.f);
-            out[r * ldo + c] = BWD ? dy[r * lddy + c] * act_grad(v, act, slope) : act_apply(v, act, slope);
         }
     }
 }
@@ -336,9 +358,19 @@ __global__ void rstd_from_var_kernel(const float* __restrict__ var, float eps, f
     if (c < C) rstd[c] = (float)(1.0 / sqrt((double)var[c] + (double)eps));
 }
 
-static int ew_grid(long long total) {
-    long long b = (total + 255) / 256;
-    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+// row-block grid for the elementwise kernels: ~8 rows per thread, at most 8192 blocks
+static int row_grid(long long rows, int rpi) {
+    long long b = (rows + (long long)rpi * 8 - 1) / ((long long)rpi * 8);
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+static RowMap ew_map(int C, bool vec) {
+    int cw = vec ? C / 4 : C;
+    int lanes = cw > 256 ? 256 : cw;
+    // lanes must divide 256 for a clean (row, lane) split; fall back to one row per iteration otherwise
+    RowMap m;
+    if (256 % lanes == 0) { m.lanes = lanes; m.rpi = 256 / lanes; }
+    else { m.lanes = lanes; m.rpi = 1; }
+    return m;
 }
 
 static bool vec_ok(int C, std::initializer_list<int> lds) {
@@ -448,13 +480,15 @@ int mi355seg_norm_act_fwd_f32(const float* x, int ldx, const float* mean, const 
     SEG_CHECK_ARG(act >= 0 && act <= 3, "norm_act_fwd: bad activation code %d", act);
     hipStream_t st = (hipStream_t)stream;
     bool v = vec_ok(C, {ldx, ldy, res ? ldres : 4});
-    long long total = rows * groups * (v ? C / 4 : C);
+    RowMap rm = ew_map(C, v);
+    dim3 grid(row_grid(rows, rm.rpi), groups);
+    ProfScope ps(PF_NORM, 0.0, 4.0 * rows * groups * C * (res ? 3.0 : 2.0), st);
     if (v)
-        hipLaunchKernelGGL((norm_act_fwd_kernel<true>), dim3(ew_grid(total)), dim3(256), 0, st, x, ldx, mean, rstd, gamma,
-                           beta, res, ldres, y, ldy, rows, groups, C, act, slope);
+        hipLaunchKernelGGL((norm_act_fwd_kernel<true>), grid, dim3(256), 0, st, x, ldx, mean, rstd, gamma,
+                           beta, res, ldres, y, ldy, rows, C, rm.lanes, rm.rpi, act, slope);
     else
-        hipLaunchKernelGGL((norm_act_fwd_kernel<false>), dim3(ew_grid(total)), dim3(256), 0, st, x, ldx, mean, rstd, gamma,
-                           beta, res, ldres, y, ldy, rows, groups, C, act, slope);
+        hipLaunchKernelGGL((norm_act_fwd_kernel<false>), grid, dim3(256), 0, st, x, ldx, mean, rstd, gamma,
+                           beta, res, ldres, y, ldy, rows, C, rm.lanes, rm.rpi, act, slope);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
@@ -485,13 +519,15 @@ int mi355seg_norm_act_bwd_f32(const float* dy, int lddy, const float* x, int ldx
                        groups, s1, s2, dgamma, dbeta);
     SEG_CHECK_LAUNCH();
     bool v = vec_ok(C, {lddy, ldx, lddx, res ? ldres : 4, dres ? lddres : 4});
-    long long total = rows * groups * (v ? C / 4 : C);
+    RowMap rm = ew_map(C, v);
+    dim3 grid(row_grid(rows, rm.rpi), groups);
+    ProfScope ps(PF_NORM, 0.0, 4.0 * rows * groups * C * 3.0, st);
     if (v)
-        hipLaunchKernelGGL((norm_act_bwd_apply_kernel<true>), dim3(ew_grid(total)), dim3(256), 0, st, dy, lddy, x, ldx, mean,
-                           rstd, gamma, beta, res, ldres, s1, s2, dx, lddx, dres, lddres, rows, groups, C, act, slope);
+        hipLaunchKernelGGL((norm_act_bwd_apply_kernel<true>), grid, dim3(256), 0, st, dy, lddy, x, ldx, mean,
+                           rstd, gamma, beta, res, ldres, s1, s2, dx, lddx, dres, lddres, rows, C, rm.lanes, rm.rpi, act, slope);
     else
-        hipLaunchKernelGGL((norm_act_bwd_apply_kernel<false>), dim3(ew_grid(total)), dim3(256), 0, st, dy, lddy, x, ldx, mean,
-                           rstd, gamma, beta, res, ldres, s1, s2, dx, lddx, dres, lddres, rows, groups, C, act, slope);
+        hipLaunchKernelGGL((norm_act_bwd_apply_kernel<false>), grid, dim3(256), 0, st, dy, lddy, x, ldx, mean,
+                           rstd, gamma, beta, res, ldres, s1, s2, dx, lddx, dres, lddres, rows, C, rm.lanes, rm.rpi, act, slope);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
@@ -507,13 +543,14 @@ int mi355seg_act_fwd_f32(const float* x, int ldx, const float* res, int ldres, f
                          long long rows, int C, int act, float slope, void* stream) {
     SEG_CHECK_ARG(x && y && rows > 0 && C > 0 && act >= 0 && act <= 3, "act_fwd: bad arguments");
     bool v = vec_ok(C, {ldx, ldy, res ? ldres : 4});
-    long long total = rows * (v ? C / 4 : C);
+    RowMap rm = ew_map(C, v);
+    dim3 grid(row_grid(rows, rm.rpi));
     if (v)
-        hipLaunchKernelGGL((act_kernel<true, false>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, nullptr, 0, x,
-                           ldx, res, ldres, y, ldy, rows, C, act, slope);
+        hipLaunchKernelGGL((act_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, nullptr, 0, x,
+                           ldx, res, ldres, y, ldy, rows, C, rm.lanes, rm.rpi, act, slope);
     else
-        hipLaunchKernelGGL((act_kernel<false, false>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, nullptr, 0, x,
-                           ldx, res, ldres, y, ldy, rows, C, act, slope);
+        hipLaunchKernelGGL((act_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, nullptr, 0, x,
+                           ldx, res, ldres, y, ldy, rows, C, rm.lanes, rm.rpi, act, slope);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
@@ -522,13 +559,14 @@ int mi355seg_act_bwd_f32(const float* dy, int lddy, const float* x, int ldx, con
                          float* dx, int lddx, long long rows, int C, int act, float slope, void* stream) {
     SEG_CHECK_ARG(dy && x && dx && rows > 0 && C > 0 && act >= 0 && act <= 3, "act_bwd: bad arguments");
     bool v = vec_ok(C, {lddy, ldx, lddx, res ? ldres : 4});
-    long long total = rows * (v ? C / 4 : C);
+    RowMap rm = ew_map(C, v);
+    dim3 grid(row_grid(rows, rm.rpi));
     if (v)
-        hipLaunchKernelGGL((act_kernel<true, true>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx,
-                           res, ldres, dx, lddx, rows, C, act, slope);
+        hipLaunchKernelGGL((act_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx,
+                           res, ldres, dx, lddx, rows, C, rm.lanes, rm.rpi, act, slope);
     else
-        hipLaunchKernelGGL((act_kernel<false, true>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, lddy, x,
-                           ldx, res, ldres, dx, lddx, rows, C, act, slope);
+        hipLaunchKernelGGL((act_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, dy, lddy, x,
+                           ldx, res, ldres, dx, lddx, rows, C, rm.lanes, rm.rpi, act, slope);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }

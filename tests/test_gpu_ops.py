@@ -53,6 +53,8 @@ CONV_CASES = [
     (1, 64, 64, 8, 16, 256, 3, 1, 1),      # BX=8, MB=2
     (2, 16, 16, 16, 48, 96, 3, 1, 1),      # 3 chunks, NBW=1
     (1, 8, 8, 16, 4, 32, 3, 1, 1),         # direct stem kernel, Cin=4
+    (1, 4, 8, 32, 1, 32, 3, 1, 1),         # LDS-tiled Cin=1 stem (TX=32)
+    (2, 6, 8, 64, 1, 16, 3, 1, 1),         # LDS-tiled Cin=1 stem (TX=64)
     (2, 8, 8, 8, 32, 2, 1, 1, 0),          # direct head kernel, Cout=2
     (1, 4, 4, 8, 256, 4, 1, 1, 0),         # direct head kernel, 64 lanes per voxel
     (1, 16, 16, 32, 64, 32, 1, 1, 0),      # k1 on the MFMA igemm + MFMA pointwise wgrad
@@ -92,7 +94,7 @@ def test_conv3d_fused_batch_statistics(seg):
     import ctypes
     F = seg.functional
     L = seg.lib()
-    for (N, D, H, W, Cin, Cout) in [(2, 16, 16, 32, 32, 64), (1, 8, 8, 8, 4, 8)]:
+    for (N, D, H, W, Cin, Cout) in [(2, 16, 16, 32, 32, 64), (1, 8, 8, 8, 4, 8), (2, 4, 8, 64, 1, 32)]:
         x = cl(rnd(N, Cin, D, H, W, seed=1))
         w = rnd(Cout, Cin, 3, 3, 3, seed=2, scale=0.1).cuda()
         b = rnd(Cout, seed=3).cuda()
