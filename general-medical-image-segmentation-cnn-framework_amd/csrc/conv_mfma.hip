@@ -56,6 +56,9 @@ struct IgemmArgs {
     int cpt;            // chunks per input tap  (== nchunks when in_mul == 1)
     int nNpt;           // N-tiles per output tap (== nN when out_mul == 1)
     int in_mul, out_mul;
+    int nM;             // M-tiles
+    int ksplit, cps;    // K-splits and chunks per split (nchunks == ksplit * cps)
+    long long split_stride;   // floats between the output slabs of consecutive K-splits
 };
 
 // ---------------------------------------------------------------- weight packing
@@ -86,6 +89,11 @@ __global__ void pack_wq_kernel(const float* __restrict__ w, float* __restrict__ 
 }
 
 // ---------------------------------------------------------------- the kernel
+// One virtual tile = (M-tile, N-tile, K-split) per workgroup; up to two workgroups share a CU and the
+// hardware dispatcher staggers them, so one stages its halo while the other issues MFMAs (a persistent
+// variant was measured 8-10 % slower on the large layers: co-resident workgroups fall into lockstep).
+// With ksplit > 1 (few-tile deep layers) every split writes raw partial sums to its own slab and a
+// tiny second kernel adds them in fixed order.
 template <int KS, int BX, int MB, int NBW>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
     using T = Tile<KS, BX, MB>;
@@ -99,12 +107,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
     const int h = lane >> 5, i = lane & 31;
 
     // XCD-aware block -> tile map: blocks dealt round-robin to the 8 XCDs get contiguous tile ranges,
-    // so halo-sharing neighbours and the N-tiles of one M-tile share an L2 (bijective for any grid size).
+    // so halo-sharing neighbours and the N-tiles / K-splits of one M-tile share an L2 (bijective).
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int ks = t % a.ksplit; t /= a.ksplit;
     const int ntile = t % a.nN;
-    int mt = t / a.nN;
+    const int mtile = t / a.nN;
+    int mt = mtile;
     const int txi = mt % a.ntx; mt /= a.ntx;
     const int tyi = mt % a.nty; mt /= a.nty;
     const int tzi = mt % a.ntz;
@@ -131,8 +141,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
         abase[mb] = (((line / T::TY) * T::HY + (line % T::TY)) * T::HX + xx) * PITCH + 4 * h;
     }
 
-    const int nchunks = a.nchunks;
-    const float* wlane = a.wq + (long long)ntile * nchunks * CHUNK_FLOATS + (h * NT + i) * 4;
+    const int c0 = ks * a.cps, c1 = c0 + a.cps;             // this split's chunk range
+    const float* wlane = a.wq + (long long)ntile * a.nchunks * CHUNK_FLOATS + (h * NT + i) * 4;
 
     // ---- halo staging: global -> registers (issue early) -> LDS (write late)
     f32x4 stage[T::NITER];
@@ -164,12 +174,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
         }
     };
 
-    load_stage(0);
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
+    load_stage(c0);
+    for (int chunk = c0; chunk < c1; ++chunk) {
         __syncthreads();                 // every wave is done reading the previous chunk
         write_stage();
         __syncthreads();
-        if (chunk + 1 < nchunks) load_stage(chunk + 1);
+        if (chunk + 1 < c1) load_stage(chunk + 1);
 
         const float* wp = wlane + (long long)chunk * CHUNK_FLOATS;
         f32x4 bcur[NBW], bnxt[NBW];
@@ -204,6 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
     }
 
     // ---- epilogue: bias, store, optional BatchNorm partial statistics
+    float* yout = a.y + (long long)ks * a.split_stride;
     float ssum[NBW], ssq[NBW];
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
@@ -221,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
                 const int gy = (y0 + line % T::TY) * a.out_mul + ((tapn >> 1) & 1);
                 const int gx = (x0 + xx) * a.out_mul + (tapn & 1);
                 const float val = acc[mb][nb][v] + bv;
-                a.y[((((long long)n * (a.D * a.out_mul) + gz) * (a.H * a.out_mul) + gy) * (a.W * a.out_mul) + gx) * a.ldy + col] = val;
+                yout[((((long long)n * (a.D * a.out_mul) + gz) * (a.H * a.out_mul) + gy) * (a.W * a.out_mul) + gx) * a.ldy + col] = val;
                 s1 += val; s2 += val * val;
             }
         }
@@ -240,10 +251,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) { s1 += lds[(w * NT + tid) * 2]; s2 += lds[(w * NT + tid) * 2 + 1]; }
-            const int mtile = t / a.nN;
             float* dst = a.spart + ((long long)mtile * a.Cout + n0 + tid) * 2;
             dst[0] = s1; dst[1] = s2;
         }
+    }
+}
+
+// y[r][c] = bias[c] + sum_k part[k][r][c]   (split-K second stage; fixed order)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int ksplit, long long stride,
+        const float* __restrict__ bias, float* __restrict__ y, int ldy, long long rows, int C) {
+    const int cw = C / 4;
+    const long long total = rows * cw;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long r = idx / cw;
+        const int c = (int)(idx % cw) * 4;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (bias) s = *reinterpret_cast<const f32x4*>(bias + c);
+        for (int k = 0; k < ksplit; ++k) s += *reinterpret_cast<const f32x4*>(part + k * stride + r * C + c);
+        *reinterpret_cast<f32x4*>(y + r * ldy + c) = s;
     }
 }
 
@@ -303,6 +328,7 @@ bool conv_mfma_supported(int N, int D, int H, int W, int Cin, int Cout, int k, i
     return igemm_plan(N, D, H, W, Cin, Cout, 1, &p);
 }
 
+static int pick_ksplit(int tiles, int nchunks);
 size_t conv_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
     if (!((k == 3 && pad == 1) || (k == 1 && pad == 0)) || stride != 1) return 0;
     size_t best = 0;
@@ -312,7 +338,9 @@ size_t conv_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, 
         int ci = pass ? Cout : Cin, co = pass ? Cin : Cout;
         IgemmPlan p;
         if (!igemm_plan(N, D, H, W, ci, co, 1, &p)) continue;
-        size_t need = align_up(T * Cin * Cout * sizeof(float), 256) + align_up((size_t)p.nM * co * 2 * sizeof(float), 256) + 1024;
+        const int ks = pick_ksplit(p.nM * p.nN, ci / CK);
+        size_t need = align_up(T * Cin * Cout * sizeof(float), 256) + align_up((size_t)p.nM * co * 2 * sizeof(float), 256) +
+                      (ks > 1 ? align_up((size_t)ks * N * D * H * W * co * sizeof(float), 256) + colsum_ws_bytes(co) : 0) + 1024;
         if (need > best) best = need;
     }
     size_t wg = k == 3 ? wgrad_mfma_ws_bytes(N, D, H, W, Cin, Cout) : pw_wgrad_ws_bytes((long long)N * D * H * W, Cin, Cout, 1);
@@ -342,6 +370,19 @@ static void dispatch_igemm(const IgemmPlan& p, const IgemmArgs& a, int nwg, hipS
 
 static int pack_grid(long long total) { return (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256); }
 
+static int persistent_grid(int total) { return total; }     // one virtual tile per workgroup
+
+// K-split factor for layers with too few tiles to fill 2 x 256 workgroup slots
+static int pick_ksplit(int tiles, int nchunks) {
+    int best = 1;
+    for (int k = 2; k <= 16; k *= 2) {
+        if (nchunks % k || nchunks / k < 2) break;
+        if (tiles * (k / 2) >= 512) break;
+        best = k;
+    }
+    return best;
+}
+
 // k == 3 (pad 1) or k == 1 (pad 0), stride 1
 int conv_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W,
                   int Cin, int Cout, int k, int dgrad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -349,21 +390,34 @@ int conv_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, fl
     SEG_CHECK_ARG(igemm_plan(N, D, H, W, Cin, Cout, 1, &p), "conv_fwd_mfma: unsupported shape");
     SEG_CHECK_ARG(((uintptr_t)x % 16) == 0, "conv_fwd_mfma: input pointer must be 16-byte aligned");
     const int T = k * k * k;
+    const int nchunks = Cin / CK;
+    const long long nvox = (long long)N * D * H * W;
+    const int ksplit = (ldy % 4 == 0) ? pick_ksplit(p.nM * p.nN, nchunks) : 1;
     Carver cv(ws);
     float* wq = cv.take<float>((size_t)T * Cin * Cout);
-    float* spart = ssum ? cv.take<float>((size_t)p.nM * Cout * 2) : nullptr;
-    SEG_CHECK_WS(cv.used(), ws_bytes);
+    float* spart = (ssum && ksplit == 1) ? cv.take<float>((size_t)p.nM * Cout * 2) : nullptr;
+    float* slabs = ksplit > 1 ? cv.take<float>((size_t)ksplit * nvox * Cout) : nullptr;
+    size_t tail = cv.used();
+    SEG_CHECK_WS(tail + ((ssum && ksplit > 1) ? colsum_ws_bytes(Cout) : 0), ws_bytes);
     hipLaunchKernelGGL(pack_wq_kernel, dim3(pack_grid((long long)T * Cin * Cout)), dim3(256), 0, st, w, wq, Cin, Cout, T, 32 * p.NBW, dgrad ? 1 : 0, 0);
     SEG_CHECK_LAUNCH();
-    IgemmArgs a{x, wq, bias, y, spart, ldx, ldy, N, D, H, W, Cout, p.ntx, p.nty, p.ntz, p.nN, Cin / CK, Cin / CK, p.nN, 1, 1};
-    const int nwg = p.nM * p.nN;
-    const double vox = (double)N * D * H * W;
+    IgemmArgs a{x, wq, ksplit > 1 ? nullptr : bias, ksplit > 1 ? slabs : y, spart, ldx, ksplit > 1 ? Cout : ldy, N, D, H, W, Cout,
+                p.ntx, p.nty, p.ntz, p.nN, nchunks, nchunks, p.nN, 1, 1, p.nM, ksplit, nchunks / ksplit, nvox * Cout};
+    const int nwg = persistent_grid(p.nM * p.nN * ksplit);
+    const double vox = (double)nvox;
     {
         ProfScope ps(PF_IGEMM, 2.0 * vox * T * Cin * Cout, 4.0 * (vox * (Cin + Cout) + (double)T * Cin * Cout), st);
         if (k == 3) dispatch_igemm<3>(p, a, nwg, st); else dispatch_igemm<1>(p, a, nwg, st);
         SEG_CHECK_LAUNCH();
+        if (ksplit > 1) {
+            long long tot = nvox * (Cout / 4);
+            int grid = (int)((tot + 255) / 256 > 2048 ? 2048 : (tot + 255) / 256);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, slabs, ksplit, nvox * Cout, bias, y, ldy, nvox, Cout);
+            SEG_CHECK_LAUNCH();
+        }
     }
     if (ssum) {
+        if (ksplit > 1) return channel_sums(y, ldy, nvox, Cout, ssum, ssq, nullptr, 0, (char*)ws + tail, ws_bytes - tail, st);
         hipLaunchKernelGGL(igemm_stats_finalize_kernel, dim3(Cout), dim3(256), 0, st, spart, p.nM, Cout, ssum, ssq);
         SEG_CHECK_LAUNCH();
     }
@@ -385,10 +439,11 @@ int convt_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, f
     SEG_CHECK_WS(cv.used(), ws_bytes);
     hipLaunchKernelGGL(pack_wq_kernel, dim3(pack_grid((long long)8 * Cin * Cout)), dim3(256), 0, st, w, wq, Cin, 8 * Cout, 1, 32 * p.NBW, 2, Cout);
     SEG_CHECK_LAUNCH();
-    IgemmArgs a{x, wq, bias, y, nullptr, ldx, ldy, N, D, H, W, Cout, p.ntx, p.nty, p.ntz, p.nN, Cin / CK, Cin / CK, p.nN / 8, 1, 2};
+    IgemmArgs a{x, wq, bias, y, nullptr, ldx, ldy, N, D, H, W, Cout, p.ntx, p.nty, p.ntz, p.nN, Cin / CK, Cin / CK, p.nN / 8, 1, 2,
+                p.nM, 1, Cin / CK, 0};
     const double vox = (double)N * D * H * W;
     ProfScope ps(PF_CONVT, 2.0 * vox * 8 * Cin * Cout, 4.0 * (vox * (Cin + 8.0 * Cout) + 8.0 * Cin * Cout), st);
-    dispatch_igemm<1>(p, a, p.nM * p.nN, st);
+    dispatch_igemm<1>(p, a, persistent_grid(p.nM * p.nN), st);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
@@ -403,10 +458,11 @@ int convt_dgrad_mfma(const float* dy, int lddy, const float* w, float* dx, int l
     SEG_CHECK_WS(cv.used(), ws_bytes);
     hipLaunchKernelGGL(pack_wq_kernel, dim3(pack_grid((long long)8 * Cin * Cout)), dim3(256), 0, st, w, wq, 8 * Cout, Cin, 1, 32 * p.NBW, 3, Cout);
     SEG_CHECK_LAUNCH();
-    IgemmArgs a{dy, wq, nullptr, dx, nullptr, lddy, lddx, N, D, H, W, Cin, p.ntx, p.nty, p.ntz, p.nN, 8 * Cout / CK, Cout / CK, p.nN, 2, 1};
+    IgemmArgs a{dy, wq, nullptr, dx, nullptr, lddy, lddx, N, D, H, W, Cin, p.ntx, p.nty, p.ntz, p.nN, 8 * Cout / CK, Cout / CK, p.nN, 2, 1,
+                p.nM, 1, 8 * Cout / CK, 0};
     const double vox = (double)N * D * H * W;
     ProfScope ps(PF_CONVT, 2.0 * vox * 8 * Cin * Cout, 4.0 * (vox * (Cin + 8.0 * Cout) + 8.0 * Cin * Cout), st);
-    dispatch_igemm<1>(p, a, p.nM * p.nN, st);
+    dispatch_igemm<1>(p, a, persistent_grid(p.nM * p.nN), st);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
