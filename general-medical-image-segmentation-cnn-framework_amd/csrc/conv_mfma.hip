@@ -20,6 +20,7 @@
 // channel roles swapped; only the weight packing differs.
 #include "common.h"
 #include "internal.h"
+#include <stdlib.h>
 
 namespace seg {
 
@@ -59,6 +60,7 @@ struct IgemmArgs {
     int nM;             // M-tiles
     int ksplit, cps;    // K-splits and chunks per split (nchunks == ksplit * cps)
     long long split_stride;   // floats between the output slabs of consecutive K-splits
+    int dbg;            // timing experiments only (MI355SEG_DBG): 1 no re-staging, 2 B loaded once per chunk, 4 no stores
 };
 
 // ---------------------------------------------------------------- weight packing
@@ -176,15 +178,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
 
     load_stage(c0);
     for (int chunk = c0; chunk < c1; ++chunk) {
+        const float* wp = wlane + (long long)chunk * CHUNK_FLOATS;
+        // B fragments run PFD steps ahead of the MFMAs that consume them (register ring, static indices).
+        // The ring's first PFD loads are issued BEFORE the next chunk's halo prefetch: vmcnt retires in
+        // order, so a B load queued behind 13 halo loads (possible HBM misses) would stall the first MFMAs.
+        constexpr int NSTEP = NTAP * (CK / 8);
+        constexpr int PFD = NSTEP > 4 ? 4 : 1;
+        f32x4 bq[PFD + 1][NBW];
+#pragma unroll
+        for (int d = 0; d < PFD; ++d)
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) bq[d][nb] = *reinterpret_cast<const f32x4*>(wp + d * STEP_FLOATS + nb * 128);
+        if (!(a.dbg & 1) || chunk == c0) {
         __syncthreads();                 // every wave is done reading the previous chunk
         write_stage();
         __syncthreads();
-        if (chunk + 1 < c1) load_stage(chunk + 1);
-
-        const float* wp = wlane + (long long)chunk * CHUNK_FLOATS;
-        f32x4 bcur[NBW], bnxt[NBW];
-#pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) bcur[nb] = *reinterpret_cast<const f32x4*>(wp + nb * 128);
+        }
+        if (chunk + 1 < c1 && !(a.dbg & 1)) load_stage(chunk + 1);
 #pragma unroll
         for (int tap = 0; tap < NTAP; ++tap) {
             const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
@@ -192,10 +202,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
 #pragma unroll
             for (int kk = 0; kk < CK / 8; ++kk) {
                 const int step = tap * (CK / 8) + kk;
-                if (step + 1 < NTAP * (CK / 8)) {
+                const int cur = step % (PFD + 1), fill = (step + PFD) % (PFD + 1);
+                if (step + PFD < NSTEP && !(a.dbg & 2)) {
 #pragma unroll
                     for (int nb = 0; nb < NBW; ++nb)
-                        bnxt[nb] = *reinterpret_cast<const f32x4*>(wp + (step + 1) * STEP_FLOATS + nb * 128);
+                        bq[fill][nb] = *reinterpret_cast<const f32x4*>(wp + (step + PFD) * STEP_FLOATS + nb * 128);
                 }
                 f32x4 av[MB];
 #pragma unroll
@@ -206,9 +217,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
                     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                         for (int nb = 0; nb < NBW; ++nb)
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb][s], bcur[nb][s], acc[mb][nb], 0, 0, 0);
-#pragma unroll
-                for (int nb = 0; nb < NBW; ++nb) bcur[nb] = bnxt[nb];
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb][s], bq[cur][nb][s], acc[mb][nb], 0, 0, 0);
             }
         }
     }
@@ -232,6 +241,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
                 const int gy = (y0 + line % T::TY) * a.out_mul + ((tapn >> 1) & 1);
                 const int gx = (x0 + xx) * a.out_mul + (tapn & 1);
                 const float val = acc[mb][nb][v] + bv;
+                if (!(a.dbg & 4) || val == 12345.678f)
                 yout[((((long long)n * (a.D * a.out_mul) + gz) * (a.H * a.out_mul) + gy) * (a.W * a.out_mul) + gx) * a.ldy + col] = val;
                 s1 += val; s2 += val * val;
             }
@@ -311,7 +321,9 @@ static bool igemm_plan(int N, int D, int H, int W, int Kc, int Nc, int ntaps_out
     int tz2, tz1;
     long long m2 = tiles(2, &tz2), m1 = tiles(1, &tz1);
     int MB;
-    if (m2 > 0 && m2 * nN >= 512) MB = 2;
+    static const char* force = getenv("MI355SEG_IGEMM_MB");          // tuning knob (1 or 2)
+    if (force && force[0] == '1' && m1 > 0) MB = 1;
+    else if (m2 > 0 && m2 * nN >= 512) MB = 2;
     else if (m1 > 0) MB = 1;
     else if (m2 > 0) MB = 2;
     else return false;
@@ -368,6 +380,7 @@ static void dispatch_igemm(const IgemmPlan& p, const IgemmArgs& a, int nwg, hipS
 #undef IGEMM_CASE
 }
 
+static int dbg_flags() { static const char* e = getenv("MI355SEG_DBG"); return e ? atoi(e) : 0; }
 static int pack_grid(long long total) { return (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256); }
 
 static int persistent_grid(int total) { return total; }     // one virtual tile per workgroup
@@ -402,7 +415,7 @@ int conv_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, fl
     hipLaunchKernelGGL(pack_wq_kernel, dim3(pack_grid((long long)T * Cin * Cout)), dim3(256), 0, st, w, wq, Cin, Cout, T, 32 * p.NBW, dgrad ? 1 : 0, 0);
     SEG_CHECK_LAUNCH();
     IgemmArgs a{x, wq, ksplit > 1 ? nullptr : bias, ksplit > 1 ? slabs : y, spart, ldx, ksplit > 1 ? Cout : ldy, N, D, H, W, Cout,
-                p.ntx, p.nty, p.ntz, p.nN, nchunks, nchunks, p.nN, 1, 1, p.nM, ksplit, nchunks / ksplit, nvox * Cout};
+                p.ntx, p.nty, p.ntz, p.nN, nchunks, nchunks, p.nN, 1, 1, p.nM, ksplit, nchunks / ksplit, nvox * Cout, dbg_flags()};
     const int nwg = persistent_grid(p.nM * p.nN * ksplit);
     const double vox = (double)nvox;
     {
@@ -440,7 +453,7 @@ int convt_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, f
     hipLaunchKernelGGL(pack_wq_kernel, dim3(pack_grid((long long)8 * Cin * Cout)), dim3(256), 0, st, w, wq, Cin, 8 * Cout, 1, 32 * p.NBW, 2, Cout);
     SEG_CHECK_LAUNCH();
     IgemmArgs a{x, wq, bias, y, nullptr, ldx, ldy, N, D, H, W, Cout, p.ntx, p.nty, p.ntz, p.nN, Cin / CK, Cin / CK, p.nN / 8, 1, 2,
-                p.nM, 1, Cin / CK, 0};
+                p.nM, 1, Cin / CK, 0, 0};
     const double vox = (double)N * D * H * W;
     ProfScope ps(PF_CONVT, 2.0 * vox * 8 * Cin * Cout, 4.0 * (vox * (Cin + 8.0 * Cout) + 8.0 * Cin * Cout), st);
     dispatch_igemm<1>(p, a, persistent_grid(p.nM * p.nN), st);
@@ -459,7 +472,7 @@ int convt_dgrad_mfma(const float* dy, int lddy, const float* w, float* dx, int l
     hipLaunchKernelGGL(pack_wq_kernel, dim3(pack_grid((long long)8 * Cin * Cout)), dim3(256), 0, st, w, wq, 8 * Cout, Cin, 1, 32 * p.NBW, 3, Cout);
     SEG_CHECK_LAUNCH();
     IgemmArgs a{dy, wq, nullptr, dx, nullptr, lddy, lddx, N, D, H, W, Cin, p.ntx, p.nty, p.ntz, p.nN, 8 * Cout / CK, Cout / CK, p.nN, 2, 1,
-                p.nM, 1, 8 * Cout / CK, 0};
+                p.nM, 1, 8 * Cout / CK, 0, 0};
     const double vox = (double)N * D * H * W;
     ProfScope ps(PF_CONVT, 2.0 * vox * 8 * Cin * Cout, 4.0 * (vox * (Cin + 8.0 * Cout) + 8.0 * Cin * Cout), st);
     dispatch_igemm<1>(p, a, persistent_grid(p.nM * p.nN), st);

@@ -3,9 +3,9 @@
 //   dW[tap][ci][co] = sum over voxels v of  x[v + tap][ci] * dy[v][co]
 //
 // i.e. 27 GEMMs (one per tap) with M = Cin, N = Cout and K = all output voxels.  A
-// workgroup (4 waves, one per SIMD, up to 512 registers each) owns one 32(ci) x 32(co)
-// block pair and a strip of 256-voxel spatial tiles; its 27 tap-tiles are dealt to the
-// four waves (7/7/7/6), so the whole 27 x 32 x 32 slab stays in accumulators while the
+// workgroup (8 waves, two per SIMD so each covers the other's LDS / barrier stalls) owns one
+// 32(ci) x 32(co) block pair and a strip of 256-voxel spatial tiles; its 27 tap-tiles are dealt to
+// the eight waves (4/4/4/3/3/3/3/3 = 7/7/7/6 per SIMD), so the whole 27 x 32 x 32 slab stays in accumulators while the
 // workgroup walks its strip.  Per tile the x halo (32 channels) and the dy tile live in
 // LDS; both MFMA operands are conflict-free ds_read_b32 (lanes = 32 consecutive channels
 // of one voxel) and the dy fragment of a k-step is shared by the wave's 7 MFMAs.  The
@@ -20,6 +20,10 @@ namespace seg {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+constexpr int WG_WAVES = 8;                 // 2 waves per SIMD cover each other's LDS / barrier stalls
+constexpr int WG_THREADS = WG_WAVES * 64;
+constexpr int TPW = (27 + WG_WAVES - 1) / WG_WAVES;   // tap-tiles per wave (4; waves >= 27 % 8 own one fewer)
+
 template <int BX>
 struct WTile {
     static constexpr int TY = BX == 8 ? 8 : 4;
@@ -28,8 +32,8 @@ struct WTile {
     static constexpr int HX = BX + 2, HY = TY + 2, HZ = TZ + 2;
     static constexpr int NVOX = HX * HY * HZ;
     static constexpr int XPIECES = NVOX * 8;              // 16-byte pieces of the x halo (32 ch)
-    static constexpr int XITER = (XPIECES + 255) / 256;
-    static constexpr int DYITER = 256 * 8 / 256;          // dy tile: 256 voxels x 32 ch
+    static constexpr int XITER = (XPIECES + WG_THREADS - 1) / WG_THREADS;
+    static constexpr int DYITER = 256 * 8 / WG_THREADS;   // dy tile: 256 voxels x 32 ch
     static constexpr int X_FLOATS = NVOX * 32;
     static constexpr int LDS_BYTES = (X_FLOATS + 256 * 32) * 4;
 };
@@ -40,8 +44,38 @@ struct WgradArgs {
     int ntx, nty, ntz, ntiles, nstrips, npairs, ncob;
 };
 
+// MFMAs of one staged tile for a wave that owns NT tap-tiles: 128 k-steps (2 voxels each), fully
+// unrolled so every LDS offset is an immediate, with the operands of step k+1 read before the MFMAs
+// of step k are issued (explicit one-step software pipeline; the compiler does not build it itself).
+template <int BX, int NT>
+__device__ __forceinline__ void wgrad_tile_mfma(f32x16 (&acc)[TPW], const float* __restrict__ xs, const float* __restrict__ ds,
+                                                const int (&abase)[TPW], int bbase) {
+    using T = WTile<BX>;
+    constexpr int KSTEPS = 128;
+    auto xoff = [](int ks) { const int line = ks / (BX / 2), xp = ks % (BX / 2);
+                             return (((line / T::TY) * T::HY + (line % T::TY)) * T::HX) * 32 + xp * 64; };
+    auto doff = [](int ks) { const int line = ks / (BX / 2), xp = ks % (BX / 2); return line * BX * 32 + xp * 64; };
+    float ac[NT], an[NT], bc, bn = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) { ac[tt] = xs[abase[tt] + xoff(0)]; an[tt] = 0.f; }
+    bc = ds[bbase + doff(0)];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+        if (ks + 1 < KSTEPS) {
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) an[tt] = xs[abase[tt] + xoff(ks + 1)];
+            bn = ds[bbase + doff(ks + 1)];
+        }
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[tt], bc, acc[tt], 0, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) ac[tt] = an[tt];
+        bc = bn;
+    }
+}
+
 template <int BX>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(WgradArgs a) {
     using T = WTile<BX>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;
@@ -58,20 +92,21 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgradArgs a) {
     const int cib = pair / a.ncob, cob = pair % a.ncob;
     const int ci0 = cib * 32, co0 = cob * 32;
 
-    // the (up to) 7 taps of this wave: wave, wave+4, ... ; the 7th of wave 3 is a clamped dummy
-    int abase[7];
+    // the taps of this wave: wave, wave + 8, wave + 16 (, wave + 24 for waves 0-2)
+    const bool has_last = wave + WG_WAVES * (TPW - 1) <= 26;       // wave-uniform
+    int abase[TPW];
 #pragma unroll
-    for (int tt = 0; tt < 7; ++tt) {
-        int tap = wave + 4 * tt;
+    for (int tt = 0; tt < TPW; ++tt) {
+        int tap = wave + WG_WAVES * tt;
         if (tap > 26) tap = 26;
         const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
         abase[tt] = (((dz * T::HY + dy) * T::HX + dx) + h) * 32 + i;
     }
     const int bbase = h * 32 + i;
 
-    f32x16 acc[7];
+    f32x16 acc[TPW];
 #pragma unroll
-    for (int tt = 0; tt < 7; ++tt)
+    for (int tt = 0; tt < TPW; ++tt)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[tt][v] = 0.f;
 
@@ -85,7 +120,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgradArgs a) {
         const int x0 = txi * BX, y0 = tyi * T::TY, z0 = tzi * T::TZ;
 #pragma unroll
         for (int it = 0; it < T::XITER; ++it) {
-            const int p = it * 256 + tid;
+            const int p = it * WG_THREADS + tid;
             const int vox = p >> 3, part = p & 7;
             const int hz = vox / (T::HY * T::HX), rem = vox % (T::HY * T::HX);
             const int hy = rem / T::HX, hx = rem % T::HX;
@@ -97,7 +132,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgradArgs a) {
         }
 #pragma unroll
         for (int it = 0; it < T::DYITER; ++it) {
-            const int p = it * 256 + tid;
+            const int p = it * WG_THREADS + tid;
             const int vox = p >> 3, part = p & 7;
             const int line = vox / BX, xx = vox % BX;
             const int gz = z0 + line / T::TY, gy = y0 + line % T::TY, gx = x0 + xx;
@@ -107,11 +142,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgradArgs a) {
     auto write_stage = [&]() {
 #pragma unroll
         for (int it = 0; it < T::XITER; ++it) {
-            const int p = it * 256 + tid;
+            const int p = it * WG_THREADS + tid;
             if (p < T::XPIECES) *reinterpret_cast<f32x4*>(xs + p * 4) = sx[it];
         }
 #pragma unroll
-        for (int it = 0; it < T::DYITER; ++it) *reinterpret_cast<f32x4*>(ds + (it * 256 + tid) * 4) = sd[it];
+        for (int it = 0; it < T::DYITER; ++it) *reinterpret_cast<f32x4*>(ds + (it * WG_THREADS + tid) * 4) = sd[it];
     };
 
     int tile = strip;
@@ -121,27 +156,14 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgradArgs a) {
         write_stage();
         __syncthreads();
         if (tile + a.nstrips < a.ntiles) load_stage(tile + a.nstrips);
-#pragma unroll 2
-        for (int line = 0; line < T::LINES; ++line) {
-            const int lbase = (((line / T::TY) * T::HY + (line % T::TY)) * T::HX) * 32;
-            const float* xl = xs + lbase;
-            const float* dl = ds + line * BX * 32 + bbase;
-#pragma unroll
-            for (int xp = 0; xp < BX / 2; ++xp) {
-                const float b = dl[xp * 64];
-#pragma unroll
-                for (int tt = 0; tt < 7; ++tt) {
-                    const float av = xl[abase[tt] + xp * 64];
-                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[tt], 0, 0, 0);
-                }
-            }
-        }
+        if (has_last) wgrad_tile_mfma<BX, TPW>(acc, xs, ds, abase, bbase);
+        else wgrad_tile_mfma<BX, TPW - 1>(acc, xs, ds, abase, bbase);
     }
 
     // slab store: part[strip][tap][ci][co]; rows of the 32x32 tile = ci, lanes (cols) = co
 #pragma unroll
-    for (int tt = 0; tt < 7; ++tt) {
-        const int tap = wave + 4 * tt;
+    for (int tt = 0; tt < TPW; ++tt) {
+        const int tap = wave + WG_WAVES * tt;
         if (tap > 26) break;
         float* dst = a.part + (((long long)strip * 27 + tap) * a.Cin + ci0) * a.Cout + co0 + i;
 #pragma unroll
@@ -190,10 +212,10 @@ static void launch_wgrad(const WgradArgs& a, int nwg, hipStream_t st) {
     using T = WTile<BX>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_wgrad_kernel<BX>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<BX>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_wgrad_kernel<BX>), dim3(nwg), dim3(256), T::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv_wgrad_kernel<BX>), dim3(nwg), dim3(WG_THREADS), T::LDS_BYTES, st, a);
 }
 
 int conv_wgrad_mfma(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin,
