@@ -1,0 +1,78 @@
+"""Data-parallel plumbing on CPU: two gloo ranks (the N > 1 path of bench.py / engine).
+Checks the three DDP semantics the reference gets from accelerate (train.py:167-169,211):
+mean gradient all-reduce, rank-0 buffer broadcast, global metric reduction."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Conv3d(1, 4, 3, padding=1), torch.nn.BatchNorm3d(4), torch.nn.ReLU(),
+                               torch.nn.Conv3d(4, 2, 1))
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import mi355seg
+    from mi355seg import distributed as D
+    r, w, _ = D.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and D.world_size() == world
+    model = _make_model().train()
+    # make rank-1's buffers differ, then broadcast rank 0's
+    if rank == 1:
+        for b in model.buffers():
+            b.add_(1)
+    D.broadcast_buffers(model)
+    ref = _make_model()
+    for a, b in zip(model.buffers(), ref.buffers()):
+        assert torch.equal(a, b)
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(2, 1, 4, 4, 4, generator=g)
+    model(x).square().mean().backward()
+    local = [p.grad.clone() for p in model.parameters()]
+    D.GradAllReducer(model, bucket_mb=0.0001)(model)          # tiny buckets -> several collectives
+    red = [p.grad.clone() for p in model.parameters()]
+    counts = torch.tensor([1 + rank, 2, 3, 4 * (rank + 1)], dtype=torch.int64)
+    c, l = D.all_reduce_metric(counts, torch.tensor(float(rank + 1)))
+    out[rank] = (local, red, c, l)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_and_buffer_broadcast():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    l0, r0, c0, m0 = out[0]
+    l1, r1, c1, m1 = out[1]
+    for a, b, ra, rb in zip(l0, l1, r0, r1):
+        assert torch.allclose(ra, (a + b) / 2, atol=1e-7)
+        assert torch.equal(ra, rb)                              # every rank holds the same reduced gradient
+    assert c0.tolist() == [3, 4, 6, 12] and c1.tolist() == c0.tolist()
+    assert abs(float(m0) - 1.5) < 1e-7
+
+
+def test_single_process_is_a_noop():
+    import mi355seg
+    from mi355seg import distributed as D
+    assert D.world_size() == 1
+    m = _make_model()
+    m(torch.randn(1, 1, 4, 4, 4)).sum().backward()
+    g = [p.grad.clone() for p in m.parameters()]
+    D.GradAllReducer(m)(m)
+    D.broadcast_buffers(m)
+    assert all(torch.equal(a, p.grad) for a, p in zip(g, m.parameters()))
