@@ -182,6 +182,79 @@ __global__ __launch_bounds__(256) void sums_finalize5_kernel(const double* __res
     if (threadIdx.x == 0) for (int j = 0; j < 5; ++j) out[j] = acc[j];
 }
 
+__global__ __launch_bounds__(256) void dice_sums_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
+        const double* __restrict__ g5, long long numel, int apply_sigmoid, float* __restrict__ dx) {
+    const float g0 = (float)g5[0], g1 = (float)g5[1], g3 = (float)g5[3];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (long long)gridDim.x * blockDim.x) {
+        float a = x[i], d = 1.f;
+        if (apply_sigmoid) { a = 1.f / (1.f + expf(-a)); d = a * (1.f - a); }
+        dx[i] = (g0 * t[i] + g1 + 2.f * g3 * a) * d;
+    }
+}
+
+constexpr int kMaxClasses = 16;
+
+__global__ __launch_bounds__(256) void softmax_ch_kernel(const float* __restrict__ x, float* __restrict__ y, long long N, int K, long long S) {
+    const long long total = N * S;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / S, s = i % S;
+        const float* p = x + n * K * S + s;
+        float v[kMaxClasses], m = -INFINITY;
+        for (int k = 0; k < K; ++k) { v[k] = p[(long long)k * S]; m = fmaxf(m, v[k]); }
+        float sum = 0.f;
+        for (int k = 0; k < K; ++k) { v[k] = expf(v[k] - m); sum += v[k]; }
+        const float inv = 1.f / sum;
+        float* q = y + n * K * S + s;
+        for (int k = 0; k < K; ++k) q[(long long)k * S] = v[k] * inv;
+    }
+}
+__global__ __launch_bounds__(256) void softmax_ch_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx,
+                                                              long long N, int K, long long S) {
+    const long long total = N * S;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / S, s = i % S, base = n * K * S + s;
+        float dot = 0.f;
+        for (int k = 0; k < K; ++k) dot += dy[base + (long long)k * S] * y[base + (long long)k * S];
+        for (int k = 0; k < K; ++k) dx[base + (long long)k * S] = y[base + (long long)k * S] * (dy[base + (long long)k * S] - dot);
+    }
+}
+
+__global__ __launch_bounds__(kLossThreads) void ce3d_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ lab,
+        const float* __restrict__ w, long long N, int K, long long S, double* __restrict__ part) {
+    __shared__ double sh[4];
+    double acc[1] = {0.0};
+    const long long total = N * S;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / S, s = i % S;
+        const float* p = x + n * K * S + s;
+        float m = -INFINITY;
+        for (int k = 0; k < K; ++k) m = fmaxf(m, p[(long long)k * S]);
+        float sum = 0.f;
+        for (int k = 0; k < K; ++k) sum += expf(p[(long long)k * S] - m);
+        const int l = (int)lab[i];
+        const float nll = (m + logf(sum)) - p[(long long)l * S];
+        acc[0] += (double)(w ? w[l] * nll : nll);
+    }
+    block_sum<1>(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc[0];
+}
+__global__ __launch_bounds__(256) void ce3d_bwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ lab, const float* __restrict__ w,
+        const float* __restrict__ gscale, long long N, int K, long long S, float inv_count, float* __restrict__ dx) {
+    const long long total = N * S;
+    const float g = gscale[0] * inv_count;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / S, s = i % S, base = n * K * S + s;
+        float m = -INFINITY;
+        for (int k = 0; k < K; ++k) m = fmaxf(m, x[base + (long long)k * S]);
+        float sum = 0.f;
+        for (int k = 0; k < K; ++k) sum += expf(x[base + (long long)k * S] - m);
+        const int l = (int)lab[i];
+        const float sc = g * (w ? w[l] : 1.f), inv = 1.f / sum;
+        for (int k = 0; k < K; ++k)
+            dx[base + (long long)k * S] = sc * (expf(x[base + (long long)k * S] - m) * inv - (k == l ? 1.f : 0.f));
+    }
+}
+
 }  // namespace seg
 
 using namespace seg;
@@ -265,6 +338,48 @@ int mi355seg_dice_sums_f32(const float* x, const float* t, long long numel, int 
     hipLaunchKernelGGL(dice_sums_kernel, dim3(nblk), dim3(kLossThreads), 0, st, x, t, numel, apply_sigmoid, (double*)ws);
     SEG_CHECK_LAUNCH();
     hipLaunchKernelGGL(sums_finalize5_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nblk, out5);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+int mi355seg_dice_sums_bwd_f32(const float* x, const float* t, const double* g5, long long numel, int apply_sigmoid,
+                               float* dx, void* stream) {
+    SEG_CHECK_ARG(x && t && g5 && dx && numel > 0, "dice_sums_bwd: bad arguments");
+    hipLaunchKernelGGL(dice_sums_bwd_kernel, dim3(loss_grid(numel) * 2), dim3(256), 0, (hipStream_t)stream, x, t, g5, numel, apply_sigmoid, dx);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+int mi355seg_softmax_ch_f32(const float* x, float* y, long long N, int K, long long S, void* stream) {
+    SEG_CHECK_ARG(x && y && N > 0 && K > 0 && K <= kMaxClasses && S > 0, "softmax_ch: bad arguments (K <= %d)", kMaxClasses);
+    hipLaunchKernelGGL(softmax_ch_kernel, dim3(loss_grid(N * S) * 2), dim3(256), 0, (hipStream_t)stream, x, y, N, K, S);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_softmax_ch_bwd_f32(const float* y, const float* dy, float* dx, long long N, int K, long long S, void* stream) {
+    SEG_CHECK_ARG(y && dy && dx && N > 0 && K > 0 && S > 0, "softmax_ch_bwd: bad arguments");
+    hipLaunchKernelGGL(softmax_ch_bwd_kernel, dim3(loss_grid(N * S) * 2), dim3(256), 0, (hipStream_t)stream, y, dy, dx, N, K, S);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+int mi355seg_ce3d_fwd_f32(const float* logits, const int64_t* labels, const float* weight, long long N, int K, long long S,
+                          int size_average, float* loss, void* ws, size_t ws_bytes, void* stream) {
+    SEG_CHECK_ARG(logits && labels && loss && N > 0 && K > 0 && S > 0, "ce3d_fwd: bad arguments");
+    int nblk = loss_grid(N * S);
+    SEG_CHECK_WS((size_t)nblk * sizeof(double), ws_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ce3d_fwd_kernel, dim3(nblk), dim3(kLossThreads), 0, st, logits, labels, weight, N, K, S, (double*)ws);
+    SEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nblk, size_average ? (double)(N * S) : 1.0, loss);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_ce3d_bwd_f32(const float* logits, const int64_t* labels, const float* weight, const float* gscale,
+                          long long N, int K, long long S, int size_average, float* dlogits, void* stream) {
+    SEG_CHECK_ARG(logits && labels && gscale && dlogits && N > 0 && K > 0 && S > 0, "ce3d_bwd: bad arguments");
+    hipLaunchKernelGGL(ce3d_bwd_kernel, dim3(loss_grid(N * S) * 2), dim3(256), 0, (hipStream_t)stream, logits, labels, weight, gscale,
+                       N, K, S, size_average ? 1.f / (float)(N * S) : 1.f, dlogits);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }

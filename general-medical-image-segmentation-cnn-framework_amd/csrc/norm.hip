@@ -44,14 +44,31 @@ static bool red_plan(long long rows, int C, int ld, RedPlan* p) {
 // Generic two-sum column reduction.  F::eval(row, c, ...) returns the two addends of an
 // element.  Partials: part[((g*nblk + b)*C + c)*2 + {0,1}].
 // ---------------------------------------------------------------------------------------
-struct StatsF {     // sum x, sum x^2
-    const float* x; int ldx;
-    __device__ __forceinline__ void eval(long long r, int g, int c, int C, float& a, float& b) const {
-        float v = x[r * ldx + c];
+// pivot of channel c in group g: the mean of 8 samples spread over the group's rows.  Sums are taken of
+// (x - pivot), so var = E[(x-p)^2] - E[x-p]^2 does not cancel when |mean| >> std (nearly constant channels).
+__device__ __forceinline__ float stats_pivot(const float* __restrict__ x, int ldx, long long rbase, long long rows, int c) {
+    float p = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p += x[(rbase + (rows * k) / 8) * ldx + c];
+    return p * 0.125f;
+}
+
+struct StatsF {     // sum (x - pivot), sum (x - pivot)^2 ; pivots fetched once per thread
+    const float* x; int ldx; long long rows;
+    struct State { float p[4]; };
+    __device__ __forceinline__ State prepC(int g, int c, int nj, int C) const { return prep(g, c, nj); }
+    __device__ __forceinline__ State prep(int g, int c, int nj) const {
+        State s;
+        for (int j = 0; j < 4; ++j) s.p[j] = j < nj ? stats_pivot(x, ldx, (long long)g * rows, rows, c + j) : 0.f;
+        return s;
+    }
+    __device__ __forceinline__ void eval(const State& st, long long r, int g, int c, int C, float& a, float& b) const {
+        float v = x[r * ldx + c] - st.p[0];
         a = v; b = v * v;
     }
-    __device__ __forceinline__ void eval4(long long r, int g, int c, int C, float4& a, float4& b) const {
+    __device__ __forceinline__ void eval4(const State& st, long long r, int g, int c, int C, float4& a, float4& b) const {
         float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        v.x -= st.p[0]; v.y -= st.p[1]; v.z -= st.p[2]; v.w -= st.p[3];
         a = v; b = make_float4(v.x * v.x, v.y * v.y, v.z * v.z, v.w * v.w);
     }
 };
@@ -59,25 +76,34 @@ struct StatsF {     // sum x, sum x^2
 struct BwdF {       // sum dz, sum dz*xhat  with dz = dy*act'(z), z = xhat*gamma+beta (+res)
     const float* dy; int lddy; const float* x; int ldx; const float* mean; const float* rstd;
     const float* gamma; const float* beta; const float* res; int ldres; int act; float slope;
-    __device__ __forceinline__ void one(long long r, int g, int c, int C, float dyv, float xv, float rv, float& a, float& b) const {
-        float m = mean[g * C + c], rs = rstd[g * C + c];
-        float xh = (xv - m) * rs;
-        float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-        float z = fmaf(xh, ga, be) + rv;
+    struct State { float m[4], rs[4], ga[4], be[4]; };
+    __device__ __forceinline__ State prep(int g, int c, int nj) const { return State(); }
+    __device__ __forceinline__ State prepC(int g, int c, int nj, int C) const {
+        State s;
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = j < nj;
+            s.m[j] = ok ? mean[g * C + c + j] : 0.f; s.rs[j] = ok ? rstd[g * C + c + j] : 0.f;
+            s.ga[j] = (ok && gamma) ? gamma[c + j] : 1.f; s.be[j] = (ok && beta) ? beta[c + j] : 0.f;
+        }
+        return s;
+    }
+    __device__ __forceinline__ void one(const State& st, int j, float dyv, float xv, float rv, float& a, float& b) const {
+        float xh = (xv - st.m[j]) * st.rs[j];
+        float z = fmaf(xh, st.ga[j], st.be[j]) + rv;
         float dz = dyv * act_grad(z, act, slope);
         a = dz; b = dz * xh;
     }
-    __device__ __forceinline__ void eval(long long r, int g, int c, int C, float& a, float& b) const {
-        one(r, g, c, C, dy[r * lddy + c], x[r * ldx + c], res ? res[r * ldres + c] : 0.f, a, b);
+    __device__ __forceinline__ void eval(const State& st, long long r, int g, int c, int C, float& a, float& b) const {
+        one(st, 0, dy[r * lddy + c], x[r * ldx + c], res ? res[r * ldres + c] : 0.f, a, b);
     }
-    __device__ __forceinline__ void eval4(long long r, int g, int c, int C, float4& a, float4& b) const {
+    __device__ __forceinline__ void eval4(const State& st, long long r, int g, int c, int C, float4& a, float4& b) const {
         float4 d = *reinterpret_cast<const float4*>(dy + r * lddy + c);
         float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
         float4 rr = res ? *reinterpret_cast<const float4*>(res + r * ldres + c) : make_float4(0, 0, 0, 0);
-        one(r, g, c + 0, C, d.x, v.x, rr.x, a.x, b.x);
-        one(r, g, c + 1, C, d.y, v.y, rr.y, a.y, b.y);
-        one(r, g, c + 2, C, d.z, v.z, rr.z, a.z, b.z);
-        one(r, g, c + 3, C, d.w, v.w, rr.w, a.w, b.w);
+        one(st, 0, d.x, v.x, rr.x, a.x, b.x);
+        one(st, 1, d.y, v.y, rr.y, a.y, b.y);
+        one(st, 2, d.z, v.z, rr.z, a.z, b.z);
+        one(st, 3, d.w, v.w, rr.w, a.w, b.w);
     }
 };
 
@@ -95,9 +121,10 @@ __global__ __launch_bounds__(kRedThreads) void colreduce2_kernel(F f, long long 
     if (VEC) {
         float4 sa = make_float4(0, 0, 0, 0), sb = sa;
         if (active) {
+            const typename F::State fst = f.prepC(g, lane * 4, 4, C);
             for (long long r = (long long)blockIdx.x * rpi + rsub; r < rows; r += (long long)nblk * rpi) {
                 float4 a, b;
-                f.eval4(rbase + r, g, lane * 4, C, a, b);
+                f.eval4(fst, rbase + r, g, lane * 4, C, a, b);
                 sa.x += a.x; sa.y += a.y; sa.z += a.z; sa.w += a.w;
                 sb.x += b.x; sb.y += b.y; sb.z += b.z; sb.w += b.w;
             }
@@ -120,9 +147,10 @@ __global__ __launch_bounds__(kRedThreads) void colreduce2_kernel(F f, long long 
     } else {
         float sa = 0.f, sb = 0.f;
         if (active) {
+            const typename F::State fst = f.prepC(g, lane, 1, C);
             for (long long r = (long long)blockIdx.x * rpi + rsub; r < rows; r += (long long)nblk * rpi) {
                 float a, b;
-                f.eval(rbase + r, g, lane, C, a, b);
+                f.eval(fst, rbase + r, g, lane, C, a, b);
                 sa += a; sb += b;
             }
         }
@@ -159,7 +187,8 @@ static int launch_colreduce2(const F& f, long long rows, int groups, int C, int 
 // shuffle reduction -> fixed summation order (deterministic).
 __global__ __launch_bounds__(64) void stats_finalize_kernel(const float* __restrict__ part, int nblk, int C, int groups, double rows,
                                       float eps, float* __restrict__ mean, float* __restrict__ rstd,
-                                      float* __restrict__ rmean, float* __restrict__ rvar, float momentum) {
+                                      float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
+                                      const float* __restrict__ x, int ldx) {
     const int i = blockIdx.x;
     const int g = i / C, c = i % C;
     double s = 0.0, q = 0.0;
@@ -169,9 +198,10 @@ __global__ __launch_bounds__(64) void stats_finalize_kernel(const float* __restr
     }
     s = wave_sum(s); q = wave_sum(q);
     if (threadIdx.x != 0) return;
-    double m = s / rows;
+    double m = s / rows;                              // mean of (x - pivot)
     double var = q / rows - m * m;
     if (var < 0.0) var = 0.0;
+    m += (double)stats_pivot(x, ldx, (long long)g * (long long)rows, (long long)rows, c);
     mean[i] = (float)m;
     rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
     if (rmean) {
@@ -353,6 +383,30 @@ __global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ dy, 
     }
 }
 
+template <bool VEC>
+__global__ __launch_bounds__(256) void scale_channels_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
+        float* __restrict__ y, int ldy, long long rows, int C, int lanes, int rpi) {
+    const int g = blockIdx.y;
+    const int cw = VEC ? C / 4 : C;
+    const int rsub = threadIdx.x / lanes;
+    if (rsub >= rpi) return;
+    const long long rbase = (long long)g * rows;
+    for (int cc = threadIdx.x % lanes; cc < cw; cc += lanes) {
+        const int c = cc * (VEC ? 4 : 1);
+        float4 sc = make_float4(scale[g * C + c], 0, 0, 0);
+        if (VEC) { sc.y = scale[g * C + c + 1]; sc.z = scale[g * C + c + 2]; sc.w = scale[g * C + c + 3]; }
+        for (long long r = (long long)blockIdx.x * rpi + rsub; r < rows; r += (long long)gridDim.x * rpi) {
+            const long long row = rbase + r;
+            if (VEC) {
+                float4 v = *reinterpret_cast<const float4*>(x + row * ldx + c);
+                *reinterpret_cast<float4*>(y + row * ldy + c) = make_float4(v.x * sc.x, v.y * sc.y, v.z * sc.z, v.w * sc.w);
+            } else {
+                y[row * ldy + c] = x[row * ldx + c] * sc.x;
+            }
+        }
+    }
+}
+
 __global__ void rstd_from_var_kernel(const float* __restrict__ var, float eps, float* __restrict__ rstd, int C) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < C) rstd[c] = (float)(1.0 / sqrt((double)var[c] + (double)eps));
@@ -383,10 +437,13 @@ static bool vec_ok(int C, std::initializer_list<int> lds) {
 // on the generic path).  part must hold nblk*C*2 floats.
 struct SumF {
     const float* x; int ldx;
-    __device__ __forceinline__ void eval(long long r, int g, int c, int C, float& a, float& b) const {
+    struct State { int dummy; };
+    __device__ __forceinline__ State prep(int g, int c, int nj) const { return State{0}; }
+    __device__ __forceinline__ State prepC(int g, int c, int nj, int C) const { return State{0}; }
+    __device__ __forceinline__ void eval(const State&, long long r, int g, int c, int C, float& a, float& b) const {
         float v = x[r * ldx + c]; a = v; b = v * v;
     }
-    __device__ __forceinline__ void eval4(long long r, int g, int c, int C, float4& a, float4& b) const {
+    __device__ __forceinline__ void eval4(const State&, long long r, int g, int c, int C, float4& a, float4& b) const {
         float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
         a = v; b = make_float4(v.x * v.x, v.y * v.y, v.z * v.z, v.w * v.w);
     }
@@ -453,11 +510,11 @@ int mi355seg_norm_stats_f32(const float* x, int ldx, long long rows, int groups,
     SEG_CHECK_WS(need, ws_bytes);
     float* part = (float*)ws;
     hipStream_t st = (hipStream_t)stream;
-    StatsF f{x, ldx};
+    StatsF f{x, ldx, rows};
     int rc = launch_colreduce2(f, rows, groups, C, ldx, part, &p, st);
     if (rc) return rc;
     hipLaunchKernelGGL(stats_finalize_kernel, dim3(groups * C), dim3(64), 0, st, part, p.nblk, C,
-                       groups, (double)rows, eps, mean, rstd, running_mean, running_var, momentum);
+                       groups, (double)rows, eps, mean, rstd, running_mean, running_var, momentum, x, ldx);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
@@ -535,6 +592,18 @@ int mi355seg_norm_act_bwd_f32(const float* dy, int lddy, const float* x, int ldx
 int mi355seg_rstd_from_var_f32(const float* var, float eps, float* rstd, int C, void* stream) {
     SEG_CHECK_ARG(var && rstd && C > 0, "rstd_from_var: bad arguments");
     hipLaunchKernelGGL(rstd_from_var_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, var, eps, rstd, C);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+int mi355seg_scale_channels_f32(const float* x, int ldx, const float* scale, float* y, int ldy,
+                                long long rows, int groups, int C, void* stream) {
+    SEG_CHECK_ARG(x && scale && y && rows > 0 && groups > 0 && C > 0 && ldx >= C && ldy >= C, "scale_channels: bad arguments");
+    bool v = vec_ok(C, {ldx, ldy});
+    RowMap rm = ew_map(C, v);
+    dim3 grid(row_grid(rows, rm.rpi), groups);
+    if (v) hipLaunchKernelGGL((scale_channels_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, scale, y, ldy, rows, C, rm.lanes, rm.rpi);
+    else hipLaunchKernelGGL((scale_channels_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, scale, y, ldy, rows, C, rm.lanes, rm.rpi);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }

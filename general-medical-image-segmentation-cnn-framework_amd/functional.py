@@ -290,6 +290,34 @@ def activation(x, act, slope=0.01, residual=None):
     return _Act.apply(x, residual, int(act), float(slope))
 
 
+class _ScaleChannels(Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        x, ldx = cl_view(x, "dropout input")
+        N, D, H, W, C = x.shape
+        scale = scale.contiguous().to(torch.float32)
+        if scale.numel() != N * C:
+            raise Mi355SegError(f"scale_channels: scale must hold N*C = {N * C} values, got {scale.numel()}")
+        y = torch.empty((N, D, H, W, C), dtype=x.dtype, device=x.device)
+        lib().call("mi355seg_scale_channels_f32", _p(x), ldx, _p(scale), _p(y), C, D * H * W, N, C, _stream())
+        ctx.save_for_backward(scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (scale,) = ctx.saved_tensors
+        dy, lddy = cl_view(dy, "dropout grad")
+        N, D, H, W, C = dy.shape
+        dx = torch.empty((N, D, H, W, C), dtype=dy.dtype, device=dy.device)
+        lib().call("mi355seg_scale_channels_f32", _p(dy), lddy, _p(scale), _p(dx), C, D * H * W, N, C, _stream())
+        return dx, None
+
+
+def scale_channels(x, scale):
+    """y[n,...,c] = x[n,...,c] * scale[n,c] -- the arithmetic of nn.Dropout3d given its mask."""
+    return _ScaleChannels.apply(x, scale)
+
+
 # ----------------------------------------------------------------------------- pool / upsample
 class _MaxPool2(Function):
     @staticmethod
@@ -422,3 +450,90 @@ def dice_sums(x, t, apply_sigmoid=False):
     out = torch.empty(5, dtype=torch.float64, device=x.device)
     L.call("mi355seg_dice_sums_f32", _p(x), _p(t), x.numel(), int(bool(apply_sigmoid)), _p(out), _p(ws), ws.numel(), _stream())
     return out
+
+
+class _DiceSums(Function):
+    """S = (sum a*t, sum a, sum t, sum a*a, sum t*t) with autograd w.r.t. x (a = sigmoid(x) or x)."""
+
+    @staticmethod
+    def forward(ctx, x, t, apply_sigmoid):
+        x, t = x.contiguous(), t.contiguous().to(torch.float32)
+        out = dice_sums(x, t, apply_sigmoid)
+        ctx.save_for_backward(x, t)
+        ctx.apply_sigmoid = bool(apply_sigmoid)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t = ctx.saved_tensors
+        g = g.contiguous().to(torch.float64)
+        dx = torch.empty_like(x)
+        lib().call("mi355seg_dice_sums_bwd_f32", _p(x), _p(t), _p(g), x.numel(), int(ctx.apply_sigmoid), _p(dx), _stream())
+        return dx, None, None
+
+
+def dice_sums_autograd(x, t, apply_sigmoid=False):
+    return _DiceSums.apply(x, t, apply_sigmoid)
+
+
+class _SoftmaxCh(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_cuda(x, "softmax input")
+        x = x.contiguous()
+        N, K = x.shape[0], x.shape[1]
+        S = x[0, 0].numel()
+        y = torch.empty_like(x)
+        lib().call("mi355seg_softmax_ch_f32", _p(x), _p(y), N, K, S, _stream())
+        ctx.save_for_backward(y)
+        ctx.geom = (N, K, S)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        N, K, S = ctx.geom
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        lib().call("mi355seg_softmax_ch_bwd_f32", _p(y), _p(dy), _p(dx), N, K, S, _stream())
+        return dx
+
+
+def softmax_channels(x):
+    """torch.softmax(x, dim=1) for an NCDHW tensor."""
+    return _SoftmaxCh.apply(x)
+
+
+class _CE3D(Function):
+    @staticmethod
+    def forward(ctx, logits, labels, weight, size_average):
+        _require_cuda(logits, "cross_entropy_3D input")
+        logits = logits.contiguous()
+        labels = labels.contiguous().to(torch.int64)
+        N, K = logits.shape[0], logits.shape[1]
+        S = logits[0, 0].numel()
+        if labels.numel() != N * S:
+            raise ValueError(f"Expected target size {N * S}, got {labels.numel()}")
+        if weight is not None:
+            weight = weight.to(device=logits.device, dtype=torch.float32).contiguous()
+        L = lib()
+        ws = workspace(L.query("mi355seg_loss_ws_bytes", logits.numel()), logits.device)
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        L.call("mi355seg_ce3d_fwd_f32", _p(logits), _p(labels), _p(weight), N, K, S, int(bool(size_average)), _p(loss),
+               _p(ws), ws.numel(), _stream())
+        ctx.save_for_backward(logits, labels, weight)
+        ctx.cfg = (N, K, S, int(bool(size_average)))
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, weight = ctx.saved_tensors
+        N, K, S, sa = ctx.cfg
+        g = g.contiguous().to(torch.float32)
+        d = torch.empty_like(logits)
+        lib().call("mi355seg_ce3d_bwd_f32", _p(logits), _p(labels), _p(weight), _p(g), N, K, S, sa, _p(d), _stream())
+        return d, None, None, None
+
+
+def cross_entropy_3d(logits, labels, weight=None, size_average=True):
+    return _CE3D.apply(logits, labels, weight, size_average)

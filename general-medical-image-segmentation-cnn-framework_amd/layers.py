@@ -78,6 +78,26 @@ class Upsample(nn.Upsample):
         return F.upsample_nearest_2x(x)
 
 
+class Dropout3d(nn.Dropout3d):
+    """nn.Dropout3d: whole channels of a sample are zeroed with probability p and the rest scaled by
+    1/(1-p).  The keep-mask comes from the device RNG; parity tests inject the oracle's mask through
+    ``forced_masks`` (a list consumed front to back, each a bool/float tensor [N, C])."""
+
+    def __init__(self, p=0.5, inplace=False):
+        super().__init__(p, inplace)
+        self.forced_masks = []
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        N, C = x.shape[0], x.shape[-1]
+        if self.forced_masks:
+            keep = self.forced_masks.pop(0).to(device=x.device, dtype=torch.float32).reshape(N, C)
+        else:
+            keep = torch.bernoulli(torch.full((N, C), 1.0 - self.p, device=x.device))
+        return F.scale_channels(x, keep / (1.0 - self.p))
+
+
 class ReLU(nn.ReLU):
     def forward(self, x):
         return F.activation(x, F.ACT_RELU)

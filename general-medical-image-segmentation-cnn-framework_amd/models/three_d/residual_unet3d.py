@@ -1,0 +1,142 @@
+"""Residual U-Net (Isensee et al.) on the MI355X kernels -- drop-in for the reference's
+models/three_d/residual_unet3d.py (class ``UNet``).
+
+Same constructor (``UNet(in_channels, n_classes, base_n_filter=8)``, residual_unet3d.py:11), the
+same 26 conv-weight ``state_dict`` keys and forward semantics
+(residual_unet3d.py:109-204): bias-free convs, InstanceNorm3d without affine fused with
+LeakyReLU(0.01), Dropout3d(0.6), nearest x2 upsampling, weight-shared
+``norm_lrelu_conv_c{2..5}`` applied twice per level (autograd accumulates both weight
+gradients), deep-supervision sum.
+"""
+import torch
+import torch.nn as nn
+
+from ... import functional as F
+from ...layers import Conv3d, Dropout3d, InstanceNorm3d, LeakyReLU, Upsample
+
+_LRELU = (F.ACT_LRELU, 0.01)
+
+
+class _NormLreluConv(nn.Sequential):
+    """[InstanceNorm3d, LeakyReLU, Conv3d] with the norm and activation fused (keys '.2.weight')."""
+
+    def forward(self, x):
+        norm, _act, conv = self.children()
+        return conv(norm.forward_act(x, *_LRELU))
+
+
+class _ConvNormLrelu(nn.Sequential):
+    """[Conv3d, InstanceNorm3d, LeakyReLU] (keys '.0.weight')."""
+
+    def forward(self, x):
+        conv, norm, _act = self.children()
+        return norm.forward_act(conv(x), *_LRELU)
+
+
+class _NormLreluUpConvNormLrelu(nn.Sequential):
+    """[InstanceNorm3d, LeakyReLU, Upsample, Conv3d, InstanceNorm3d, LeakyReLU] (keys '.3.weight')."""
+
+    def forward(self, x):
+        n0, _a0, up, conv, n1, _a1 = self.children()
+        return n1.forward_act(conv(up(n0.forward_act(x, *_LRELU))), *_LRELU)
+
+
+def _conv3(cin, cout, stride=1):
+    return Conv3d(cin, cout, kernel_size=3, stride=stride, padding=1, bias=False)
+
+
+def _conv1(cin, cout):
+    return Conv3d(cin, cout, kernel_size=1, stride=1, padding=0, bias=False)
+
+
+class UNet(nn.Module):
+    def __init__(self, in_channels, n_classes, base_n_filter=8):
+        super().__init__()
+        self.in_channels = in_channels
+        self.n_classes = n_classes
+        self.base_n_filter = b = base_n_filter
+        self.lrelu = LeakyReLU()
+        self.dropout3d = Dropout3d(p=0.6)
+        self.upsacle = Upsample(scale_factor=2, mode="nearest")
+        self.softmax = nn.Softmax(dim=1)          # unused members kept for attribute parity
+        self.sigmoid = nn.Sigmoid()
+
+        self.conv3d_c1_1 = _conv3(in_channels, b)
+        self.conv3d_c1_2 = _conv3(b, b)
+        self.lrelu_conv_c1 = self.lrelu_conv(b, b)
+        self.inorm3d_c1 = InstanceNorm3d(b)
+        self.conv3d_c2 = _conv3(b, b * 2, 2)
+        self.norm_lrelu_conv_c2 = self.norm_lrelu_conv(b * 2, b * 2)
+        self.inorm3d_c2 = InstanceNorm3d(b * 2)
+        self.conv3d_c3 = _conv3(b * 2, b * 4, 2)
+        self.norm_lrelu_conv_c3 = self.norm_lrelu_conv(b * 4, b * 4)
+        self.inorm3d_c3 = InstanceNorm3d(b * 4)
+        self.conv3d_c4 = _conv3(b * 4, b * 8, 2)
+        self.norm_lrelu_conv_c4 = self.norm_lrelu_conv(b * 8, b * 8)
+        self.inorm3d_c4 = InstanceNorm3d(b * 8)
+        self.conv3d_c5 = _conv3(b * 8, b * 16, 2)
+        self.norm_lrelu_conv_c5 = self.norm_lrelu_conv(b * 16, b * 16)
+        self.norm_lrelu_upscale_conv_norm_lrelu_l0 = self.norm_lrelu_upscale_conv_norm_lrelu(b * 16, b * 8)
+        self.conv3d_l0 = _conv1(b * 8, b * 8)
+        self.inorm3d_l0 = InstanceNorm3d(b * 8)
+        self.conv_norm_lrelu_l1 = self.conv_norm_lrelu(b * 16, b * 16)
+        self.conv3d_l1 = _conv1(b * 16, b * 8)
+        self.norm_lrelu_upscale_conv_norm_lrelu_l1 = self.norm_lrelu_upscale_conv_norm_lrelu(b * 8, b * 4)
+        self.conv_norm_lrelu_l2 = self.conv_norm_lrelu(b * 8, b * 8)
+        self.conv3d_l2 = _conv1(b * 8, b * 4)
+        self.norm_lrelu_upscale_conv_norm_lrelu_l2 = self.norm_lrelu_upscale_conv_norm_lrelu(b * 4, b * 2)
+        self.conv_norm_lrelu_l3 = self.conv_norm_lrelu(b * 4, b * 4)
+        self.conv3d_l3 = _conv1(b * 4, b * 2)
+        self.norm_lrelu_upscale_conv_norm_lrelu_l3 = self.norm_lrelu_upscale_conv_norm_lrelu(b * 2, b)
+        self.conv_norm_lrelu_l4 = self.conv_norm_lrelu(b * 2, b * 2)
+        self.conv3d_l4 = _conv1(b * 2, n_classes)
+        self.ds2_1x1_conv3d = _conv1(b * 8, n_classes)
+        self.ds3_1x1_conv3d = _conv1(b * 4, n_classes)
+
+    # the reference's factory names (residual_unet3d.py:82-107)
+    def conv_norm_lrelu(self, feat_in, feat_out):
+        return _ConvNormLrelu(_conv3(feat_in, feat_out), InstanceNorm3d(feat_out), LeakyReLU())
+
+    def norm_lrelu_conv(self, feat_in, feat_out):
+        return _NormLreluConv(InstanceNorm3d(feat_in), LeakyReLU(), _conv3(feat_in, feat_out))
+
+    def lrelu_conv(self, feat_in, feat_out):
+        return nn.Sequential(LeakyReLU(), _conv3(feat_in, feat_out))
+
+    def norm_lrelu_upscale_conv_norm_lrelu(self, feat_in, feat_out):
+        return _NormLreluUpConvNormLrelu(InstanceNorm3d(feat_in), LeakyReLU(), Upsample(scale_factor=2, mode="nearest"),
+                                         _conv3(feat_in, feat_out), InstanceNorm3d(feat_out), LeakyReLU())
+
+    def forward(self, x):
+        h = F.to_channels_last(x)
+        # level 1 context (:110-121): the sum feeds LeakyReLU (context_1) and InstanceNorm->LeakyReLU
+        h = self.conv3d_c1_1(h)
+        res = h
+        h = self.conv3d_c1_2(self.lrelu(h))
+        h = self.lrelu_conv_c1(self.dropout3d(h))
+        h = F.activation(h, F.ACT_NONE, residual=res)
+        ctx = [self.lrelu(h)]
+        h = self.inorm3d_c1.forward_act(h, *_LRELU)
+        for lvl in (2, 3, 4, 5):                               # (:123-168)
+            h = getattr(self, f"conv3d_c{lvl}")(h)
+            res = h
+            blk = getattr(self, f"norm_lrelu_conv_c{lvl}")     # shared weights, applied twice
+            h = blk(self.dropout3d(blk(h)))
+            h = F.activation(h, F.ACT_NONE, residual=res)
+            if lvl < 5:
+                h = getattr(self, f"inorm3d_c{lvl}").forward_act(h, *_LRELU)
+                ctx.append(h)
+        h = self.norm_lrelu_upscale_conv_norm_lrelu_l0(h)
+        h = self.inorm3d_l0.forward_act(self.conv3d_l0(h), *_LRELU)
+        ds = {}
+        for lvl in (1, 2, 3):                                  # localisation (:174-194)
+            h = torch.cat([h, ctx[4 - lvl]], dim=-1)
+            h = getattr(self, f"conv_norm_lrelu_l{lvl}")(h)
+            ds[lvl] = h
+            h = getattr(self, f"conv3d_l{lvl}")(h)
+            h = getattr(self, f"norm_lrelu_upscale_conv_norm_lrelu_l{lvl}")(h)
+        h = torch.cat([h, ctx[0]], dim=-1)
+        out_pred = self.conv3d_l4(self.conv_norm_lrelu_l4(h))
+        s = F.activation(self.upsacle(self.ds2_1x1_conv3d(ds[2])), F.ACT_NONE, residual=self.ds3_1x1_conv3d(ds[3]))
+        out = F.activation(out_pred, F.ACT_NONE, residual=self.upsacle(s))
+        return F.to_channels_first(out)

@@ -136,6 +136,12 @@ int mi355seg_act_fwd_f32(const float* x, int ldx, const float* res, int ldres, f
 int mi355seg_act_bwd_f32(const float* dy, int lddy, const float* x, int ldx, const float* res, int ldres,
                          float* dx, int lddx, long long rows, int C, int act, float slope, void* stream);
 
+/* nn.Dropout3d (vnet3d.py:90,99; residual_unet3d.py:18): y[r,c] = x[r,c] * scale[g*C + c], the per-(sample,
+ * channel) keep-mask / (1-p) being supplied by the caller (device RNG in production, the oracle's mask in
+ * parity tests).  The backward is the same call on dy. */
+int mi355seg_scale_channels_f32(const float* x, int ldx, const float* scale, float* y, int ldy,
+                                long long rows, int groups, int C, void* stream);
+
 /* ------------------------------------------------------------------ Pool / upsample
  * nn.MaxPool3d(2,2) (unet3d.py:19-25): y [N,D/2,H/2,W/2,C]; idx = 3-bit argmax code
  * (dz*4+dy*2+dx of the first maximum in PyTorch scan order) per output element. */
@@ -182,6 +188,23 @@ int mi355seg_bce_argmax_dice_f32(const float* logits, const float* target, long 
  * apply_sigmoid else x.  Deterministic wavefront-shuffle + two-stage reduce. */
 int mi355seg_dice_sums_f32(const float* x, const float* t, long long numel, int apply_sigmoid,
                            double* out5, void* ws, size_t ws_bytes, void* stream);
+
+/* d/dx of  L(S0..S4)  with S = dice_sums(x, t): dx[i] = (g[0]*t + g[1] + 2*g[3]*a) * da/dx, a = sigmoid(x) or x.
+ * g = dL/dS as 5 device doubles (g[2], g[4] multiply target-only sums and do not reach x). */
+int mi355seg_dice_sums_bwd_f32(const float* x, const float* t, const double* g5, long long numel, int apply_sigmoid,
+                               float* dx, void* stream);
+
+/* softmax over the channel dim of an NCDHW tensor [N,K,S] (DiceLossss softmax=True, loss_function.py:170-171) */
+int mi355seg_softmax_ch_f32(const float* x, float* y, long long N, int K, long long S, void* stream);
+/* dx = y * (dy - sum_k dy*y) */
+int mi355seg_softmax_ch_bwd_f32(const float* y, const float* dy, float* dx, long long N, int K, long long S, void* stream);
+
+/* cross_entropy_3D (loss_function.py:8-16): loss[0] = sum_v w[label_v] * (logsumexp_k x[v,k] - x[v,label_v]),
+ * divided by the voxel count when size_average.  logits NCDHW [N,K,S], labels int64 [N,S], weight [K] or NULL. */
+int mi355seg_ce3d_fwd_f32(const float* logits, const int64_t* labels, const float* weight, long long N, int K, long long S,
+                          int size_average, float* loss, void* ws, size_t ws_bytes, void* stream);
+int mi355seg_ce3d_bwd_f32(const float* logits, const int64_t* labels, const float* weight, const float* gscale,
+                          long long N, int K, long long S, int size_average, float* dlogits, void* stream);
 
 /* ------------------------------------------------------------------ In-library kernel timing
  * Optional HIP-event timing of the kernel families, on the stream each kernel is launched

@@ -48,6 +48,16 @@ def make_input(shape, freq=0.01, phase=0.0) -> torch.Tensor:
     return torch.from_numpy(v.astype(np.float32)).reshape(shape)
 
 
+def make_input_rough(shape, seed=0.0) -> torch.Tensor:
+    """Closed-form white-noise-like volume in [-1, 1): frac(sin(12.9898 i + seed) * 43758.5453) * 2 - 1.
+    Used where a smooth input would make InstanceNorm channels nearly constant (ill-conditioned parity)."""
+    n = int(np.prod(shape))
+    i = np.arange(n, dtype=np.float64)
+    v = np.sin(12.9898 * i + seed) * 43758.5453
+    v = (v - np.floor(v)) * 2.0 - 1.0
+    return torch.from_numpy(v.astype(np.float32)).reshape(shape)
+
+
 def make_labels(shape, thresh=0.8) -> torch.Tensor:
     """Binary labels ``cos(0.003*i) > thresh`` as float (train.py feeds float gt)."""
     n = int(np.prod(shape))

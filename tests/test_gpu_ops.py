@@ -303,3 +303,25 @@ def test_missing_library_fails_loudly(seg, monkeypatch):
         L._Lib()
     with pytest.raises(L.Mi355SegError):
         seg.functional.conv3d(torch.zeros(1, 2, 2, 2, 1), torch.zeros(1, 1, 3, 3, 3), None, 1, 1)   # CPU tensor
+
+
+@pytest.mark.parametrize("offset,scale", [(0.3, 4.5), (50.0, 0.5), (-3.0, 1e-2)])
+@pytest.mark.parametrize("shape", [(2, 8, 8, 8, 128), (1, 16, 12, 20, 32), (2, 4, 6, 10, 6)])
+def test_norm_statistics_are_accurate_and_shift_invariant(seg, shape, offset, scale):
+    """mean / rstd / running_var against float64, including channels whose |mean| >> std."""
+    F = seg.functional
+    L = seg.lib()
+    N, D, H, W, C = shape
+    x = (rnd(N, D, H, W, C, seed=9) * scale + offset).cuda()
+    rows = N * D * H * W
+    mean = torch.empty(C, device="cuda"); rstd = torch.empty(C, device="cuda")
+    rm = torch.zeros(C, device="cuda"); rv = torch.ones(C, device="cuda")
+    ws = F.workspace(L.query("mi355seg_norm_ws_bytes", rows, 1, C), x.device)
+    L.call("mi355seg_norm_stats_f32", x.data_ptr(), C, rows, 1, C, 1e-5, mean.data_ptr(), rstd.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+           0.1, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+    xd = x.double().reshape(rows, C).cpu()
+    m64, v64 = xd.mean(0), xd.var(0, unbiased=False)
+    assert ((mean.cpu().double() - m64).abs() / (m64.abs() + v64.sqrt())).max() < 1e-6
+    assert ((rstd.cpu().double() * (v64 + 1e-5).sqrt()) - 1).abs().max() < 2e-6
+    ref_rv = 0.9 + 0.1 * xd.var(0, unbiased=True)
+    assert ((rv.cpu().double() - ref_rv).abs() / ref_rv).max() < 1e-6
