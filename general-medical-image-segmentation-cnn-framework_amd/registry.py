@@ -1,0 +1,27 @@
+"""Model registry: ``config.network`` -> constructor call, as the reference's if/elif chain
+(train.py:324-373, predict.py:233-276).  Networks on the hot path are built from the
+MI355X drop-ins; the reference's other networks are out of scope and named as such."""
+
+IN_SCOPE = ("unet", "vnet", "res_unet", "unetr")
+OUT_OF_SCOPE = ("er_net", "re_net", "IS", "densenet", "vtnet", "densevoxelnet", "csrnet", "dunet")
+
+
+def build_model(config):
+    """``config`` needs .network, .in_classes, .out_classes (attribute or key access)."""
+    get = (lambda k: config[k]) if isinstance(config, dict) else (lambda k: getattr(config, k))
+    network = get("network")
+    if network == "unet":                                   # train.py:328-331
+        from .models.three_d.unet3d import UNet3D
+        return UNet3D(in_channels=get("in_classes"), out_channels=get("out_classes"), init_features=32)
+    if network == "vnet":                                   # train.py:358-361
+        from .models.three_d.vnet3d import VNet
+        return VNet(in_channels=get("in_classes"), classes=get("out_classes"))
+    if network == "res_unet":                               # train.py:324-327
+        from .models.three_d.residual_unet3d import UNet
+        return UNet(in_channels=get("in_classes"), n_classes=get("out_classes"), base_n_filter=32)
+    if network == "unetr":                                  # train.py:346-349 (the reference ignores in/out classes)
+        from .models.three_d.unetr import UNETR
+        return UNETR()
+    if network in OUT_OF_SCOPE:
+        raise NotImplementedError(f"network '{network}' is outside the MI355X hot-path scope (SURVEY.md section 2)")
+    raise ValueError(f"unknown network '{network}'")

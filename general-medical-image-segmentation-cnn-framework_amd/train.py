@@ -1,0 +1,115 @@
+"""``python train.py config=unet config.key=value`` -- the reference's training entry point (train.py:90-388)
+on the MI355X hot path: same config keys, registry names, init policy, optimizer / StepLR, step semantics
+(train.py:187-221 via engine.train_step) and checkpoint format
+(``{"model", "optim", "scheduler", "epoch"}`` in latest_checkpoint.pt / checkpoint_%04d.pt, train.py:285-306;
+resume when load_mode == 1, train.py:123-140).  TensorBoard / rich / accelerate are replaced by a JSONL scalar
+log, the logging module and mi355seg.distributed."""
+import json
+import logging
+import os
+import sys
+import time
+
+import torch
+from torch.optim.lr_scheduler import StepLR
+
+from . import distributed as D
+from .config import compose, parse_patch_size
+from .data import make_loader
+from .engine import train_step, weights_init_normal
+from .registry import build_model
+
+
+class AverageMeter:
+    def __init__(self):
+        self.val = self.sum = self.count = self.avg = 0.0
+
+    def update(self, v, n=1):
+        self.val = v
+        self.sum += v * n
+        self.count += n
+        self.avg = self.sum / max(self.count, 1)
+
+
+def get_logger(config):
+    os.makedirs(config.hydra_path, exist_ok=True)
+    log = logging.getLogger("mi355seg.train")
+    log.setLevel(logging.DEBUG)
+    log.handlers.clear()
+    log.addHandler(logging.StreamHandler(sys.stdout))
+    log.addHandler(logging.FileHandler(os.path.join(config.hydra_path, f"{config.job_name}.log")))
+    log.propagate = False
+    return log
+
+
+def train(config, model, logger):
+    rank, world, local = D.init_from_env()
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    model = model.to(device)
+    optimizer = torch.optim.Adam(model.parameters(), lr=config.init_lr)          # train.py:109
+    scheduler = StepLR(optimizer, step_size=config.scheduler_step_size, gamma=config.scheduler_gamma) \
+        if config.use_scheduler else None                                       # train.py:119-120
+    elapsed_epochs = 0
+    if config.load_mode == 1:                                                   # train.py:123-140
+        logger.info(f"load model from: {config.ckpt}")
+        ckpt = torch.load(config.ckpt, map_location="cpu")
+        state = {k[len("module."):] if k.startswith("module.") else k: v for k, v in ckpt["model"].items()}
+        model.load_state_dict(state)                                            # accepts the reference's DDP-prefixed keys
+        optimizer.load_state_dict(ckpt["optim"])
+        if scheduler is not None and ckpt.get("scheduler") is not None:
+            scheduler.load_state_dict(ckpt["scheduler"])
+        elapsed_epochs = ckpt["epoch"]
+    model.train()
+    scalars = open(os.path.join(config.hydra_path, "scalars.jsonl"), "a") if rank == 0 else None
+    loader = make_loader(config, device, config.in_classes, seed=1234 + rank)
+    reducer = D.GradAllReducer(model) if world > 1 else None
+    epochs = config.epochs - elapsed_epochs
+    iteration = elapsed_epochs * len(loader)
+    loss_meter, dice_meter = AverageMeter(), AverageMeter()
+    for epoch in range(elapsed_epochs + 1, elapsed_epochs + epochs + 1):
+        t_epoch = time.time()
+        for i, batch in enumerate(loader):
+            t0 = time.time()
+            x, gt = batch["source"]["data"], batch["gt"]["data"]
+            if world > 1:
+                D.broadcast_buffers(model)
+            out = train_step(model, optimizer, x, gt, grad_hook=reducer)        # train.py:187-221
+            iteration += 1
+            loss_meter.update(out["loss"].item(), x.size(0))
+            dice_meter.update(out["dice"], x.size(0))
+            if scalars:
+                scalars.write(json.dumps({"iteration": iteration, "Training/Loss": loss_meter.val, "Training/dice": dice_meter.val}) + "\n")
+                scalars.flush()
+            logger.info(f"\nEpoch: {epoch} Batch: {i}, train time: {time.time() - t0:.3f}s\nLoss: {loss_meter.val}\nDice: {dice_meter.val}\n")
+        if scheduler is not None:
+            scheduler.step()
+            logger.info(f"Learning rate:  {scheduler.get_last_lr()[0]}")
+        logger.info(f"\nEpoch {epoch} used time:  {time.time() - t_epoch:.3f} s\nLoss Avg:  {loss_meter.avg}\nDice Avg:  {dice_meter.avg}\n")
+        if rank == 0:
+            state = {"model": model.state_dict(), "optim": optimizer.state_dict(),
+                     "scheduler": scheduler.state_dict() if scheduler is not None else None, "epoch": epoch}
+            torch.save(state, os.path.join(config.hydra_path, config.latest_checkpoint_file))
+            if epoch % config.epochs_per_checkpoint == 0:
+                torch.save(state, os.path.join(config.hydra_path, f"checkpoint_{epoch:04d}.pt"))
+    if scalars:
+        scalars.close()
+    return {"loss_avg": loss_meter.avg, "dice_avg": dice_meter.avg, "epoch": elapsed_epochs + epochs}
+
+
+def main(argv=None, conf_dir=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    conf_dir = conf_dir or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "conf")
+    config = compose(conf_dir, argv, job_name="train")
+    parse_patch_size(config)
+    model = build_model(config)                          # train.py:324-373
+    model.apply(weights_init_normal(config.init_type))   # train.py:374
+    logger = get_logger(config)
+    logger.info("\nParameter Settings:\n" + "".join(f"{k}: {v}\n" for k, v in config.items()))
+    result = train(config, model, logger)
+    logger.info(f"scalar log saved in:{config.hydra_path}")
+    return config, result
+
+
+if __name__ == "__main__":
+    main()

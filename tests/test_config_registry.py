@@ -1,0 +1,49 @@
+"""Host logic of the drop-in boundary (no GPU): Hydra-style composition / overrides / interpolation and the
+``config.network`` registry."""
+import datetime
+import os
+
+import pytest
+
+import mi355seg
+from mi355seg.config import compose, parse_patch_size
+from mi355seg.registry import build_model
+
+CONF = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "conf")
+
+
+def test_compose_defaults_and_interpolation():
+    now = datetime.datetime(2026, 1, 2, 3, 4, 5)
+    c = compose(CONF, [], job_name="train", now=now)
+    assert c.network == "unet" and c.in_classes == 1 and c.out_classes == 2
+    assert c.output_dir == "./logs/unet"
+    assert c.hydra_path.endswith(os.path.join("logs", "unet", "train-2026-01-02", "03-04-05"))
+    assert c.job_name == "train" and c.init_type == "kaiming" and c.load_mode == 0
+    assert parse_patch_size(c) == (64, 64, 64)
+
+
+def test_overrides_and_group_selection():
+    c = compose(CONF, ["config=vnet", "config.epochs=7", "config.patch_size=32", "config.init_lr=0.01", "config.ckpt=/x/y.pt"])
+    assert c.network == "vnet" and c.epochs == 7 and c.init_lr == 0.01 and c.ckpt == "/x/y.pt"
+    assert parse_patch_size(c) == 32
+    c = compose(CONF, ["config.patch_size=16, 32, 48"])
+    assert parse_patch_size(c) == (16, 32, 48)
+    with pytest.raises(AssertionError):
+        parse_patch_size(compose(CONF, ["config.patch_size=1,2,3,4"]))
+    with pytest.raises(FileNotFoundError):
+        compose(CONF, ["config=does_not_exist"])
+    with pytest.raises(ValueError):
+        compose(CONF, ["epochs=3"])
+
+
+def test_registry_builds_in_scope_networks_with_reference_constructors():
+    m = build_model({"network": "unet", "in_classes": 1, "out_classes": 2})
+    assert sum(p.numel() for p in m.parameters()) == 22_581_250
+    m = build_model({"network": "vnet", "in_classes": 1, "out_classes": 2})
+    assert sum(p.numel() for p in m.parameters()) == 45_600_316
+    m = build_model({"network": "res_unet", "in_classes": 4, "out_classes": 4})
+    assert sum(p.numel() for p in m.parameters()) == 28_499_072
+    with pytest.raises(NotImplementedError):
+        build_model({"network": "densenet", "in_classes": 1, "out_classes": 2})
+    with pytest.raises(ValueError):
+        build_model({"network": "nope", "in_classes": 1, "out_classes": 2})

@@ -88,3 +88,26 @@ def test_unet3d_matches_oracle_other_shape(seg):
     for k, p in b.named_parameters():
         ref = ga[k].grad      # conv biases in front of a BatchNorm have an exactly-zero true gradient
         assert (p.grad.cpu() - ref).abs().max() <= 2e-4 * float(ref.abs().max()) + 1e-6 * gmax, k
+
+
+def test_train_cli_checkpoints_and_resume(seg, tmp_path):
+    """`train.py config=unet config.k=v`: two epochs on synthetic patches, reference checkpoint format, resume."""
+    from mi355seg.train import main
+    out = str(tmp_path / "logs")
+    args = ["config=unet", f"config.output_dir={out}", "config.patch_size=32,32,32", "config.batch_size=1",
+            "config.iters_per_epoch=2", "config.epochs=2"]
+    cfg, res = main(args)
+    assert res["epoch"] == 2 and 0.0 < res["loss_avg"] < 2.0
+    latest = os.path.join(cfg.hydra_path, "latest_checkpoint.pt")
+    assert os.path.exists(latest) and os.path.exists(os.path.join(cfg.hydra_path, "checkpoint_0002.pt"))
+    ck = torch.load(latest, map_location="cpu")
+    assert set(ck) == {"model", "optim", "scheduler", "epoch"} and ck["epoch"] == 2
+    assert "encoder1.enc1conv1.weight" in ck["model"] and len(ck["model"]) == 136
+    # the reference saves DDP-wrapped state dicts ("module." prefix, train.py:286-306): resume must accept them
+    ck["model"] = {"module." + k: v for k, v in ck["model"].items()}
+    pref = str(tmp_path / "prefixed.pt")
+    torch.save(ck, pref)
+    cfg2, res2 = main(args[:-1] + ["config.epochs=3", "config.load_mode=1", f"config.ckpt={pref}"])
+    assert res2["epoch"] == 3
+    lines = open(os.path.join(cfg2.hydra_path, "scalars.jsonl")).read().strip().splitlines()
+    assert len(lines) == 2 and "Training/dice" in lines[0]
