@@ -21,6 +21,7 @@
 #include "common.h"
 #include "internal.h"
 #include <stdlib.h>
+#include <initializer_list>
 
 namespace seg {
 
@@ -241,9 +242,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
                 const int gy = (y0 + line % T::TY) * a.out_mul + ((tapn >> 1) & 1);
                 const int gx = (x0 + xx) * a.out_mul + (tapn & 1);
                 const float val = acc[mb][nb][v] + bv;
-                if (!(a.dbg & 4) || val == 12345.678f)
+                // partial tiles (extents that are not tile multiples): rows outside the volume are dropped
+                const bool inside = (z0 + line / T::TY) < a.D && (y0 + line % T::TY) < a.H && (x0 + xx) < a.W;
+                if (inside && (!(a.dbg & 4) || val == 12345.678f))
                 yout[((((long long)n * (a.D * a.out_mul) + gz) * (a.H * a.out_mul) + gy) * (a.W * a.out_mul) + gx) * a.ldy + col] = val;
-                s1 += val; s2 += val * val;
+                if (inside) { s1 += val; s2 += val * val; }
             }
         }
         ssum[nb] = s1; ssq[nb] = s2;
@@ -307,28 +310,31 @@ struct IgemmPlan { int BX, MB, NBW, TZ, nM, nN, ntx, nty, ntz; };
 
 // Kc = GEMM K channels per tap-chunk unit (multiple of 16), Nc = GEMM N per output tap (multiple of 32)
 static bool igemm_plan(int N, int D, int H, int W, int Kc, int Nc, int ntaps_out, IgemmPlan* p) {
-    if (Kc % CK || Nc % 32 || H % 4) return false;
-    int BX = (W % 32 == 0) ? 32 : (W % 16 == 0) ? 16 : (W % 8 == 0) ? 8 : 0;
-    if (!BX) return false;
+    if (Kc % CK || Nc % 32) return false;
+    // x-extent of an M-block: the candidate with the least padding (ties -> the wider one)
+    int BX = 0; long long best = -1;
+    for (int bx : {32, 16, 8}) {
+        long long padded = (long long)((W + bx - 1) / bx) * bx;
+        if (best < 0 || padded < best) { best = padded; BX = bx; }
+    }
+    if (W < 4) return false;                                   // degenerate volumes stay on the generic path
     const int NBW = (Nc % 64 == 0) ? 2 : 1;
     const int nN = Nc / (32 * NBW) * ntaps_out;
     auto tiles = [&](int MB, int* tz) {
         int lines = 4 * MB * (32 / BX);
         *tz = lines / 4;
-        if (D % *tz) return (long long)-1;
-        return (long long)N * (D / *tz) * (H / 4) * (W / BX);
+        return (long long)N * ((D + *tz - 1) / *tz) * ((H + 3) / 4) * ((W + BX - 1) / BX);
     };
+    auto waste = [&](int tz) { return (double)(((D + tz - 1) / tz) * tz) / D; };
     int tz2, tz1;
     long long m2 = tiles(2, &tz2), m1 = tiles(1, &tz1);
     int MB;
     static const char* force = getenv("MI355SEG_IGEMM_MB");          // tuning knob (1 or 2)
-    if (force && force[0] == '1' && m1 > 0) MB = 1;
-    else if (m2 > 0 && m2 * nN >= 512) MB = 2;
-    else if (m1 > 0) MB = 1;
-    else if (m2 > 0) MB = 2;
-    else return false;
+    if (force && force[0] == '1') MB = 1;
+    else if (m2 * nN >= 512 && waste(tz2) <= waste(tz1) * 1.2) MB = 2;
+    else MB = 1;
     p->BX = BX; p->MB = MB; p->NBW = NBW; p->TZ = MB == 2 ? tz2 : tz1;
-    p->ntx = W / BX; p->nty = H / 4; p->ntz = D / p->TZ;
+    p->ntx = (W + BX - 1) / BX; p->nty = (H + 3) / 4; p->ntz = (D + p->TZ - 1) / p->TZ;
     p->nM = N * p->ntz * p->nty * p->ntx; p->nN = nN;
     return true;
 }

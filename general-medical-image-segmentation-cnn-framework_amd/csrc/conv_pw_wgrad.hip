@@ -54,13 +54,16 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(PwArgs a) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[tt][v] = 0.f;
 
+    const long long nvox = (long long)a.N * a.D * a.H * a.W;
     f32x4 sx[C::XIT], sd[C::DIT];
     auto load_stage = [&](int tile) {
         const long long v0 = (long long)tile * C::V;
 #pragma unroll
         for (int it = 0; it < C::XIT; ++it) {
             const int p = it * 256 + tid;
-            sx[it] = *reinterpret_cast<const f32x4*>(a.x + (v0 + (p >> 3)) * a.ldx + ci0 + (p & 7) * 4);
+            f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+            if (v0 + (p >> 3) < nvox) xv = *reinterpret_cast<const f32x4*>(a.x + (v0 + (p >> 3)) * a.ldx + ci0 + (p & 7) * 4);
+            sx[it] = xv;
         }
 #pragma unroll
         for (int it = 0; it < C::DIT; ++it) {
@@ -76,7 +79,9 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(PwArgs a) {
             } else {
                 ov = v0 + vl;
             }
-            sd[it] = *reinterpret_cast<const f32x4*>(a.dy + ov * a.lddy + co0 + part * 4);
+            f32x4 dv = {0.f, 0.f, 0.f, 0.f};
+            if (v0 + vl < nvox) dv = *reinterpret_cast<const f32x4*>(a.dy + ov * a.lddy + co0 + part * 4);
+            sd[it] = dv;
         }
     };
     auto write_stage = [&]() {
@@ -136,8 +141,7 @@ struct PwPlan { int ntiles, nstrips, npairs; };
 static bool pw_plan(long long nvox, int Cin, int Cout, int T, PwPlan* p) {
     if (Cin % 32 || Cout % 32 || (T != 1 && T != 8)) return false;
     const int V = T == 8 ? 64 : 256;
-    if (nvox % V) return false;
-    p->ntiles = (int)(nvox / V);
+    p->ntiles = (int)((nvox + V - 1) / V);
     p->npairs = (Cin / 32) * (Cout / 32);
     int want = (512 + p->npairs - 1) / p->npairs;
     long long cap = (long long)(64u << 20) / ((long long)T * Cin * Cout * 4);

@@ -14,6 +14,7 @@
 // emits the PyTorch (Cout,Cin,3,3,3) layout -> bitwise reproducible, no atomics.
 #include "common.h"
 #include "internal.h"
+#include <initializer_list>
 
 namespace seg {
 
@@ -136,7 +137,10 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(WgradArgs a) 
             const int vox = p >> 3, part = p & 7;
             const int line = vox / BX, xx = vox % BX;
             const int gz = z0 + line / T::TY, gy = y0 + line % T::TY, gx = x0 + xx;
-            sd[it] = *reinterpret_cast<const f32x4*>(a.dy + ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.lddy + co0 + part * 4);
+            f32x4 dv = {0.f, 0.f, 0.f, 0.f};          // partial tiles: voxels outside the volume contribute nothing
+            if (gz < a.D && gy < a.H && gx < a.W)
+                dv = *reinterpret_cast<const f32x4*>(a.dy + ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.lddy + co0 + part * 4);
+            sd[it] = dv;
         }
     };
     auto write_stage = [&]() {
@@ -177,12 +181,14 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(WgradArgs a) 
 struct WgradPlan { int BX, ntx, nty, ntz, ntiles, nstrips, npairs; };
 
 static bool wgrad_plan(int N, int D, int H, int W, int Cin, int Cout, WgradPlan* p) {
-    if (Cin % 32 || Cout % 32) return false;
-    int BX = (W % 32 == 0) ? 32 : (W % 16 == 0) ? 16 : (W % 8 == 0) ? 8 : 0;
-    if (!BX) return false;
+    if (Cin % 32 || Cout % 32 || W < 4) return false;
+    int BX = 0; long long best = -1;
+    for (int bx : {32, 16, 8}) {
+        long long padded = (long long)((W + bx - 1) / bx) * bx;
+        if (best < 0 || padded < best) { best = padded; BX = bx; }
+    }
     const int TY = BX == 8 ? 8 : 4, TZ = (256 / BX) / TY;
-    if (H % TY || D % TZ) return false;
-    p->BX = BX; p->ntx = W / BX; p->nty = H / TY; p->ntz = D / TZ;
+    p->BX = BX; p->ntx = (W + BX - 1) / BX; p->nty = (H + TY - 1) / TY; p->ntz = (D + TZ - 1) / TZ;
     p->ntiles = N * p->ntz * p->nty * p->ntx;
     p->npairs = (Cin / 32) * (Cout / 32);
     int want = (256 + p->npairs - 1) / p->npairs;      // one workgroup per CU (136 KB of LDS each)

@@ -59,6 +59,11 @@ CONV_CASES = [
     (1, 4, 4, 8, 256, 4, 1, 1, 0),         # direct head kernel, 64 lanes per voxel
     (1, 16, 16, 32, 64, 32, 1, 1, 0),      # k1 on the MFMA igemm + MFMA pointwise wgrad
     (2, 8, 8, 8, 32, 64, 1, 1, 0),
+    (1, 6, 6, 6, 64, 64, 3, 1, 1),         # partial MFMA tiles (UNETR 6^3 level)
+    (2, 12, 12, 12, 32, 64, 3, 1, 1),      # partial tiles, W = 12
+    (1, 10, 12, 20, 32, 32, 3, 1, 1),      # cfg-4 style 20 x 24 x 20 family
+    (1, 5, 7, 9, 32, 32, 3, 1, 1),         # odd extents
+    (1, 6, 6, 6, 64, 32, 1, 1, 0),         # k1, partial tiles
     (1, 8, 8, 8, 16, 16, 5, 1, 2),
     (2, 8, 8, 8, 8, 16, 2, 2, 0),
     (1, 8, 12, 8, 16, 32, 3, 2, 1),
@@ -131,7 +136,8 @@ def test_conv3d_channel_slices_and_no_bias(seg):
 
 
 @pytest.mark.parametrize("case", [(2, 4, 4, 4, 16, 8), (1, 8, 8, 8, 64, 32), (1, 3, 5, 4, 6, 10), (2, 2, 2, 2, 512, 256),
-                                  (2, 8, 8, 8, 512, 256), (1, 16, 16, 16, 128, 64), (1, 16, 32, 32, 64, 32)])
+                                  (2, 8, 8, 8, 512, 256), (1, 16, 16, 16, 128, 64), (1, 16, 32, 32, 64, 32),
+                                  (1, 6, 6, 6, 64, 32), (1, 3, 5, 6, 32, 32), (2, 12, 12, 12, 128, 64)])
 def test_conv_transpose3d_k2s2(seg, case):
     N, D, H, W, Cin, Cout = case
     F = seg.functional
