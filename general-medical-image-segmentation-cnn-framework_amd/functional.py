@@ -537,3 +537,129 @@ class _CE3D(Function):
 
 def cross_entropy_3d(logits, labels, weight=None, size_average=True):
     return _CE3D.apply(logits, labels, weight, size_average)
+
+
+# ----------------------------------------------------------------------------- UNETR encoder ops
+def _gemm(A, a_rs, a_cs, a_b0, a_b1, B, b_rs, b_cs, b_b0, b_b1, C, c_rs, c_b0, c_b1, bias, M, N, K, nb0=1, nb1=1,
+          alpha=1.0, relu=0, accumulate=0):
+    lib().call("mi355seg_gemm_f32", A, a_rs, a_cs, a_b0, a_b1, B, b_rs, b_cs, b_b0, b_b1, C, c_rs, c_b0, c_b1, bias,
+               M, N, K, nb0, nb1, alpha, relu, accumulate, _stream())
+
+
+class _Linear(Function):
+    """y[M,N] = x[M,K] @ W[N,K]^T + b, optionally followed by ReLU (fused into the GEMM epilogue)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        _require_cuda(x, "linear input")
+        shp = x.shape
+        x2 = x.contiguous().view(-1, shp[-1])
+        w = w.contiguous()
+        M, K, N = x2.shape[0], x2.shape[1], w.shape[0]
+        y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+        _gemm(_p(x2), K, 1, 0, 0, _p(w), 1, K, 0, 0, _p(y), N, 0, 0, _p(b), M, N, K, relu=int(relu))
+        ctx.save_for_backward(x2, w, y if relu else None)
+        ctx.cfg = (shp, M, N, K, bool(relu), b is not None)
+        return y.view(*shp[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, yrelu = ctx.saved_tensors
+        shp, M, N, K, relu, has_b = ctx.cfg
+        dy2 = dy.contiguous().view(M, N)
+        if relu:
+            dy2 = dy2 * (yrelu > 0).to(dy2.dtype)          # tiny [tokens, d_ff] mask; plumbing
+        dx = torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
+        _gemm(_p(dy2), N, 1, 0, 0, _p(w), K, 1, 0, 0, _p(dx), K, 0, 0, None, M, K, N)
+        dw = torch.empty_like(w)
+        _gemm(_p(dy2), 1, N, 0, 0, _p(x2), K, 1, 0, 0, _p(dw), K, 0, 0, None, N, K, M)
+        db = None
+        if has_b:
+            L = lib()
+            ws = workspace(L.query("mi355seg_norm_ws_bytes", M, 1, N), dy2.device)
+            db = torch.empty(N, dtype=dy2.dtype, device=dy2.device)
+            L.call("mi355seg_colsum_f32", _p(dy2), N, M, N, _p(db), _p(ws), ws.numel(), _stream())
+        return dx.view(*shp), dw, db, None
+
+
+def linear(x, weight, bias=None, relu=False):
+    return _Linear.apply(x, weight, bias, relu)
+
+
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _require_cuda(x, "layer_norm input")
+        shp = x.shape
+        E = shp[-1]
+        x2 = x.contiguous().view(-1, E)
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        lib().call("mi355seg_layernorm_fwd_f32", _p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, E, eps, _stream())
+        ctx.save_for_backward(x2, gamma, mean, rstd)
+        ctx.shp = shp
+        return y.view(*shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, gamma, mean, rstd = ctx.saved_tensors
+        rows, E = x2.shape
+        dy2 = dy.contiguous().view(rows, E)
+        dx = torch.empty_like(x2)
+        dg = torch.empty(E, dtype=torch.float32, device=x2.device)
+        db = torch.empty(E, dtype=torch.float32, device=x2.device)
+        lib().call("mi355seg_layernorm_bwd_f32", _p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), rows, E, _stream())
+        return dx.view(*ctx.shp), dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return _LayerNorm.apply(x, gamma, beta, float(eps))
+
+
+class _Attention(Function):
+    """softmax(Q K^T / sqrt(d)) V per (batch, head) with Q,K,V stored [B, P, H*d] (unetr.py:74-98).
+    ``keep`` (optional, [B,H,P,P], already divided by 1-p) is the attention-dropout mask."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, keep):
+        _require_cuda(q, "attention input")
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        B, P, E = q.shape
+        d = E // heads
+        alpha = 1.0 / (d ** 0.5)
+        scores = torch.empty((B, heads, P, P), dtype=q.dtype, device=q.device)
+        _gemm(_p(q), E, 1, P * E, d, _p(k), 1, E, P * E, d, _p(scores), P, heads * P * P, P * P, None, P, P, d, B, heads, alpha)
+        probs = torch.empty_like(scores)
+        lib().call("mi355seg_softmax_rows_f32", _p(scores), _p(probs), B * heads * P, P, _stream())
+        pd = probs if keep is None else probs * keep
+        ctxl = torch.empty((B, P, E), dtype=q.dtype, device=q.device)
+        _gemm(_p(pd), P, 1, heads * P * P, P * P, _p(v), E, 1, P * E, d, _p(ctxl), E, P * E, d, None, P, d, P, B, heads)
+        ctx.save_for_backward(q, k, v, probs, keep)
+        ctx.cfg = (B, P, E, heads, d, alpha)
+        return ctxl
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, probs, keep = ctx.saved_tensors
+        B, P, E, heads, d, alpha = ctx.cfg
+        do = do.contiguous()
+        pd = probs if keep is None else probs * keep
+        HPP, PP = heads * P * P, P * P
+        dpd = torch.empty_like(probs)                                   # dP = dO V^T
+        _gemm(_p(do), E, 1, P * E, d, _p(v), 1, E, P * E, d, _p(dpd), P, HPP, PP, None, P, P, d, B, heads)
+        dv = torch.empty_like(v)                                        # dV = Pd^T dO
+        _gemm(_p(pd), 1, P, HPP, PP, _p(do), E, 1, P * E, d, _p(dv), E, P * E, d, None, P, d, P, B, heads)
+        dp = dpd if keep is None else dpd * keep
+        ds = torch.empty_like(probs)
+        lib().call("mi355seg_softmax_rows_bwd_f32", _p(probs), _p(dp), _p(ds), B * heads * P, P, _stream())
+        dq = torch.empty_like(q)                                        # dQ = alpha dS K
+        _gemm(_p(ds), P, 1, HPP, PP, _p(k), E, 1, P * E, d, _p(dq), E, P * E, d, None, P, d, P, B, heads, alpha)
+        dk = torch.empty_like(k)                                        # dK = alpha dS^T Q
+        _gemm(_p(ds), 1, P, HPP, PP, _p(q), E, 1, P * E, d, _p(dk), E, P * E, d, None, P, d, P, B, heads, alpha)
+        return dq, dk, dv, None, None
+
+
+def attention(q, k, v, heads, keep=None):
+    return _Attention.apply(q, k, v, int(heads), keep)

@@ -121,3 +121,42 @@ def act_code(m):
         if isinstance(m, cls):
             return code, (m.negative_slope if isinstance(m, nn.LeakyReLU) else 0.0)
     raise NotImplementedError(f"no fused form for activation {type(m).__name__}")
+
+
+class Linear(nn.Linear):
+    """nn.Linear on the MFMA GEMM; ``forward_relu`` fuses a following ReLU into the epilogue."""
+
+    def forward(self, x):
+        return F.linear(x, self.weight, self.bias)
+
+    def forward_relu(self, x):
+        return F.linear(x, self.weight, self.bias, relu=True)
+
+
+class LayerNorm(nn.LayerNorm):
+    def forward(self, x):
+        if len(self.normalized_shape) != 1 or not self.elementwise_affine:
+            raise NotImplementedError("LayerNorm: only 1-D normalized_shape with affine is implemented")
+        return F.layer_norm(x, self.weight, self.bias, self.eps)
+
+
+class Dropout(nn.Dropout):
+    """Element-wise nn.Dropout on token tensors [..., E]; the arithmetic is the channel-scale kernel with one
+    "sample" per token row.  ``forced_masks`` as in Dropout3d (mask shape = input shape)."""
+
+    def __init__(self, p=0.5, inplace=False):
+        super().__init__(p, inplace)
+        self.forced_masks = []
+
+    def draw(self, shape, device):
+        if self.forced_masks:
+            return self.forced_masks.pop(0).to(device=device, dtype=torch.float32).reshape(shape) / (1.0 - self.p)
+        return torch.bernoulli(torch.full(shape, 1.0 - self.p, device=device)) / (1.0 - self.p)
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        E = x.shape[-1]
+        x2 = x.contiguous().view(-1, 1, 1, 1, E)
+        scale = self.draw((x2.shape[0], E), x.device)
+        return F.scale_channels(x2, scale).view(x.shape)

@@ -206,6 +206,25 @@ int mi355seg_ce3d_fwd_f32(const float* logits, const int64_t* labels, const floa
 int mi355seg_ce3d_bwd_f32(const float* logits, const int64_t* labels, const float* weight, const float* gscale,
                           long long N, int K, long long S, int size_average, float* dlogits, void* stream);
 
+/* ------------------------------------------------------------------ UNETR encoder (unetr.py:54-168)
+ * Strided, batched fp32 GEMM on the MFMA:  C[b0,b1][m][n] (+)= alpha * sum_k A[..][m][k] * B[..][k][n]  (+ bias[n]) (relu).
+ * Element strides: A(m,k) at a_rs*m + a_cs*k + a_b0*b0 + a_b1*b1, B(k,n) likewise, C(m,n) at c_rs*m + n + c_b0*b0 + c_b1*b1.
+ * Replaces nn.Linear (unetr.py:61-66,120-121), torch.matmul of the attention (unetr.py:88,94) and their backward. */
+int mi355seg_gemm_f32(const float* A, long long a_rs, long long a_cs, long long a_b0, long long a_b1,
+                      const float* B, long long b_rs, long long b_cs, long long b_b0, long long b_b1,
+                      float* C, long long c_rs, long long c_b0, long long c_b1, const float* bias,
+                      int M, int N, int K, int nb0, int nb1, float alpha, int relu, int accumulate, void* stream);
+/* nn.LayerNorm(E, eps) over the last dim of [rows, E] (unetr.py:151-152); mean/rstd [rows] are saved for backward */
+int mi355seg_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                               long long rows, int E, float eps, void* stream);
+int mi355seg_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                               float* dx, float* dgamma, float* dbeta, long long rows, int E, void* stream);
+/* nn.Softmax(dim=-1) on [rows, L] (unetr.py:71,90) and its backward dx = y * (dy - sum(dy*y)) */
+int mi355seg_softmax_rows_f32(const float* x, float* y, long long rows, int L, void* stream);
+int mi355seg_softmax_rows_bwd_f32(const float* y, const float* dy, float* dx, long long rows, int L, void* stream);
+/* out[c] = sum over rows of x[r, c] (bias gradient of nn.Linear); ws >= mi355seg_norm_ws_bytes(rows, 1, C) */
+int mi355seg_colsum_f32(const float* x, int ldx, long long rows, int C, float* out, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------ In-library kernel timing
  * Optional HIP-event timing of the kernel families, on the stream each kernel is launched
  * on (used by bench.py for the live roofline numbers; off by default, zero cost when off).

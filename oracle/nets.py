@@ -288,3 +288,137 @@ class ResUNet(nn.Module):
         # deep supervision (:196-202)
         s = self.upsacle(self.ds2_1x1_conv3d(ds[2])) + self.ds3_1x1_conv3d(ds[3])
         return out_pred + self.upsacle(s)
+
+
+# --------------------------------------------------------------------------- UNETR
+class _SingleDeconv(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.block = nn.ConvTranspose3d(cin, cout, kernel_size=2, stride=2, padding=0, output_padding=0)
+
+    def forward(self, x):
+        return self.block(x)
+
+
+class _SingleConv(nn.Module):
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.block = nn.Conv3d(cin, cout, kernel_size=k, stride=1, padding=(k - 1) // 2)
+
+    def forward(self, x):
+        return self.block(x)
+
+
+class _ConvBlock(nn.Module):        # unetr.py:27-37
+    def __init__(self, cin, cout, k=3):
+        super().__init__()
+        self.block = nn.Sequential(_SingleConv(cin, cout, k), nn.BatchNorm3d(cout), nn.ReLU(True))
+
+    def forward(self, x):
+        return self.block(x)
+
+
+class _DeconvBlock(nn.Module):      # unetr.py:40-51
+    def __init__(self, cin, cout, k=3):
+        super().__init__()
+        self.block = nn.Sequential(_SingleDeconv(cin, cout), _SingleConv(cout, cout, k), nn.BatchNorm3d(cout), nn.ReLU(True))
+
+    def forward(self, x):
+        return self.block(x)
+
+
+class _SelfAttention(nn.Module):    # unetr.py:54-99
+    def __init__(self, heads, E, dropout):
+        super().__init__()
+        self.h, self.d = heads, int(E / heads)
+        self.query, self.key, self.value = nn.Linear(E, E), nn.Linear(E, E), nn.Linear(E, E)
+        self.out = nn.Linear(E, E)
+        self.attn_dropout, self.proj_dropout = nn.Dropout(dropout), nn.Dropout(dropout)
+
+    def forward(self, x):
+        B, P, E = x.shape
+        split = lambda t: t.view(B, P, self.h, self.d).permute(0, 2, 1, 3)
+        q, k, v = split(self.query(x)), split(self.key(x)), split(self.value(x))
+        s = torch.matmul(q, k.transpose(-1, -2)) / (self.d ** 0.5)
+        p = self.attn_dropout(torch.softmax(s, dim=-1))
+        c = torch.matmul(p, v).permute(0, 2, 1, 3).contiguous().view(B, P, E)
+        return self.proj_dropout(self.out(c))
+
+
+class _FFN(nn.Module):              # unetr.py:116-125 (dropout default 0.1 regardless of the model's argument)
+    def __init__(self, E, dff=2048, dropout=0.1):
+        super().__init__()
+        self.w_1, self.w_2, self.dropout = nn.Linear(E, dff), nn.Linear(dff, E), nn.Dropout(dropout)
+
+    def forward(self, x):
+        return self.w_2(self.dropout(torch.relu(self.w_1(x))))
+
+
+class _Block(nn.Module):            # unetr.py:148-168
+    def __init__(self, E, heads, dropout):
+        super().__init__()
+        self.attention_norm, self.mlp_norm = nn.LayerNorm(E, eps=1e-6), nn.LayerNorm(E, eps=1e-6)
+        self.mlp = _FFN(E, 2048)
+        self.attn = _SelfAttention(heads, E, dropout)
+
+    def forward(self, x):
+        x = self.attn(self.attention_norm(x)) + x
+        return self.mlp(self.mlp_norm(x)) + x
+
+
+class _Embeddings(nn.Module):       # unetr.py:128-145
+    def __init__(self, cin, E, cube, patch, dropout):
+        super().__init__()
+        self.n_patches = int(cube[0] * cube[1] * cube[2] / patch ** 3)
+        self.patch_embeddings = nn.Conv3d(cin, E, kernel_size=patch, stride=patch)
+        self.position_embeddings = nn.Parameter(torch.zeros(1, self.n_patches, E))
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x):
+        t = self.patch_embeddings(x).flatten(2).transpose(-1, -2)
+        return self.dropout(t + self.position_embeddings)
+
+
+class _Transformer(nn.Module):      # unetr.py:171-191
+    def __init__(self, cin, E, cube, patch, heads, layers, dropout, taps):
+        super().__init__()
+        self.embeddings = _Embeddings(cin, E, cube, patch, dropout)
+        self.layer = nn.ModuleList([_Block(E, heads, dropout) for _ in range(layers)])
+        self.encoder_norm = nn.LayerNorm(E, eps=1e-6)      # never applied in the reference forward
+        self.taps = taps
+
+    def forward(self, x):
+        out, h = [], self.embeddings(x)
+        for i, blk in enumerate(self.layer):
+            h = blk(h)
+            if i + 1 in self.taps:
+                out.append(h)
+        return out
+
+
+class UNETR(nn.Module):
+    """UNETR (unetr.py:194-294)."""
+
+    def __init__(self, img_shape=(128, 128, 128), input_dim=4, output_dim=3, embed_dim=768, patch_size=16, num_heads=12, dropout=0.1):
+        super().__init__()
+        E = self.embed_dim = embed_dim
+        self.patch_dim = [int(s / patch_size) for s in img_shape]
+        self.transformer = _Transformer(input_dim, E, img_shape, patch_size, num_heads, 12, dropout, [3, 6, 9, 12])
+        self.decoder0 = nn.Sequential(_ConvBlock(input_dim, 32, 3), _ConvBlock(32, 64, 3))
+        self.decoder3 = nn.Sequential(_DeconvBlock(E, 512), _DeconvBlock(512, 256), _DeconvBlock(256, 128))
+        self.decoder6 = nn.Sequential(_DeconvBlock(E, 512), _DeconvBlock(512, 256))
+        self.decoder9 = _DeconvBlock(E, 512)
+        self.decoder12_upsampler = _SingleDeconv(E, 512)
+        self.decoder9_upsampler = nn.Sequential(_ConvBlock(1024, 512), _ConvBlock(512, 512), _ConvBlock(512, 512), _SingleDeconv(512, 256))
+        self.decoder6_upsampler = nn.Sequential(_ConvBlock(512, 256), _ConvBlock(256, 256), _SingleDeconv(256, 128))
+        self.decoder3_upsampler = nn.Sequential(_ConvBlock(256, 128), _ConvBlock(128, 128), _SingleDeconv(128, 64))
+        self.decoder0_header = nn.Sequential(_ConvBlock(128, 64), _ConvBlock(64, 64), _SingleConv(64, output_dim, 1))
+
+    def forward(self, x):
+        vol = lambda t: t.transpose(-1, -2).reshape(-1, self.embed_dim, *self.patch_dim)
+        z3, z6, z9, z12 = [vol(t) for t in self.transformer(x)]
+        z12 = self.decoder12_upsampler(z12)
+        z9 = self.decoder9_upsampler(torch.cat([self.decoder9(z9), z12], dim=1))
+        z6 = self.decoder6_upsampler(torch.cat([self.decoder6(z6), z9], dim=1))
+        z3 = self.decoder3_upsampler(torch.cat([self.decoder3(z3), z6], dim=1))
+        return self.decoder0_header(torch.cat([self.decoder0(x), z3], dim=1))

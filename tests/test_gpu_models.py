@@ -178,3 +178,88 @@ def test_dropout3d_device_rng_statistics(seg):
     assert set(per.unique().tolist()) <= {0.0, 2.0}
     assert 0.3 < float((per > 0).float().mean()) < 0.7
     assert torch.equal(d.eval()(x), x)
+
+
+def test_unetr_vs_reference_fixture(seg, golden_dir):
+    """UNETR (row a9): ViT encoder on the MFMA GEMM / LayerNorm / softmax kernels + conv decoder, against the
+    reference fixture; the reference's always-on FFN dropout masks (unetr.py:154) are injected by module name."""
+    from mi355seg.models.three_d.unetr import UNETR
+    from oracle.fill import make_input_rough
+    g = np.load(os.path.join(golden_dir, "unetr_small.npz"))
+    kw = dict(img_shape=(32, 32, 32), input_dim=1, output_dim=2, embed_dim=96, patch_size=16, num_heads=4, dropout=0.0)
+    m = fill_module_(UNETR(**kw))
+    with torch.no_grad():
+        m.transformer.embeddings.position_embeddings.copy_(0.1 * make_input_rough((1, 8, 96), seed=3.0))
+    m = m.cuda()
+    x = make_input_rough((2, 1, 32, 32, 32)).cuda()
+    m.eval()
+    with torch.no_grad():
+        pe = m(x).cpu().numpy()
+    assert np.abs(pe - g["pred_eval"]).max() < TOL
+    m.train()
+    mods = dict(m.named_modules())
+    n_inj = 0
+    for k in g.files:
+        if k.startswith("dmask/"):
+            mods[k[6:]].forced_masks = [torch.from_numpy(g[k].astype(np.float32))]
+            n_inj += 1
+    assert n_inj == 12
+    gt2 = two_channel_gt(make_labels((2, 1, 32, 32, 32))).cuda()
+    pred = m(x)
+    loss = seg.functional.bce_with_logits(pred, gt2)
+    loss.backward()
+    assert np.abs(pred.detach().cpu().numpy() - g["pred"]).max() < TOL
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    params = dict(m.named_parameters())
+    assert params["transformer.encoder_norm.weight"].grad is None      # never applied in the forward (unetr.py:176)
+    for k in g.files:
+        if k.startswith("grad/"):
+            ref, got = g[k], _sample(params[k[5:]].grad)
+            assert np.abs(got - ref).max() <= 3e-4 * max(1e-4, np.abs(ref).max()), k
+
+
+def test_transformer_ops_against_aten(seg):
+    import torch.nn.functional as TF
+    F = seg.functional
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 50, 96, generator=g)
+    w = torch.randn(200, 96, generator=g) * 0.1
+    b = torch.randn(200, generator=g) * 0.1
+    for relu in (False, True):
+        xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        yr = TF.linear(xr, wr, br)
+        yr = torch.relu(yr) if relu else yr
+        go = torch.randn(yr.shape, generator=g)
+        yr.backward(go)
+        xg, wg, bg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+        yg = F.linear(xg, wg, bg, relu=relu)
+        yg.backward(go.cuda())
+        assert (yg.detach().cpu() - yr.detach()).abs().max() < 1e-5
+        for a, r in ((xg, xr), (wg, wr), (bg, br)):
+            assert (a.grad.cpu() - r.grad).abs().max() < 1e-5 * max(1.0, float(r.grad.abs().max()))
+    ga, be = torch.rand(96, generator=g) + 0.5, torch.randn(96, generator=g)
+    xr, gr, brr = (x * 3 + 1).requires_grad_(True), ga.clone().requires_grad_(True), be.clone().requires_grad_(True)
+    yr = TF.layer_norm(xr, (96,), gr, brr, 1e-6)
+    go = torch.randn(yr.shape, generator=g)
+    yr.backward(go)
+    xg, gg, bg = (x * 3 + 1).cuda().requires_grad_(True), ga.cuda().requires_grad_(True), be.cuda().requires_grad_(True)
+    yg = F.layer_norm(xg, gg, bg, 1e-6)
+    yg.backward(go.cuda())
+    assert (yg.detach().cpu() - yr.detach()).abs().max() < 1e-5
+    assert (xg.grad.cpu() - xr.grad).abs().max() < 1e-5 and (gg.grad.cpu() - gr.grad).abs().max() < 1e-4
+    assert (bg.grad.cpu() - brr.grad).abs().max() < 1e-4
+    # attention, 4 heads of 24, with an attention-dropout mask
+    q, k, v = [torch.randn(2, 50, 96, generator=g) for _ in range(3)]
+    keep = (torch.rand(2, 4, 50, 50, generator=g) > 0.1).float() / 0.9
+    qs = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    sp = lambda t: t.view(2, 50, 4, 24).permute(0, 2, 1, 3)
+    pr = torch.softmax(sp(qs[0]) @ sp(qs[1]).transpose(-1, -2) / 24 ** 0.5, -1) * keep
+    yr = (pr @ sp(qs[2])).permute(0, 2, 1, 3).reshape(2, 50, 96)
+    go = torch.randn(yr.shape, generator=g)
+    yr.backward(go)
+    qg = [t.cuda().requires_grad_(True) for t in (q, k, v)]
+    yg = F.attention(qg[0], qg[1], qg[2], 4, keep.cuda())
+    yg.backward(go.cuda())
+    assert (yg.detach().cpu() - yr.detach()).abs().max() < 1e-5
+    for a, r in zip(qg, qs):
+        assert (a.grad.cpu() - r.grad).abs().max() < 1e-5

@@ -31,7 +31,7 @@ def _same_keys(a, b):
 def _fwd_bwd(m, x):
     y = m(x)
     y.square().mean().backward()
-    return y.detach(), {k: p.grad.clone() for k, p in m.named_parameters()}
+    return y.detach(), {k: (p.grad.clone() if p.grad is not None else None) for k, p in m.named_parameters()}
 
 
 def test_unet3d_bit_identical():
@@ -74,4 +74,23 @@ def test_resunet_bit_identical():
     yb, gb = _fwd_bwd(b, x)
     assert torch.equal(ya, yb)
     for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
+
+
+def test_unetr_bit_identical():
+    R = _ref("models.three_d.unetr", "UNETR")
+    kw = dict(img_shape=(32, 32, 32), input_dim=1, output_dim=2, embed_dim=96, patch_size=16, num_heads=4, dropout=0.1)
+    a = fill_module_(R(**kw)).train()
+    b = fill_module_(nets.UNETR(**kw)).train()
+    _same_keys(a, b)
+    x = make_input((2, 1, 32, 32, 32))
+    torch.manual_seed(9)
+    ya, ga = _fwd_bwd(a, x)
+    torch.manual_seed(9)
+    yb, gb = _fwd_bwd(b, x)
+    assert torch.equal(ya, yb)
+    for k in ga:
+        if ga[k] is None:
+            assert gb[k] is None
+            continue
         assert torch.equal(ga[k], gb[k]), k
