@@ -28,11 +28,12 @@ namespace seg {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int CK = 16;          // input channels per LDS chunk
-constexpr int PITCH = CK + 4;   // floats per halo voxel in LDS (odd number of 16-B slots)
-
-template <int KS, int BX, int MB>
+// CK = input channels per LDS chunk: 16 for k3 (65 KB halo tile, two workgroups per CU), 8 for k5 (the 5^3 halo
+// is 4x larger), 64 for k1 / ConvTranspose where there is no halo and few MFMAs per chunk otherwise.
+// PITCH = CK + 4 floats per voxel keeps an odd number of 16-byte slots -> conflict-free ds_read_b128.
+template <int KS, int BX, int MB, int CK>
 struct Tile {
+    static constexpr int PITCH = CK + 4;
     static constexpr int HALO = KS / 2;
     static constexpr int NTAP = KS * KS * KS;
     static constexpr int LPB = 32 / BX;           // x-lines per 32-voxel M-block
@@ -70,7 +71,7 @@ struct IgemmArgs {
 //   mode 1 (conv dgrad):   B = W[ci_f = n .. swapped roles, taps reversed]              W: (Cin_k, Cout_k, T)
 //   mode 2 (convT fwd):    n = (tapn, co): B = Wt[ci][co][tapn]                          Wt: (Cin, Cout, 8), T = 1
 //   mode 3 (convT dgrad):  chunk = (tapk, cc): B = Wt[ci = n][co = cc*16 + ..][tapk]     Wt: (Cin_f, Cout_f, 8), T = 1
-__global__ void pack_wq_kernel(const float* __restrict__ w, float* __restrict__ wq, int K, int Nn, int T, int NT, int mode, int aux) {
+__global__ void pack_wq_kernel(const float* __restrict__ w, float* __restrict__ wq, int K, int Nn, int T, int NT, int mode, int aux, int CK) {
     const long long total = (long long)K * Nn * T;        // K = channels in the GEMM K dim (taps of mode 3 included)
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         long long r = idx;
@@ -97,9 +98,11 @@ __global__ void pack_wq_kernel(const float* __restrict__ w, float* __restrict__ 
 // variant was measured 8-10 % slower on the large layers: co-resident workgroups fall into lockstep).
 // With ksplit > 1 (few-tile deep layers) every split writes raw partial sums to its own slab and a
 // tiny second kernel adds them in fixed order.
-template <int KS, int BX, int MB, int NBW>
+template <int KS, int BX, int MB, int NBW, int CK>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
-    using T = Tile<KS, BX, MB>;
+    using T = Tile<KS, BX, MB, CK>;
+    constexpr int PITCH = T::PITCH;
+    constexpr int PPV = CK / 4;                            // 16-byte pieces per voxel
     constexpr int NT = 32 * NBW;
     constexpr int NTAP = T::NTAP;
     constexpr int STEP_FLOATS = 2 * NT * 4;                 // packed weights consumed per (tap, kk) step
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
 #pragma unroll
         for (int it = 0; it < T::NITER; ++it) {
             const int p = it * 256 + tid;
-            const int vox = p >> 2, part = p & 3;
+            const int vox = p / PPV, part = p % PPV;
             const int hz = vox / (T::HY * T::HX), rem = vox % (T::HY * T::HX);
             const int hy = rem / T::HX, hx = rem % T::HX;
             const int tapk = chunk / a.cpt, cch = chunk - tapk * a.cpt;     // input child (ConvT dgrad), else 0
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
 #pragma unroll
         for (int it = 0; it < T::NITER; ++it) {
             const int p = it * 256 + tid;
-            if (p < T::NPIECE) *reinterpret_cast<f32x4*>(lds + (p >> 2) * PITCH + (p & 3) * 4) = stage[it];
+            if (p < T::NPIECE) *reinterpret_cast<f32x4*>(lds + (p / PPV) * PITCH + (p % PPV) * 4) = stage[it];
         }
     };
 
@@ -252,20 +255,53 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
         ssum[nb] = s1; ssq[nb] = s2;
     }
     if (a.spart) {
+        // BatchNorm batch statistics of this tile, cancellation-free: per channel the tile sum, then the tile
+        // mean, then M2 = sum (y - tile_mean)^2 from the accumulators still in registers; the second stage
+        // combines (n, sum, M2) of all tiles in fp64 (Chan et al.).  spart[mtile][c] = {sum, M2, n}.
         __syncthreads();                 // LDS halo no longer needed
+        float cnt = 0.f;
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
             float s1 = ssum[nb] + __shfl_xor(ssum[nb], 32, 64);
-            float s2 = ssq[nb] + __shfl_xor(ssq[nb], 32, 64);
-            if (h == 0) { lds[(wave * NT + nb * 32 + i) * 2] = s1; lds[(wave * NT + nb * 32 + i) * 2 + 1] = s2; }
+            if (h == 0) lds[wave * NT + nb * 32 + i] = s1;
+        }
+        {   // valid rows of this tile (same for every channel)
+            const int vz = min(T::TZ, a.D - z0), vy = min(T::TY, a.H - y0), vx = min(BX, a.W - x0);
+            cnt = (float)(vz * vy * vx);
+        }
+        __syncthreads();
+        float tmean[NBW];
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            const int c = nb * 32 + i;
+            tmean[nb] = (lds[c] + lds[NT + c] + lds[2 * NT + c] + lds[3 * NT + c]) / cnt;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            const float bv = a.bias ? a.bias[n0 + nb * 32 + i] : 0.f;
+            float m2 = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int m = wave * MB + mb;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int r = (v & 3) + 8 * (v >> 2) + 4 * h;
+                    const int line = m * T::LPB + r / BX, xx = r % BX;
+                    const bool inside = (z0 + line / T::TY) < a.D && (y0 + line % T::TY) < a.H && (x0 + xx) < a.W;
+                    const float d = acc[mb][nb][v] + bv - tmean[nb];
+                    if (inside) m2 += d * d;
+                }
+            }
+            m2 += __shfl_xor(m2, 32, 64);
+            if (h == 0) lds[4 * NT + wave * NT + nb * 32 + i] = m2;
         }
         __syncthreads();
         if (tid < NT) {
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) { s1 += lds[(w * NT + tid) * 2]; s2 += lds[(w * NT + tid) * 2 + 1]; }
-            float* dst = a.spart + ((long long)mtile * a.Cout + n0 + tid) * 2;
-            dst[0] = s1; dst[1] = s2;
+            const float s1 = lds[tid] + lds[NT + tid] + lds[2 * NT + tid] + lds[3 * NT + tid];
+            const float m2 = lds[4 * NT + tid] + lds[5 * NT + tid] + lds[6 * NT + tid] + lds[7 * NT + tid];
+            float* dst = a.spart + ((long long)mtile * a.Cout + n0 + tid) * 3;
+            dst[0] = s1; dst[1] = m2; dst[2] = cnt;
         }
     }
 }
@@ -285,39 +321,64 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-// per-channel fp64 finalise of the epilogue partials: block per channel, fixed order
+// per-channel fp64 combine of the per-tile (sum, M2, n) triples: block per channel, fixed order.
+// Emits sum(y) and sum(y^2) as doubles (sum^2 = M2_total + N * mean^2 is exact enough in fp64 for the
+// var = E[y^2] - mean^2 that mi355seg_norm_stats_from_sums_f32 forms afterwards).
 __global__ __launch_bounds__(256) void igemm_stats_finalize_kernel(const float* __restrict__ spart, int nM, int Cout,
                                                                     double* __restrict__ sum, double* __restrict__ sq) {
     __shared__ double sh[8];
+    __shared__ double gmean;
     const int c = blockIdx.x;
-    double s1 = 0.0, s2 = 0.0;
-    for (int m = threadIdx.x; m < nM; m += 256) {
-        const float* p = spart + ((long long)m * Cout + c) * 2;
-        s1 += (double)p[0]; s2 += (double)p[1];
-    }
-    s1 = wave_sum(s1); s2 = wave_sum(s2);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) { sh[wv * 2] = s1; sh[wv * 2 + 1] = s2; }
+    double s1 = 0.0, n = 0.0;
+    for (int m = threadIdx.x; m < nM; m += 256) {
+        const float* p = spart + ((long long)m * Cout + c) * 3;
+        s1 += (double)p[0]; n += (double)p[2];
+    }
+    s1 = wave_sum(s1); n = wave_sum(n);
+    if (lane == 0) { sh[wv * 2] = s1; sh[wv * 2 + 1] = n; }
+    __syncthreads();
+    const double S = sh[0] + sh[2] + sh[4] + sh[6], Nn = sh[1] + sh[3] + sh[5] + sh[7];
+    if (threadIdx.x == 0) gmean = S / Nn;
+    __syncthreads();
+    const double mean = gmean;
+    double m2 = 0.0;
+    for (int m = threadIdx.x; m < nM; m += 256) {
+        const float* p = spart + ((long long)m * Cout + c) * 3;
+        const double nt = (double)p[2], d = (double)p[0] / nt - mean;
+        m2 += (double)p[1] + nt * d * d;
+    }
+    m2 = wave_sum(m2);
+    __syncthreads();
+    if (lane == 0) sh[wv] = m2;
     __syncthreads();
     if (threadIdx.x == 0) {
-        sum[c] = sh[0] + sh[2] + sh[4] + sh[6];
-        sq[c] = sh[1] + sh[3] + sh[5] + sh[7];
+        const double M2 = sh[0] + sh[1] + sh[2] + sh[3];
+        sum[c] = S;
+        sq[c] = M2 + Nn * mean * mean;
     }
 }
 
 // ---------------------------------------------------------------- host side
-struct IgemmPlan { int BX, MB, NBW, TZ, nM, nN, ntx, nty, ntz; };
+struct IgemmPlan { int KS, CK, BX, MB, NBW, TZ, nM, nN, ntx, nty, ntz; };
 
-// Kc = GEMM K channels per tap-chunk unit (multiple of 16), Nc = GEMM N per output tap (multiple of 32)
-static bool igemm_plan(int N, int D, int H, int W, int Kc, int Nc, int ntaps_out, IgemmPlan* p) {
-    if (Kc % CK || Nc % 32) return false;
+static int pick_ck(int KS, int Kc) {
+    if (KS == 5) return 8;
+    if (KS == 1 && Kc % 64 == 0) return 64;
+    return 16;
+}
+
+// Kc = GEMM K channels per input tap (multiple of CK), Nc = GEMM N per output tap (multiple of 32)
+static bool igemm_plan(int KS, int N, int D, int H, int W, int Kc, int Nc, int ntaps_out, IgemmPlan* p) {
+    if (KS != 1 && KS != 3 && KS != 5) return false;
+    const int CK = pick_ck(KS, Kc);
+    if (Kc % CK || Nc % 32 || W < 4) return false;          // degenerate volumes stay on the generic path
     // x-extent of an M-block: the candidate with the least padding (ties -> the wider one)
     int BX = 0; long long best = -1;
     for (int bx : {32, 16, 8}) {
         long long padded = (long long)((W + bx - 1) / bx) * bx;
         if (best < 0 || padded < best) { best = padded; BX = bx; }
     }
-    if (W < 4) return false;                                   // degenerate volumes stay on the generic path
     const int NBW = (Nc % 64 == 0) ? 2 : 1;
     const int nN = Nc / (32 * NBW) * ntaps_out;
     auto tiles = [&](int MB, int* tz) {
@@ -328,68 +389,81 @@ static bool igemm_plan(int N, int D, int H, int W, int Kc, int Nc, int ntaps_out
     auto waste = [&](int tz) { return (double)(((D + tz - 1) / tz) * tz) / D; };
     int tz2, tz1;
     long long m2 = tiles(2, &tz2), m1 = tiles(1, &tz1);
+    (void)m1;
     int MB;
     static const char* force = getenv("MI355SEG_IGEMM_MB");          // tuning knob (1 or 2)
-    if (force && force[0] == '1') MB = 1;
+    if (KS == 5) MB = 1;                                             // the 5^3 halo of a 2-block tile does not fit twice per CU
+    else if (force && force[0] == '1') MB = 1;
     else if (m2 * nN >= 512 && waste(tz2) <= waste(tz1) * 1.2) MB = 2;
     else MB = 1;
-    p->BX = BX; p->MB = MB; p->NBW = NBW; p->TZ = MB == 2 ? tz2 : tz1;
+    p->KS = KS; p->CK = CK; p->BX = BX; p->MB = MB; p->NBW = NBW; p->TZ = MB == 2 ? tz2 : tz1;
     p->ntx = (W + BX - 1) / BX; p->nty = (H + 3) / 4; p->ntz = (D + p->TZ - 1) / p->TZ;
     p->nM = N * p->ntz * p->nty * p->ntx; p->nN = nN;
     return true;
 }
 
+static bool igemm_shape_ok(int k, int stride, int pad) {
+    return stride == 1 && ((k == 1 && pad == 0) || (k == 3 && pad == 1) || (k == 5 && pad == 2));
+}
+
 bool conv_mfma_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int ldy) {
-    if (!((k == 3 && pad == 1) || (k == 1 && pad == 0)) || stride != 1) return false;
-    if (ldx % 4) return false;
+    if (!igemm_shape_ok(k, stride, pad) || (ldx % 4)) return false;
     IgemmPlan p;
-    return igemm_plan(N, D, H, W, Cin, Cout, 1, &p);
+    return igemm_plan(k, N, D, H, W, Cin, Cout, 1, &p);
 }
 
 static int pick_ksplit(int tiles, int nchunks);
 size_t conv_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
-    if (!((k == 3 && pad == 1) || (k == 1 && pad == 0)) || stride != 1) return 0;
+    if (!igemm_shape_ok(k, stride, pad)) return 0;
     size_t best = 0;
     const size_t T = (size_t)k * k * k;
     // the same workspace must serve fwd (Cin->Cout) and dgrad (Cout->Cin)
     for (int pass = 0; pass < 2; ++pass) {
         int ci = pass ? Cout : Cin, co = pass ? Cin : Cout;
         IgemmPlan p;
-        if (!igemm_plan(N, D, H, W, ci, co, 1, &p)) continue;
-        const int ks = pick_ksplit(p.nM * p.nN, ci / CK);
-        size_t need = align_up(T * Cin * Cout * sizeof(float), 256) + align_up((size_t)p.nM * co * 2 * sizeof(float), 256) +
+        if (!igemm_plan(k, N, D, H, W, ci, co, 1, &p)) continue;
+        const int ks = pick_ksplit(p.nM * p.nN, ci / p.CK);
+        size_t need = align_up(T * Cin * Cout * sizeof(float), 256) + align_up((size_t)p.nM * co * 3 * sizeof(float), 256) +
                       (ks > 1 ? align_up((size_t)ks * N * D * H * W * co * sizeof(float), 256) + colsum_ws_bytes(co) : 0) + 1024;
         if (need > best) best = need;
     }
-    size_t wg = k == 3 ? wgrad_mfma_ws_bytes(N, D, H, W, Cin, Cout) : pw_wgrad_ws_bytes((long long)N * D * H * W, Cin, Cout, 1);
+    size_t wg = k == 3 ? wgrad_mfma_ws_bytes(N, D, H, W, Cin, Cout) : (k == 1 ? pw_wgrad_ws_bytes((long long)N * D * H * W, Cin, Cout, 1) : 0);
     return best > wg ? best : wg;
 }
 
-template <int KS, int BX, int MB, int NBW>
+template <int KS, int BX, int MB, int NBW, int CK>
 static void launch_igemm(const IgemmArgs& a, int nwg, hipStream_t st) {
-    using T = Tile<KS, BX, MB>;
+    using T = Tile<KS, BX, MB, CK>;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<KS, BX, MB, NBW>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<KS, BX, MB, NBW, CK>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<KS, BX, MB, NBW>), dim3(nwg), dim3(256), T::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<KS, BX, MB, NBW, CK>), dim3(nwg), dim3(256), T::LDS_BYTES, st, a);
 }
 
-template <int KS>
-static void dispatch_igemm(const IgemmPlan& p, const IgemmArgs& a, int nwg, hipStream_t st) {
+template <int KS, int CK, bool ALLOW_MB2>
+static void dispatch_igemm_ck(const IgemmPlan& p, const IgemmArgs& a, int nwg, hipStream_t st) {
 #define IGEMM_CASE(bx, mb, nbw) \
-    if (p.BX == bx && p.MB == mb && p.NBW == nbw) launch_igemm<KS, bx, mb, nbw>(a, nwg, st)
-    IGEMM_CASE(32, 2, 2); else IGEMM_CASE(32, 2, 1); else IGEMM_CASE(32, 1, 2); else IGEMM_CASE(32, 1, 1);
-    else IGEMM_CASE(16, 2, 2); else IGEMM_CASE(16, 2, 1); else IGEMM_CASE(16, 1, 2); else IGEMM_CASE(16, 1, 1);
-    else IGEMM_CASE(8, 2, 2); else IGEMM_CASE(8, 2, 1); else IGEMM_CASE(8, 1, 2); else IGEMM_CASE(8, 1, 1);
+    if (p.BX == bx && p.MB == mb && p.NBW == nbw) launch_igemm<KS, bx, mb, nbw, CK>(a, nwg, st)
+    if (ALLOW_MB2) {
+        IGEMM_CASE(32, 2, 2); else IGEMM_CASE(32, 2, 1); else IGEMM_CASE(16, 2, 2); else IGEMM_CASE(16, 2, 1);
+        else IGEMM_CASE(8, 2, 2); else IGEMM_CASE(8, 2, 1);
+    }
+    IGEMM_CASE(32, 1, 2); else IGEMM_CASE(32, 1, 1); else IGEMM_CASE(16, 1, 2); else IGEMM_CASE(16, 1, 1);
+    else IGEMM_CASE(8, 1, 2); else IGEMM_CASE(8, 1, 1);
 #undef IGEMM_CASE
+}
+
+static void dispatch_igemm(const IgemmPlan& p, const IgemmArgs& a, int nwg, hipStream_t st) {
+    if (p.KS == 3) dispatch_igemm_ck<3, 16, true>(p, a, nwg, st);
+    else if (p.KS == 5) dispatch_igemm_ck<5, 8, false>(p, a, nwg, st);
+    else if (p.CK == 64) dispatch_igemm_ck<1, 64, true>(p, a, nwg, st);
+    else dispatch_igemm_ck<1, 16, true>(p, a, nwg, st);
 }
 
 static int dbg_flags() { static const char* e = getenv("MI355SEG_DBG"); return e ? atoi(e) : 0; }
 static int pack_grid(long long total) { return (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256); }
-
-static int persistent_grid(int total) { return total; }     // one virtual tile per workgroup
 
 // K-split factor for layers with too few tiles to fill 2 x 256 workgroup slots
 static int pick_ksplit(int tiles, int nchunks) {
@@ -402,31 +476,31 @@ static int pick_ksplit(int tiles, int nchunks) {
     return best;
 }
 
-// k == 3 (pad 1) or k == 1 (pad 0), stride 1
+// k in {1, 3, 5}, pad = k/2, stride 1
 int conv_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W,
                   int Cin, int Cout, int k, int dgrad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st) {
     IgemmPlan p;
-    SEG_CHECK_ARG(igemm_plan(N, D, H, W, Cin, Cout, 1, &p), "conv_fwd_mfma: unsupported shape");
+    SEG_CHECK_ARG(igemm_plan(k, N, D, H, W, Cin, Cout, 1, &p), "conv_fwd_mfma: unsupported shape");
     SEG_CHECK_ARG(((uintptr_t)x % 16) == 0, "conv_fwd_mfma: input pointer must be 16-byte aligned");
     const int T = k * k * k;
-    const int nchunks = Cin / CK;
+    const int nchunks = Cin / p.CK;
     const long long nvox = (long long)N * D * H * W;
     const int ksplit = (ldy % 4 == 0) ? pick_ksplit(p.nM * p.nN, nchunks) : 1;
     Carver cv(ws);
     float* wq = cv.take<float>((size_t)T * Cin * Cout);
-    float* spart = (ssum && ksplit == 1) ? cv.take<float>((size_t)p.nM * Cout * 2) : nullptr;
+    float* spart = (ssum && ksplit == 1) ? cv.take<float>((size_t)p.nM * Cout * 3) : nullptr;
     float* slabs = ksplit > 1 ? cv.take<float>((size_t)ksplit * nvox * Cout) : nullptr;
     size_t tail = cv.used();
     SEG_CHECK_WS(tail + ((ssum && ksplit > 1) ? colsum_ws_bytes(Cout) : 0), ws_bytes);
-    hipLaunchKernelGGL(pack_wq_kernel, dim3(pack_grid((long long)T * Cin * Cout)), dim3(256), 0, st, w, wq, Cin, Cout, T, 32 * p.NBW, dgrad ? 1 : 0, 0);
+    hipLaunchKernelGGL(pack_wq_kernel, dim3(pack_grid((long long)T * Cin * Cout)), dim3(256), 0, st, w, wq, Cin, Cout, T, 32 * p.NBW, dgrad ? 1 : 0, 0, p.CK);
     SEG_CHECK_LAUNCH();
     IgemmArgs a{x, wq, ksplit > 1 ? nullptr : bias, ksplit > 1 ? slabs : y, spart, ldx, ksplit > 1 ? Cout : ldy, N, D, H, W, Cout,
                 p.ntx, p.nty, p.ntz, p.nN, nchunks, nchunks, p.nN, 1, 1, p.nM, ksplit, nchunks / ksplit, nvox * Cout, dbg_flags()};
-    const int nwg = persistent_grid(p.nM * p.nN * ksplit);
+    const int nwg = p.nM * p.nN * ksplit;
     const double vox = (double)nvox;
     {
         ProfScope ps(PF_IGEMM, 2.0 * vox * T * Cin * Cout, 4.0 * (vox * (Cin + Cout) + (double)T * Cin * Cout), st);
-        if (k == 3) dispatch_igemm<3>(p, a, nwg, st); else dispatch_igemm<1>(p, a, nwg, st);
+        dispatch_igemm(p, a, nwg, st);
         SEG_CHECK_LAUNCH();
         if (ksplit > 1) {
             long long tot = nvox * (Cout / 4);
@@ -445,24 +519,25 @@ int conv_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, fl
 
 // ---- ConvTranspose3d k2 s2 on the same kernel (KS = 1)
 bool convt_mfma_supported(int N, int D, int H, int W, int Cin, int Cout, int ldx, int ldy) {
-    IgemmPlan p;
-    return (ldx % 4) == 0 && (ldy % 4) == 0 && igemm_plan(N, D, H, W, Cin, Cout, 8, &p) && igemm_plan(N, D, H, W, Cout, Cin, 1, &p) && Cin % 32 == 0;
+    IgemmPlan p, q;
+    return (ldx % 4) == 0 && (ldy % 4) == 0 && igemm_plan(1, N, D, H, W, Cin, Cout, 8, &p) && igemm_plan(1, N, D, H, W, Cout, Cin, 1, &q) &&
+           Cin % 32 == 0;
 }
 
 int convt_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W,
                    int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t st) {
     IgemmPlan p;
-    SEG_CHECK_ARG(igemm_plan(N, D, H, W, Cin, Cout, 8, &p), "convt_fwd_mfma: unsupported shape");
+    SEG_CHECK_ARG(igemm_plan(1, N, D, H, W, Cin, Cout, 8, &p), "convt_fwd_mfma: unsupported shape");
     Carver cv(ws);
     float* wq = cv.take<float>((size_t)8 * Cin * Cout);
     SEG_CHECK_WS(cv.used(), ws_bytes);
-    hipLaunchKernelGGL(pack_wq_kernel, dim3(pack_grid((long long)8 * Cin * Cout)), dim3(256), 0, st, w, wq, Cin, 8 * Cout, 1, 32 * p.NBW, 2, Cout);
+    hipLaunchKernelGGL(pack_wq_kernel, dim3(pack_grid((long long)8 * Cin * Cout)), dim3(256), 0, st, w, wq, Cin, 8 * Cout, 1, 32 * p.NBW, 2, Cout, p.CK);
     SEG_CHECK_LAUNCH();
-    IgemmArgs a{x, wq, bias, y, nullptr, ldx, ldy, N, D, H, W, Cout, p.ntx, p.nty, p.ntz, p.nN, Cin / CK, Cin / CK, p.nN / 8, 1, 2,
-                p.nM, 1, Cin / CK, 0, 0};
+    IgemmArgs a{x, wq, bias, y, nullptr, ldx, ldy, N, D, H, W, Cout, p.ntx, p.nty, p.ntz, p.nN, Cin / p.CK, Cin / p.CK, p.nN / 8, 1, 2,
+                p.nM, 1, Cin / p.CK, 0, 0};
     const double vox = (double)N * D * H * W;
     ProfScope ps(PF_CONVT, 2.0 * vox * 8 * Cin * Cout, 4.0 * (vox * (Cin + 8.0 * Cout) + 8.0 * Cin * Cout), st);
-    dispatch_igemm<1>(p, a, persistent_grid(p.nM * p.nN), st);
+    dispatch_igemm(p, a, p.nM * p.nN, st);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
@@ -471,17 +546,17 @@ int convt_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, f
 int convt_dgrad_mfma(const float* dy, int lddy, const float* w, float* dx, int lddx, int N, int D, int H, int W,
                      int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t st) {
     IgemmPlan p;
-    SEG_CHECK_ARG(igemm_plan(N, D, H, W, Cout, Cin, 1, &p), "convt_dgrad_mfma: unsupported shape");
+    SEG_CHECK_ARG(igemm_plan(1, N, D, H, W, Cout, Cin, 1, &p), "convt_dgrad_mfma: unsupported shape");
     Carver cv(ws);
     float* wq = cv.take<float>((size_t)8 * Cin * Cout);
     SEG_CHECK_WS(cv.used(), ws_bytes);
-    hipLaunchKernelGGL(pack_wq_kernel, dim3(pack_grid((long long)8 * Cin * Cout)), dim3(256), 0, st, w, wq, 8 * Cout, Cin, 1, 32 * p.NBW, 3, Cout);
+    hipLaunchKernelGGL(pack_wq_kernel, dim3(pack_grid((long long)8 * Cin * Cout)), dim3(256), 0, st, w, wq, 8 * Cout, Cin, 1, 32 * p.NBW, 3, Cout, p.CK);
     SEG_CHECK_LAUNCH();
-    IgemmArgs a{dy, wq, nullptr, dx, nullptr, lddy, lddx, N, D, H, W, Cin, p.ntx, p.nty, p.ntz, p.nN, 8 * Cout / CK, Cout / CK, p.nN, 2, 1,
-                p.nM, 1, 8 * Cout / CK, 0, 0};
+    IgemmArgs a{dy, wq, nullptr, dx, nullptr, lddy, lddx, N, D, H, W, Cin, p.ntx, p.nty, p.ntz, p.nN, 8 * Cout / p.CK, Cout / p.CK, p.nN, 2, 1,
+                p.nM, 1, 8 * Cout / p.CK, 0, 0};
     const double vox = (double)N * D * H * W;
     ProfScope ps(PF_CONVT, 2.0 * vox * 8 * Cin * Cout, 4.0 * (vox * (Cin + 8.0 * Cout) + 8.0 * Cin * Cout), st);
-    dispatch_igemm<1>(p, a, persistent_grid(p.nM * p.nN), st);
+    dispatch_igemm(p, a, p.nM * p.nN, st);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }

@@ -43,6 +43,11 @@ int convt_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, f
                    int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t st);
 int convt_dgrad_mfma(const float* dy, int lddy, const float* w, float* dx, int lddx, int N, int D, int H, int W,
                      int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t st);
+// conv_gwgrad.hip -- MFMA gather-wgrad for any cubic kernel / stride / padding
+size_t gwgrad_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad);
+bool gwgrad_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int lddy);
+int conv_gwgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
+                int k, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 // conv_pw_wgrad.hip -- K = voxels GEMM wgrads (T = 1: Conv3d k1, T = 8: ConvTranspose3d k2 s2)
 size_t pw_wgrad_ws_bytes(long long nvox, int Cin, int Cout, int T);
 bool pw_wgrad_supported(long long nvox, int Cin, int Cout, int T, int ldx, int lddy);

@@ -298,15 +298,21 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(const float* __
         const float* __restrict__ x, int ldx, const float* __restrict__ mean, const float* __restrict__ rstd,
         const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ res, int ldres,
         const float* __restrict__ s1, const float* __restrict__ s2, float* __restrict__ dx, int lddx,
-        float* __restrict__ dres, int lddres, long long rows, int C, int lanes, int rpi, int act, float slope) {
+        float* __restrict__ dres, int lddres, long long rows, int C, int lanes, int rpi, int act, float slope,
+        float* __restrict__ dxpart) {
     constexpr int NJ = VEC ? 4 : 1;
+    __shared__ float shs[256 * 4];
     const int g = blockIdx.y;
     const int cw = VEC ? C / 4 : C;
     const int rsub = threadIdx.x / lanes;
-    if (rsub >= rpi) return;
+    const bool active = rsub < rpi;
+    if (!active && !dxpart) return;
     const long long rbase = (long long)g * rows;
     const float invM = 1.f / (float)rows;
-    for (int cc = threadIdx.x % lanes; cc < cw; cc += lanes) {
+    float colsum[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) colsum[j] = 0.f;
+    for (int cc = threadIdx.x % lanes; active && cc < cw; cc += lanes) {
         const int c = cc * NJ;
         float m[NJ], rs[NJ], ga[NJ], be[NJ], k1[NJ], k2[NJ];
 #pragma unroll
@@ -337,6 +343,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(const float* __
                 const float dz = dv[j] * act_grad(z, act, slope);
                 oz[j] = dz;
                 od[j] = ga[j] * rs[j] * (dz - k1[j] - xh * k2[j]);
+                colsum[j] += od[j];
             }
             if (VEC) {
                 *reinterpret_cast<float4*>(dx + row * lddx + c) = make_float4(od[0], od[NJ > 1 ? 1 : 0], od[NJ > 1 ? 2 : 0], od[NJ > 1 ? 3 : 0]);
@@ -345,6 +352,23 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(const float* __
                 dx[row * lddx + c] = od[0];
                 if (dres) dres[row * lddres + c] = oz[0];
             }
+        }
+    }
+    if (dxpart) {       // per-block column sums of dx (= the bias gradient of the convolution feeding this norm);
+                        // only used when lanes == cw (one channel slot per thread), see the launcher
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) shs[threadIdx.x * NJ + j] = colsum[j];
+        __syncthreads();
+        if (threadIdx.x < lanes) {
+            float acc[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
+            for (int q = 0; q < rpi; ++q)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[j] += shs[(q * lanes + threadIdx.x) * NJ + j];
+            float* dst = dxpart + ((long long)blockIdx.x * C + threadIdx.x * NJ) * 2;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { dst[j * 2] = acc[j]; dst[j * 2 + 1] = 0.f; }
         }
     }
 }
@@ -435,22 +459,27 @@ static bool vec_ok(int C, std::initializer_list<int> lds) {
 
 // channel sums of a [rows, C] matrix as doubles (used for dbias and conv-epilogue stats
 // on the generic path).  part must hold nblk*C*2 floats.
-struct SumF {
-    const float* x; int ldx;
-    struct State { int dummy; };
-    __device__ __forceinline__ State prep(int g, int c, int nj) const { return State{0}; }
-    __device__ __forceinline__ State prepC(int g, int c, int nj, int C) const { return State{0}; }
-    __device__ __forceinline__ void eval(const State&, long long r, int g, int c, int C, float& a, float& b) const {
-        float v = x[r * ldx + c]; a = v; b = v * v;
+struct SumF {        // sums of (x - pivot) and (x - pivot)^2; pivot = 0 when only the plain sum is wanted
+    const float* x; int ldx; long long rows; int use_pivot;
+    struct State { float p[4]; };
+    __device__ __forceinline__ State prepC(int g, int c, int nj, int C) const {
+        State s;
+        for (int j = 0; j < 4; ++j) s.p[j] = (use_pivot && j < nj) ? stats_pivot(x, ldx, 0, rows, c + j) : 0.f;
+        return s;
     }
-    __device__ __forceinline__ void eval4(const State&, long long r, int g, int c, int C, float4& a, float4& b) const {
+    __device__ __forceinline__ void eval(const State& st, long long r, int g, int c, int C, float& a, float& b) const {
+        float v = x[r * ldx + c] - st.p[0]; a = v; b = v * v;
+    }
+    __device__ __forceinline__ void eval4(const State& st, long long r, int g, int c, int C, float4& a, float4& b) const {
         float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        v.x -= st.p[0]; v.y -= st.p[1]; v.z -= st.p[2]; v.w -= st.p[3];
         a = v; b = make_float4(v.x * v.x, v.y * v.y, v.z * v.z, v.w * v.w);
     }
 };
 
 __global__ __launch_bounds__(64) void sums_finalize_kernel(const float* __restrict__ part, int nblk, int C, double* __restrict__ sum,
-                                     double* __restrict__ sq, float* __restrict__ fsum, int accumulate) {
+                                     double* __restrict__ sq, float* __restrict__ fsum, int accumulate,
+                                     const float* __restrict__ x, int ldx, long long rows, int use_pivot) {
     const int c = blockIdx.x;
     double a = 0.0, b = 0.0;
     for (int k = threadIdx.x; k < nblk; k += 64) {
@@ -459,6 +488,11 @@ __global__ __launch_bounds__(64) void sums_finalize_kernel(const float* __restri
     }
     a = wave_sum(a); b = wave_sum(b);
     if (threadIdx.x != 0) return;
+    if (use_pivot) {            // undo the shift in fp64: sum x = S1 + N p, sum x^2 = S2 + 2 p S1 + N p^2
+        const double pv = (double)stats_pivot(x, ldx, 0, rows, c), n = (double)rows;
+        b = b + 2.0 * pv * a + n * pv * pv;
+        a = a + n * pv;
+    }
     if (sum) sum[c] = a;
     if (sq) sq[c] = b;
     if (fsum) fsum[c] = accumulate ? fsum[c] + (float)a : (float)a;
@@ -467,7 +501,8 @@ __global__ __launch_bounds__(64) void sums_finalize_kernel(const float* __restri
 size_t colsum_ws_bytes(int C) { return align_up((size_t)kMaxRedBlocks * C * 2 * sizeof(float), 256); }
 
 int finalize_channel_partials(const float* part, int nblk, int C, double* sum, double* sq, hipStream_t st) {
-    hipLaunchKernelGGL(sums_finalize_kernel, dim3(C), dim3(64), 0, st, part, nblk, C, sum, sq, (float*)nullptr, 0);
+    hipLaunchKernelGGL(sums_finalize_kernel, dim3(C), dim3(64), 0, st, part, nblk, C, sum, sq, (float*)nullptr, 0,
+                       (const float*)nullptr, 0, 0LL, 0);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
@@ -478,10 +513,11 @@ int channel_sums(const float* x, int ldx, long long rows, int C, double* sum, do
     SEG_CHECK_WS(colsum_ws_bytes(C), ws_bytes);
     float* part = (float*)ws;
     RedPlan p;
-    SumF f{x, ldx};
+    const int use_pivot = sq != nullptr;          // second moments: shift by a data pivot against cancellation
+    SumF f{x, ldx, rows, use_pivot};
     int rc = launch_colreduce2(f, rows, 1, C, ldx, part, &p, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(sums_finalize_kernel, dim3(C), dim3(64), 0, st, part, p.nblk, C, sum, sq, fsum, accumulate);
+    hipLaunchKernelGGL(sums_finalize_kernel, dim3(C), dim3(64), 0, st, part, p.nblk, C, sum, sq, fsum, accumulate, x, ldx, rows, use_pivot);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
@@ -495,7 +531,8 @@ extern "C" {
 size_t mi355seg_norm_ws_bytes(long long rows, int groups, int C) {
     (void)rows;
     size_t g = (size_t)(groups < 1 ? 1 : groups);
-    return align_up(g * kMaxRedBlocks * (size_t)C * 2 * sizeof(float), 256) + 2 * align_up(g * C * sizeof(float), 256) + 1024;
+    return align_up(g * kMaxRedBlocks * (size_t)C * 2 * sizeof(float), 256) + 2 * align_up(g * C * sizeof(float), 256) +
+           align_up((size_t)8192 * C * 2 * sizeof(float), 256) + 1024;
 }
 
 int mi355seg_norm_stats_f32(const float* x, int ldx, long long rows, int groups, int C, float eps,
@@ -550,23 +587,30 @@ int mi355seg_norm_act_fwd_f32(const float* x, int ldx, const float* mean, const 
     return MI355SEG_OK;
 }
 
-int mi355seg_norm_act_bwd_f32(const float* dy, int lddy, const float* x, int ldx,
-                              const float* mean, const float* rstd, const float* gamma, const float* beta,
-                              const float* res, int ldres,
-                              float* dx, int lddx, float* dgamma, float* dbeta, float* dres, int lddres,
-                              long long rows, int groups, int C, int act, float slope,
-                              void* ws, size_t ws_bytes, void* stream) {
+static int norm_act_bwd_impl(const float* dy, int lddy, const float* x, int ldx,
+                             const float* mean, const float* rstd, const float* gamma, const float* beta,
+                             const float* res, int ldres,
+                             float* dx, int lddx, float* dgamma, float* dbeta, float* dres, int lddres, float* dx_colsum,
+                             long long rows, int groups, int C, int act, float slope,
+                             void* ws, size_t ws_bytes, void* stream) {
     SEG_CHECK_ARG(dy && x && mean && rstd && dx && rows > 0 && groups > 0 && C > 0, "norm_act_bwd: bad arguments");
     SEG_CHECK_ARG(!(dgamma && groups != 1), "norm_act_bwd: affine grads need groups == 1");
+    SEG_CHECK_ARG(!(dx_colsum && groups != 1), "norm_act_bwd: dx column sums need groups == 1");
     SEG_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "norm_act_bwd: dgamma/dbeta must come together");
     RedPlan p;
     int ldmin = 4;
     if ((lddy % 4) || (ldx % 4) || (res && (ldres % 4))) ldmin = 1;
     SEG_CHECK_ARG(red_plan(rows, C, ldmin, &p), "norm_act_bwd: unsupported channel count C=%d", C);
+    bool v = vec_ok(C, {lddy, ldx, lddx, res ? ldres : 4, dres ? lddres : 4});
+    RowMap rm = ew_map(C, v);
+    int nrb = row_grid(rows, rm.rpi);
+    if (dx_colsum && nrb > 1024) nrb = 1024;       // bounds the per-block partials the column-sum finalise walks
+    const bool fused_sum = dx_colsum && rm.lanes == (v ? C / 4 : C) && (256 % rm.lanes) == 0;
     Carver cv(ws);
     float* part = cv.take<float>((size_t)groups * p.nblk * C * 2);
     float* s1 = cv.take<float>((size_t)groups * C);
     float* s2 = cv.take<float>((size_t)groups * C);
+    float* dxpart = fused_sum ? cv.take<float>((size_t)nrb * C * 2) : nullptr;
     SEG_CHECK_WS(cv.used(), ws_bytes);
     hipStream_t st = (hipStream_t)stream;
     BwdF f{dy, lddy, x, ldx, mean, rstd, gamma, beta, res, ldres, act, slope};
@@ -575,18 +619,47 @@ int mi355seg_norm_act_bwd_f32(const float* dy, int lddy, const float* x, int ldx
     hipLaunchKernelGGL(bwd_finalize_kernel, dim3(groups * C), dim3(64), 0, st, part, p.nblk, C,
                        groups, s1, s2, dgamma, dbeta);
     SEG_CHECK_LAUNCH();
-    bool v = vec_ok(C, {lddy, ldx, lddx, res ? ldres : 4, dres ? lddres : 4});
-    RowMap rm = ew_map(C, v);
-    dim3 grid(row_grid(rows, rm.rpi), groups);
-    ProfScope ps(PF_NORM, 0.0, 4.0 * rows * groups * C * 3.0, st);
-    if (v)
-        hipLaunchKernelGGL((norm_act_bwd_apply_kernel<true>), grid, dim3(256), 0, st, dy, lddy, x, ldx, mean,
-                           rstd, gamma, beta, res, ldres, s1, s2, dx, lddx, dres, lddres, rows, C, rm.lanes, rm.rpi, act, slope);
-    else
-        hipLaunchKernelGGL((norm_act_bwd_apply_kernel<false>), grid, dim3(256), 0, st, dy, lddy, x, ldx, mean,
-                           rstd, gamma, beta, res, ldres, s1, s2, dx, lddx, dres, lddres, rows, C, rm.lanes, rm.rpi, act, slope);
-    SEG_CHECK_LAUNCH();
+    dim3 grid(nrb, groups);
+    {
+        ProfScope ps(PF_NORM, 0.0, 4.0 * rows * groups * C * 3.0, st);
+        if (v)
+            hipLaunchKernelGGL((norm_act_bwd_apply_kernel<true>), grid, dim3(256), 0, st, dy, lddy, x, ldx, mean,
+                               rstd, gamma, beta, res, ldres, s1, s2, dx, lddx, dres, lddres, rows, C, rm.lanes, rm.rpi, act, slope, dxpart);
+        else
+            hipLaunchKernelGGL((norm_act_bwd_apply_kernel<false>), grid, dim3(256), 0, st, dy, lddy, x, ldx, mean,
+                               rstd, gamma, beta, res, ldres, s1, s2, dx, lddx, dres, lddres, rows, C, rm.lanes, rm.rpi, act, slope, dxpart);
+        SEG_CHECK_LAUNCH();
+    }
+    if (dx_colsum) {
+        if (fused_sum) {
+            hipLaunchKernelGGL(sums_finalize_kernel, dim3(C), dim3(64), 0, st, dxpart, nrb, C, (double*)nullptr, (double*)nullptr, dx_colsum, 0,
+                               (const float*)nullptr, 0, 0LL, 0);
+            SEG_CHECK_LAUNCH();
+        } else {
+            return channel_sums(dx, lddx, rows, C, nullptr, nullptr, dx_colsum, 0, ws, ws_bytes, st);
+        }
+    }
     return MI355SEG_OK;
+}
+
+int mi355seg_norm_act_bwd_f32(const float* dy, int lddy, const float* x, int ldx,
+                              const float* mean, const float* rstd, const float* gamma, const float* beta,
+                              const float* res, int ldres,
+                              float* dx, int lddx, float* dgamma, float* dbeta, float* dres, int lddres,
+                              long long rows, int groups, int C, int act, float slope,
+                              void* ws, size_t ws_bytes, void* stream) {
+    return norm_act_bwd_impl(dy, lddy, x, ldx, mean, rstd, gamma, beta, res, ldres, dx, lddx, dgamma, dbeta, dres, lddres, nullptr,
+                             rows, groups, C, act, slope, ws, ws_bytes, stream);
+}
+
+int mi355seg_norm_act_bwd_colsum_f32(const float* dy, int lddy, const float* x, int ldx,
+                                     const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                     const float* res, int ldres,
+                                     float* dx, int lddx, float* dgamma, float* dbeta, float* dres, int lddres, float* dx_colsum,
+                                     long long rows, int groups, int C, int act, float slope,
+                                     void* ws, size_t ws_bytes, void* stream) {
+    return norm_act_bwd_impl(dy, lddy, x, ldx, mean, rstd, gamma, beta, res, ldres, dx, lddx, dgamma, dbeta, dres, lddres, dx_colsum,
+                             rows, groups, C, act, slope, ws, ws_bytes, stream);
 }
 
 int mi355seg_rstd_from_var_f32(const float* var, float eps, float* rstd, int C, void* stream) {

@@ -259,6 +259,88 @@ def instance_norm_act(x, eps=1e-5, act=ACT_NONE, slope=0.01):
     return _NormAct.apply(x, None, None, None, None, None, True, 0.0, float(eps), int(act), float(slope), True)
 
 
+class _ConvBnAct(Function):
+    """act(BatchNorm3d(conv3d(x))) as one autograd node: the batch statistics come out of the convolution's
+    epilogue (no separate pass over y) and the convolution's bias gradient comes out of the BatchNorm backward
+    pass (no separate pass over dy).  Training mode only updates running stats exactly as nn.BatchNorm3d."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, rmean, rvar, stride, pad, training, momentum, eps, act, slope):
+        x, ldx = cl_view(x, "conv3d input")
+        N, D, H, W, Cin = x.shape
+        Cout, k = w.shape[0], w.shape[2]
+        if w.shape[1] != Cin:
+            raise Mi355SegError(f"conv3d: weight {tuple(w.shape)} does not match input channels {Cin}")
+        w = w.contiguous()
+        Do, Ho, Wo = [(e + 2 * pad - k) // stride + 1 for e in (D, H, W)]
+        dev = x.device
+        y = torch.empty((N, Do, Ho, Wo, Cout), dtype=x.dtype, device=dev)
+        L = lib()
+        ws = workspace(max(L.query("mi355seg_conv3d_ws_bytes", N, D, H, W, Cin, Cout, k, stride, pad),
+                           L.query("mi355seg_norm_ws_bytes", N * Do * Ho * Wo, 1, Cout)), dev)
+        rows = N * Do * Ho * Wo
+        if training:
+            sums = torch.empty(2 * Cout, dtype=torch.float64, device=dev)
+            L.call("mi355seg_conv3d_fwd_f32", _p(x), ldx, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
+                   sums.data_ptr(), sums.data_ptr() + 8 * Cout, _p(ws), ws.numel(), _stream())
+            mean = torch.empty(Cout, dtype=torch.float32, device=dev)
+            rstd = torch.empty(Cout, dtype=torch.float32, device=dev)
+            L.call("mi355seg_norm_stats_from_sums_f32", sums.data_ptr(), sums.data_ptr() + 8 * Cout, rows, Cout, eps,
+                   _p(mean), _p(rstd), _p(rmean), _p(rvar), momentum, _stream())
+        else:
+            L.call("mi355seg_conv3d_fwd_f32", _p(x), ldx, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
+                   None, None, _p(ws), ws.numel(), _stream())
+            mean = rmean
+            rstd = torch.empty(Cout, dtype=torch.float32, device=dev)
+            L.call("mi355seg_rstd_from_var_f32", _p(rvar), eps, _p(rstd), Cout, _stream())
+        a = torch.empty_like(y)
+        L.call("mi355seg_norm_act_fwd_f32", _p(y), Cout, _p(mean), _p(rstd), _p(gamma), _p(beta), None, 0,
+               _p(a), Cout, rows, 1, Cout, act, slope, _stream())
+        ctx.save_for_backward(x, w, y, mean, rstd, gamma, beta)
+        ctx.cfg = (N, D, H, W, Cin, Cout, k, stride, pad, ldx, b is not None, rows, act, slope, bool(training))
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        x, w, y, mean, rstd, gamma, beta = ctx.saved_tensors
+        N, D, H, W, Cin, Cout, k, stride, pad, ldx, has_b, rows, act, slope, training = ctx.cfg
+        if not training:
+            raise Mi355SegError("backward through eval-mode BatchNorm (running statistics) is not supported")
+        da, ldda = cl_view(da, "conv+norm grad")
+        L = lib()
+        dev = x.device
+        ws = workspace(max(L.query("mi355seg_conv3d_ws_bytes", N, D, H, W, Cin, Cout, k, stride, pad),
+                           L.query("mi355seg_norm_ws_bytes", rows, 1, Cout)), dev)
+        dy = torch.empty_like(y)
+        dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(Cout, dtype=torch.float32, device=dev)
+        db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
+        L.call("mi355seg_norm_act_bwd_colsum_f32", _p(da), ldda, _p(y), Cout, _p(mean), _p(rstd), _p(gamma), _p(beta), None, 0,
+               _p(dy), Cout, _p(dgamma), _p(dbeta), None, 0, _p(db), rows, 1, Cout, act, slope, _p(ws), ws.numel(), _stream())
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((N, D, H, W, Cin), dtype=x.dtype, device=dev)
+            L.call("mi355seg_conv3d_dgrad_f32", _p(dy), Cout, _p(w), _p(dx), Cin, N, D, H, W, Cin, Cout, k, stride, pad,
+                   _p(ws), ws.numel(), _stream())
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            L.call("mi355seg_conv3d_wgrad_f32", _p(dy), Cout, _p(x), ldx, _p(dw), None, N, D, H, W, Cin, Cout, k, stride, pad,
+                   0, _p(ws), ws.numel(), _stream())
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+
+
+def conv_bn_act(x, conv, bn, act=ACT_NONE, slope=0.01):
+    """act(bn(conv(x))) for a layers.Conv3d / layers.BatchNorm3d pair (module objects carry the parameters)."""
+    if bn.momentum is None or not bn.affine or not bn.track_running_stats:
+        raise NotImplementedError("conv_bn_act: BatchNorm3d must be affine with running statistics and a momentum")
+    stride = conv.stride[0] if isinstance(conv.stride, (tuple, list)) else conv.stride
+    pad = conv.padding[0] if isinstance(conv.padding, (tuple, list)) else conv.padding
+    if bn.training:
+        bn.num_batches_tracked.add_(1)
+    return _ConvBnAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, int(stride), int(pad),
+                            bool(bn.training), float(bn.momentum), float(bn.eps), int(act), float(slope))
+
+
 class _Act(Function):
     @staticmethod
     def forward(ctx, x, res, act, slope):

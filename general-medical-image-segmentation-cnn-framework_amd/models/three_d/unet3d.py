@@ -21,8 +21,8 @@ class _DoubleConv(nn.Sequential):
 
     def forward(self, x):
         conv1, norm1, _r1, conv2, norm2, _r2 = self.children()
-        x = norm1.forward_act(conv1(x), F.ACT_RELU)
-        return norm2.forward_act(conv2(x), F.ACT_RELU)
+        x = F.conv_bn_act(x, conv1, norm1, F.ACT_RELU)          # conv + batch statistics + BN + ReLU, one autograd node
+        return F.conv_bn_act(x, conv2, norm2, F.ACT_RELU)
 
 
 class UNet3D(nn.Module):

@@ -38,9 +38,9 @@ class SingleConv3DBlock(nn.Module):
 class _ConvBnRelu(nn.Sequential):
     def forward(self, x):
         mods = list(self.children())
-        for m in mods[:-2]:
+        for m in mods[:-3]:
             x = m(x)
-        return mods[-2].forward_act(x, F.ACT_RELU)          # BatchNorm3d + ReLU fused
+        return F.conv_bn_act(x, mods[-3].block, mods[-2], F.ACT_RELU)     # conv + statistics + BN + ReLU fused
 
 
 class Conv3DBlock(nn.Module):

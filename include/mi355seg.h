@@ -125,6 +125,15 @@ int mi355seg_norm_act_bwd_f32(const float* dy, int lddy, const float* x, int ldx
                               long long rows, int groups, int C, int act, float slope,
                               void* ws, size_t ws_bytes, void* stream);
 
+/* Same, and additionally dx_colsum[c] = sum over rows of dx[r, c] (groups == 1): when the norm follows a
+ * convolution that is exactly the convolution's bias gradient, so the separate reduction pass over dy is saved. */
+int mi355seg_norm_act_bwd_colsum_f32(const float* dy, int lddy, const float* x, int ldx,
+                                     const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                     const float* res, int ldres,
+                                     float* dx, int lddx, float* dgamma, float* dbeta, float* dres, int lddres, float* dx_colsum,
+                                     long long rows, int groups, int C, int act, float slope,
+                                     void* ws, size_t ws_bytes, void* stream);
+
 /* Eval-mode BatchNorm (running stats) is norm_act_fwd with mean=running_mean and
  * rstd = 1/sqrt(running_var+eps) computed by: */
 int mi355seg_rstd_from_var_f32(const float* var, float eps, float* rstd, int C, void* stream);
