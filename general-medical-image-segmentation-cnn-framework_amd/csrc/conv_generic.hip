@@ -290,6 +290,8 @@ size_t mi355seg_conv3d_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, i
     size_t b = conv_mfma_ws_bytes(N, D, H, W, Cin, Cout, k, stride, pad);
     size_t c = (stem_supported(Cin, Cout, k, stride, pad, 4) || head_supported(Cin, Cout, k, stride, pad, 4)) ? small_ws_bytes(Cin, Cout, k) : 0;
     size_t d = gwgrad_ws_bytes(N, D, H, W, Cin, Cout, k, stride, pad);
+    if ((smallcin_wgrad_supported(Cin, Cout, k) || smallcout_wgrad_supported(Cin, Cout, k, 4)) && small_wgrad_ws_bytes(Cin, Cout, k) > d)
+        d = small_wgrad_ws_bytes(Cin, Cout, k);
     if (b > a) a = b;
     if (d > a) a = d;
     return a > c ? a : c;
@@ -360,6 +362,10 @@ int mi355seg_conv3d_wgrad_f32(const float* dy, int lddy, const float* x, int ldx
         return stem_wgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, st);
     if (head_supported(Cin, Cout, k, stride, pad, ldx))
         return head_wgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, st);
+    if (smallcin_wgrad_supported(Cin, Cout, k))
+        return smallcin_wgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, stride, pad, accumulate, ws, ws_bytes, st);
+    if (smallcout_wgrad_supported(Cin, Cout, k, ldx) && ((uintptr_t)x % 16) == 0)
+        return smallcout_wgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, stride, pad, accumulate, ws, ws_bytes, st);
     if (gwgrad_supported(N, D, H, W, Cin, Cout, k, stride, pad, ldx, lddy) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0)
         return conv_gwgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, stride, pad, accumulate, ws, ws_bytes, st);
     return conv_wgrad_generic(dy, lddy, x, ldx, dw, g, accumulate, ws, ws_bytes, st);

@@ -352,6 +352,196 @@ static int small_grid(long long nvox, int vpb) {
     return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
 }
 
+// ---------------------------------------------------------------- small-channel wgrad, any k / stride / pad
+struct SmallConv { int N, D, H, W, Do, Ho, Wo, Cin, Cout, k, stride, pad, T, ldx, lddy; };
+
+// (A) few input channels: thread = (output voxel, VW output channels); grid = (blocks, Cin, tap groups);
+//     acc[tap of the group][VW] += x[in(v, tap)][ci] * dy[v][co..co+VW).  part[blk][tap][ci][co]
+template <int TPG, int VW>
+__global__ __launch_bounds__(256) void smallcin_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+        float* __restrict__ part, SmallConv g) {
+    extern __shared__ __attribute__((aligned(16))) float sred[];
+    const int LPV = g.Cout / VW, VPB = 256 / LPV;
+    const int cq = threadIdx.x % LPV, vl = threadIdx.x / LPV;
+    const int ci = blockIdx.y, tg = blockIdx.z;
+    const long long nvox = (long long)g.N * g.Do * g.Ho * g.Wo;
+    float acc[TPG][VW];
+#pragma unroll
+    for (int t = 0; t < TPG; ++t)
+#pragma unroll
+        for (int j = 0; j < VW; ++j) acc[t][j] = 0.f;
+    for (long long v = (long long)blockIdx.x * VPB + vl; v < nvox; v += (long long)gridDim.x * VPB) {
+        int ow = (int)(v % g.Wo); long long r = v / g.Wo;
+        int oh = (int)(r % g.Ho); r /= g.Ho;
+        int od = (int)(r % g.Do); int n = (int)(r / g.Do);
+        float d[VW];
+#pragma unroll
+        for (int j = 0; j < VW; ++j) d[j] = dy[v * g.lddy + cq * VW + j];
+#pragma unroll
+        for (int t = 0; t < TPG; ++t) {
+            const int tap = tg * TPG + t;
+            const int kw = tap % g.k, kh = (tap / g.k) % g.k, kd = tap / (g.k * g.k);
+            const int iz = od * g.stride - g.pad + kd, iy = oh * g.stride - g.pad + kh, ix = ow * g.stride - g.pad + kw;
+            float xv = 0.f;
+            if (tap < g.T && (unsigned)iz < (unsigned)g.D && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+                xv = x[((((long long)n * g.D + iz) * g.H + iy) * g.W + ix) * g.ldx + ci];
+#pragma unroll
+            for (int j = 0; j < VW; ++j) acc[t][j] += xv * d[j];
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < TPG; ++t)
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+            float s = acc[t][j];
+            for (int o = 32; o >= LPV; o >>= 1) s += __shfl_xor(s, o, 64);
+            acc[t][j] = s;
+        }
+    if (lane < LPV) {
+#pragma unroll
+        for (int t = 0; t < TPG; ++t)
+#pragma unroll
+            for (int j = 0; j < VW; ++j) sred[((wave * TPG + t) * LPV + lane) * VW + j] = acc[t][j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TPG * g.Cout; i += 256) {
+        const int t = i / g.Cout, co = i % g.Cout, tap = tg * TPG + t;
+        if (tap >= g.T) continue;
+        float s = 0.f;
+        for (int w = 0; w < 4; ++w) s += sred[((w * TPG + t) * LPV + co / VW) * VW + co % VW];
+        part[(((long long)blockIdx.x * g.T + tap) * g.Cin + ci) * g.Cout + co] = s;
+    }
+}
+
+// (B) few output channels: thread = (output voxel, input-channel quad); grid = (blocks, tap groups);
+//     acc[tap][co] (f32x4 over the quad) += dy[v][co] * x[in(v, tap)][c4*4 .. +3].  part[blk][tap][ci][co]
+template <int COUT, int TPG>
+__global__ __launch_bounds__(256) void smallcout_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+        float* __restrict__ part, SmallConv g) {
+    extern __shared__ __attribute__((aligned(16))) float sred[];
+    const int LPV = g.Cin / 4, VPB = 256 / LPV;
+    const int c4 = threadIdx.x % LPV, vl = threadIdx.x / LPV;
+    const int tg = blockIdx.y;
+    const long long nvox = (long long)g.N * g.Do * g.Ho * g.Wo;
+    f32x4 acc[TPG][COUT];
+#pragma unroll
+    for (int t = 0; t < TPG; ++t)
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[t][co] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long long v = (long long)blockIdx.x * VPB + vl; v < nvox; v += (long long)gridDim.x * VPB) {
+        int ow = (int)(v % g.Wo); long long r = v / g.Wo;
+        int oh = (int)(r % g.Ho); r /= g.Ho;
+        int od = (int)(r % g.Do); int n = (int)(r / g.Do);
+        float d[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) d[co] = dy[v * g.lddy + co];
+#pragma unroll
+        for (int t = 0; t < TPG; ++t) {
+            const int tap = tg * TPG + t;
+            const int kw = tap % g.k, kh = (tap / g.k) % g.k, kd = tap / (g.k * g.k);
+            const int iz = od * g.stride - g.pad + kd, iy = oh * g.stride - g.pad + kh, ix = ow * g.stride - g.pad + kw;
+            f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+            if (tap < g.T && (unsigned)iz < (unsigned)g.D && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+                xv = *reinterpret_cast<const f32x4*>(x + ((((long long)n * g.D + iz) * g.H + iy) * g.W + ix) * g.ldx + c4 * 4);
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) acc[t][co] += d[co] * xv;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < TPG; ++t)
+#pragma unroll
+        for (int co = 0; co < COUT; ++co)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s = acc[t][co][j];
+                for (int o = 32; o >= LPV; o >>= 1) s += __shfl_xor(s, o, 64);
+                acc[t][co][j] = s;
+            }
+    if (lane < LPV) {
+#pragma unroll
+        for (int t = 0; t < TPG; ++t)
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) *reinterpret_cast<f32x4*>(sred + (((wave * TPG + t) * COUT + co) * LPV + lane) * 4) = acc[t][co];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TPG * g.Cin * COUT; i += 256) {
+        const int co = i % COUT, ci = (i / COUT) % g.Cin, t = i / (COUT * g.Cin), tap = tg * TPG + t;
+        if (tap >= g.T) continue;
+        float s = 0.f;
+        for (int w = 0; w < 4; ++w) s += sred[(((w * TPG + t) * COUT + co) * LPV + (ci / 4)) * 4 + ci % 4];
+        part[(((long long)blockIdx.x * g.T + tap) * g.Cin + ci) * COUT + co] = s;
+    }
+}
+
+static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+bool smallcin_wgrad_supported(int Cin, int Cout, int k) {
+    if (Cin > 4 || k > 7) return false;
+    const int vw = (Cout % 4 == 0) ? 4 : 1, lpv = Cout / vw;
+    return pow2(lpv) && lpv <= 64;
+}
+bool smallcout_wgrad_supported(int Cin, int Cout, int k, int ldx) {
+    const int lpv = Cin / 4;
+    return (Cout == 2 || Cout == 4) && Cin % 4 == 0 && pow2(lpv) && lpv <= 16 && ldx % 4 == 0 && k <= 7;   // LDS: 4*TPG*COUT*lpv*16 B
+}
+
+size_t small_wgrad_ws_bytes(int Cin, int Cout, int k) {
+    return align_up((size_t)512 * k * k * k * Cin * Cout * sizeof(float), 256) + 1024;
+}
+
+int smallcin_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
+                   int k, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+    SmallConv g{N, D, H, W, (D + 2 * pad - k) / stride + 1, (H + 2 * pad - k) / stride + 1, (W + 2 * pad - k) / stride + 1,
+                Cin, Cout, k, stride, pad, k * k * k, ldx, lddy};
+    const long long nvox = (long long)N * g.Do * g.Ho * g.Wo;
+    const int vw = (Cout % 4 == 0) ? 4 : 1, lpv = Cout / vw;
+    int nblk = small_grid(nvox, 256 / lpv);
+    if (nblk > 512) nblk = 512;
+    SEG_CHECK_WS((size_t)nblk * g.T * Cin * Cout * sizeof(float), ws_bytes);
+    float* part = (float*)ws;
+    const int TPG = 25;
+    dim3 grid(nblk, Cin, (g.T + TPG - 1) / TPG);
+    size_t lds = (size_t)4 * TPG * Cout * 4;
+    {
+        ProfScope ps(PF_DIRECT, 2.0 * nvox * g.T * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
+        if (vw == 4) hipLaunchKernelGGL((smallcin_wgrad_kernel<25, 4>), grid, dim3(256), lds, st, x, dy, part, g);
+        else hipLaunchKernelGGL((smallcin_wgrad_kernel<25, 1>), grid, dim3(256), lds, st, x, dy, part, g);
+        SEG_CHECK_LAUNCH();
+    }
+    wgrad_reduce(part, dw, nblk, g.T, Cin, Cout, accumulate, st);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+int smallcout_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
+                    int k, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+    SmallConv g{N, D, H, W, (D + 2 * pad - k) / stride + 1, (H + 2 * pad - k) / stride + 1, (W + 2 * pad - k) / stride + 1,
+                Cin, Cout, k, stride, pad, k * k * k, ldx, lddy};
+    const long long nvox = (long long)N * g.Do * g.Ho * g.Wo;
+    int nblk = small_grid(nvox, 256 / (Cin / 4));
+    if (nblk > 512) nblk = 512;
+    SEG_CHECK_WS((size_t)nblk * g.T * Cin * Cout * sizeof(float), ws_bytes);
+    float* part = (float*)ws;
+    {
+        ProfScope ps(PF_DIRECT, 2.0 * nvox * g.T * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
+        if (Cout == 2) {
+            constexpr int TPG = 25;
+            dim3 grid(nblk, (g.T + TPG - 1) / TPG);
+            hipLaunchKernelGGL((smallcout_wgrad_kernel<2, TPG>), grid, dim3(256), (size_t)4 * TPG * 2 * (Cin / 4) * 16, st, x, dy, part, g);
+        } else {
+            constexpr int TPG = 13;
+            dim3 grid(nblk, (g.T + TPG - 1) / TPG);
+            hipLaunchKernelGGL((smallcout_wgrad_kernel<4, TPG>), grid, dim3(256), (size_t)4 * TPG * 4 * (Cin / 4) * 16, st, x, dy, part, g);
+        }
+        SEG_CHECK_LAUNCH();
+    }
+    wgrad_reduce(part, dw, nblk, g.T, Cin, Cout, accumulate, st);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
 bool stem_supported(int Cin, int Cout, int k, int stride, int pad, int ldy) {
     const int lpv = Cout / 4;
     return k == 3 && stride == 1 && pad == 1 && (Cin == 1 || Cin == 2 || Cin == 4) && Cout % 4 == 0 && Cout >= 4 && Cout <= 64 &&

@@ -23,6 +23,13 @@ int head_fwd(const float* x, int ldx, const float* w, const float* bias, float* 
              int Cout, hipStream_t st);
 int head_dgrad(const float* dy, int lddy, const float* w, float* dx, int lddx, int N, int D, int H, int W, int Cin, int Cout,
                hipStream_t st);
+bool smallcin_wgrad_supported(int Cin, int Cout, int k);
+bool smallcout_wgrad_supported(int Cin, int Cout, int k, int ldx);
+size_t small_wgrad_ws_bytes(int Cin, int Cout, int k);
+int smallcin_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
+                   int k, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+int smallcout_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
+                    int k, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 int head_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
                int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 

@@ -507,9 +507,32 @@ int finalize_channel_partials(const float* part, int nblk, int C, double* sum, d
     return MI355SEG_OK;
 }
 
-// exported to the other translation units
+static int channel_sums_chunk(const float* x, int ldx, long long rows, int C, double* sum, double* sq, float* fsum, int accumulate,
+                              void* ws, size_t ws_bytes, hipStream_t st);
+
+// exported to the other translation units.  The reducer handles power-of-two widths up to 1024 (16 B per lane) or
+// any width up to 256, so wider / ragged channel counts are walked in such chunks (e.g. 768 = 512 + 256).
 int channel_sums(const float* x, int ldx, long long rows, int C, double* sum, double* sq, float* fsum, int accumulate,
                  void* ws, size_t ws_bytes, hipStream_t st) {
+    int c0 = 0;
+    while (c0 < C) {
+        int rem = C - c0, take;
+        if (rem >= 4 && (ldx % 4) == 0 && (c0 % 4) == 0 && ((uintptr_t)x % 16) == 0) {
+            take = 4;
+            while (take * 2 <= rem && take * 2 <= 1024) take *= 2;
+        } else {
+            take = rem < 256 ? rem : 256;
+        }
+        int rc = channel_sums_chunk(x + c0, ldx, rows, take, sum ? sum + c0 : nullptr, sq ? sq + c0 : nullptr, fsum ? fsum + c0 : nullptr,
+                                    accumulate, ws, ws_bytes, st);
+        if (rc) return rc;
+        c0 += take;
+    }
+    return MI355SEG_OK;
+}
+
+static int channel_sums_chunk(const float* x, int ldx, long long rows, int C, double* sum, double* sq, float* fsum, int accumulate,
+                              void* ws, size_t ws_bytes, hipStream_t st) {
     SEG_CHECK_WS(colsum_ws_bytes(C), ws_bytes);
     float* part = (float*)ws;
     RedPlan p;

@@ -214,21 +214,7 @@ int mi355seg_softmax_rows_bwd_f32(const float* y, const float* dy, float* dx, lo
 /* out[c] = sum_rows x[r, c]  (bias gradients of Linear layers) */
 int mi355seg_colsum_f32(const float* x, int ldx, long long rows, int C, float* out, void* ws, size_t ws_bytes, void* stream) {
     SEG_CHECK_ARG(x && out && rows > 0 && C > 0 && ldx >= C, "colsum: bad arguments");
-    // the per-channel reducer handles power-of-two widths up to 1024 (16 B/lane) or any width up to 256: walk C in such chunks
-    int c0 = 0;
-    while (c0 < C) {
-        int rem = C - c0, take;
-        if (rem >= 4 && (ldx % 4) == 0 && (c0 % 4) == 0) {
-            take = 4;
-            while (take * 2 <= rem && take * 2 <= 1024) take *= 2;
-        } else {
-            take = rem < 256 ? rem : 256;
-        }
-        int rc = channel_sums(x + c0, ldx, rows, take, nullptr, nullptr, out + c0, 0, ws, ws_bytes, (hipStream_t)stream);
-        if (rc) return rc;
-        c0 += take;
-    }
-    return MI355SEG_OK;
+    return channel_sums(x, ldx, rows, C, nullptr, nullptr, out, 0, ws, ws_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -65,6 +65,10 @@ CONV_CASES = [
     (1, 5, 7, 9, 32, 32, 3, 1, 1),         # odd extents
     (1, 6, 6, 6, 64, 32, 1, 1, 0),         # k1, partial tiles
     (1, 8, 8, 8, 16, 16, 5, 1, 2),
+    (2, 8, 8, 16, 1, 16, 5, 1, 2),         # V-Net in_tr: small-Cin direct wgrad, k5
+    (1, 8, 8, 16, 32, 2, 5, 1, 2),         # V-Net out_tr.conv1: small-Cout direct wgrad, k5
+    (2, 8, 8, 8, 2, 2, 1, 1, 0),           # V-Net out_tr.conv2: 2 -> 2, k1
+    (1, 8, 8, 8, 4, 8, 2, 2, 0),           # small-Cin strided
     (1, 8, 12, 32, 32, 64, 5, 1, 2),       # k5 on the MFMA igemm (V-Net LUConv), CK = 8
     (2, 6, 6, 6, 8, 32, 5, 1, 2),          # k5, partial tiles, single chunk
     (1, 16, 16, 16, 128, 128, 5, 1, 2),
