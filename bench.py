@@ -37,11 +37,31 @@ WORKLOADS = {
 }
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box
+    exposes all 256 hardware threads but grants a share of them; oversubscribing 256 threads on that share is
+    several times slower than matching it)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return min(n, 64)           # ATen CPU conv scaling is flat beyond a few dozen threads
+
+
 def cpu_baseline(sample_shape, steps=1):
     """Oracle (== reference arithmetic on ATen CPU) train step timed on the host cores."""
     from oracle.nets import UNet3D as OracleUNet
     from oracle.step import train_step as oracle_step, weights_init_normal
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     m = OracleUNet(1, 2, 32)
@@ -189,7 +209,7 @@ def main():
     res["step_roofline"] = {"conv_t_mfma_ms": t_mfma, "conv_t_hbm_ms": t_hbm, "frac_of_mfma_bound": t_mfma / ms, "frac_of_hbm_bound": t_hbm / ms}
     if world == 1 and not args.no_cpu_baseline:
         shape = tuple(int(v) for v in args.cpu_sample.split(","))
-        res["cpu_baseline"] = cpu_baseline(shape)
+        res["cpu_baseline"] = cpu_baseline(shape, steps=3)
         res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
     print(json.dumps(res))
     if world > 1:
