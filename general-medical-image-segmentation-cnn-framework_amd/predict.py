@@ -1,0 +1,124 @@
+"""``python predict.py config=unet config.ckpt=/abs/path`` -- the reference's sliding-window inference
+(predict.py:62-183) on the MI355X path: registry + ``ckpt["model"]`` load (predict.py:79-81), per-volume
+ZNormalization, grid patches with overlap, eval-mode forward, argmax, crop-mode aggregation, Dice/Jaccard.
+
+The patch grid and the 'crop' aggregation restate torchio's GridSampler / GridAggregator (third-party, pinned
+torchio==0.20.3 in the reference's requirements.txt, absent here): per axis the patch origins are
+``range(0, size + 1 - patch, patch - overlap)`` plus a last origin flush with the border; each predicted patch
+is cropped by ``overlap // 2`` on every side that does not touch the volume border before it is pasted.
+NIfTI / HD95 output (SimpleITK, monai) is out of scope; volumes are ``.npy`` and metrics go to metrics.csv.
+"""
+import csv
+import glob
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import functional as F
+from .config import compose, parse_patch_size
+from .registry import build_model
+from .utils.metric import metric_from_counts
+
+
+def grid_locations(size, patch, overlap):
+    """All patch origins [(z, y, x)] covering a volume of ``size`` (torchio GridSampler._get_patches_locations)."""
+    axes = []
+    for s, p, o in zip(size, patch, overlap):
+        if p > s:
+            raise ValueError(f"patch size {p} larger than the volume extent {s}")
+        if o >= p or o % 2:
+            raise ValueError(f"patch overlap {o} must be even and smaller than the patch size {p}")
+        idx = list(range(0, s + 1 - p, p - o))
+        if idx[-1] != s - p:
+            idx.append(s - p)
+        axes.append(idx)
+    return [(z, y, x) for z in axes[0] for y in axes[1] for x in axes[2]]
+
+
+def crop_window(loc, patch, size, overlap):
+    """(src slices into the patch, dst slices into the volume) of torchio's GridAggregator overlap_mode='crop'."""
+    src, dst = [], []
+    for l, p, s, o in zip(loc, patch, size, overlap):
+        a = o // 2 if l != 0 else 0
+        b = o // 2 if l + p != s else 0
+        src.append(slice(a, p - b))
+        dst.append(slice(l + a, l + p - b))
+    return tuple(src), tuple(dst)
+
+
+@torch.no_grad()
+def sliding_window_predict(model, volume, patch_size, overlap=(4, 4, 36), batch_size=1):
+    """volume: float tensor [C, D, H, W] on the GPU -> int64 label volume [1, D, H, W] (argmax over classes)."""
+    C, D, H, W = volume.shape
+    ps = (patch_size,) * 3 if isinstance(patch_size, int) else tuple(patch_size)
+    size = (D, H, W)
+    locs = grid_locations(size, ps, overlap)
+    out = torch.zeros((1, D, H, W), dtype=torch.int64, device=volume.device)
+    was_training = model.training
+    model.eval()
+    for i in range(0, len(locs), batch_size):
+        chunk = locs[i:i + batch_size]
+        x = torch.stack([volume[:, z:z + ps[0], y:y + ps[1], w:w + ps[2]] for (z, y, w) in chunk])
+        labels = F.argmax_channels(model(x.contiguous()))               # predict.py:133,139
+        for j, loc in enumerate(chunk):
+            src, dst = crop_window(loc, ps, size, overlap)
+            out[(0,) + dst] = labels[j, 0][src]
+    model.train(was_training)
+    return out
+
+
+def znorm(v):
+    """tio.ZNormalization (predict.py:94): zero mean / unit std over the whole volume."""
+    return (v - v.mean()) / (v.std() + 1e-8)
+
+
+def predict(config, model, log=print):
+    device = torch.device("cuda", 0)
+    if config.ckpt and str(config.ckpt) != "None":
+        ckpt = torch.load(config.ckpt, map_location="cpu")
+        state = {k[len("module."):] if k.startswith("module.") else k: v for k, v in ckpt["model"].items()}
+        model.load_state_dict(state)
+    model = model.to(device).eval()
+    ps = config.patch_size
+    ps = (ps,) * 3 if isinstance(ps, int) else tuple(ps)
+    overlap = tuple(min(o, p - 2) // 2 * 2 for o, p in zip((4, 4, 36), ps))   # predict.py:100 overlap, kept valid for small patches
+    os.makedirs(config.hydra_path, exist_ok=True)
+    if str(config.pred_data_path) == "synthetic":
+        g = torch.Generator().manual_seed(7)
+        cases = [("synthetic_%d" % i, torch.randn((config.in_classes,) + tuple(2 * p for p in ps), generator=g),
+                  (torch.rand((1,) + tuple(2 * p for p in ps), generator=g) > 0.9).float()) for i in range(2)]
+    else:
+        cases = []
+        for f in sorted(glob.glob(os.path.join(config.pred_data_path, "*.npy"))):
+            x = torch.from_numpy(np.load(f).astype(np.float32))
+            y = torch.from_numpy(np.load(os.path.join(config.pred_gt_path, os.path.basename(f))).astype(np.float32))
+            cases.append((os.path.splitext(os.path.basename(f))[0], x[None] if x.dim() == 3 else x, y[None] if y.dim() == 3 else y))
+    rows = []
+    for name, x, gt in cases:
+        vol = znorm(x.to(device))
+        mask = sliding_window_predict(model, vol, ps, overlap, batch_size=max(1, int(config.batch_size)))
+        counts = F.dice_counts(gt.to(device).to(torch.int64).reshape(mask.shape), mask)
+        jac, dice = metric_from_counts(counts.cpu().tolist())
+        np.save(os.path.join(config.hydra_path, f"{name}_pred.npy"), mask.cpu().numpy().astype(np.uint8))
+        rows.append({"file": name, "jaccard": jac, "dice": dice})
+        log(f"{name}: dice {dice:.4f} jaccard {jac:.4f}")
+    with open(os.path.join(config.hydra_path, "metrics.csv"), "w", newline="") as fh:
+        wr = csv.DictWriter(fh, fieldnames=["file", "jaccard", "dice"])
+        wr.writeheader()
+        wr.writerows(rows)
+    return rows
+
+
+def main(argv=None, conf_dir=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    conf_dir = conf_dir or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "conf")
+    config = compose(conf_dir, argv, job_name="predict")
+    parse_patch_size(config)
+    model = build_model(config)
+    return config, predict(config, model)
+
+
+if __name__ == "__main__":
+    main()

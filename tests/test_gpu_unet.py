@@ -111,3 +111,27 @@ def test_train_cli_checkpoints_and_resume(seg, tmp_path):
     assert res2["epoch"] == 3
     lines = open(os.path.join(cfg2.hydra_path, "scalars.jsonl")).read().strip().splitlines()
     assert len(lines) == 2 and "Training/dice" in lines[0]
+
+
+def test_predict_cli_sliding_window(seg, tmp_path):
+    """predict.py: checkpoint load, eval-mode BN (running stats), grid patches + crop aggregation, metrics.csv."""
+    from mi355seg.predict import main as predict_main, sliding_window_predict
+    from mi355seg.train import main as train_main
+    out = str(tmp_path / "logs")
+    common = ["config=unet", f"config.output_dir={out}", "config.patch_size=32,32,32", "config.batch_size=2"]
+    cfg, _ = train_main(common + ["config.iters_per_epoch=2", "config.epochs=1"])
+    ckpt = os.path.join(cfg.hydra_path, "latest_checkpoint.pt")
+    cfg2, rows = predict_main(common + [f"config.ckpt={ckpt}"])
+    assert len(rows) == 2 and all(0.0 <= r["dice"] <= 1.0 for r in rows)
+    assert os.path.exists(os.path.join(cfg2.hydra_path, "metrics.csv"))
+    pred = np.load(os.path.join(cfg2.hydra_path, "synthetic_0_pred.npy"))
+    assert pred.shape == (1, 64, 64, 64) and set(np.unique(pred)) <= {0, 1}
+    # a volume that is exactly one patch: sliding window == plain eval forward + argmax
+    from mi355seg.models.three_d.unet3d import UNet3D
+    m = fill_module_(UNet3D(1, 2, 8)).cuda().eval()
+    vol = make_input((1, 32, 32, 32)).cuda()
+    a = sliding_window_predict(m, vol, (32, 32, 32), (4, 4, 4))
+    with torch.no_grad():
+        b = m(vol[None]).argmax(1)
+    assert torch.equal(a, b)
+    assert not m.training
