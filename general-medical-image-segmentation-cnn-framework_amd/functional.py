@@ -190,6 +190,55 @@ class _ConvT3dK2S2(Function):
         return dx, dw, db
 
 
+class _ConvT3dK2S2Cat(Function):
+    """cat(conv_transpose3d_k2s2(x), skip) along channels without the copy: ``skip`` must be the right channel slice
+    of a buffer with exactly Cout free channels on its left (conv_bn_act(..., left_pad=Cout)); the up-convolution is
+    written into those channels and the whole buffer is returned."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, skip):
+        x, ldx = cl_view(x, "conv_transpose3d input")
+        N, D, H, W, Cin = x.shape
+        Cout = w.shape[1]
+        base = skip._base
+        Cs = skip.shape[-1]
+        ok = (base is not None and base.dim() == 5 and base.is_contiguous() and tuple(base.shape[:4]) == (N, 2 * D, 2 * H, 2 * W)
+              and base.shape[-1] == Cout + Cs and skip.data_ptr() == base.data_ptr() + 4 * Cout and skip.stride() == base.stride())
+        if not ok:
+            raise Mi355SegError("conv_transpose3d_k2s2_cat: `skip` is not the right channel slice of a matching concat buffer")
+        w = w.contiguous()
+        L = lib()
+        ws = workspace(L.query("mi355seg_convt3d_k2s2_ws_bytes", N, D, H, W, Cin, Cout), x.device)
+        L.call("mi355seg_convt3d_k2s2_fwd_f32", _p(x), ldx, _p(w), _p(b), _p(base), Cout + Cs, N, D, H, W, Cin, Cout,
+               _p(ws), ws.numel(), _stream())
+        ctx.save_for_backward(x, w)
+        ctx.geom = (N, D, H, W, Cin, Cout, Cs, ldx, b is not None)
+        return base
+
+    @staticmethod
+    def backward(ctx, dcat):
+        x, w = ctx.saved_tensors
+        N, D, H, W, Cin, Cout, Cs, ldx, has_b = ctx.geom
+        dcat, ldd = cl_view(dcat, "conv_transpose3d grad")
+        L = lib()
+        ws = workspace(L.query("mi355seg_convt3d_k2s2_ws_bytes", N, D, H, W, Cin, Cout), x.device)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((N, D, H, W, Cin), dtype=x.dtype, device=x.device)
+            L.call("mi355seg_convt3d_k2s2_dgrad_f32", _p(dcat), ldd, _p(w), _p(dx), Cin, N, D, H, W, Cin, Cout,
+                   _p(ws), ws.numel(), _stream())
+        if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
+            dw = torch.empty_like(w)
+            db = torch.empty(Cout, dtype=x.dtype, device=x.device) if has_b else None
+            L.call("mi355seg_convt3d_k2s2_wgrad_f32", _p(dcat), ldd, _p(x), ldx, _p(dw), _p(db), N, D, H, W, Cin, Cout,
+                   _p(ws), ws.numel(), _stream())
+        return dx, dw, db, dcat[..., Cout:]
+
+
+def conv_transpose3d_k2s2_cat(x, weight, bias, skip):
+    return _ConvT3dK2S2Cat.apply(x, weight, bias, skip)
+
+
 def conv_transpose3d_k2s2(x, weight, bias=None):
     """nn.ConvTranspose3d(kernel_size=2, stride=2) on a channel-last tensor."""
     return _ConvT3dK2S2.apply(x, weight, bias)
@@ -265,7 +314,7 @@ class _ConvBnAct(Function):
     pass (no separate pass over dy).  Training mode only updates running stats exactly as nn.BatchNorm3d."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, rmean, rvar, stride, pad, training, momentum, eps, act, slope):
+    def forward(ctx, x, w, b, gamma, beta, rmean, rvar, stride, pad, training, momentum, eps, act, slope, left_pad):
         x, ldx = cl_view(x, "conv3d input")
         N, D, H, W, Cin = x.shape
         Cout, k = w.shape[0], w.shape[2]
@@ -293,9 +342,15 @@ class _ConvBnAct(Function):
             mean = rmean
             rstd = torch.empty(Cout, dtype=torch.float32, device=dev)
             L.call("mi355seg_rstd_from_var_f32", _p(rvar), eps, _p(rstd), Cout, _stream())
-        a = torch.empty_like(y)
+        if left_pad:
+            # the activation lands in the RIGHT channel slice of a wider buffer whose left `left_pad` channels a later
+            # up-convolution fills (conv_transpose3d_k2s2_cat): the skip concatenation then costs no copy
+            full = torch.empty((N, Do, Ho, Wo, left_pad + Cout), dtype=x.dtype, device=dev)
+            a = full[..., left_pad:]
+        else:
+            a = torch.empty_like(y)
         L.call("mi355seg_norm_act_fwd_f32", _p(y), Cout, _p(mean), _p(rstd), _p(gamma), _p(beta), None, 0,
-               _p(a), Cout, rows, 1, Cout, act, slope, _stream())
+               a.data_ptr(), left_pad + Cout, rows, 1, Cout, act, slope, _stream())
         ctx.save_for_backward(x, w, y, mean, rstd, gamma, beta)
         ctx.cfg = (N, D, H, W, Cin, Cout, k, stride, pad, ldx, b is not None, rows, act, slope, bool(training))
         return a
@@ -326,10 +381,10 @@ class _ConvBnAct(Function):
             dw = torch.empty_like(w)
             L.call("mi355seg_conv3d_wgrad_f32", _p(dy), Cout, _p(x), ldx, _p(dw), None, N, D, H, W, Cin, Cout, k, stride, pad,
                    0, _p(ws), ws.numel(), _stream())
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
-def conv_bn_act(x, conv, bn, act=ACT_NONE, slope=0.01):
+def conv_bn_act(x, conv, bn, act=ACT_NONE, slope=0.01, left_pad=0):
     """act(bn(conv(x))) for a layers.Conv3d / layers.BatchNorm3d pair (module objects carry the parameters)."""
     if bn.momentum is None or not bn.affine or not bn.track_running_stats:
         raise NotImplementedError("conv_bn_act: BatchNorm3d must be affine with running statistics and a momentum")
@@ -338,7 +393,7 @@ def conv_bn_act(x, conv, bn, act=ACT_NONE, slope=0.01):
     if bn.training:
         bn.num_batches_tracked.add_(1)
     return _ConvBnAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, int(stride), int(pad),
-                            bool(bn.training), float(bn.momentum), float(bn.eps), int(act), float(slope))
+                            bool(bn.training), float(bn.momentum), float(bn.eps), int(act), float(slope), int(left_pad))
 
 
 class _Act(Function):

@@ -19,10 +19,12 @@ class _DoubleConv(nn.Sequential):
     """(conv k3 p1 -> BN -> ReLU) x 2 with the reference's child names (unet3d.py:73-104).
     ``forward`` fuses each BN with its ReLU."""
 
-    def forward(self, x):
+    def forward(self, x, left_pad=0):
+        """``left_pad`` > 0: the block's output is the right channel slice of a buffer with ``left_pad`` free channels
+        on its left, ready for the decoder's concat-free up-convolution (encoder blocks only)."""
         conv1, norm1, _r1, conv2, norm2, _r2 = self.children()
         x = F.conv_bn_act(x, conv1, norm1, F.ACT_RELU)          # conv + batch statistics + BN + ReLU, one autograd node
-        return F.conv_bn_act(x, conv2, norm2, F.ACT_RELU)
+        return F.conv_bn_act(x, conv2, norm2, F.ACT_RELU, left_pad=left_pad)
 
 
 class UNet3D(nn.Module):
@@ -61,12 +63,14 @@ class UNet3D(nn.Module):
 
     def forward(self, x):
         h = F.to_channels_last(x)
-        enc1 = self.encoder1(h)
-        enc2 = self.encoder2(self.pool1(enc1))
-        enc3 = self.encoder3(self.pool2(enc2))
-        enc4 = self.encoder4(self.pool3(enc3))
+        # each encoder output is written as the RIGHT half of its level's concat buffer; the matching up-convolution
+        # later fills the LEFT half (torch.cat((up, skip), dim=1) of unet3d.py:59-68 without the copy)
+        enc1 = self.encoder1(h, left_pad=self.upconv1.out_channels)
+        enc2 = self.encoder2(self.pool1(enc1), left_pad=self.upconv2.out_channels)
+        enc3 = self.encoder3(self.pool2(enc2), left_pad=self.upconv3.out_channels)
+        enc4 = self.encoder4(self.pool3(enc3), left_pad=self.upconv4.out_channels)
         h = self.bottleneck(self.pool4(enc4))
         for up, dec, skip in ((self.upconv4, self.decoder4, enc4), (self.upconv3, self.decoder3, enc3),
                               (self.upconv2, self.decoder2, enc2), (self.upconv1, self.decoder1, enc1)):
-            h = dec(torch.cat((up(h), skip), dim=-1))      # channel concat: up first, skip second
+            h = dec(F.conv_transpose3d_k2s2_cat(h, up.weight, up.bias, skip))
         return F.to_channels_first(self.conv(h))

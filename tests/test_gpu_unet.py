@@ -107,7 +107,8 @@ def test_train_cli_checkpoints_and_resume(seg, tmp_path):
     ck["model"] = {"module." + k: v for k, v in ck["model"].items()}
     pref = str(tmp_path / "prefixed.pt")
     torch.save(ck, pref)
-    cfg2, res2 = main(args[:-1] + ["config.epochs=3", "config.load_mode=1", f"config.ckpt={pref}"])
+    args2 = [a if not a.startswith("config.output_dir=") else f"config.output_dir={tmp_path / 'logs_resume'}" for a in args[:-1]]
+    cfg2, res2 = main(args2 + ["config.epochs=3", "config.load_mode=1", f"config.ckpt={pref}"])   # own run dir (same-second runs)
     assert res2["epoch"] == 3
     lines = open(os.path.join(cfg2.hydra_path, "scalars.jsonl")).read().strip().splitlines()
     assert len(lines) == 2 and "Training/dice" in lines[0]
