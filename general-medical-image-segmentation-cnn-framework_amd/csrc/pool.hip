@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restri
 // one thread per INPUT element: gradient flows to the window's arg-max position only
 template <bool VEC>
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ dy, int lddy, const uint8_t* __restrict__ idx,
-        float* __restrict__ dx, int lddx, int N, int D, int H, int W, int C) {
+        float* __restrict__ dx, int lddx, int N, int D, int H, int W, int C, const float* __restrict__ add, int ldadd) {
     const int Do = D / 2, Ho = H / 2, Wo = W / 2;
     const int cw = VEC ? C / 4 : C;
     const long long total = (long long)N * D * H * W * cw;
@@ -71,10 +71,12 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
                 o.x = cd.x == me ? g.x : 0.f; o.y = cd.y == me ? g.y : 0.f;
                 o.z = cd.z == me ? g.z : 0.f; o.w = cd.w == me ? g.w : 0.f;
             }
+            if (add) { float4 q = *reinterpret_cast<const float4*>(add + v * ldadd + c); o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
             *reinterpret_cast<float4*>(dx + v * lddx + c) = o;
         } else {
             float o = 0.f;
             if (inside && idx[ov * C + c] == me) o = dy[ov * lddy + c];
+            if (add) o += add[v * ldadd + c];
             dx[v * lddx + c] = o;
         }
     }
@@ -151,7 +153,16 @@ int mi355seg_maxpool2_bwd_f32(const float* dy, int lddy, const uint8_t* idx, flo
     SEG_CHECK_ARG(dy && dx && idx && N > 0 && D >= 2 && H >= 2 && W >= 2 && C > 0 && lddy >= C && lddx >= C, "maxpool2_bwd: bad arguments");
     bool v = (C % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0);
     long long total = (long long)N * D * H * W * (v ? C / 4 : C);
-    POOL_DISPATCH(maxpool2_bwd_kernel, v, total, dy, lddy, idx, dx, lddx, N, D, H, W, C);
+    POOL_DISPATCH(maxpool2_bwd_kernel, v, total, dy, lddy, idx, dx, lddx, N, D, H, W, C, (const float*)nullptr, 0);
+    return MI355SEG_OK;
+}
+int mi355seg_maxpool2_bwd_add_f32(const float* dy, int lddy, const uint8_t* idx, const float* add, int ldadd, float* dx, int lddx,
+                                  int N, int D, int H, int W, int C, void* stream) {
+    SEG_CHECK_ARG(dy && dx && idx && add && N > 0 && D >= 2 && H >= 2 && W >= 2 && C > 0 && lddy >= C && lddx >= C && ldadd >= C,
+                  "maxpool2_bwd_add: bad arguments");
+    bool v = (C % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) && (ldadd % 4 == 0) && ((uintptr_t)add % 16) == 0;
+    long long total = (long long)N * D * H * W * (v ? C / 4 : C);
+    POOL_DISPATCH(maxpool2_bwd_kernel, v, total, dy, lddy, idx, dx, lddx, N, D, H, W, C, add, ldadd);
     return MI355SEG_OK;
 }
 int mi355seg_upsample2_fwd_f32(const float* x, int ldx, float* y, int ldy, int N, int D, int H, int W, int C, void* stream) {

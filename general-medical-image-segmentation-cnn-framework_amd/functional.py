@@ -478,6 +478,36 @@ class _MaxPool2(Function):
         return dx
 
 
+class _PoolAndSkip(Function):
+    """(max_pool3d_2x(x), x): the pooled tensor for the next level and x itself for the skip connection, as ONE
+    autograd node so that the two incoming gradients are summed inside the pool-backward kernel."""
+
+    @staticmethod
+    def forward(ctx, x):
+        xv, ldx = cl_view(x, "max_pool3d input")
+        N, D, H, W, C = xv.shape
+        y = torch.empty((N, D // 2, H // 2, W // 2, C), dtype=xv.dtype, device=xv.device)
+        idx = torch.empty((N, D // 2, H // 2, W // 2, C), dtype=torch.uint8, device=xv.device)
+        lib().call("mi355seg_maxpool2_fwd_f32", _p(xv), ldx, _p(y), C, _p(idx), N, D, H, W, C, _stream())
+        ctx.save_for_backward(idx)
+        ctx.geom = (N, D, H, W, C)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        (idx,) = ctx.saved_tensors
+        N, D, H, W, C = ctx.geom
+        dy, lddy = cl_view(dy, "max_pool3d grad")
+        ds, lds = cl_view(dskip, "skip grad")
+        dx = torch.empty((N, D, H, W, C), dtype=dy.dtype, device=dy.device)
+        lib().call("mi355seg_maxpool2_bwd_add_f32", _p(dy), lddy, _p(idx), _p(ds), lds, _p(dx), C, N, D, H, W, C, _stream())
+        return dx
+
+
+def max_pool3d_2x_and_skip(x):
+    return _PoolAndSkip.apply(x)
+
+
 def max_pool3d_2x(x):
     """nn.MaxPool3d(kernel_size=2, stride=2)."""
     return _MaxPool2.apply(x)

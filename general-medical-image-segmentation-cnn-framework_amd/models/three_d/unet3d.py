@@ -65,11 +65,12 @@ class UNet3D(nn.Module):
         h = F.to_channels_last(x)
         # each encoder output is written as the RIGHT half of its level's concat buffer; the matching up-convolution
         # later fills the LEFT half (torch.cat((up, skip), dim=1) of unet3d.py:59-68 without the copy)
-        enc1 = self.encoder1(h, left_pad=self.upconv1.out_channels)
-        enc2 = self.encoder2(self.pool1(enc1), left_pad=self.upconv2.out_channels)
-        enc3 = self.encoder3(self.pool2(enc2), left_pad=self.upconv3.out_channels)
-        enc4 = self.encoder4(self.pool3(enc3), left_pad=self.upconv4.out_channels)
-        h = self.bottleneck(self.pool4(enc4))
+        # pool + skip leave each encoder block as one autograd node (their two gradients are summed in the pool backward)
+        p1, enc1 = F.max_pool3d_2x_and_skip(self.encoder1(h, left_pad=self.upconv1.out_channels))
+        p2, enc2 = F.max_pool3d_2x_and_skip(self.encoder2(p1, left_pad=self.upconv2.out_channels))
+        p3, enc3 = F.max_pool3d_2x_and_skip(self.encoder3(p2, left_pad=self.upconv3.out_channels))
+        p4, enc4 = F.max_pool3d_2x_and_skip(self.encoder4(p3, left_pad=self.upconv4.out_channels))
+        h = self.bottleneck(p4)
         for up, dec, skip in ((self.upconv4, self.decoder4, enc4), (self.upconv3, self.decoder3, enc3),
                               (self.upconv2, self.decoder2, enc2), (self.upconv1, self.decoder1, enc1)):
             h = dec(F.conv_transpose3d_k2s2_cat(h, up.weight, up.bias, skip))

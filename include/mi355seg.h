@@ -158,6 +158,10 @@ int mi355seg_maxpool2_fwd_f32(const float* x, int ldx, float* y, int ldy, uint8_
                               int N, int D, int H, int W, int C, void* stream);
 int mi355seg_maxpool2_bwd_f32(const float* dy, int lddy, const uint8_t* idx, float* dx, int lddx,
                               int N, int D, int H, int W, int C, void* stream);
+/* dx = maxpool_backward(dy) + add: the encoder activation feeds both the pool and the skip connection
+ * (unet3d.py:51-54,59-68); this folds autograd's gradient accumulation of the two branches into the pool backward. */
+int mi355seg_maxpool2_bwd_add_f32(const float* dy, int lddy, const uint8_t* idx, const float* add, int ldadd, float* dx, int lddx,
+                                  int N, int D, int H, int W, int C, void* stream);
 /* nn.Upsample(scale_factor=2, mode='nearest') (residual_unet3d.py:19,103) */
 int mi355seg_upsample2_fwd_f32(const float* x, int ldx, float* y, int ldy,
                                int N, int D, int H, int W, int C, void* stream);
