@@ -99,12 +99,15 @@ def main():
     from mi355seg.engine import train_step, weights_init_normal
     from mi355seg.models.three_d.unet3d import UNet3D
 
-    rank, world, local = D.init_from_env()
+    # MI355SEG_DIST_BACKEND=gloo lets the N > 1 path be rehearsed on a one-GPU box (ranks share cuda:0); the
+    # driver's real runs use the default: nccl == RCCL over xGMI, one rank per GPU
+    rank, world, local = D.init_from_env(backend=os.environ.get("MI355SEG_DIST_BACKEND"))
     if args.gpus != world:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the product path)"
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     L = mi355seg.lib()
