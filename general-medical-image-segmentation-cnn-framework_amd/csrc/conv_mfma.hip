@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
                 f32x4 av[MB];
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) av[mb] = *reinterpret_cast<const f32x4*>(lds + abase[mb] + tapoff + kk * 8);
+                if (a.dbg & 8) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
 #pragma unroll
                         for (int nb = 0; nb < NBW; ++nb)
                             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb][s], bq[cur][nb][s], acc[mb][nb], 0, 0, 0);
+                if (a.dbg & 8) __builtin_amdgcn_s_setprio(0);
             }
         }
     }
