@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void nsc_to_ncs_kernel(const float* __restrict
 template <bool ADD>
 __global__ __launch_bounds__(256) void rows_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd,
                                                     long long rows, int C) {
-    const bool v = (C % 4 == 0) && (lds % 4 == 0) && (ldd % 4 == 0);
+    const bool v = (C % 4 == 0) && (lds % 4 == 0) && (ldd % 4 == 0) && (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
     const int cw = v ? C / 4 : C;
     const long long total = rows * cw;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -97,6 +97,38 @@ __global__ __launch_bounds__(256) void rows_kernel(const float* __restrict__ src
 }  // namespace seg
 
 using namespace seg;
+
+// y[r, j*C + c] = x[r, c] (j < rep) and its adjoint dx[r, c] = sum_j dy[r, j*C + c]; C*rep is small (V-Net: 16).
+__global__ __launch_bounds__(256) void repeat_ch_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                                        long long rows, int C, int rep) {
+    const int CR = C * rep;
+    const long long total = rows * CR;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / CR;
+        const int c = (int)(i - r * CR);
+        y[r * ldy + c] = x[r * ldx + c % C];
+    }
+}
+__global__ __launch_bounds__(256) void repeat_ch_bwd_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx,
+                                                            long long rows, int C, int rep) {
+    const long long total = rows * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / C;
+        const int c = (int)(i - r * C);
+        float s = 0.f;
+        for (int j = 0; j < rep; ++j) s += dy[r * lddy + j * C + c];
+        dx[r * lddx + c] = s;
+    }
+}
+__global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o,
+                                                  long long n) {
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
+        reinterpret_cast<float4*>(o)[i] = make_float4(u.x * v.x, u.y * v.y, u.z * v.z, u.w * v.w);
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) o[i] = a[i] * b[i];
+}
 
 extern "C" {
 
@@ -160,6 +192,26 @@ int mi355seg_add_rows_f32(const float* src, int ldsrc, float* dst, int lddst, lo
     SEG_CHECK_ARG(src && dst && rows > 0 && C > 0 && ldsrc >= C && lddst >= C, "add_rows: bad arguments");
     hipLaunchKernelGGL((rows_kernel<true>), dim3(rows_grid(rows * C / 4 + 1)), dim3(256), 0, (hipStream_t)stream, src, ldsrc,
                        dst, lddst, rows, C);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+int mi355seg_repeat_channels_f32(const float* x, int ldx, float* y, int ldy, long long rows, int C, int rep, void* stream) {
+    SEG_CHECK_ARG(x && y && rows > 0 && C > 0 && rep > 0 && ldx >= C && ldy >= C * rep, "repeat_channels: bad arguments");
+    hipLaunchKernelGGL(repeat_ch_kernel, dim3(rows_grid(rows * C * rep)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, C, rep);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_repeat_channels_bwd_f32(const float* dy, int lddy, float* dx, int lddx, long long rows, int C, int rep, void* stream) {
+    SEG_CHECK_ARG(dy && dx && rows > 0 && C > 0 && rep > 0 && lddx >= C && lddy >= C * rep, "repeat_channels_bwd: bad arguments");
+    hipLaunchKernelGGL(repeat_ch_bwd_kernel, dim3(rows_grid(rows * C)), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx, lddx, rows, C, rep);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_mul_f32(const float* a, const float* b, float* out, long long n, void* stream) {
+    SEG_CHECK_ARG(a && b && out && n > 0, "mul: bad arguments");
+    SEG_CHECK_ARG(((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) % 16 == 0, "mul: operands must be 16-byte aligned");
+    hipLaunchKernelGGL(mul_kernel, dim3(rows_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }

@@ -706,6 +706,73 @@ def cross_entropy_3d(logits, labels, weight=None, size_average=True):
     return _CE3D.apply(logits, labels, weight, size_average)
 
 
+# ----------------------------------------------------------------------------- channel concat / repeat
+class _CatChannels(Function):
+    """torch.cat((a, b), dim=1) of the reference (vnet3d.py:101, residual_unet3d.py:183-209, unetr.py:286-293) in
+    channel-last form: two strided slice copies into one buffer; the backward hands out the two slices as views."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, lda = cl_view(a, "cat_channels first input")
+        b, ldb = cl_view(b, "cat_channels second input")
+        if a.shape[:4] != b.shape[:4]:
+            raise Mi355SegError(f"cat_channels: spatial shapes differ: {tuple(a.shape)} vs {tuple(b.shape)}")
+        N, D, H, W, Ca = a.shape
+        Cb = b.shape[4]
+        out = torch.empty((N, D, H, W, Ca + Cb), dtype=a.dtype, device=a.device)
+        rows = N * D * H * W
+        L = lib()
+        L.call("mi355seg_copy_rows_f32", _p(a), lda, _p(out), Ca + Cb, rows, Ca, _stream())
+        L.call("mi355seg_copy_rows_f32", _p(b), ldb, out.data_ptr() + 4 * Ca, Ca + Cb, rows, Cb, _stream())
+        ctx.ca = Ca
+        return out
+
+    @staticmethod
+    def backward(ctx, dcat):
+        return dcat[..., :ctx.ca], dcat[..., ctx.ca:]
+
+
+def cat_channels(a, b):
+    return _CatChannels.apply(a, b)
+
+
+class _RepeatChannels(Function):
+    """x.repeat(1, rep, 1, 1, 1) (vnet3d.py:55-56) in channel-last form."""
+
+    @staticmethod
+    def forward(ctx, x, rep):
+        x, ldx = cl_view(x, "repeat_channels input")
+        N, D, H, W, C = x.shape
+        y = torch.empty((N, D, H, W, C * rep), dtype=x.dtype, device=x.device)
+        lib().call("mi355seg_repeat_channels_f32", _p(x), ldx, _p(y), C * rep, N * D * H * W, C, rep, _stream())
+        ctx.cfg = (C, rep)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        C, rep = ctx.cfg
+        dy, lddy = cl_view(dy, "repeat_channels grad")
+        N, D, H, W, _ = dy.shape
+        dx = torch.empty((N, D, H, W, C), dtype=dy.dtype, device=dy.device)
+        lib().call("mi355seg_repeat_channels_bwd_f32", _p(dy), lddy, _p(dx), C, N * D * H * W, C, rep, _stream())
+        return dx, None
+
+
+def repeat_channels(x, rep):
+    return _RepeatChannels.apply(x, int(rep))
+
+
+def _mul(a, b, out=None):
+    """Elementwise product of two equally shaped contiguous fp32 tensors (no autograd; used inside Functions)."""
+    a, b = a.contiguous(), b.contiguous()
+    if a.shape != b.shape:
+        raise Mi355SegError(f"mul: shapes differ: {tuple(a.shape)} vs {tuple(b.shape)}")
+    if out is None:
+        out = torch.empty_like(a)
+    lib().call("mi355seg_mul_f32", _p(a), _p(b), _p(out), a.numel(), _stream())
+    return out
+
+
 # ----------------------------------------------------------------------------- UNETR encoder ops
 def _gemm(A, a_rs, a_cs, a_b0, a_b1, B, b_rs, b_cs, b_b0, b_b1, C, c_rs, c_b0, c_b1, bias, M, N, K, nb0=1, nb1=1,
           alpha=1.0, relu=0, accumulate=0):
@@ -734,8 +801,10 @@ class _Linear(Function):
         x2, w, yrelu = ctx.saved_tensors
         shp, M, N, K, relu, has_b = ctx.cfg
         dy2 = dy.contiguous().view(M, N)
-        if relu:
-            dy2 = dy2 * (yrelu > 0).to(dy2.dtype)          # tiny [tokens, d_ff] mask; plumbing
+        if relu:                                            # dy * 1[y > 0]: the ReLU backward kernel, keyed on the saved output
+            g = torch.empty_like(dy2)
+            lib().call("mi355seg_act_bwd_f32", _p(dy2), N, _p(yrelu), N, None, 0, _p(g), N, M, N, ACT_RELU, 0.0, _stream())
+            dy2 = g
         dx = torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
         _gemm(_p(dy2), N, 1, 0, 0, _p(w), K, 1, 0, 0, _p(dx), K, 0, 0, None, M, K, N)
         dw = torch.empty_like(w)
@@ -800,7 +869,7 @@ class _Attention(Function):
         _gemm(_p(q), E, 1, P * E, d, _p(k), 1, E, P * E, d, _p(scores), P, heads * P * P, P * P, None, P, P, d, B, heads, alpha)
         probs = torch.empty_like(scores)
         lib().call("mi355seg_softmax_rows_f32", _p(scores), _p(probs), B * heads * P, P, _stream())
-        pd = probs if keep is None else probs * keep
+        pd = probs if keep is None else _mul(probs, keep)
         ctxl = torch.empty((B, P, E), dtype=q.dtype, device=q.device)
         _gemm(_p(pd), P, 1, heads * P * P, P * P, _p(v), E, 1, P * E, d, _p(ctxl), E, P * E, d, None, P, d, P, B, heads)
         ctx.save_for_backward(q, k, v, probs, keep)
@@ -812,13 +881,13 @@ class _Attention(Function):
         q, k, v, probs, keep = ctx.saved_tensors
         B, P, E, heads, d, alpha = ctx.cfg
         do = do.contiguous()
-        pd = probs if keep is None else probs * keep
+        pd = probs if keep is None else _mul(probs, keep)
         HPP, PP = heads * P * P, P * P
         dpd = torch.empty_like(probs)                                   # dP = dO V^T
         _gemm(_p(do), E, 1, P * E, d, _p(v), 1, E, P * E, d, _p(dpd), P, HPP, PP, None, P, P, d, B, heads)
         dv = torch.empty_like(v)                                        # dV = Pd^T dO
         _gemm(_p(pd), 1, P, HPP, PP, _p(do), E, 1, P * E, d, _p(dv), E, P * E, d, None, P, d, P, B, heads)
-        dp = dpd if keep is None else dpd * keep
+        dp = dpd if keep is None else _mul(dpd, keep, out=dpd)
         ds = torch.empty_like(probs)
         lib().call("mi355seg_softmax_rows_bwd_f32", _p(probs), _p(dp), _p(ds), B * heads * P, P, _stream())
         dq = torch.empty_like(q)                                        # dQ = alpha dS K

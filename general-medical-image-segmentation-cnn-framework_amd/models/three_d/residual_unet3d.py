@@ -8,7 +8,6 @@ LeakyReLU(0.01), Dropout3d(0.6), nearest x2 upsampling, weight-shared
 ``norm_lrelu_conv_c{2..5}`` applied twice per level (autograd accumulates both weight
 gradients), deep-supervision sum.
 """
-import torch
 import torch.nn as nn
 
 from ... import functional as F
@@ -130,12 +129,12 @@ class UNet(nn.Module):
         h = self.inorm3d_l0.forward_act(self.conv3d_l0(h), *_LRELU)
         ds = {}
         for lvl in (1, 2, 3):                                  # localisation (:174-194)
-            h = torch.cat([h, ctx[4 - lvl]], dim=-1)
+            h = F.cat_channels(h, ctx[4 - lvl])
             h = getattr(self, f"conv_norm_lrelu_l{lvl}")(h)
             ds[lvl] = h
             h = getattr(self, f"conv3d_l{lvl}")(h)
             h = getattr(self, f"norm_lrelu_upscale_conv_norm_lrelu_l{lvl}")(h)
-        h = torch.cat([h, ctx[0]], dim=-1)
+        h = F.cat_channels(h, ctx[0])
         out_pred = self.conv3d_l4(self.conv_norm_lrelu_l4(h))
         s = F.activation(self.upsacle(self.ds2_1x1_conv3d(ds[2])), F.ACT_NONE, residual=self.ds3_1x1_conv3d(ds[3]))
         out = F.activation(out_pred, F.ACT_NONE, residual=self.upsacle(s))

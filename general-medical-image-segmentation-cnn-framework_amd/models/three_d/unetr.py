@@ -1,189 +1,223 @@
 """UNETR on the MI355X kernels -- drop-in for the reference's models/three_d/unetr.py.
 
-Same constructor (``UNETR(img_shape, input_dim, output_dim, embed_dim, patch_size, num_heads, dropout)``,
-unetr.py:195), the same 338 ``state_dict`` keys and forward semantics
-(unetr.py:277-294).  The ViT encoder (12 x [LayerNorm, 12-head attention, FFN 768->2048->768 ReLU], taps
-after layers 3/6/9/12; ``encoder_norm`` is constructed but never applied, as in the reference) runs on the
-strided batched MFMA GEMM + LayerNorm + softmax kernels; token tensors [N, P, E] ARE the channel-last
-volumes [N, p0, p1, p2, E] the reference builds with ``transpose(-1, -2).view(...)`` (unetr.py:280-283), so
-the hand-over to the conv decoder is a free view.  The decoder reuses the U-Net conv / ConvT / BN+ReLU kernels.
-"""
-import copy
+Interface contract kept from the reference: the constructor ``UNETR(img_shape, input_dim, output_dim, embed_dim,
+patch_size, num_heads, dropout)`` (unetr.py:195), the same 338 ``state_dict`` keys (SURVEY.md appendix D -- which
+fixes the class nesting ``decoderN.i.block.j.block``) and the forward semantics of unetr.py:277-294.
 
+How it runs here: the ViT encoder (12 x [LayerNorm, 12-head attention, FFN 768->2048->768 ReLU], taps after layers
+3/6/9/12; ``encoder_norm`` is constructed but never applied, as in the reference) uses the strided batched MFMA
+GEMM + LayerNorm + softmax kernels.  A token tensor [N, P, E] IS the channel-last volume [N, p0, p1, p2, E] that
+the reference builds with ``transpose(-1, -2).view(...)`` (unetr.py:280-283), so the hand-over to the conv decoder
+is a free view.  The decoder reuses the U-Net conv / ConvT / fused conv+BN+ReLU kernels; its stages are declared
+in ``_DECODER_PLAN`` below instead of being spelled out one by one.
+"""
 import torch
 import torch.nn as nn
 
 from ... import functional as F
 from ...layers import BatchNorm3d, Conv3d, ConvTranspose3d, Dropout, LayerNorm, Linear, ReLU
 
+_FFN_WIDTH = 2048
+_DEPTH = 12
+_TAPS = (3, 6, 9, 12)
 
-class SingleDeconv3DBlock(nn.Module):
-    def __init__(self, in_planes, out_planes):
+
+# ------------------------------------------------------------------------------------------- decoder bricks
+class _Holder(nn.Module):
+    """A module with a single child called ``block`` (the nesting the reference's state_dict keys encode)."""
+
+    def __init__(self, child):
         super().__init__()
-        self.block = ConvTranspose3d(in_planes, out_planes, kernel_size=2, stride=2, padding=0, output_padding=0)
+        self.block = child
 
     def forward(self, x):
         return self.block(x)
 
 
-class SingleConv3DBlock(nn.Module):
-    def __init__(self, in_planes, out_planes, kernel_size):
-        super().__init__()
-        self.block = Conv3d(in_planes, out_planes, kernel_size=kernel_size, stride=1, padding=((kernel_size - 1) // 2))
+class SingleDeconv3DBlock(_Holder):
+    """ConvT k2 s2 (unetr.py:9-16)."""
+
+    def __init__(self, cin, cout):
+        super().__init__(ConvTranspose3d(cin, cout, kernel_size=2, stride=2))
+
+
+class SingleConv3DBlock(_Holder):
+    """'same' conv of odd kernel size (unetr.py:19-27)."""
+
+    def __init__(self, cin, cout, ksize):
+        super().__init__(Conv3d(cin, cout, kernel_size=ksize, stride=1, padding=(ksize - 1) // 2))
+
+
+class _FusedTail(nn.Sequential):
+    """[..., SingleConv3DBlock, BatchNorm3d, ReLU]: the last three run as ONE conv + statistics + BN + ReLU pass."""
 
     def forward(self, x):
-        return self.block(x)
-
-
-class _ConvBnRelu(nn.Sequential):
-    def forward(self, x):
-        mods = list(self.children())
-        for m in mods[:-3]:
+        *head, conv, bn, _relu = self.children()
+        for m in head:
             x = m(x)
-        return F.conv_bn_act(x, mods[-3].block, mods[-2], F.ACT_RELU)     # conv + statistics + BN + ReLU fused
+        return F.conv_bn_act(x, conv.block, bn, F.ACT_RELU)
 
 
-class Conv3DBlock(nn.Module):
-    def __init__(self, in_planes, out_planes, kernel_size=3):
-        super().__init__()
-        self.block = _ConvBnRelu(SingleConv3DBlock(in_planes, out_planes, kernel_size), BatchNorm3d(out_planes), ReLU(True))
+class Conv3DBlock(_Holder):
+    """conv -> BN -> ReLU (unetr.py:30-41)."""
 
-    def forward(self, x):
-        return self.block(x)
+    def __init__(self, cin, cout, ksize=3):
+        super().__init__(_FusedTail(SingleConv3DBlock(cin, cout, ksize), BatchNorm3d(cout), ReLU(True)))
 
 
-class Deconv3DBlock(nn.Module):
-    def __init__(self, in_planes, out_planes, kernel_size=3):
-        super().__init__()
-        self.block = _ConvBnRelu(SingleDeconv3DBlock(in_planes, out_planes), SingleConv3DBlock(out_planes, out_planes, kernel_size),
-                                 BatchNorm3d(out_planes), ReLU(True))
+class Deconv3DBlock(_Holder):
+    """ConvT k2 s2 -> conv -> BN -> ReLU (unetr.py:44-56)."""
 
-    def forward(self, x):
-        return self.block(x)
+    def __init__(self, cin, cout, ksize=3):
+        super().__init__(_FusedTail(SingleDeconv3DBlock(cin, cout), SingleConv3DBlock(cout, cout, ksize),
+                                    BatchNorm3d(cout), ReLU(True)))
 
 
-def _add(a, b):
-    """a + b on token tensors [N, P, E] (residual adds, unetr.py:160,166)."""
-    N, P, E = a.shape
-    return F.activation(a.reshape(N, 1, 1, P, E), F.ACT_NONE, residual=b.reshape(N, 1, 1, P, E)).view(N, P, E)
+_BRICKS = {"conv": Conv3DBlock, "deconv": Deconv3DBlock, "up": SingleDeconv3DBlock,
+           "head": lambda cin, cout: SingleConv3DBlock(cin, cout, 1)}
+
+
+def _chain(spec, subst):
+    """spec: ((brick, cin, cout), ...) with the placeholders 'E' / 'in' / 'out' resolved through ``subst``."""
+    mods = [_BRICKS[kind](subst.get(a, a), subst.get(b, b)) for kind, a, b in spec]
+    return mods[0] if len(mods) == 1 else nn.Sequential(*mods)
+
+
+# attribute -> stages, in the reference's registration order (unetr.py:214-275)
+_DECODER_PLAN = (
+    ("decoder0", (("conv", "in", 32), ("conv", 32, 64))),
+    ("decoder3", (("deconv", "E", 512), ("deconv", 512, 256), ("deconv", 256, 128))),
+    ("decoder6", (("deconv", "E", 512), ("deconv", 512, 256))),
+    ("decoder9", (("deconv", "E", 512),)),
+    ("decoder12_upsampler", (("up", "E", 512),)),
+    ("decoder9_upsampler", (("conv", 1024, 512), ("conv", 512, 512), ("conv", 512, 512), ("up", 512, 256))),
+    ("decoder6_upsampler", (("conv", 512, 256), ("conv", 256, 256), ("up", 256, 128))),
+    ("decoder3_upsampler", (("conv", 256, 128), ("conv", 128, 128), ("up", 128, 64))),
+    ("decoder0_header", (("conv", 128, 64), ("conv", 64, 64), ("head", 64, "out"))),
+)
+
+
+# ------------------------------------------------------------------------------------------- ViT encoder
+def _token_sum(a, b):
+    """a + b on token tensors [N, P, E] (the residual adds of unetr.py:160,166) through the fused add kernel."""
+    n, p, e = a.shape
+    as5d = lambda t: t.reshape(n, 1, 1, p, e)
+    return F.activation(as5d(a), F.ACT_NONE, residual=as5d(b)).view(n, p, e)
 
 
 class SelfAttention(nn.Module):
+    """Multi-head attention with separate q/k/v/out projections (unetr.py:59-110)."""
+
     def __init__(self, num_heads, embed_dim, dropout):
         super().__init__()
         self.num_attention_heads = num_heads
-        self.attention_head_size = int(embed_dim / num_heads)
-        self.all_head_size = self.num_attention_heads * self.attention_head_size
-        self.query = Linear(embed_dim, self.all_head_size)
-        self.key = Linear(embed_dim, self.all_head_size)
-        self.value = Linear(embed_dim, self.all_head_size)
+        self.attention_head_size = embed_dim // num_heads
+        self.all_head_size = self.attention_head_size * num_heads
+        for name in ("query", "key", "value"):
+            setattr(self, name, Linear(embed_dim, self.all_head_size))
         self.out = Linear(embed_dim, embed_dim)
-        self.attn_dropout = Dropout(dropout)
-        self.proj_dropout = Dropout(dropout)
-        self.softmax = nn.Softmax(dim=-1)
+        self.attn_dropout, self.proj_dropout = Dropout(dropout), Dropout(dropout)
+        self.softmax = nn.Softmax(dim=-1)            # kept for interface parity; the fused kernel does the work
         self.vis = False
 
     def forward(self, hidden_states):
-        q, k, v = self.query(hidden_states), self.key(hidden_states), self.value(hidden_states)
-        keep = None
+        q, k, v = (proj(hidden_states) for proj in (self.query, self.key, self.value))
+        mask = None
         if self.training and self.attn_dropout.p > 0.0:
-            B, P, _ = q.shape
-            keep = self.attn_dropout.draw((B, self.num_attention_heads, P, P), q.device)
-        context = F.attention(q, k, v, self.num_attention_heads, keep)
-        return self.proj_dropout(self.out(context)), None
+            mask = self.attn_dropout.draw((q.shape[0], self.num_attention_heads, q.shape[1], q.shape[1]), q.device)
+        mixed = F.attention(q, k, v, self.num_attention_heads, mask)
+        return self.proj_dropout(self.out(mixed)), None
 
 
 class PositionwiseFeedForward(nn.Module):
-    def __init__(self, d_model=786, d_ff=2048, dropout=0.1):
+    """w_2(dropout(relu(w_1 x))) (unetr.py:127-138); the 786 default is the reference's (never used) typo."""
+
+    def __init__(self, d_model=786, d_ff=_FFN_WIDTH, dropout=0.1):
         super().__init__()
-        self.w_1 = Linear(d_model, d_ff)
-        self.w_2 = Linear(d_ff, d_model)
+        self.w_1, self.w_2 = Linear(d_model, d_ff), Linear(d_ff, d_model)
         self.dropout = Dropout(dropout)
 
     def forward(self, x):
-        return self.w_2(self.dropout(self.w_1.forward_relu(x)))
+        hidden = self.w_1.forward_relu(x)            # bias + ReLU in the GEMM epilogue
+        return self.w_2(self.dropout(hidden))
+
+
+def _patch_count(cube, patch):
+    return int((cube[0] * cube[1] * cube[2]) / (patch * patch * patch))
 
 
 class Embeddings(nn.Module):
+    """Patch embedding (conv kernel = stride = patch) + learned positions + dropout (unetr.py:141-156)."""
+
     def __init__(self, input_dim, embed_dim, cube_size, patch_size, dropout):
         super().__init__()
-        self.n_patches = int((cube_size[0] * cube_size[1] * cube_size[2]) / (patch_size * patch_size * patch_size))
-        self.patch_size = patch_size
-        self.embed_dim = embed_dim
-        self.patch_embeddings = Conv3d(in_channels=input_dim, out_channels=embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.n_patches, self.patch_size, self.embed_dim = _patch_count(cube_size, patch_size), patch_size, embed_dim
+        self.patch_embeddings = Conv3d(input_dim, embed_dim, kernel_size=patch_size, stride=patch_size)
         self.position_embeddings = nn.Parameter(torch.zeros(1, self.n_patches, embed_dim))
         self.dropout = Dropout(dropout)
 
     def forward(self, x):
         """x: channel-last [N, D, H, W, Cin] -> tokens [N, P, E]."""
-        t = self.patch_embeddings(x)
-        N = t.shape[0]
-        t = t.reshape(N, self.n_patches, self.embed_dim)
-        return self.dropout(_add(t, self.position_embeddings.expand(N, -1, -1)))
+        tokens = self.patch_embeddings(x)
+        batch = tokens.shape[0]
+        tokens = tokens.reshape(batch, self.n_patches, self.embed_dim)
+        return self.dropout(_token_sum(tokens, self.position_embeddings.expand(batch, -1, -1)))
 
 
 class TransformerBlock(nn.Module):
+    """Pre-norm block: x + attn(LN x), then x + ffn(LN x) (unetr.py:159-192)."""
+
     def __init__(self, embed_dim, num_heads, dropout, cube_size, patch_size):
         super().__init__()
         self.attention_norm = LayerNorm(embed_dim, eps=1e-6)
         self.mlp_norm = LayerNorm(embed_dim, eps=1e-6)
-        self.mlp_dim = int((cube_size[0] * cube_size[1] * cube_size[2]) / (patch_size * patch_size * patch_size))
-        self.mlp = PositionwiseFeedForward(embed_dim, 2048)      # the reference leaves the FFN dropout at its 0.1 default
+        self.mlp_dim = _patch_count(cube_size, patch_size)
+        self.mlp = PositionwiseFeedForward(embed_dim, _FFN_WIDTH)     # FFN dropout stays at its 0.1 default, as upstream
         self.attn = SelfAttention(num_heads, embed_dim, dropout)
 
     def forward(self, x):
-        a, weights = self.attn(self.attention_norm(x))
-        x = _add(a, x)
-        return _add(self.mlp(self.mlp_norm(x)), x), weights
+        attended, weights = self.attn(self.attention_norm(x))
+        x = _token_sum(attended, x)
+        return _token_sum(self.mlp(self.mlp_norm(x)), x), weights
 
 
 class Transformer(nn.Module):
     def __init__(self, input_dim, embed_dim, cube_size, patch_size, num_heads, num_layers, dropout, extract_layers):
         super().__init__()
         self.embeddings = Embeddings(input_dim, embed_dim, cube_size, patch_size, dropout)
-        self.layer = nn.ModuleList()
-        self.encoder_norm = LayerNorm(embed_dim, eps=1e-6)       # constructed but never applied (unetr.py:176)
+        self.layer = nn.ModuleList(TransformerBlock(embed_dim, num_heads, dropout, cube_size, patch_size)
+                                   for _ in range(num_layers))
+        self.encoder_norm = LayerNorm(embed_dim, eps=1e-6)            # constructed but never applied (unetr.py:176)
         self.extract_layers = extract_layers
-        for _ in range(num_layers):
-            self.layer.append(copy.deepcopy(TransformerBlock(embed_dim, num_heads, dropout, cube_size, patch_size)))
 
     def forward(self, x):
-        taps = []
-        h = self.embeddings(x)
-        for depth, blk in enumerate(self.layer):
-            h, _ = blk(h)
-            if depth + 1 in self.extract_layers:
+        h, taps = self.embeddings(x), []
+        for index, block in enumerate(self.layer, start=1):
+            h, _ = block(h)
+            if index in self.extract_layers:
                 taps.append(h)
         return taps
 
 
+# ------------------------------------------------------------------------------------------- the network
 class UNETR(nn.Module):
     def __init__(self, img_shape=(128, 128, 128), input_dim=4, output_dim=3, embed_dim=768, patch_size=16, num_heads=12, dropout=0.1):
         super().__init__()
         self.input_dim, self.output_dim, self.embed_dim = input_dim, output_dim, embed_dim
         self.img_shape, self.patch_size, self.num_heads, self.dropout = img_shape, patch_size, num_heads, dropout
-        self.num_layers = 12
-        self.ext_layers = [3, 6, 9, 12]
-        self.patch_dim = [int(x / patch_size) for x in img_shape]
-        self.transformer = Transformer(input_dim, embed_dim, img_shape, patch_size, num_heads, self.num_layers, dropout, self.ext_layers)
-        self.decoder0 = nn.Sequential(Conv3DBlock(input_dim, 32, 3), Conv3DBlock(32, 64, 3))
-        self.decoder3 = nn.Sequential(Deconv3DBlock(embed_dim, 512), Deconv3DBlock(512, 256), Deconv3DBlock(256, 128))
-        self.decoder6 = nn.Sequential(Deconv3DBlock(embed_dim, 512), Deconv3DBlock(512, 256))
-        self.decoder9 = Deconv3DBlock(embed_dim, 512)
-        self.decoder12_upsampler = SingleDeconv3DBlock(embed_dim, 512)
-        self.decoder9_upsampler = nn.Sequential(Conv3DBlock(1024, 512), Conv3DBlock(512, 512), Conv3DBlock(512, 512),
-                                                SingleDeconv3DBlock(512, 256))
-        self.decoder6_upsampler = nn.Sequential(Conv3DBlock(512, 256), Conv3DBlock(256, 256), SingleDeconv3DBlock(256, 128))
-        self.decoder3_upsampler = nn.Sequential(Conv3DBlock(256, 128), Conv3DBlock(128, 128), SingleDeconv3DBlock(128, 64))
-        self.decoder0_header = nn.Sequential(Conv3DBlock(128, 64), Conv3DBlock(64, 64), SingleConv3DBlock(64, output_dim, 1))
+        self.num_layers, self.ext_layers = _DEPTH, list(_TAPS)
+        self.patch_dim = [int(extent / patch_size) for extent in img_shape]
+        self.transformer = Transformer(input_dim, embed_dim, img_shape, patch_size, num_heads, _DEPTH, dropout, self.ext_layers)
+        subst = {"E": embed_dim, "in": input_dim, "out": output_dim}
+        for attr, spec in _DECODER_PLAN:
+            setattr(self, attr, _chain(spec, subst))
 
     def forward(self, x):
         z0 = F.to_channels_last(x)
-        N = z0.shape[0]
-        z3, z6, z9, z12 = [t.reshape(N, *self.patch_dim, self.embed_dim) for t in self.transformer(z0)]
-        z12 = self.decoder12_upsampler(z12)
-        z9 = self.decoder9_upsampler(torch.cat([self.decoder9(z9), z12], dim=-1))
-        z6 = self.decoder6_upsampler(torch.cat([self.decoder6(z6), z9], dim=-1))
-        z3 = self.decoder3_upsampler(torch.cat([self.decoder3(z3), z6], dim=-1))
-        out = self.decoder0_header(torch.cat([self.decoder0(z0), z3], dim=-1))
-        return F.to_channels_first(out)
+        batch = z0.shape[0]
+        z3, z6, z9, z12 = (t.reshape(batch, *self.patch_dim, self.embed_dim) for t in self.transformer(z0))
+        up = self.decoder12_upsampler(z12)
+        for lateral, tap, merge in ((self.decoder9, z9, self.decoder9_upsampler), (self.decoder6, z6, self.decoder6_upsampler),
+                                    (self.decoder3, z3, self.decoder3_upsampler), (self.decoder0, z0, self.decoder0_header)):
+            up = merge(F.cat_channels(lateral(tap), up))
+        return F.to_channels_first(up)

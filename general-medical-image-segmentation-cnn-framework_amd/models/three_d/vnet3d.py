@@ -1,143 +1,138 @@
 """V-Net on the MI355X kernels -- drop-in for the reference's models/three_d/vnet3d.py.
 
-Same constructor (``VNet(elu=True, in_channels=1, classes=2)``, vnet3d.py:129), same
-``state_dict`` keys (``in_tr.conv1.weight`` ... ``out_tr.conv2.bias``) and
-forward semantics (vnet3d.py:146-157).  Activations are channel-last; every BatchNorm runs fused
-with the residual add and ELU that follow it (vnet3d.py:57-58,79,103).  Only the default
-``elu=True`` branch is implemented (the PReLU branch is dead at the reference's defaults).
+Interface contract kept from the reference: ``VNet(elu=True, in_channels=1, classes=2)`` (vnet3d.py:129), the
+``state_dict`` keys ``in_tr.conv1.weight`` ... ``out_tr.conv2.bias`` and the forward
+semantics of vnet3d.py:146-157.  Everything else is organised for the kernels: activations stay channel-last,
+every BatchNorm is one fused launch with the residual add and the ELU that follow it (vnet3d.py:57-58,79,103),
+and the channel concat / repeat are strided slice copies.  Only the default ``elu=True`` branch exists (the
+PReLU branch is dead at the reference's defaults).
 """
-import torch
 import torch.nn as nn
 
 from ... import functional as F
 from ...layers import BatchNorm3d, Conv3d, ConvTranspose3d, Dropout3d, ELU
 
+_K5 = dict(kernel_size=5, padding=2)
+_STEM_WIDTH = 16
+# (attribute, input channels, number of k5 conv units) for the encoder; (attribute, in, out, units) for the decoder
+_ENCODER = (("down_tr32", 16, 1), ("down_tr64", 32, 2), ("down_tr128", 64, 3), ("down_tr256", 128, 2))
+_DECODER = (("up_tr256", 256, 256, 2), ("up_tr128", 256, 128, 2), ("up_tr64", 128, 64, 1), ("up_tr32", 64, 32, 1))
 
-def _elu_only(elu):
+
+def _act_module(elu):
     if not elu:
         raise NotImplementedError("VNet(elu=False) (PReLU) is not implemented; the reference default is elu=True")
     return ELU(inplace=True)
 
 
-class LUConv(nn.Module):
-    """conv k5 p2 -> BN -> ELU (vnet3d.py:21-31)."""
+def _bn_elu(bn, conv_out, residual=None):
+    return bn.forward_act(conv_out, F.ACT_ELU, residual=residual)
 
-    def __init__(self, nchan, elu):
+
+class LUConv(nn.Module):
+    """One k5 unit: ELU(BN(conv(x)))  (vnet3d.py:21-31)."""
+
+    def __init__(self, width, elu):
         super().__init__()
-        self.relu1 = _elu_only(elu)
-        self.conv1 = Conv3d(nchan, nchan, kernel_size=5, padding=2)
-        self.bn1 = BatchNorm3d(nchan)
+        self.relu1 = _act_module(elu)
+        self.conv1 = Conv3d(width, width, **_K5)
+        self.bn1 = BatchNorm3d(width)
 
     def forward(self, x):
-        return self.bn1.forward_act(self.conv1(x), F.ACT_ELU)
+        return _bn_elu(self.bn1, self.conv1(x))
 
 
-def _make_nConv(nchan, depth, elu):
-    return nn.Sequential(*[LUConv(nchan, elu) for _ in range(depth)])
+def _make_nConv(width, units, elu):
+    return nn.Sequential(*(LUConv(width, elu) for _ in range(units)))
 
 
 class InputTransition(nn.Module):
-    """ELU(BN(conv k5(x)) + x repeated to 16 channels)  (vnet3d.py:41-58)."""
+    """ELU(BN(conv k5(x)) + x tiled to 16 channels)  (vnet3d.py:41-58)."""
 
     def __init__(self, in_channels, elu):
         super().__init__()
-        self.num_features = 16
-        self.in_channels = in_channels
-        self.conv1 = Conv3d(in_channels, self.num_features, kernel_size=5, padding=2)
-        self.bn1 = BatchNorm3d(self.num_features)
-        self.relu1 = _elu_only(elu)
+        self.in_channels, self.num_features = in_channels, _STEM_WIDTH
+        self.conv1 = Conv3d(in_channels, _STEM_WIDTH, **_K5)
+        self.bn1 = BatchNorm3d(_STEM_WIDTH)
+        self.relu1 = _act_module(elu)
 
     def forward(self, x):
-        rep = int(self.num_features / self.in_channels)
-        x16 = x.repeat(1, 1, 1, 1, rep)                       # channel-last: last dim is the channel
-        return self.bn1.forward_act(self.conv1(x), F.ACT_ELU, residual=x16)
+        tiled = F.repeat_channels(x, self.num_features // self.in_channels)
+        return _bn_elu(self.bn1, self.conv1(x), residual=tiled)
 
 
 class DownTransition(nn.Module):
-    """conv k2 s2 -> BN -> ELU -> n x LUConv -> (+ down) -> ELU  (vnet3d.py:61-80)."""
+    """down = ELU(BN(conv k2 s2)); ELU(units(down) + down)  (vnet3d.py:61-80)."""
 
-    def __init__(self, inChans, nConvs, elu, dropout=False):
+    def __init__(self, cin, units, elu, dropout=False):
         super().__init__()
-        outChans = 2 * inChans
-        self.down_conv = Conv3d(inChans, outChans, kernel_size=2, stride=2)
-        self.bn1 = BatchNorm3d(outChans)
-        self.relu1 = _elu_only(elu)
-        self.relu2 = _elu_only(elu)
+        self.down_conv = Conv3d(cin, 2 * cin, kernel_size=2, stride=2)
+        self.bn1 = BatchNorm3d(2 * cin)
+        self.relu1, self.relu2 = _act_module(elu), _act_module(elu)
         self.do1 = Dropout3d() if dropout else nn.Identity()
-        self.ops = _make_nConv(outChans, nConvs, elu)
+        self.ops = _make_nConv(2 * cin, units, elu)
 
     def forward(self, x):
-        down = self.bn1.forward_act(self.down_conv(x), F.ACT_ELU)
-        out = self.ops(self.do1(down))
-        return F.activation(out, F.ACT_ELU, residual=down)
+        down = _bn_elu(self.bn1, self.down_conv(x))
+        return F.activation(self.ops(self.do1(down)), F.ACT_ELU, residual=down)
 
 
 class UpTransition(nn.Module):
-    """Dropout3d(skip); ConvT k2 s2 -> BN -> ELU; cat; n x LUConv; (+ cat) -> ELU  (vnet3d.py:83-104)."""
+    """cat = [ELU(BN(ConvT k2 s2(x))), Dropout3d(skip)]; ELU(units(cat) + cat)  (vnet3d.py:83-104)."""
 
-    def __init__(self, inChans, outChans, nConvs, elu, dropout=False):
+    def __init__(self, cin, cout, units, elu, dropout=False):
         super().__init__()
-        self.up_conv = ConvTranspose3d(inChans, outChans // 2, kernel_size=2, stride=2)
-        self.bn1 = BatchNorm3d(outChans // 2)
+        self.up_conv = ConvTranspose3d(cin, cout // 2, kernel_size=2, stride=2)
+        self.bn1 = BatchNorm3d(cout // 2)
         self.do1 = Dropout3d() if dropout else nn.Identity()
         self.do2 = Dropout3d()
-        self.relu1 = _elu_only(elu)
-        self.relu2 = _elu_only(elu)
-        self.ops = _make_nConv(outChans, nConvs, elu)
+        self.relu1, self.relu2 = _act_module(elu), _act_module(elu)
+        self.ops = _make_nConv(cout, units, elu)
 
     def forward(self, x, skipx):
-        skip = self.do2(skipx)
-        up = self.bn1.forward_act(self.up_conv(self.do1(x)), F.ACT_ELU)
-        xcat = torch.cat((up, skip), dim=-1)
-        return F.activation(self.ops(xcat), F.ACT_ELU, residual=xcat)
+        kept_skip = self.do2(skipx)                      # the reference draws the skip mask first (vnet3d.py:99)
+        up = _bn_elu(self.bn1, self.up_conv(self.do1(x)))
+        both = F.cat_channels(up, kept_skip)
+        return F.activation(self.ops(both), F.ACT_ELU, residual=both)
 
 
 class OutputTransition(nn.Module):
-    """conv k5 -> BN -> ELU -> conv k1  (vnet3d.py:107-121)."""
+    """conv k1(ELU(BN(conv k5(x))))  (vnet3d.py:107-121)."""
 
     def __init__(self, in_channels, classes, elu):
         super().__init__()
         self.classes = classes
-        self.conv1 = Conv3d(in_channels, classes, kernel_size=5, padding=2)
+        self.conv1 = Conv3d(in_channels, classes, **_K5)
         self.bn1 = BatchNorm3d(classes)
         self.conv2 = Conv3d(classes, classes, kernel_size=1)
-        self.relu1 = _elu_only(elu)
+        self.relu1 = _act_module(elu)
 
     def forward(self, x):
-        return self.conv2(self.bn1.forward_act(self.conv1(x), F.ACT_ELU))
+        return self.conv2(_bn_elu(self.bn1, self.conv1(x)))
 
 
 class VNet(nn.Module):
     def __init__(self, elu=True, in_channels=1, classes=2):
         super().__init__()
-        if 16 % in_channels:
+        if _STEM_WIDTH % in_channels:
             raise ValueError("VNet: in_channels must divide 16 (vnet3d.py:55 repeat_rate)")
-        self.classes = classes
-        self.in_channels = in_channels
+        self.classes, self.in_channels = classes, in_channels
         self.in_tr = InputTransition(in_channels, elu=elu)
-        self.down_tr32 = DownTransition(16, 1, elu)
-        self.down_tr64 = DownTransition(32, 2, elu)
-        self.down_tr128 = DownTransition(64, 3, elu, dropout=False)
-        self.down_tr256 = DownTransition(128, 2, elu, dropout=False)
-        self.up_tr256 = UpTransition(256, 256, 2, elu, dropout=False)
-        self.up_tr128 = UpTransition(256, 128, 2, elu, dropout=False)
-        self.up_tr64 = UpTransition(128, 64, 1, elu)
-        self.up_tr32 = UpTransition(64, 32, 1, elu)
+        for attr, cin, units in _ENCODER:
+            setattr(self, attr, DownTransition(cin, units, elu))
+        for attr, cin, cout, units in _DECODER:
+            setattr(self, attr, UpTransition(cin, cout, units, elu))
         self.out_tr = OutputTransition(32, classes, elu)
 
     def dropout_layers(self):
         """The four always-on skip dropouts in call order (for mask injection in parity tests)."""
-        return [self.up_tr256.do2, self.up_tr128.do2, self.up_tr64.do2, self.up_tr32.do2]
+        return [getattr(self, attr).do2 for attr, *_ in _DECODER]
 
     def forward(self, x):
-        h = F.to_channels_last(x)
-        out16 = self.in_tr(h)
-        out32 = self.down_tr32(out16)
-        out64 = self.down_tr64(out32)
-        out128 = self.down_tr128(out64)
-        out256 = self.down_tr256(out128)
-        h = self.up_tr256(out256, out128)
-        h = self.up_tr128(h, out64)
-        h = self.up_tr64(h, out32)
-        h = self.up_tr32(h, out16)
+        feats = [self.in_tr(F.to_channels_last(x))]
+        for attr, *_ in _ENCODER:
+            feats.append(getattr(self, attr)(feats[-1]))
+        h = feats.pop()
+        for attr, *_ in _DECODER:
+            h = getattr(self, attr)(h, feats.pop())
         return F.to_channels_first(self.out_tr(h))

@@ -261,6 +261,12 @@ int mi355seg_ndhwc_to_ncdhw_f32(const float* src, int ldsrc, float* dst, long lo
 int mi355seg_copy_rows_f32(const float* src, int ldsrc, float* dst, int lddst, long long rows, int C, void* stream);
 /* dst[r, 0:C] += src[r, 0:C] */
 int mi355seg_add_rows_f32(const float* src, int ldsrc, float* dst, int lddst, long long rows, int C, void* stream);
+/* x.repeat(1, rep, 1, 1, 1) in channel-last form (vnet3d.py:55-56): y[r, j*C + c] = x[r, c], and its adjoint
+ * dx[r, c] = sum_j dy[r, j*C + c]. */
+int mi355seg_repeat_channels_f32(const float* x, int ldx, float* y, int ldy, long long rows, int C, int rep, void* stream);
+int mi355seg_repeat_channels_bwd_f32(const float* dy, int lddy, float* dx, int lddx, long long rows, int C, int rep, void* stream);
+/* out[i] = a[i] * b[i] (attention-probability dropout mask, unetr.py:112; out may alias a). */
+int mi355seg_mul_f32(const float* a, const float* b, float* out, long long n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -260,6 +260,28 @@ def test_maxpool_and_upsample(seg, C):
     assert (cf(xg.grad) - xr.grad).abs().max() < 1e-5
 
 
+def test_cat_and_repeat_channels(seg):
+    """torch.cat(dim=1) / x.repeat(1, rep, 1, 1, 1) of the reference in channel-last form: bit-exact copies, exact adjoints."""
+    F = seg.functional
+    for ca, cb in ((8, 8), (3, 5), (16, 2)):
+        a, b = rnd(2, 3, 4, 5, ca, seed=2).cuda().requires_grad_(True), rnd(2, 3, 4, 5, cb, seed=3).cuda().requires_grad_(True)
+        y = F.cat_channels(a, b)
+        assert torch.equal(y, torch.cat((a, b), dim=-1))
+        g = rnd(2, 3, 4, 5, ca + cb, seed=4).cuda()
+        y.backward(g)
+        assert torch.equal(a.grad, g[..., :ca]) and torch.equal(b.grad, g[..., ca:])
+    for c, rep in ((1, 16), (2, 8), (4, 4)):
+        x = rnd(2, 3, 4, 5, c, seed=5).cuda().requires_grad_(True)
+        y = F.repeat_channels(x, rep)
+        assert torch.equal(y, x.repeat(1, 1, 1, 1, rep))
+        g = rnd(2, 3, 4, 5, c * rep, seed=6).cuda()
+        y.backward(g)
+        want = g.double().view(2, 3, 4, 5, rep, c).sum(4)
+        assert (x.grad.double() - want).abs().max() < 1e-5
+    u, v = rnd(7, 13, 11, seed=7).cuda(), rnd(7, 13, 11, seed=8).cuda()
+    assert torch.equal(F._mul(u, v), u * v)
+
+
 def test_layout_roundtrip(seg):
     F = seg.functional
     x = rnd(2, 5, 4, 6, 7, seed=1)
