@@ -1,8 +1,8 @@
 // transformer.hip -- the UNETR encoder's dense ops (unetr.py:54-168): Linear / attention matmuls as one
 // strided, batched fp32-MFMA GEMM, LayerNorm and row softmax with their backward.  At 96^3 the encoder is
 // 216 tokens x 768 (0.09 TFLOP per step vs 4.6 TFLOP of decoder convs), so these kernels are written for
-// correctness and low launch count, not tuned: 64x64 tiles, K-step 16, operands staged in LDS with a
-// layout-dependent (coalesced) global read; a wavefront per row for LayerNorm / softmax (DPP shuffles).
+// low latency at few-hundred-row sizes: 64x64 tiles, K-step 32 with register prefetch, float4 global reads
+// along whichever operand index is contiguous, deterministic split-K when the tile count cannot fill the chip; a wavefront per row for LayerNorm / softmax (DPP shuffles).
 #include "common.h"
 #include "internal.h"
 
@@ -15,41 +15,94 @@ struct GemmArgs {
     long long a_rs, a_cs, a_b0, a_b1, b_rs, b_cs, b_b0, b_b1, c_rs, c_b0, c_b1;
     int M, N, K, nb1;
     float alpha; int relu, accumulate;
+    int S, kchunk, avec, bvec;      // split-K factor, K range per split, float4 global reads allowed for A / B
+    float* slabs;                   // [S][M][N] partial products when S > 1
 };
 
-constexpr int GT = 64, GK = 16, LDA_S = GK + 1, LDB_S = GT + 1;
+constexpr int GT = 64, GK = 32, LDA_S = GK + 1, LDB_S = GT + 1;
 
+// One operand tile (64 "outer" rows x GK k-columns) moves global -> 8 registers per thread -> LDS.  ``ofast``: the outer
+// index is the unit-stride one.  ``vec``: 16-byte reads along the unit-stride index (host-verified alignment), with a
+// per-group scalar fallback at the M/N/K edges.  LDS element (o, k) lives at o * so + k * sk.
+struct TileMover {
+    const float* base; long long os, ks; int o0, olim, klim; bool ofast, vec;
+    __device__ __forceinline__ void coords(int slot, int tid, int& o, int& k) const {
+        if (vec) {
+            const int q = slot * 256 + tid;                  // 512 float4 groups
+            if (ofast) { k = q >> 4; o = (q & 15) << 2; } else { o = q >> 3; k = (q & 7) << 2; }
+        } else {
+            const int q = slot * 256 + tid;                  // 2048 scalars
+            if (ofast) { k = q >> 6; o = q & 63; } else { o = q >> 5; k = q & 31; }
+        }
+    }
+    __device__ __forceinline__ void load(int k0, int tid, float (&r)[8]) const {
+        if (vec) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                int o, k; coords(e, tid, o, k);
+                const float* p = base + (long long)(o0 + o) * os + (long long)(k0 + k) * ks;
+                const bool full = ofast ? (o0 + o + 3 < olim && k0 + k < klim) : (o0 + o < olim && k0 + k + 3 < klim);
+                if (full) {
+                    const float4 v = *reinterpret_cast<const float4*>(p);
+                    r[4 * e] = v.x; r[4 * e + 1] = v.y; r[4 * e + 2] = v.z; r[4 * e + 3] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int oo = o + (ofast ? j : 0), kk = k + (ofast ? 0 : j);
+                        r[4 * e + j] = (o0 + oo < olim && k0 + kk < klim) ? p[j] : 0.f;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int o, k; coords(e, tid, o, k);
+                r[e] = (o0 + o < olim && k0 + k < klim) ? base[(long long)(o0 + o) * os + (long long)(k0 + k) * ks] : 0.f;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float* lds, int so, int sk, int tid, const float (&r)[8]) const {
+        if (vec) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                int o, k; coords(e, tid, o, k);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lds[(o + (ofast ? j : 0)) * so + (k + (ofast ? 0 : j)) * sk] = r[4 * e + j];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { int o, k; coords(e, tid, o, k); lds[o * so + k * sk] = r[e]; }
+        }
+    }
+};
+
+// C[b][M,N] (+)= alpha * A[b][M,K] B[b][K,N] + bias, arbitrary strides, 64x64 tile per workgroup (4 waves, one 32x32 fp32
+// MFMA accumulator each), K walked in steps of 32 with the next step's operands prefetched into registers while the
+// current one is multiplied.  blockIdx.z = batch * S + split; with S > 1 the raw partial tile goes to its slab and
+// gemm_splitk_epilogue applies alpha / bias / accumulate / ReLU after a fixed-order sum (deterministic).
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     __shared__ float As[GT * LDA_S];
     __shared__ float Bs[GK * LDB_S];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, i = lane & 31;
     const int wr = wave >> 1, wc = wave & 1;
-    const int b0 = blockIdx.z / g.nb1, b1 = blockIdx.z % g.nb1;
-    const float* A = g.A + b0 * g.a_b0 + b1 * g.a_b1;
-    const float* B = g.B + b0 * g.b_b0 + b1 * g.b_b1;
-    float* C = g.C + b0 * g.c_b0 + b1 * g.c_b1;
+    const int split = blockIdx.z % g.S, bz = blockIdx.z / g.S;
+    const int b0 = bz / g.nb1, b1 = bz % g.nb1;
     const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int kbeg = split * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    const TileMover ta{g.A + b0 * g.a_b0 + b1 * g.a_b1, g.a_rs, g.a_cs, m0, g.M, kend, g.a_rs == 1 && g.a_cs != 1, g.avec != 0};
+    const TileMover tb{g.B + b0 * g.b_b0 + b1 * g.b_b1, g.b_cs, g.b_rs, n0, g.N, kend, g.b_cs == 1, g.bvec != 0};
     f32x16 acc;
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[v] = 0.f;
-    const bool a_kfast = g.a_cs == 1, b_nfast = g.b_cs == 1;
-    for (int k0 = 0; k0 < g.K; k0 += GK) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int idx = e * 256 + tid;
-            int m, k;
-            if (a_kfast) { m = idx / GK; k = idx % GK; } else { k = idx / GT; m = idx % GT; }
-            float v = 0.f;
-            if (m0 + m < g.M && k0 + k < g.K) v = A[(long long)(m0 + m) * g.a_rs + (long long)(k0 + k) * g.a_cs];
-            As[m * LDA_S + k] = v;
-            int kb, n;
-            if (b_nfast) { kb = idx / GT; n = idx % GT; } else { n = idx / GK; kb = idx % GK; }
-            float w = 0.f;
-            if (k0 + kb < g.K && n0 + n < g.N) w = B[(long long)(k0 + kb) * g.b_rs + (long long)(n0 + n) * g.b_cs];
-            Bs[kb * LDB_S + n] = w;
-        }
+    float ra[8], rb[8];
+    ta.load(kbeg, tid, ra);
+    tb.load(kbeg, tid, rb);
+    for (int k0 = kbeg; k0 < kend; k0 += GK) {
+        ta.store(As, LDA_S, 1, tid, ra);
+        tb.store(Bs, 1, LDB_S, tid, rb);
         __syncthreads();
+        if (k0 + GK < kend) { ta.load(k0 + GK, tid, ra); tb.load(k0 + GK, tid, rb); }
 #pragma unroll
         for (int kk = 0; kk < GK / 2; ++kk) {
             const float av = As[(wr * 32 + i) * LDA_S + kk * 2 + h];
@@ -59,20 +112,55 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         __syncthreads();
     }
     const int col = n0 + wc * 32 + i;
-    if (col < g.N) {
-        const float bv = g.bias ? g.bias[col] : 0.f;
+    if (col >= g.N) return;
+    if (g.S > 1) {
+        float* slab = g.slabs + (long long)split * g.M * g.N;
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int row = m0 + wr * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-            if (row < g.M) {
-                float* dst = C + (long long)row * g.c_rs + col;
-                float val = g.alpha * acc[v] + bv;
-                if (g.accumulate) val += *dst;
-                if (g.relu) val = val > 0.f ? val : 0.f;
-                *dst = val;
-            }
+            if (row < g.M) slab[(long long)row * g.N + col] = acc[v];
+        }
+        return;
+    }
+    float* C = g.C + b0 * g.c_b0 + b1 * g.c_b1;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int row = m0 + wr * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+        if (row < g.M) {
+            float* dst = C + (long long)row * g.c_rs + col;
+            float val = g.alpha * acc[v] + bv;
+            if (g.accumulate) val += *dst;
+            if (g.relu) val = val > 0.f ? val : 0.f;
+            *dst = val;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void gemm_splitk_epilogue(GemmArgs g) {
+    const long long total = (long long)g.M * g.N;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int row = (int)(e / g.N), col = (int)(e - (long long)row * g.N);
+        float s = 0.f;
+        for (int k = 0; k < g.S; ++k) s += g.slabs[(long long)k * total + e];
+        float* dst = g.C + (long long)row * g.c_rs + col;
+        float val = g.alpha * s + (g.bias ? g.bias[col] : 0.f);
+        if (g.accumulate) val += *dst;
+        if (g.relu) val = val > 0.f ? val : 0.f;
+        *dst = val;
+    }
+}
+
+// Split K only for single-batch GEMMs that would leave most of the 256 CUs idle (UNETR's 216-token Linears).
+static void gemm_plan(int M, int N, int K, int nb, int& S, int& kchunk) {
+    const long long tiles = (long long)cdiv(M, GT) * cdiv(N, GT) * nb;
+    S = 1; kchunk = (int)cdiv(K, GK) * GK;
+    if (nb != 1 || tiles >= 192 || K < 128) return;
+    const int want = (int)cdiv(384, tiles);
+    int chunk = (int)cdiv(cdiv(K, want), GK) * GK;
+    if (chunk < 64) chunk = 64;
+    S = (int)cdiv(K, chunk);
+    if (S > 1) kchunk = chunk; else S = 1;
 }
 
 // ---------------------------------------------------------------- LayerNorm (one wavefront per row)
@@ -171,15 +259,38 @@ using namespace seg;
 
 extern "C" {
 
+size_t mi355seg_gemm_ws_bytes(int M, int N, int K, int nb0, int nb1) {
+    if (M <= 0 || N <= 0 || K <= 0 || nb0 <= 0 || nb1 <= 0) return 0;
+    int S, kchunk;
+    gemm_plan(M, N, K, nb0 * nb1, S, kchunk);
+    return S > 1 ? (size_t)S * M * N * sizeof(float) : 0;
+}
+
 int mi355seg_gemm_f32(const float* A, long long a_rs, long long a_cs, long long a_b0, long long a_b1,
                       const float* B, long long b_rs, long long b_cs, long long b_b0, long long b_b1,
                       float* C, long long c_rs, long long c_b0, long long c_b1, const float* bias,
-                      int M, int N, int K, int nb0, int nb1, float alpha, int relu, int accumulate, void* stream) {
-    SEG_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && nb0 > 0 && nb1 > 0 && (long long)nb0 * nb1 < 65536, "gemm: bad arguments");
-    GemmArgs g{A, B, C, bias, a_rs, a_cs, a_b0, a_b1, b_rs, b_cs, b_b0, b_b1, c_rs, c_b0, c_b1, M, N, K, nb1, alpha, relu, accumulate};
-    dim3 grid(cdiv(N, GT), cdiv(M, GT), nb0 * nb1);
+                      int M, int N, int K, int nb0, int nb1, float alpha, int relu, int accumulate,
+                      void* ws, size_t ws_bytes, void* stream) {
+    SEG_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && nb0 > 0 && nb1 > 0 && (long long)nb0 * nb1 < 4096, "gemm: bad arguments");
+    int S, kchunk;
+    gemm_plan(M, N, K, nb0 * nb1, S, kchunk);
+    if (S > 1 && (!ws || ws_bytes < (size_t)S * M * N * sizeof(float))) { S = 1; kchunk = (int)cdiv(K, GK) * GK; }   // no room: unsplit
+    auto vec_ok = [](const float* p, long long fast, long long other, long long b0s, long long b1s) {
+        return fast == 1 && other % 4 == 0 && b0s % 4 == 0 && b1s % 4 == 0 && (uintptr_t)p % 16 == 0;
+    };
+    const bool a_ofast = a_rs == 1 && a_cs != 1, b_ofast = b_cs == 1;
+    const int avec = vec_ok(A, a_ofast ? a_rs : a_cs, a_ofast ? a_cs : a_rs, a_b0, a_b1);
+    const int bvec = vec_ok(B, b_ofast ? b_cs : b_rs, b_ofast ? b_rs : b_cs, b_b0, b_b1);
+    GemmArgs g{A, B, C, bias, a_rs, a_cs, a_b0, a_b1, b_rs, b_cs, b_b0, b_b1, c_rs, c_b0, c_b1, M, N, K, nb1, alpha, relu, accumulate,
+               S, kchunk, avec, bvec, (float*)ws};
+    dim3 grid(cdiv(N, GT), cdiv(M, GT), nb0 * nb1 * S);
     hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
     SEG_CHECK_LAUNCH();
+    if (S > 1) {
+        const long long blocks = cdiv((long long)M * N, 256);
+        hipLaunchKernelGGL(gemm_splitk_epilogue, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, (hipStream_t)stream, g);
+        SEG_CHECK_LAUNCH();
+    }
     return MI355SEG_OK;
 }
 

@@ -776,8 +776,11 @@ def _mul(a, b, out=None):
 # ----------------------------------------------------------------------------- UNETR encoder ops
 def _gemm(A, a_rs, a_cs, a_b0, a_b1, B, b_rs, b_cs, b_b0, b_b1, C, c_rs, c_b0, c_b1, bias, M, N, K, nb0=1, nb1=1,
           alpha=1.0, relu=0, accumulate=0):
-    lib().call("mi355seg_gemm_f32", A, a_rs, a_cs, a_b0, a_b1, B, b_rs, b_cs, b_b0, b_b1, C, c_rs, c_b0, c_b1, bias,
-               M, N, K, nb0, nb1, alpha, relu, accumulate, _stream())
+    L = lib()
+    need = L.query("mi355seg_gemm_ws_bytes", M, N, K, nb0, nb1)
+    ws = workspace(need, torch.device("cuda", torch.cuda.current_device())) if need else None
+    L.call("mi355seg_gemm_f32", A, a_rs, a_cs, a_b0, a_b1, B, b_rs, b_cs, b_b0, b_b1, C, c_rs, c_b0, c_b1, bias,
+           M, N, K, nb0, nb1, alpha, relu, accumulate, _p(ws), ws.numel() if ws is not None else 0, _stream())
 
 
 class _Linear(Function):

@@ -226,7 +226,11 @@ int mi355seg_ce3d_bwd_f32(const float* logits, const int64_t* labels, const floa
 int mi355seg_gemm_f32(const float* A, long long a_rs, long long a_cs, long long a_b0, long long a_b1,
                       const float* B, long long b_rs, long long b_cs, long long b_b0, long long b_b1,
                       float* C, long long c_rs, long long c_b0, long long c_b1, const float* bias,
-                      int M, int N, int K, int nb0, int nb1, float alpha, int relu, int accumulate, void* stream);
+                      int M, int N, int K, int nb0, int nb1, float alpha, int relu, int accumulate,
+                      void* ws, size_t ws_bytes, void* stream);
+/* Scratch for the deterministic split-K path (single-batch GEMMs with too few 64x64 tiles to fill 256 CUs); 0 when
+ * the shape is not split.  With a smaller / NULL workspace the GEMM runs unsplit. */
+size_t mi355seg_gemm_ws_bytes(int M, int N, int K, int nb0, int nb1);
 /* nn.LayerNorm(E, eps) over the last dim of [rows, E] (unetr.py:151-152); mean/rstd [rows] are saved for backward */
 int mi355seg_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                                long long rows, int E, float eps, void* stream);

@@ -282,6 +282,62 @@ def test_cat_and_repeat_channels(seg):
     assert torch.equal(F._mul(u, v), u * v)
 
 
+GEMM_CASES = [
+    # M, N, K, a_transposed, b_transposed, bias, relu, accumulate
+    (216, 768, 768, False, True, True, False, False),     # Linear fwd (x @ W^T): 48 tiles -> split-K
+    (216, 2048, 768, False, True, True, True, False),     # FFN w_1 + ReLU epilogue
+    (216, 768, 2048, False, False, False, False, False),  # Linear dgrad (dy @ W)
+    (768, 768, 216, True, False, False, False, False),    # Linear wgrad (dy^T @ x), K = tokens
+    (37, 53, 29, False, False, True, False, True),        # ragged, unaligned strides -> scalar reads, accumulate
+    (130, 70, 260, True, True, False, False, True),       # ragged split-K with both operands transposed
+]
+
+
+@pytest.mark.parametrize("case", GEMM_CASES)
+def test_gemm_strided(seg, case):
+    """mi355seg_gemm_f32 (nn.Linear / torch.matmul of unetr.py:61-121 and their adjoints) against an fp64 matmul."""
+    M, N, K, ta, tb, has_bias, relu, acc = case
+    F = seg.functional
+    A = rnd(*((K, M) if ta else (M, K)), seed=1).cuda()
+    B = rnd(*((N, K) if tb else (K, N)), seed=2).cuda()
+    bias = rnd(N, seed=3).cuda() if has_bias else None
+    C0 = rnd(M, N, seed=4).cuda()
+    C = C0.clone()
+    a_rs, a_cs = (1, M) if ta else (K, 1)
+    b_rs, b_cs = (1, K) if tb else (N, 1)
+    F._gemm(A.data_ptr(), a_rs, a_cs, 0, 0, B.data_ptr(), b_rs, b_cs, 0, 0, C.data_ptr(), N, 0, 0,
+            None if bias is None else bias.data_ptr(), M, N, K, alpha=0.5, relu=int(relu), accumulate=int(acc))
+    want = 0.5 * ((A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double()))
+    if has_bias:
+        want = want + bias.double()
+    if acc:
+        want = want + C0.double()
+    if relu:
+        want = want.clamp_min(0)
+    assert (C.double() - want).abs().max() < 2e-5 * max(1.0, K ** 0.5)
+    C2 = C0.clone()                                  # split-K sums in a fixed order: bitwise repeatable
+    F._gemm(A.data_ptr(), a_rs, a_cs, 0, 0, B.data_ptr(), b_rs, b_cs, 0, 0, C2.data_ptr(), N, 0, 0,
+            None if bias is None else bias.data_ptr(), M, N, K, alpha=0.5, relu=int(relu), accumulate=int(acc))
+    assert torch.equal(C, C2)
+
+
+@pytest.mark.parametrize("P", [216, 27])
+def test_gemm_batched_attention_shapes(seg, P):
+    """Per-(batch, head) Q K^T and P V with the head split expressed in strides (unetr.py:74-98)."""
+    F = seg.functional
+    Bn, H, d = 2, 3, 64
+    E = H * d
+    q, k, v = (rnd(Bn, P, E, seed=s).cuda() for s in (1, 2, 3))
+    scores = torch.empty(Bn, H, P, P, device="cuda")
+    F._gemm(q.data_ptr(), E, 1, P * E, d, k.data_ptr(), 1, E, P * E, d, scores.data_ptr(), P, H * P * P, P * P, None, P, P, d, Bn, H, 0.125)
+    qh, kh, vh = (t.double().view(Bn, P, H, d).permute(0, 2, 1, 3) for t in (q, k, v))
+    assert (scores.double() - 0.125 * qh @ kh.transpose(-1, -2)).abs().max() < 1e-4
+    out = torch.empty(Bn, P, E, device="cuda")
+    F._gemm(scores.data_ptr(), P, 1, H * P * P, P * P, v.data_ptr(), E, 1, P * E, d, out.data_ptr(), E, P * E, d, None, P, d, P, Bn, H)
+    want = (scores.double() @ vh).permute(0, 2, 1, 3).reshape(Bn, P, E)
+    assert (out.double() - want).abs().max() < 1e-3
+
+
 def test_layout_roundtrip(seg):
     F = seg.functional
     x = rnd(2, 5, 4, 6, 7, seed=1)
