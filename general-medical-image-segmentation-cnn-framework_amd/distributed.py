@@ -6,9 +6,9 @@ The reference delegates multi-GPU to accelerate -> DistributedDataParallel
 step, and a broadcast of module buffers from rank 0 at every forward.  The same three
 semantics are kept here.  Gradient payload is 90-585 MB per step for the models in scope:
 on point-to-point xGMI (7 links x ~153 GB/s per GPU) that is ~1 ms against a >=40 ms
-fp32 step, so the gradients travel as a few large flat buckets after backward -- large
-messages are what the per-link ring bandwidth wants -- rather than many small
-overlapped ones."""
+fp32 step, so the gradients travel as a few large flat buckets (32 MB: large messages are
+what the per-link ring bandwidth wants), each launched from a gradient hook as soon as
+backward has filled it, so the transfer hides under the remaining backward kernels."""
 import os
 
 import torch
@@ -37,14 +37,20 @@ def world_size():
 
 
 class GradAllReducer:
-    """Mean all-reduce of every parameter gradient through flat fp32 buckets.
+    """Mean all-reduce of every parameter gradient through flat fp32 buckets, overlapped with backward.
 
-    ``bucket_mb`` bounds the bucket size; buckets are filled in reverse parameter order
-    (the order backward produces gradients) and reduced with asynchronous collectives that
-    are all in flight together before the first wait."""
+    Buckets are filled in reverse parameter order (the order backward produces gradients) up to ``bucket_mb``.
+    A post-accumulate-grad hook on every parameter counts down its bucket; the moment a bucket's last gradient
+    lands, the bucket is flattened on the compute stream and its asynchronous all-reduce starts on the
+    communicator's stream while backward keeps producing the earlier layers' gradients.  Calling the reducer
+    after ``loss.backward()`` (``train_step(..., grad_hook=reducer)``) launches whatever was not triggered by a
+    hook (parameters that received no gradient), waits for every collective and scatters the means back into
+    ``p.grad``.  ``overlap=False`` skips the hooks (everything is launched at the call).  ``always=True`` runs
+    the collectives even in a single-rank group (used to exercise the RCCL path on a one-GPU box)."""
 
-    def __init__(self, model, bucket_mb=64.0):
+    def __init__(self, model, bucket_mb=32.0, overlap=True, always=False):
         self.params = [p for p in model.parameters() if p.requires_grad]
+        self.always = always
         cap = int(bucket_mb * (1 << 20) / 4)
         self.buckets, cur, n = [], [], 0
         for p in reversed(self.params):
@@ -56,25 +62,54 @@ class GradAllReducer:
         if cur:
             self.buckets.append(cur)
         self._flat = [None] * len(self.buckets)
+        self._pending = [len(b) for b in self.buckets]
+        self._works = [None] * len(self.buckets)
+        self._handles = []
+        if overlap:
+            for bi, bucket in enumerate(self.buckets):
+                for p in bucket:
+                    self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+
+    def _active(self):
+        return self.always or world_size() > 1
+
+    def _make_hook(self, bi):
+        def hook(_param):
+            if not self._active():
+                return
+            self._pending[bi] -= 1
+            if self._pending[bi] == 0:
+                self._launch(bi)
+        return hook
+
+    def _launch(self, bi):
+        bucket = self.buckets[bi]
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
+        total = sum(g.numel() for g in grads)
+        flat = self._flat[bi]
+        if flat is None or flat.numel() != total or flat.device != grads[0].device:
+            flat = torch.empty(total, dtype=grads[0].dtype, device=grads[0].device)
+            self._flat[bi] = flat
+        torch.cat([g.reshape(-1) for g in grads], out=flat)
+        self._works[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
+    def detach(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
 
     def __call__(self, model=None):
-        ws = world_size()
-        if ws == 1:
+        if not self._active():
             return
-        works = []
+        for bi in range(len(self.buckets)):
+            if self._works[bi] is None:
+                self._launch(bi)
+        inv = 1.0 / world_size()
         for bi, bucket in enumerate(self.buckets):
-            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
-            total = sum(g.numel() for g in grads)
+            self._works[bi].wait()
             flat = self._flat[bi]
-            if flat is None or flat.numel() != total or flat.device != grads[0].device:
-                flat = torch.empty(total, dtype=grads[0].dtype, device=grads[0].device)
-                self._flat[bi] = flat
-            torch.cat([g.reshape(-1) for g in grads], out=flat)
-            works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, bucket))
-        inv = 1.0 / ws
-        for work, flat, bucket in works:
-            work.wait()
-            flat.mul_(inv)
+            if inv != 1.0:
+                flat.mul_(inv)
             off = 0
             for p in bucket:
                 n = p.numel()
@@ -83,6 +118,8 @@ class GradAllReducer:
                 else:
                     p.grad.copy_(flat[off:off + n].view_as(p))
                 off += n
+            self._works[bi] = None
+            self._pending[bi] = len(bucket)
 
 
 def broadcast_buffers(model, src=0):

@@ -41,10 +41,25 @@ def _worker(rank, world, port, out):
         assert torch.equal(a, b)
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.randn(2, 1, 4, 4, 4, generator=g)
+    hooked = D.GradAllReducer(model, bucket_mb=0.0001)         # tiny buckets -> several collectives, launched from hooks
+    results = []
+    for step in range(2):                                      # twice: the per-bucket countdown must re-arm
+        for p in model.parameters():
+            p.grad = None
+        model(x + step).square().mean().backward()
+        local = [p.grad.clone() for p in model.parameters()]   # p.grad stays local until the reducer is called
+        assert all(w is not None for w in hooked._works)       # every bucket went out during backward
+        hooked(model)
+        results.append((local, [p.grad.clone() for p in model.parameters()]))
+    hooked.detach()
+    for p in model.parameters():
+        p.grad = None
     model(x).square().mean().backward()
-    local = [p.grad.clone() for p in model.parameters()]
-    D.GradAllReducer(model, bucket_mb=0.0001)(model)          # tiny buckets -> several collectives
-    red = [p.grad.clone() for p in model.parameters()]
+    late = D.GradAllReducer(model, bucket_mb=0.0001, overlap=False)   # no hooks: everything launched at the call
+    late(model)
+    for a, b in zip(results[0][1], model.parameters()):
+        assert torch.equal(a, b.grad)
+    local, red = results[1]
     counts = torch.tensor([1 + rank, 2, 3, 4 * (rank + 1)], dtype=torch.int64)
     c, l = D.all_reduce_metric(counts, torch.tensor(float(rank + 1)))
     out[rank] = (local, red, c, l)
