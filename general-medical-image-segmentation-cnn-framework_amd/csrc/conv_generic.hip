@@ -348,8 +348,8 @@ int mi355seg_conv3d_wgrad_f32(const float* dy, int lddy, const float* x, int ldx
         rc = channel_sums(dy, lddy, (long long)N * g.Do * g.Ho * g.Wo, Cout, nullptr, nullptr, db, accumulate, ws, ws_bytes, st);
         if (rc) return rc;
     }
-    if (k == 3 && wgrad_mfma_supported(N, D, H, W, Cin, Cout, k, stride, pad, ldx, lddy))
-        return conv_wgrad_mfma(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, st);
+    if (wgrad_mfma_supported(N, D, H, W, Cin, Cout, k, stride, pad, ldx, lddy) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0)
+        return conv_wgrad_mfma(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, accumulate, ws, ws_bytes, st);
     if (k == 1 && stride == 1 && pad == 0 && pw_wgrad_supported((long long)N * D * H * W, Cin, Cout, 1, ldx, lddy)) {
         float* part; int nstrips;
         rc = pw_wgrad_mfma(dy, lddy, x, ldx, N, D, H, W, Cin, Cout, 1, &part, &nstrips, ws, ws_bytes, st);

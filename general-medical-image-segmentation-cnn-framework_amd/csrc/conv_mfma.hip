@@ -429,7 +429,7 @@ size_t conv_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, 
                       (ks > 1 ? align_up((size_t)ks * N * D * H * W * co * sizeof(float), 256) + colsum_ws_bytes(co) : 0) + 1024;
         if (need > best) best = need;
     }
-    size_t wg = k == 3 ? wgrad_mfma_ws_bytes(N, D, H, W, Cin, Cout) : (k == 1 ? pw_wgrad_ws_bytes((long long)N * D * H * W, Cin, Cout, 1) : 0);
+    size_t wg = (k == 3 || k == 5) ? wgrad_mfma_ws_bytes(N, D, H, W, Cin, Cout, k) : (k == 1 ? pw_wgrad_ws_bytes((long long)N * D * H * W, Cin, Cout, 1) : 0);
     return best > wg ? best : wg;
 }
 

@@ -60,9 +60,9 @@ size_t pw_wgrad_ws_bytes(long long nvox, int Cin, int Cout, int T);
 bool pw_wgrad_supported(long long nvox, int Cin, int Cout, int T, int ldx, int lddy);
 int pw_wgrad_mfma(const float* dy, int lddy, const float* x, int ldx, int N, int D, int H, int W, int Cin, int Cout, int T,
                   float** part_out, int* nstrips_out, void* ws, size_t ws_bytes, hipStream_t st);
-size_t wgrad_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout);
+size_t wgrad_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k);
 bool wgrad_mfma_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int lddy);
 int conv_wgrad_mfma(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin,
-                    int Cout, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+                    int Cout, int k, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 
 }  // namespace seg

@@ -71,7 +71,9 @@ CONV_CASES = [
     (1, 8, 8, 8, 4, 8, 2, 2, 0),           # small-Cin strided
     (1, 8, 12, 32, 32, 64, 5, 1, 2),       # k5 on the MFMA igemm (V-Net LUConv), CK = 8
     (2, 6, 6, 6, 8, 32, 5, 1, 2),          # k5, partial tiles, single chunk
-    (1, 16, 16, 16, 128, 128, 5, 1, 2),
+    (1, 16, 16, 16, 128, 128, 5, 1, 2),    # k5 plane-wise MFMA wgrad, BX = 16
+    (2, 5, 9, 8, 64, 32, 5, 1, 2),         # k5 MFMA wgrad, BX = 8, odd extents
+    (1, 3, 6, 40, 32, 32, 5, 1, 2),        # k5 MFMA wgrad, BX = 8 (W = 40), D smaller than the halo
     (2, 8, 8, 8, 8, 16, 2, 2, 0),
     (1, 8, 12, 8, 16, 32, 3, 2, 1),
     (2, 8, 8, 8, 16, 4, 1, 1, 0),
