@@ -292,8 +292,10 @@ size_t mi355seg_conv3d_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, i
     size_t d = gwgrad_ws_bytes(N, D, H, W, Cin, Cout, k, stride, pad);
     if ((smallcin_wgrad_supported(Cin, Cout, k) || smallcout_wgrad_supported(Cin, Cout, k, 4)) && small_wgrad_ws_bytes(Cin, Cout, k) > d)
         d = small_wgrad_ws_bytes(Cin, Cout, k);
+    size_t e = conv_gather_ws_bytes(N, D, H, W, Cin, Cout, k, stride, pad);
     if (b > a) a = b;
     if (d > a) a = d;
+    if (e > a) a = e;
     return a > c ? a : c;
 }
 
@@ -309,6 +311,8 @@ int mi355seg_conv3d_fwd_f32(const float* x, int ldx, const float* w, const float
     hipStream_t st = (hipStream_t)stream;
     if (conv_mfma_supported(N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy))
         return conv_fwd_mfma(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, /*dgrad=*/0, stats_sum, stats_sq, ws, ws_bytes, st);
+    if (conv_gather_fwd_supported(N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy) && ((uintptr_t)x % 16) == 0)
+        return conv_gather_fwd_mfma(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, stride, pad, stats_sum, stats_sq, ws, ws_bytes, st);
     if (stem_supported(Cin, Cout, k, stride, pad, ldy))
         return stem_fwd(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, stats_sum, stats_sq, ws, ws_bytes, st);
     if (head_supported(Cin, Cout, k, stride, pad, ldx)) {
@@ -330,6 +334,8 @@ int mi355seg_conv3d_dgrad_f32(const float* dy, int lddy, const float* w, float* 
     // k3 s1 p1: dgrad is the same convolution with flipped taps and Cin<->Cout swapped
     if (conv_mfma_supported(N, D, H, W, Cout, Cin, k, stride, pad, lddy, lddx))
         return conv_fwd_mfma(dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cout, Cin, k, /*dgrad=*/1, nullptr, nullptr, ws, ws_bytes, st);
+    if (conv_gather_dgrad_supported(N, D, H, W, Cin, Cout, k, stride, pad, lddy, lddx) && ((uintptr_t)dy % 16) == 0)
+        return conv_gather_dgrad_mfma(dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, k, stride, pad, ws, ws_bytes, st);
     if (head_supported(Cin, Cout, k, stride, pad, lddx))
         return head_dgrad(dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, st);
     return conv_dgrad_generic(dy, lddy, w, dx, lddx, g, ws, ws_bytes, st);

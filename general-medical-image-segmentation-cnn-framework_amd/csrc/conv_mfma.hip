@@ -63,6 +63,12 @@ struct IgemmArgs {
     int ksplit, cps;    // K-splits and chunks per split (nchunks == ksplit * cps)
     long long split_stride;   // floats between the output slabs of consecutive K-splits
     int dbg;            // timing experiments only (MI355SEG_DBG): 1 no re-staging, 2 B loaded once per chunk, 4 no stores
+    // ---- gather / scatter generalisation (strided Conv3d fwd + per-phase dgrad, ConvT with narrow Cout)
+    int Di, Hi, Wi;     // extents of the volume x points at   (input voxel = base * in_mul + toff[tap])
+    int Do, Ho, Wo;     // extents of the volume y points at   (output voxel = base * out_mul + child + c{z,y,x})
+    int cz, cy, cx;     // fixed child offset of a strided-dgrad phase launch
+    int flatn;          // != 0: N-tiles cut the flat (child tap, cout) axis, so one 32-column block may span two children
+    signed char toff[64][4];   // per K-tap input offset (z, y, x); all zero for the stride-1 halo modes
 };
 
 // ---------------------------------------------------------------- weight packing
@@ -71,7 +77,11 @@ struct IgemmArgs {
 //   mode 1 (conv dgrad):   B = W[ci_f = n .. swapped roles, taps reversed]              W: (Cin_k, Cout_k, T)
 //   mode 2 (convT fwd):    n = (tapn, co): B = Wt[ci][co][tapn]                          Wt: (Cin, Cout, 8), T = 1
 //   mode 3 (convT dgrad):  chunk = (tapk, cc): B = Wt[ci = n][co = cc*16 + ..][tapk]     Wt: (Cin_f, Cout_f, 8), T = 1
-__global__ void pack_wq_kernel(const float* __restrict__ w, float* __restrict__ wq, int K, int Nn, int T, int NT, int mode, int aux, int CK) {
+//   mode 5 (gather fwd):   chunk = (tap, cc):  B = W[co = n][ci = cc*CK + ..][tap]      W: (Cout, Cin, TW), aux = Cin, T = 1
+//   mode 6 (gather dgrad): chunk = (slot, cc): B = W[co = cc*CK + ..][ci = n][taps.t[slot]]   aux = Cout, T = 1
+struct TapList { unsigned char t[64]; };
+__global__ void pack_wq_kernel(const float* __restrict__ w, float* __restrict__ wq, int K, int Nn, int T, int NT, int mode, int aux, int CK,
+                               int TW, TapList taps) {
     const long long total = (long long)K * Nn * T;        // K = channels in the GEMM K dim (taps of mode 3 included)
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         long long r = idx;
@@ -87,7 +97,8 @@ __global__ void pack_wq_kernel(const float* __restrict__ w, float* __restrict__ 
         if (mode == 0) v = w[((long long)n * K + k) * T + tap];
         else if (mode == 1) v = w[((long long)k * Nn + n) * T + (T - 1 - tap)];
         else if (mode == 2) { int cout = aux; int tapn = n / cout, co = n % cout; v = w[((long long)k * cout + co) * 8 + tapn]; }
-        else { int cout = aux; int tapk = k / cout, co = k % cout; v = w[((long long)n * cout + co) * 8 + tapk]; }
+        else if (mode == 3 || mode == 5) { int cout = aux; int tapk = k / cout, co = k % cout; v = w[((long long)n * cout + co) * TW + tapk]; }
+        else { int cout = aux; int slot = k / cout, co = k % cout; v = w[((long long)co * Nn + n) * TW + taps.t[slot]]; }
         wq[idx] = v;
     }
 }
@@ -128,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
     const int x0 = txi * BX, y0 = tyi * T::TY, z0 = tzi * T::TZ;
     const int tapn = ntile / a.nNpt;                          // output child (ConvT fwd), else 0
     const int n0 = (ntile % a.nNpt) * NT;
-    const int Di = a.D * a.in_mul, Hi = a.H * a.in_mul, Wi = a.W * a.in_mul;
+    const int Di = a.Di, Hi = a.Hi, Wi = a.Wi;
 
     f32x16 acc[MB][NBW];
 #pragma unroll
@@ -160,9 +171,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
             const int hz = vox / (T::HY * T::HX), rem = vox % (T::HY * T::HX);
             const int hy = rem / T::HX, hx = rem % T::HX;
             const int tapk = chunk / a.cpt, cch = chunk - tapk * a.cpt;     // input child (ConvT dgrad), else 0
-            const int gz = (z0 - T::HALO + hz) * a.in_mul + ((tapk >> 2) & 1);
-            const int gy = (y0 - T::HALO + hy) * a.in_mul + ((tapk >> 1) & 1);
-            const int gx = (x0 - T::HALO + hx) * a.in_mul + (tapk & 1);
+            const int gz = (z0 - T::HALO + hz) * a.in_mul + a.toff[tapk][0];
+            const int gy = (y0 - T::HALO + hy) * a.in_mul + a.toff[tapk][1];
+            const int gx = (x0 - T::HALO + hx) * a.in_mul + a.toff[tapk][2];
             const bool ok = (p < T::NPIECE) && (unsigned)gz < (unsigned)Di && (unsigned)gy < (unsigned)Hi && (unsigned)gx < (unsigned)Wi;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (ok) {
@@ -233,7 +244,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
     float ssum[NBW], ssq[NBW];
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
-        const int col = n0 + nb * 32 + i;
+        int col = n0 + nb * 32 + i, child = tapn;
+        if (a.flatn) { const int nf = ntile * NT + nb * 32 + i; child = nf / a.Cout; col = nf - child * a.Cout; }   // per-lane child
+        const int oz = ((child >> 2) & 1) + a.cz, oy = ((child >> 1) & 1) + a.cy, ox = (child & 1) + a.cx;
         const float bv = a.bias ? a.bias[col] : 0.f;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -243,14 +256,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
             for (int v = 0; v < 16; ++v) {
                 const int r = (v & 3) + 8 * (v >> 2) + 4 * h;      // row of the 32x32 tile held in register v
                 const int line = m * T::LPB + r / BX, xx = r % BX;
-                const int gz = (z0 + line / T::TY) * a.out_mul + ((tapn >> 2) & 1);
-                const int gy = (y0 + line % T::TY) * a.out_mul + ((tapn >> 1) & 1);
-                const int gx = (x0 + xx) * a.out_mul + (tapn & 1);
+                const int gz = (z0 + line / T::TY) * a.out_mul + oz;
+                const int gy = (y0 + line % T::TY) * a.out_mul + oy;
+                const int gx = (x0 + xx) * a.out_mul + ox;
                 const float val = acc[mb][nb][v] + bv;
                 // partial tiles (extents that are not tile multiples): rows outside the volume are dropped
-                const bool inside = (z0 + line / T::TY) < a.D && (y0 + line % T::TY) < a.H && (x0 + xx) < a.W;
+                const bool inside = (z0 + line / T::TY) < a.D && (y0 + line % T::TY) < a.H && (x0 + xx) < a.W &&
+                                    gz < a.Do && gy < a.Ho && gx < a.Wo;
                 if (inside && (!(a.dbg & 4) || val == 12345.678f))
-                yout[((((long long)n * (a.D * a.out_mul) + gz) * (a.H * a.out_mul) + gy) * (a.W * a.out_mul) + gx) * a.ldy + col] = val;
+                yout[((((long long)n * a.Do + gz) * a.Ho + gy) * a.Wo + gx) * a.ldy + col] = val;
                 if (inside) { s1 += val; s2 += val * val; }
             }
         }
@@ -362,7 +376,7 @@ __global__ __launch_bounds__(256) void igemm_stats_finalize_kernel(const float* 
 }
 
 // ---------------------------------------------------------------- host side
-struct IgemmPlan { int KS, CK, BX, MB, NBW, TZ, nM, nN, ntx, nty, ntz; };
+struct IgemmPlan { int KS, CK, BX, MB, NBW, TZ, nM, nN, ntx, nty, ntz, flat; };
 
 static int pick_ck(int KS, int Kc) {
     if (KS == 5) return 8;
@@ -374,15 +388,18 @@ static int pick_ck(int KS, int Kc) {
 static bool igemm_plan(int KS, int N, int D, int H, int W, int Kc, int Nc, int ntaps_out, IgemmPlan* p) {
     if (KS != 1 && KS != 3 && KS != 5) return false;
     const int CK = pick_ck(KS, Kc);
-    if (Kc % CK || Nc % 32 || W < 4) return false;          // degenerate volumes stay on the generic path
+    // ConvT with a narrow Cout: tile the flat (child, cout) axis instead of each child's channels
+    const bool flat = ntaps_out > 1 && (Nc % 32) != 0 && ((long long)Nc * ntaps_out) % 32 == 0;
+    if (Kc % CK || (Nc % 32 && !flat) || W < 4) return false;          // degenerate volumes stay on the generic path
     // x-extent of an M-block: the candidate with the least padding (ties -> the wider one)
     int BX = 0; long long best = -1;
     for (int bx : {32, 16, 8}) {
         long long padded = (long long)((W + bx - 1) / bx) * bx;
         if (best < 0 || padded < best) { best = padded; BX = bx; }
     }
-    const int NBW = (Nc % 64 == 0) ? 2 : 1;
-    const int nN = Nc / (32 * NBW) * ntaps_out;
+    const int NBW = ((flat ? Nc * ntaps_out : Nc) % 64 == 0) ? 2 : 1;
+    const int nN = flat ? Nc * ntaps_out / (32 * NBW) : Nc / (32 * NBW) * ntaps_out;
+    p->flat = flat ? 1 : 0;
     auto tiles = [&](int MB, int* tz) {
         int lines = 4 * MB * (32 / BX);
         *tz = lines / 4;
@@ -494,10 +511,11 @@ int conv_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, fl
     float* slabs = ksplit > 1 ? cv.take<float>((size_t)ksplit * nvox * Cout) : nullptr;
     size_t tail = cv.used();
     SEG_CHECK_WS(tail + ((ssum && ksplit > 1) ? colsum_ws_bytes(Cout) : 0), ws_bytes);
-    hipLaunchKernelGGL(pack_wq_kernel, dim3(pack_grid((long long)T * Cin * Cout)), dim3(256), 0, st, w, wq, Cin, Cout, T, 32 * p.NBW, dgrad ? 1 : 0, 0, p.CK);
+    hipLaunchKernelGGL(pack_wq_kernel, dim3(pack_grid((long long)T * Cin * Cout)), dim3(256), 0, st, w, wq, Cin, Cout, T, 32 * p.NBW, dgrad ? 1 : 0, 0, p.CK, T, TapList{});
     SEG_CHECK_LAUNCH();
     IgemmArgs a{x, wq, ksplit > 1 ? nullptr : bias, ksplit > 1 ? slabs : y, spart, ldx, ksplit > 1 ? Cout : ldy, N, D, H, W, Cout,
                 p.ntx, p.nty, p.ntz, p.nN, nchunks, nchunks, p.nN, 1, 1, p.nM, ksplit, nchunks / ksplit, nvox * Cout, dbg_flags()};
+    a.Di = a.Do = D; a.Hi = a.Ho = H; a.Wi = a.Wo = W;
     const int nwg = p.nM * p.nN * ksplit;
     const double vox = (double)nvox;
     {
@@ -533,10 +551,11 @@ int convt_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, f
     Carver cv(ws);
     float* wq = cv.take<float>((size_t)8 * Cin * Cout);
     SEG_CHECK_WS(cv.used(), ws_bytes);
-    hipLaunchKernelGGL(pack_wq_kernel, dim3(pack_grid((long long)8 * Cin * Cout)), dim3(256), 0, st, w, wq, Cin, 8 * Cout, 1, 32 * p.NBW, 2, Cout, p.CK);
+    hipLaunchKernelGGL(pack_wq_kernel, dim3(pack_grid((long long)8 * Cin * Cout)), dim3(256), 0, st, w, wq, Cin, 8 * Cout, 1, 32 * p.NBW, 2, Cout, p.CK, 8, TapList{});
     SEG_CHECK_LAUNCH();
-    IgemmArgs a{x, wq, bias, y, nullptr, ldx, ldy, N, D, H, W, Cout, p.ntx, p.nty, p.ntz, p.nN, Cin / p.CK, Cin / p.CK, p.nN / 8, 1, 2,
-                p.nM, 1, Cin / p.CK, 0, 0};
+    IgemmArgs a{x, wq, bias, y, nullptr, ldx, ldy, N, D, H, W, Cout, p.ntx, p.nty, p.ntz, p.nN, Cin / p.CK, Cin / p.CK,
+                p.flat ? p.nN : p.nN / 8, 1, 2, p.nM, 1, Cin / p.CK, 0, 0};
+    a.Di = D; a.Hi = H; a.Wi = W; a.Do = 2 * D; a.Ho = 2 * H; a.Wo = 2 * W; a.flatn = p.flat;
     const double vox = (double)N * D * H * W;
     ProfScope ps(PF_CONVT, 2.0 * vox * 8 * Cin * Cout, 4.0 * (vox * (Cin + 8.0 * Cout) + 8.0 * Cin * Cout), st);
     dispatch_igemm(p, a, p.nM * p.nN, st);
@@ -552,14 +571,126 @@ int convt_dgrad_mfma(const float* dy, int lddy, const float* w, float* dx, int l
     Carver cv(ws);
     float* wq = cv.take<float>((size_t)8 * Cin * Cout);
     SEG_CHECK_WS(cv.used(), ws_bytes);
-    hipLaunchKernelGGL(pack_wq_kernel, dim3(pack_grid((long long)8 * Cin * Cout)), dim3(256), 0, st, w, wq, 8 * Cout, Cin, 1, 32 * p.NBW, 3, Cout, p.CK);
+    hipLaunchKernelGGL(pack_wq_kernel, dim3(pack_grid((long long)8 * Cin * Cout)), dim3(256), 0, st, w, wq, 8 * Cout, Cin, 1, 32 * p.NBW, 3, Cout, p.CK, 8, TapList{});
     SEG_CHECK_LAUNCH();
     IgemmArgs a{dy, wq, nullptr, dx, nullptr, lddy, lddx, N, D, H, W, Cin, p.ntx, p.nty, p.ntz, p.nN, 8 * Cout / p.CK, Cout / p.CK, p.nN, 2, 1,
                 p.nM, 1, 8 * Cout / p.CK, 0, 0};
+    a.Di = 2 * D; a.Hi = 2 * H; a.Wi = 2 * W; a.Do = D; a.Ho = H; a.Wo = W;
+    for (int t = 0; t < 8; ++t) { a.toff[t][0] = (t >> 2) & 1; a.toff[t][1] = (t >> 1) & 1; a.toff[t][2] = t & 1; }
     const double vox = (double)N * D * H * W;
     ProfScope ps(PF_CONVT, 2.0 * vox * 8 * Cin * Cout, 4.0 * (vox * (Cin + 8.0 * Cout) + 8.0 * Cin * Cout), st);
     dispatch_igemm(p, a, p.nM * p.nN, st);
     SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+// ---- strided / even-kernel Conv3d on the same kernel (KS = 1, no halo): every K-chunk is one (tap, channel chunk) and
+// gathers its own input voxel  base * stride + tap - pad  (zero outside the volume).  Used for the k3 s2 p1 convs of the
+// Residual U-Net (residual_unet3d.py:24-60) and V-Net's k2 s2 down-convolutions (vnet3d.py:66).
+static bool gather_geom_ok(int k, int stride, int pad) {
+    return k >= 1 && k <= 4 && stride >= 1 && stride <= k && pad >= 0 && pad < k && !(stride == 1 && (k == 1 || k == 3) && pad == k / 2);
+}
+static int out_extent(int n, int k, int s, int p) { return (n + 2 * p - k) / s + 1; }
+
+bool conv_gather_fwd_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int ldy) {
+    if (!gather_geom_ok(k, stride, pad) || (ldx % 4) || D + 2 * pad < k || H + 2 * pad < k || W + 2 * pad < k) return false;
+    IgemmPlan p;
+    return igemm_plan(1, N, out_extent(D, k, stride, pad), out_extent(H, k, stride, pad), out_extent(W, k, stride, pad), Cin, Cout, 1, &p);
+}
+
+// dgrad runs one launch per output phase (u mod stride): the taps that reach a phase are a fixed subset with fixed offsets
+bool conv_gather_dgrad_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int lddy, int lddx) {
+    if (!gather_geom_ok(k, stride, pad) || (lddy % 4) || D + 2 * pad < k || H + 2 * pad < k || W + 2 * pad < k) return false;
+    if (D < stride || H < stride || W / stride < 4) return false;
+    IgemmPlan p;
+    return igemm_plan(1, N, D / stride, H / stride, W / stride, Cout, Cin, 1, &p);
+}
+
+size_t conv_gather_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
+    if (!gather_geom_ok(k, stride, pad) || D + 2 * pad < k || H + 2 * pad < k || W + 2 * pad < k) return 0;
+    const size_t T = (size_t)k * k * k;
+    size_t need = align_up(T * Cin * Cout * sizeof(float), 256) + 2048;
+    IgemmPlan p;
+    if (igemm_plan(1, N, out_extent(D, k, stride, pad), out_extent(H, k, stride, pad), out_extent(W, k, stride, pad), Cin, Cout, 1, &p))
+        need += align_up((size_t)p.nM * Cout * 3 * sizeof(float), 256);
+    return need;
+}
+
+int conv_gather_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W,
+                         int Cin, int Cout, int k, int stride, int pad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int Do = out_extent(D, k, stride, pad), Ho = out_extent(H, k, stride, pad), Wo = out_extent(W, k, stride, pad);
+    IgemmPlan p;
+    SEG_CHECK_ARG(igemm_plan(1, N, Do, Ho, Wo, Cin, Cout, 1, &p), "conv_gather_fwd_mfma: unsupported shape");
+    SEG_CHECK_ARG(((uintptr_t)x % 16) == 0, "conv_gather_fwd_mfma: input pointer must be 16-byte aligned");
+    const int T = k * k * k, cpt = Cin / p.CK, nchunks = T * cpt;
+    Carver cv(ws);
+    float* wq = cv.take<float>((size_t)T * Cin * Cout);
+    float* spart = ssum ? cv.take<float>((size_t)p.nM * Cout * 3) : nullptr;
+    SEG_CHECK_WS(cv.used(), ws_bytes);
+    hipLaunchKernelGGL(pack_wq_kernel, dim3(pack_grid((long long)T * Cin * Cout)), dim3(256), 0, st, w, wq, T * Cin, Cout, 1, 32 * p.NBW, 5, Cin, p.CK, T, TapList{});
+    SEG_CHECK_LAUNCH();
+    IgemmArgs a{x, wq, bias, y, spart, ldx, ldy, N, Do, Ho, Wo, Cout, p.ntx, p.nty, p.ntz, p.nN, nchunks, cpt, p.nN, stride, 1,
+                p.nM, 1, nchunks, 0, 0};
+    a.Di = D; a.Hi = H; a.Wi = W; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
+    for (int t = 0; t < T; ++t) { a.toff[t][0] = (signed char)(t / (k * k) - pad); a.toff[t][1] = (signed char)((t / k) % k - pad); a.toff[t][2] = (signed char)(t % k - pad); }
+    const double vox = (double)N * Do * Ho * Wo;
+    {
+        ProfScope ps(PF_IGEMM, 2.0 * vox * T * Cin * Cout, 4.0 * ((double)N * D * H * W * Cin + vox * Cout + (double)T * Cin * Cout), st);
+        dispatch_igemm(p, a, p.nM * p.nN, st);
+        SEG_CHECK_LAUNCH();
+    }
+    if (ssum) {
+        hipLaunchKernelGGL(igemm_stats_finalize_kernel, dim3(Cout), dim3(256), 0, st, spart, p.nM, Cout, ssum, ssq);
+        SEG_CHECK_LAUNCH();
+    }
+    return MI355SEG_OK;
+}
+
+// dx[N,D,H,W,Cin] from dy[N,Do,Ho,Wo,Cout]:  dx[u] = sum over taps t with (u + pad - t) % stride == 0 of dy[(u + pad - t) / stride] W[.,.,t]
+int conv_gather_dgrad_mfma(const float* dy, int lddy, const float* w, float* dx, int lddx, int N, int D, int H, int W,
+                           int Cin, int Cout, int k, int stride, int pad, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int Do = out_extent(D, k, stride, pad), Ho = out_extent(H, k, stride, pad), Wo = out_extent(W, k, stride, pad);
+    SEG_CHECK_ARG(((uintptr_t)dy % 16) == 0, "conv_gather_dgrad_mfma: gradient pointer must be 16-byte aligned");
+    const int T = k * k * k;
+    Carver cv(ws);
+    float* wq_all = cv.take<float>((size_t)T * Cin * Cout);
+    SEG_CHECK_WS(cv.used(), ws_bytes);
+    size_t wq_used = 0;
+    ProfScope ps(PF_IGEMM, 2.0 * (double)N * Do * Ho * Wo * T * Cin * Cout,
+                 4.0 * ((double)N * D * H * W * Cin + (double)N * Do * Ho * Wo * Cout + (double)T * Cin * Cout), st);
+    for (int ph = 0; ph < stride * stride * stride; ++ph) {
+        const int pz = ph / (stride * stride), py = (ph / stride) % stride, px = ph % stride;
+        const int Bz = (D - pz + stride - 1) / stride, By = (H - py + stride - 1) / stride, Bx = (W - px + stride - 1) / stride;
+        if (Bz <= 0 || By <= 0 || Bx <= 0) continue;
+        int lz[4], ly[4], lx[4], dz[4], dyo[4], dxo[4], nz = 0, ny = 0, nx = 0;
+        for (int t = 0; t < k; ++t) {
+            if ((pz + pad - t) % stride == 0) { lz[nz] = t; dz[nz++] = (pz + pad - t) / stride; }
+            if ((py + pad - t) % stride == 0) { ly[ny] = t; dyo[ny++] = (py + pad - t) / stride; }
+            if ((px + pad - t) % stride == 0) { lx[nx] = t; dxo[nx++] = (px + pad - t) / stride; }
+        }
+        const int nt = nz * ny * nx;
+        SEG_CHECK_ARG(nt > 0, "conv_gather_dgrad_mfma: a phase without taps (k < stride)");
+        IgemmPlan p;
+        SEG_CHECK_ARG(igemm_plan(1, N, Bz, By, Bx, Cout, Cin, 1, &p), "conv_gather_dgrad_mfma: unsupported shape");
+        const int cpt = Cout / p.CK, nchunks = nt * cpt;
+        float* wq = wq_all + wq_used;
+        wq_used += (size_t)nt * Cin * Cout;
+        IgemmArgs a{dy, wq, nullptr, dx, nullptr, lddy, lddx, N, Bz, By, Bx, Cin, p.ntx, p.nty, p.ntz, p.nN, nchunks, cpt, p.nN, 1, stride,
+                    p.nM, 1, nchunks, 0, 0};
+        a.Di = Do; a.Hi = Ho; a.Wi = Wo; a.Do = D; a.Ho = H; a.Wo = W; a.cz = pz; a.cy = py; a.cx = px;
+        TapList tl{};
+        int slot = 0;
+        for (int iz = 0; iz < nz; ++iz)
+            for (int iy = 0; iy < ny; ++iy)
+                for (int ix = 0; ix < nx; ++ix, ++slot) {
+                    tl.t[slot] = (unsigned char)((lz[iz] * k + ly[iy]) * k + lx[ix]);
+                    a.toff[slot][0] = (signed char)dz[iz]; a.toff[slot][1] = (signed char)dyo[iy]; a.toff[slot][2] = (signed char)dxo[ix];
+                }
+        hipLaunchKernelGGL(pack_wq_kernel, dim3(pack_grid((long long)nt * Cin * Cout)), dim3(256), 0, st, w, wq, nt * Cout, Cin, 1, 32 * p.NBW, 6, Cout, p.CK, T, tl);
+        SEG_CHECK_LAUNCH();
+        dispatch_igemm(p, a, p.nM * p.nN, st);
+        SEG_CHECK_LAUNCH();
+    }
     return MI355SEG_OK;
 }
 

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(PwArgs a) {
         for (int it = 0; it < C::XIT; ++it) {
             const int p = it * 256 + tid;
             f32x4 xv = {0.f, 0.f, 0.f, 0.f};
-            if (v0 + (p >> 3) < nvox) xv = *reinterpret_cast<const f32x4*>(a.x + (v0 + (p >> 3)) * a.ldx + ci0 + (p & 7) * 4);
+            if (v0 + (p >> 3) < nvox && ci0 + (p & 7) * 4 < a.Cin) xv = *reinterpret_cast<const f32x4*>(a.x + (v0 + (p >> 3)) * a.ldx + ci0 + (p & 7) * 4);
             sx[it] = xv;
         }
 #pragma unroll
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(PwArgs a) {
                 ov = v0 + vl;
             }
             f32x4 dv = {0.f, 0.f, 0.f, 0.f};
-            if (v0 + vl < nvox) dv = *reinterpret_cast<const f32x4*>(a.dy + ov * a.lddy + co0 + part * 4);
+            if (v0 + vl < nvox && co0 + part * 4 < a.Cout) dv = *reinterpret_cast<const f32x4*>(a.dy + ov * a.lddy + co0 + part * 4);
             sd[it] = dv;
         }
     };
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(PwArgs a) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int r = (v & 3) + 8 * (v >> 2) + 4 * h;
-                dst[(long long)r * a.Cout] = acc[tt][v];
+                if (ci0 + r < a.Cin && co0 + i < a.Cout) dst[(long long)r * a.Cout] = acc[tt][v];      // ragged last blocks
             }
         }
     }
@@ -139,10 +139,10 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(PwArgs a) {
 struct PwPlan { int ntiles, nstrips, npairs; };
 
 static bool pw_plan(long long nvox, int Cin, int Cout, int T, PwPlan* p) {
-    if (Cin % 32 || Cout % 32 || (T != 1 && T != 8)) return false;
+    if (Cin % 4 || Cout % 4 || Cin < 16 || Cout < 16 || (T != 1 && T != 8)) return false;    // 16-byte channel pieces; blocks of 32 zero-padded
     const int V = T == 8 ? 64 : 256;
     p->ntiles = (int)((nvox + V - 1) / V);
-    p->npairs = (Cin / 32) * (Cout / 32);
+    p->npairs = ((Cin + 31) / 32) * ((Cout + 31) / 32);
     int want = (512 + p->npairs - 1) / p->npairs;
     long long cap = (long long)(64u << 20) / ((long long)T * Cin * Cout * 4);
     if (cap < 1) cap = 1;
@@ -174,7 +174,7 @@ int pw_wgrad_mfma(const float* dy, int lddy, const float* x, int ldx, int N, int
     Carver cv(ws);
     float* part = cv.take<float>((size_t)p.nstrips * T * Cin * Cout);
     SEG_CHECK_WS(cv.used(), ws_bytes);
-    PwArgs a{x, dy, part, ldx, lddy, N, D, H, W, Cin, Cout, p.ntiles, p.nstrips, p.npairs, Cout / 32};
+    PwArgs a{x, dy, part, ldx, lddy, N, D, H, W, Cin, Cout, p.ntiles, p.nstrips, p.npairs, (Cout + 31) / 32};
     const int nwg = p.nstrips * p.npairs;
     ProfScope ps(T == 8 ? PF_CONVT : PF_WGRAD, 2.0 * nvox * T * Cin * Cout, 4.0 * (nvox * (Cin + (double)T * Cout) + (double)T * Cin * Cout), st);
     if (T == 8) {

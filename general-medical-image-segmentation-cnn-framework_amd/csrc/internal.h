@@ -43,6 +43,13 @@ size_t conv_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, 
 bool conv_mfma_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int ldy);
 // dgrad != 0: `w` is still the (Cfwd_out=Cin_here ... ) torch weight of the FORWARD conv, i.e. shape (Cin, Cout, 27)
 // seen from this call's Cin/Cout; taps are flipped while packing.
+bool conv_gather_fwd_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int ldy);
+bool conv_gather_dgrad_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int lddy, int lddx);
+size_t conv_gather_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad);
+int conv_gather_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W,
+                         int Cin, int Cout, int k, int stride, int pad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st);
+int conv_gather_dgrad_mfma(const float* dy, int lddy, const float* w, float* dx, int lddx, int N, int D, int H, int W,
+                           int Cin, int Cout, int k, int stride, int pad, void* ws, size_t ws_bytes, hipStream_t st);
 int conv_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W,
                   int Cin, int Cout, int k, int dgrad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st);
 bool convt_mfma_supported(int N, int D, int H, int W, int Cin, int Cout, int ldx, int ldy);

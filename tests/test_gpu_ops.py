@@ -75,6 +75,13 @@ CONV_CASES = [
     (2, 5, 9, 8, 64, 32, 5, 1, 2),         # k5 MFMA wgrad, BX = 8, odd extents
     (1, 3, 6, 40, 32, 32, 5, 1, 2),        # k5 MFMA wgrad, BX = 8 (W = 40), D smaller than the halo
     (2, 8, 8, 8, 8, 16, 2, 2, 0),
+    (1, 16, 16, 32, 32, 64, 3, 2, 1),      # gather igemm: k3 s2 p1 (Res-U-Net down conv), dgrad in 8 phases
+    (1, 9, 11, 34, 16, 32, 3, 2, 1),       # gather igemm, odd extents
+    (1, 8, 16, 32, 32, 64, 2, 2, 0),       # gather igemm: k2 s2 (V-Net down conv)
+    (2, 8, 8, 16, 16, 32, 2, 2, 0),        # V-Net down_tr32: MFMA fwd, generic dgrad (Cin = 16)
+    (1, 8, 8, 32, 16, 32, 4, 4, 0),        # k4 s4, 64 taps
+    (1, 6, 6, 12, 16, 32, 2, 1, 0),        # even kernel, stride 1
+    (1, 9, 9, 17, 64, 32, 3, 2, 0),        # k3 s2 without padding, CK = 64
     (1, 8, 12, 8, 16, 32, 3, 2, 1),
     (2, 8, 8, 8, 16, 4, 1, 1, 0),
     (1, 16, 16, 16, 1, 8, 16, 16, 0),
@@ -146,7 +153,8 @@ def test_conv3d_channel_slices_and_no_bias(seg):
 
 @pytest.mark.parametrize("case", [(2, 4, 4, 4, 16, 8), (1, 8, 8, 8, 64, 32), (1, 3, 5, 4, 6, 10), (2, 2, 2, 2, 512, 256),
                                   (2, 8, 8, 8, 512, 256), (1, 16, 16, 16, 128, 64), (1, 16, 32, 32, 64, 32),
-                                  (1, 6, 6, 6, 64, 32), (1, 3, 5, 6, 32, 32), (2, 12, 12, 12, 128, 64)])
+                                  (1, 6, 6, 6, 64, 32), (1, 3, 5, 6, 32, 32), (2, 12, 12, 12, 128, 64),
+                                  (1, 8, 8, 16, 64, 16), (2, 5, 6, 7, 32, 16), (1, 4, 4, 8, 32, 4)])   # narrow Cout: flat (child, cout) tiles
 def test_conv_transpose3d_k2s2(seg, case):
     N, D, H, W, Cin, Cout = case
     F = seg.functional
