@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="1,1,128,128,128")
     ap.add_argument("--no-prof", action="store_true", help="skip the in-library HIP-event kernel timing")
+    ap.add_argument("--prof-all", action="store_true", help="HIP-event timing of every kernel family (adds ~1 %% to the step)")
+    ap.add_argument("--hip-graph", action="store_true", help="experiment: replay the whole train step as one captured HIP graph (N=1, implies --no-prof)")
     ap.add_argument("--dump-launches", default=None, help="write per-launch (family, ms, GFLOP, TFLOP/s) of the LAST timed step to this file")
     args = ap.parse_args()
 
@@ -117,13 +119,22 @@ def main():
     model = UNet3D(in_channels=cin, out_channels=ncls, init_features=width)
     model.apply(weights_init_normal("kaiming"))
     model = model.to(dev).train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=bool(args.hip_graph))
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     x = torch.randn((B, cin, Dd, Hh, Ww), generator=g).to(dev)
     gt = (torch.rand((B, 1, Dd, Hh, Ww), generator=g) > 0.9).float().to(dev)
     reducer = D.GradAllReducer(model) if world > 1 else None
 
+    graphed = None
+    if args.hip_graph:                  # experiment: the whole step as one hipGraphLaunch (single process, no kernel timing)
+        assert world == 1, "--hip-graph is a single-process experiment"
+        from mi355seg.engine import GraphedTrainStep
+        args.no_prof = True
+        graphed = GraphedTrainStep(model, opt, x, gt, warmup=3)
+
     def step():
+        if graphed is not None:
+            return graphed(x, gt, sync_metric=False)
         if world > 1:
             D.broadcast_buffers(model)
         return train_step(model, opt, x, gt, sync_metric=False, grad_hook=reducer)
@@ -135,7 +146,8 @@ def main():
         dist.barrier()
     if not args.no_prof:
         L.call("mi355seg_prof_reset")
-        L.call("mi355seg_prof_enable", 1)
+        # default: bracket only the two MFMA conv families (51 launches per step); --prof-all brackets all ~400
+        L.call("mi355seg_prof_enable", 1 if args.prof_all else 2 * 0b11)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):

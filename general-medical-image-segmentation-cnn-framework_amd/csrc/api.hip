@@ -12,7 +12,7 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---- per-family HIP-event timing ----
-bool g_prof_on = false;
+unsigned g_prof_mask = 0;
 namespace {
 struct ProfRec { hipEvent_t a, b; int family; double flops, bytes; };
 constexpr int kProfMax = 1 << 16;
@@ -135,7 +135,7 @@ extern "C" {
 const char* mi355seg_last_error(void) { return g_err; }
 int mi355seg_version(void) { return 100; }
 
-int mi355seg_prof_enable(int on) { g_prof_on = on != 0; return MI355SEG_OK; }
+int mi355seg_prof_enable(int on) { g_prof_mask = on == 1 ? 0xFFu : (on <= 0 ? 0u : ((unsigned)on >> 1)); return MI355SEG_OK; }
 int mi355seg_prof_reset(void) { g_nrec = 0; return MI355SEG_OK; }
 int mi355seg_prof_records(double* out, int max_records, int* n_host) {
     SEG_CHECK_ARG(out && n_host && max_records >= 0, "prof_records: bad arguments");

@@ -57,12 +57,12 @@ constexpr int kWave = 64;
 
 // ---- optional per-family kernel timing (api.hip) ----
 enum ProfFamily { PF_IGEMM = 0, PF_WGRAD = 1, PF_GENERIC = 2, PF_CONVT = 3, PF_NORM = 4, PF_POOL = 5, PF_LOSS = 6, PF_DIRECT = 7 };
-extern bool g_prof_on;
+extern unsigned g_prof_mask;     // bit f set: launches of ProfFamily f are bracketed by HIP events
 void prof_begin(int family, double flops, double bytes, hipStream_t st);
 void prof_end(hipStream_t st);
 struct ProfScope {
     hipStream_t st; bool on;
-    ProfScope(int family, double flops, double bytes, hipStream_t s) : st(s), on(g_prof_on) { if (on) prof_begin(family, flops, bytes, s); }
+    ProfScope(int family, double flops, double bytes, hipStream_t s) : st(s), on((g_prof_mask >> family) & 1u) { if (on) prof_begin(family, flops, bytes, s); }
     ~ProfScope() { if (on) prof_end(st); }
 };
 

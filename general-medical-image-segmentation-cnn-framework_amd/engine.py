@@ -43,6 +43,48 @@ def train_step(model, optimizer, x, gt, criterion=None, sync_metric=True, grad_h
     return out
 
 
+class GraphedTrainStep:
+    """``train_step`` captured once into a HIP graph and replayed: one ``hipGraphLaunch`` per iteration instead of
+    ~400 kernel launches from Python.  On 64^3 patches (the reference's default ``patch_size``) the eager step is
+    launch-bound -- the GPU finishes its kernels faster than one host thread can enqueue them -- and the graph
+    removes that; at 128^3 the step is GPU-bound either way.
+
+    Constraints of stream capture: fixed input shapes (the patch pipeline already guarantees them), an optimizer
+    constructed with ``capturable=True`` (its step counter lives on the device), the in-library kernel profiler
+    off, and a single process (the data-parallel gradient hooks are not captured).  Three eager warm-up steps run
+    on a side stream first -- they size the workspace and set the kernels' LDS attributes -- and, like the captured
+    step, they DO update the model, so a freshly built instance has already taken ``warmup`` optimiser steps.
+    Returned tensors are static buffers overwritten by the next call."""
+
+    def __init__(self, model, optimizer, x, gt, criterion=None, warmup=3):
+        from ._lib import lib
+        if not all(g.get("capturable", False) for g in optimizer.param_groups):
+            raise ValueError("GraphedTrainStep: build the optimizer with capturable=True (e.g. torch.optim.Adam(..., capturable=True))")
+        lib().call("mi355seg_prof_enable", 0)
+        self.model, self.optimizer, self.criterion = model, optimizer, criterion
+        self.x = x.detach().to(torch.float32).clone()
+        self.gt = gt.detach().clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                train_step(model, optimizer, self.x, self.gt, criterion, sync_metric=False)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = train_step(model, optimizer, self.x, self.gt, criterion, sync_metric=False)
+
+    def __call__(self, x, gt, sync_metric=True):
+        self.x.copy_(x, non_blocking=True)
+        self.gt.copy_(gt, non_blocking=True)
+        self.graph.replay()
+        out = dict(self.out)
+        if sync_metric:
+            out["jaccard"], out["dice"] = metric_from_counts(out["counts"].cpu().tolist())
+        return out
+
+
 def weights_init_normal(init_type):
     """The reference's init policy (train.py:33-61) for ``model.apply(...)``: Conv*/Linear
     weights by ``init_type``, their biases zeroed; only classes named *BatchNorm2d* get the

@@ -251,6 +251,8 @@ int mi355seg_colsum_f32(const float* x, int ldx, long long rows, int C, float* o
  *   out[4*f+0] = launches, out[4*f+1] = total milliseconds,
  *   out[4*f+2] = total algorithmic FLOPs, out[4*f+3] = total algorithmic bytes. */
 #define MI355SEG_PROF_FAMILIES 8
+/* on: 0 = off, 1 = every family, otherwise 2 * (bit mask of families): only those launches are bracketed, so the
+ * event records do not serialise the many small kernels of a step that is being timed as a whole. */
 int mi355seg_prof_enable(int on);
 int mi355seg_prof_reset(void);
 int mi355seg_prof_read(double* out_host, int n_doubles);

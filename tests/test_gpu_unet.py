@@ -136,3 +136,32 @@ def test_predict_cli_sliding_window(seg, tmp_path):
         b = m(vol[None]).argmax(1)
     assert torch.equal(a, b)
     assert not m.training
+
+
+def test_hip_graph_train_step_matches_eager(seg):
+    """The captured-and-replayed step (engine.GraphedTrainStep) is the same arithmetic as the eager one: identical
+    loss, Dice counters and parameters after the same number of optimiser steps."""
+    from mi355seg.engine import GraphedTrainStep, train_step
+    from mi355seg.models.three_d.unet3d import UNet3D
+    from oracle.fill import fill_module_, make_input, make_labels
+    x = make_input((1, 1, 32, 32, 32)).cuda()
+    gt = make_labels((1, 1, 32, 32, 32)).cuda()
+    xs = [x + 0.1 * i for i in range(3)]
+
+    def fresh():
+        m = fill_module_(UNet3D(1, 2, 8)).cuda().train()
+        return m, torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True)
+
+    m0, o0 = fresh()
+    eager = [train_step(m0, o0, x, gt, sync_metric=False) for _ in range(3)]          # == the graph's 3 warm-up steps
+    eager += [train_step(m0, o0, xi, gt, sync_metric=False) for xi in xs]
+    eager = [(float(e["loss"]), e["counts"].tolist()) for e in eager]
+    m1, o1 = fresh()
+    g = GraphedTrainStep(m1, o1, x, gt, warmup=2)                                      # 2 eager + 1 captured-but-not-run...
+    got = []
+    for xi in [x] + xs:                                                                # capture does not execute: replay the 3rd step
+        out = g(xi, gt, sync_metric=False)
+        got.append((float(out["loss"]), out["counts"].tolist()))
+    assert got == eager[2:]
+    for (k, a), (_, b) in zip(m0.state_dict().items(), m1.state_dict().items()):
+        assert torch.equal(a, b), k
