@@ -161,8 +161,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_generic_kernel(const float* __
 }
 
 // dw[co][ci][tap] (+)= sum_split part[split][tap][ci][co]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits, int T, int Cin,
-                                    int Cout, int accumulate) {
+// A block owns 32 output channels x CIT input channels x TT taps (TT = T unless T > 256, then CIT = 1): the slabs are
+// read along co (128-byte segments), summed in split order, transposed through LDS and written as CIT*TT-float runs of
+// the PyTorch (Cout, Cin, T) layout.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits, int T, int Cin,
+                                                           int Cout, int accumulate, int CIT, int TT) {
+    extern __shared__ float tr[];                       // [32][CIT * TT + 1]
+    const long long total = (long long)T * Cin * Cout;
+    const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * CIT, t0 = blockIdx.z * TT;
+    const int tn = min(TT, T - t0);
+    const int run = CIT * TT, pitch = run + 1;
+    for (int e = threadIdx.x; e < 32 * run; e += 256) {
+        const int col = e & 31, r = e >> 5;
+        const int cil = r % CIT, tl = r / CIT;
+        const int co = co0 + col, ci = ci0 + cil;
+        float s = 0.f;
+        if (co < Cout && ci < Cin && tl < tn) {
+            const long long i = ((long long)(t0 + tl) * Cin + ci) * Cout + co;
+            for (int k = 0; k < splits; ++k) s += part[(long long)k * total + i];
+        }
+        tr[col * pitch + cil * TT + tl] = s;
+    }
+    __syncthreads();
+    const int cin_here = min(CIT, Cin - ci0);
+    for (int e = threadIdx.x; e < 32 * run; e += 256) {
+        const int col = e / run, j = e - col * run;
+        const int cil = j / TT, tl = j - cil * TT;
+        const int co = co0 + col;
+        if (co < Cout && cil < cin_here && tl < tn) {
+            const long long o = ((long long)co * Cin + ci0 + cil) * T + t0 + tl;      // contiguous in j when TT == T
+            const float v = tr[col * pitch + j];
+            dw[o] = accumulate ? dw[o] + v : v;
+        }
+    }
+}
+
+// few output elements (narrow layers, many strips): one thread per element, every thread walks the strips
+__global__ void wgrad_reduce_flat_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits, int T, int Cin,
+                                         int Cout, int accumulate) {
     long long total = (long long)T * Cin * Cout;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         int co = (int)(i % Cout);
@@ -170,16 +206,36 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
         int ci = (int)(r % Cin);
         int t = (int)(r / Cin);
         float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += part[(long long)k * total + i];
+        int k = 0;
+        for (; k + 8 <= splits; k += 8) {                  // 8 loads in flight, added in strip order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(long long)(k + u) * total + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < splits; ++k) s += part[(long long)k * total + i];
         long long o = ((long long)co * Cin + ci) * T + t;
         dw[o] = accumulate ? dw[o] + s : s;
     }
 }
 
 void wgrad_reduce(const float* part, float* dw, int splits, int T, int Cin, int Cout, int accumulate, hipStream_t st) {
-    long long total = (long long)T * Cin * Cout;
-    int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, part, dw, splits, T, Cin, Cout, accumulate);
+    const int TT = T > 256 ? 256 : T;
+    int CIT = 256 / TT;
+    CIT = CIT < 1 ? 1 : (CIT > 32 ? 32 : CIT);
+    if (CIT > Cin) CIT = Cin;
+    auto blocks = [&](int cit) { return (long long)((Cout + 31) / 32) * ((Cin + cit - 1) / cit) * ((T + TT - 1) / TT); };
+    while (CIT > 1 && blocks(CIT) < 256) CIT = (CIT + 1) / 2;       // wide layers: enough blocks for every CU
+    if (blocks(CIT) < 256) {
+        long long total = (long long)T * Cin * Cout;
+        int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+        hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3(grid), dim3(256), 0, st, part, dw, splits, T, Cin, Cout, accumulate);
+        return;
+    }
+    const size_t lds = (size_t)32 * (CIT * TT + 1) * sizeof(float);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((Cout + 31) / 32, (Cin + CIT - 1) / CIT, (T + TT - 1) / TT), dim3(256), lds, st, part, dw,
+                       splits, T, Cin, Cout, accumulate, CIT, TT);
 }
 
 static int generic_splits(const ConvGeom& g) {
