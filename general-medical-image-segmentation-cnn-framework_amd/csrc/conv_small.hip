@@ -209,6 +209,14 @@ __global__ __launch_bounds__(256) void stem1_wgrad_kernel(const float* __restric
         const int tyi = mt % nty; mt /= nty;
         const int tzi = mt % ntz; const int n = mt / ntz;
         const int x0 = txi * TX, y0 = tyi * S1_TY, z0 = tzi * S1_TZ;
+        // the tile's dy (8 x 16 bytes per thread) is requested before the halo staging so both latencies overlap
+        f32x4 dreg[S1_TZ * S1_TY];
+#pragma unroll
+        for (int line = 0; line < S1_TZ * S1_TY; ++line) {
+            const int lz = line / S1_TY, ly = line % S1_TY;
+            const long long v = (((long long)n * g.D + z0 + lz) * g.H + y0 + ly) * g.W + x0 + xs;
+            dreg[line] = *reinterpret_cast<const f32x4*>(dy + v * lddy + cq * 4);
+        }
         __syncthreads();
         s1_stage(sm, x, g.ldx, n, z0, y0, x0, TX, g.D, g.H, g.W);
         __syncthreads();
@@ -216,8 +224,7 @@ __global__ __launch_bounds__(256) void stem1_wgrad_kernel(const float* __restric
         for (int line = 0; line < S1_TZ * S1_TY; ++line) {
             const int lz = line / S1_TY, ly = line % S1_TY;
             const float* tp = sm + (lz * HY + ly) * HX + xs;
-            const long long v = (((long long)n * g.D + z0 + lz) * g.H + y0 + ly) * g.W + x0 + xs;
-            const f32x4 d = *reinterpret_cast<const f32x4*>(dy + v * lddy + cq * 4);
+            const f32x4 d = dreg[line];
 #pragma unroll
             for (int t = 0; t < 27; ++t) {
                 const int dz = t / 9, dyy = (t / 3) % 3, dx = t % 3;
