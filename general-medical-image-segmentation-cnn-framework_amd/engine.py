@@ -24,7 +24,13 @@ def train_step(model, optimizer, x, gt, criterion=None, sync_metric=True, grad_h
     int64[4] counters stay on the device under 'counts'."""
     optimizer.zero_grad(set_to_none=True)
     gt2 = two_channel_gt(gt)
-    pred = model(x.to(torch.float32))
+    x = x.to(torch.float32)
+    if getattr(model, "takes_frequency_bands", False):      # the IS network, train.py:198-201: second output discarded
+        from .models.three_d.IS import frequency_bands
+        low_x, high_x = frequency_bands(x)
+        pred, _ = model(x, low_x, high_x)
+    else:
+        pred = model(x)
     if criterion is None:
         loss = F.bce_with_logits(pred, gt2)
     else:

@@ -61,7 +61,13 @@ def sliding_window_predict(model, volume, patch_size, overlap=(4, 4, 36), batch_
     for i in range(0, len(locs), batch_size):
         chunk = locs[i:i + batch_size]
         x = torch.stack([volume[:, z:z + ps[0], y:y + ps[1], w:w + ps[2]] for (z, y, w) in chunk])
-        labels = F.argmax_channels(model(x.contiguous()))               # predict.py:133,139
+        x = x.contiguous()
+        if getattr(model, "takes_frequency_bands", False):               # predict.py:128-131 (IS: first output only)
+            from .models.three_d.IS import frequency_bands
+            logits, _ = model(x, *frequency_bands(x))
+        else:
+            logits = model(x)
+        labels = F.argmax_channels(logits)                               # predict.py:133,139
         for j, loc in enumerate(chunk):
             src, dst = crop_window(loc, ps, size, overlap)
             out[(0,) + dst] = labels[j, 0][src]

@@ -8,6 +8,7 @@ Follows (reference file:line):
   * UNet3D      -- models/three_d/unet3d.py:10-48 (ctor), :50-71 (forward), :73-104 (block)
   * VNet        -- models/three_d/vnet3d.py:21-31, :41-58, :61-80, :83-104, :107-121, :124-157
   * ResUNet     -- models/three_d/residual_unet3d.py:11-80 (ctor), :82-107 (factories), :109-204 (forward)
+  * ISUNet3D    -- models/three_d/IS.py:10-130 (ctor: three parameter sets), :132-190 (forward: shared encoder, three decoders)
 """
 from collections import OrderedDict
 
@@ -63,6 +64,49 @@ class UNet3D(nn.Module):
             h = torch.cat((h, skips[lvl - 1]), dim=1)
             h = getattr(self, f"decoder{lvl}")(h)
         return self.conv(h)
+
+
+# --------------------------------------------------------------------------- IS (three-band U-Net)
+class ISUNet3D(nn.Module):
+    """IS.py:10-190.  Three U-Net parameter sets ("", "_", "__"); forward runs the UNSUFFIXED encoder + bottleneck on
+    the volume, its low band and its high band, with decoder set k on band k; out1 = conv(dec), out2 = conv_(sum of
+    the three decoder outputs).  The suffixed encoders / bottlenecks exist only as parameters."""
+
+    def __init__(self, in_channels=1, out_channels=3, init_features=64):
+        super().__init__()
+        f = init_features
+        widths = [f, 2 * f, 4 * f, 8 * f]
+        for tag in ("", "_", "__"):
+            prev = in_channels
+            for lvl, w in enumerate(widths, start=1):
+                setattr(self, f"encoder{lvl}{tag}", _double_conv(f"enc{lvl}", prev, w))
+                setattr(self, f"pool{lvl}{tag}", nn.MaxPool3d(kernel_size=2, stride=2))
+                prev = w
+            setattr(self, f"bottleneck{tag}", _double_conv("bottleneck", prev, 16 * f))
+            prev = 16 * f
+            for lvl in (4, 3, 2, 1):
+                w = widths[lvl - 1]
+                setattr(self, f"upconv{lvl}{tag}", nn.ConvTranspose3d(prev, w, kernel_size=2, stride=2))
+                setattr(self, f"decoder{lvl}{tag}", _double_conv(f"dec{lvl}", 2 * w, w))
+                prev = w
+        self.conv = nn.Conv3d(f, out_channels, kernel_size=1)
+        self.conv_ = nn.Conv3d(f, out_channels, kernel_size=1)
+
+    def _band(self, h, tag):
+        skips = []
+        for lvl in (1, 2, 3, 4):
+            h = getattr(self, f"encoder{lvl}")(h)
+            skips.append(h)
+            h = getattr(self, f"pool{lvl}")(h)          # IS.py:156 uses pool4_ for the low band: same parameter-free op
+        h = self.bottleneck(h)
+        for lvl in (4, 3, 2, 1):
+            h = getattr(self, f"upconv{lvl}{tag}")(h)
+            h = getattr(self, f"decoder{lvl}{tag}")(torch.cat((h, skips[lvl - 1]), dim=1))
+        return h
+
+    def forward(self, x, low_x, high_x):
+        d0, d1, d2 = self._band(x, ""), self._band(low_x, "_"), self._band(high_x, "__")
+        return self.conv(d0), self.conv_(d0 + d1 + d2)
 
 
 # --------------------------------------------------------------------------- V-Net

@@ -65,3 +65,18 @@ def train_step(model, optimizer, x, gt, criterion=bce_with_logits):
     optimizer.step()
     jd = metric(gt2.argmax(dim=1, keepdim=True), mask)
     return pred, mask, loss, jd
+
+
+def frequency_bands(x, limit=0.04):
+    """train.py:76-88,198-200 (``low_pass_torch`` / ``high_pass_torch``): keep |f| < limit (low) or |f| > limit (high)
+    on the last two axes.  The forward rfftn runs over ALL axes of the 5-D batch while the inverse runs over the last
+    three only -- upstream's behaviour, the identity on the extra axes when batch = channel = 1."""
+    import torch.fft as fft
+    spec = fft.rfftn(x)
+    out = []
+    for cmp in (torch.lt, torch.gt):
+        keep_w = cmp(torch.abs(fft.rfftfreq(x.shape[-1])), limit)
+        keep_h = cmp(torch.abs(fft.fftfreq(x.shape[-2])), limit)
+        out.append(fft.irfftn(spec * torch.outer(keep_h, keep_w).to(x), s=x.shape[-3:]))
+    return out[0], out[1]
+

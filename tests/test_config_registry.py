@@ -43,6 +43,8 @@ def test_registry_builds_in_scope_networks_with_reference_constructors():
     assert sum(p.numel() for p in m.parameters()) == 45_600_316
     m = build_model({"network": "res_unet", "in_classes": 4, "out_classes": 4})
     assert sum(p.numel() for p in m.parameters()) == 28_499_072
+    m = build_model({"network": "IS", "in_classes": 1, "out_classes": 2})
+    assert sum(p.numel() for p in m.parameters()) == 3 * (22_581_250 - 66) + 2 * 66      # three U-Net bodies, two heads
     with pytest.raises(NotImplementedError):
         build_model({"network": "densenet", "in_classes": 1, "out_classes": 2})
     with pytest.raises(ValueError):

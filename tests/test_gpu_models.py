@@ -263,3 +263,34 @@ def test_transformer_ops_against_aten(seg):
     assert (yg.detach().cpu() - yr.detach()).abs().max() < 1e-5
     for a, r in zip(qg, qs):
         assert (a.grad.cpu() - r.grad).abs().max() < 1e-5
+
+
+def test_isnet_vs_reference_fixture(seg, golden_dir):
+    """The IS network (three decoders over one shared encoder, IS.py:132-190) driven as train.py:198-209 does: FFT
+    bands in, loss on the first output.  Fixture from the reference module; band volumes compared too."""
+    from mi355seg.models.three_d.IS import UNet3D as ISNet, frequency_bands
+    g = np.load(os.path.join(golden_dir, "isnet_f4_32.npz"))
+    m = fill_module_(ISNet(in_channels=1, out_channels=2, init_features=4)).cuda().train()
+    x = make_input((1, 1, 32, 32, 32), freq=0.37).cuda()
+    gt2 = two_channel_gt(make_labels((1, 1, 32, 32, 32))).cuda()
+    low, high = frequency_bands(x)
+    assert np.abs(low.cpu().numpy() - g["low"]).max() < 1e-5 and np.abs(high.cpu().numpy() - g["high"]).max() < 1e-5
+    out1, out2 = m(x, torch.from_numpy(g["low"]).cuda(), torch.from_numpy(g["high"]).cuda())
+    loss = seg.functional.bce_with_logits(out1, gt2)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    assert np.abs(out1.detach().cpu().numpy() - g["out1"]).max() < TOL
+    assert np.abs(out2.detach().cpu().numpy() - g["out2"]).max() < TOL
+    params, bufs = dict(m.named_parameters()), dict(m.named_buffers())
+    n_grad = 0
+    for k in g.files:
+        if k.startswith("hasgrad/"):
+            assert (params[k[8:]].grad is not None) == bool(g[k]), k       # unused parameter sets stay gradient-free
+            n_grad += int(bool(g[k]))
+        elif k.startswith("grad/"):
+            ref, got = g[k], _sample(params[k[5:]].grad)
+            assert np.abs(got - ref).max() <= 3e-4 * max(1e-3, np.abs(ref).max()), k
+        elif k.startswith("buf/") and not k.endswith("num_batches_tracked"):
+            assert (np.abs(bufs[k[4:]].cpu().numpy() - g[k]) / np.maximum(1.0, np.abs(g[k]))).max() < 1e-5, k
+    assert n_grad == 82
+    assert int(bufs["encoder1.enc1norm1.num_batches_tracked"]) == 3       # one forward = three passes of the shared encoder

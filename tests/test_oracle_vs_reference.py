@@ -94,3 +94,43 @@ def test_unetr_bit_identical():
             assert gb[k] is None
             continue
         assert torch.equal(ga[k], gb[k]), k
+
+
+def test_isnet_bit_identical_and_frequency_bands():
+    """IS.py (three parameter sets, shared encoder) and the FFT band split of train.py:76-88.  train.py cannot be
+    imported (hydra / torchio absent), so its two filter functions are lifted out of its syntax tree and executed as
+    they stand -- the reference itself, not a copy -- to pin oracle.step.frequency_bands."""
+    import ast
+    import torch.fft as fft
+    from oracle.step import frequency_bands
+    tree = ast.parse(open(f"{REFERENCE}/train.py").read())
+    ns = {"torch": torch, "fft": fft}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("low_pass_torch", "high_pass_torch"):
+            exec(compile(ast.Module([node], []), "train.py", "exec"), ns)
+    x = make_input((1, 1, 16, 16, 16), freq=0.37)
+    low, high = frequency_bands(x)
+    assert torch.equal(low, ns["low_pass_torch"](x, 0.04)) and torch.equal(high, ns["high_pass_torch"](x, 0.04))
+    xb = make_input((2, 1, 8, 12, 16), freq=0.21)                     # batch 2: the all-axes forward transform quirk
+    lb, hb = frequency_bands(xb)
+    assert torch.equal(lb, ns["low_pass_torch"](xb, 0.04)) and torch.equal(hb, ns["high_pass_torch"](xb, 0.04))
+
+    R = _ref("models.three_d.IS", "UNet3D")
+    a = fill_module_(R(1, 2, 4)).train()
+    b = fill_module_(nets.ISUNet3D(1, 2, 4)).train()
+    _same_keys(a, b)
+    assert list(a.state_dict()) == list(b.state_dict())              # registration order (optimizer state index)
+    outs = []
+    x = make_input((1, 1, 32, 32, 32), freq=0.37)                    # 32^3: the bottleneck still sees 2^3 voxels for BatchNorm
+    low, high = frequency_bands(x)
+    for m in (a, b):
+        o1, o2 = m(x, low, high)
+        (o1.square().mean() + 0.5 * o2.square().mean()).backward()
+        outs.append((o1.detach(), o2.detach(), {k: p.grad for k, p in m.named_parameters()}, dict(m.named_buffers())))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for k, g in outs[0][2].items():
+        assert (g is None) == (outs[1][2][k] is None), k               # the never-called suffixed encoders get no gradient
+        if g is not None:
+            assert torch.equal(g, outs[1][2][k]), k
+    for k, v in outs[0][3].items():
+        assert torch.equal(v, outs[1][3][k]), k                        # shared-encoder BN stats advanced three times
