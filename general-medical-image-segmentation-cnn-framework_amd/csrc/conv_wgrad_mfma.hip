@@ -202,7 +202,7 @@ static bool wgrad_plan(int KS, int N, int D, int H, int W, int Cin, int Cout, Wg
     p->npairs = (Cin / 32) * (Cout / 32);
     p->taps = KS * KS * KS; p->planes = KS == 3 ? 1 : KS;
     const int per_strip = p->npairs * p->planes;
-    int want = (256 + per_strip - 1) / per_strip;      // one workgroup per CU (106-136 KB of LDS each)
+    int want = 256 / per_strip;                        // one workgroup per CU (106-136 KB of LDS each): never more than 256 in all
     long long cap = (long long)(160u << 20) / ((long long)p->taps * Cin * Cout * 4);   // keep the slab workspace <= 160 MB
     if (cap < 1) cap = 1;
     if (want > cap) want = (int)cap;
