@@ -143,7 +143,7 @@ static bool pw_plan(long long nvox, int Cin, int Cout, int T, PwPlan* p) {
     const int V = T == 8 ? 64 : 256;
     p->ntiles = (int)((nvox + V - 1) / V);
     p->npairs = ((Cin + 31) / 32) * ((Cout + 31) / 32);
-    int want = (512 + p->npairs - 1) / p->npairs;
+    int want = 512 / p->npairs;                        // two workgroups per CU: never more than 512 in all
     long long cap = (long long)(64u << 20) / ((long long)T * Cin * Cout * 4);
     if (cap < 1) cap = 1;
     if (want > cap) want = (int)cap;
