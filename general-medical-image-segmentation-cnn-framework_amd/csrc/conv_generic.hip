@@ -352,6 +352,8 @@ size_t mi355seg_conv3d_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, i
     if (b > a) a = b;
     if (d > a) a = d;
     if (e > a) a = e;
+    if (headk_supported(Cin, Cout, k, stride, pad, 4, 4, true) && headk_ws_bytes(Cin, Cout, k) > a) a = headk_ws_bytes(Cin, Cout, k);
+    if (headk_wgrad_supported(Cin, Cout, k, stride, pad, 4, 2) && headk_wgrad_ws_bytes(N, D, H, W, Cin, k) > a) a = headk_wgrad_ws_bytes(N, D, H, W, Cin, k);
     return a > c ? a : c;
 }
 
@@ -369,6 +371,11 @@ int mi355seg_conv3d_fwd_f32(const float* x, int ldx, const float* w, const float
         return conv_fwd_mfma(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, /*dgrad=*/0, stats_sum, stats_sq, ws, ws_bytes, st);
     if (conv_gather_fwd_supported(N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy) && ((uintptr_t)x % 16) == 0)
         return conv_gather_fwd_mfma(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, stride, pad, stats_sum, stats_sq, ws, ws_bytes, st);
+    if (headk_supported(Cin, Cout, k, stride, pad, ldx, ldy, false) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 8) == 0) {
+        rc = headk_conv(false, x, ldx, w, bias, y, ldy, N, D, H, W, Cin, k, ws, ws_bytes, st);
+        if (rc || !stats_sum) return rc;
+        return channel_sums(y, ldy, (long long)N * D * H * W, Cout, stats_sum, stats_sq, nullptr, 0, ws, ws_bytes, st);
+    }
     if (stem_supported(Cin, Cout, k, stride, pad, ldy))
         return stem_fwd(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, stats_sum, stats_sq, ws, ws_bytes, st);
     if (head_supported(Cin, Cout, k, stride, pad, ldx)) {
@@ -392,6 +399,8 @@ int mi355seg_conv3d_dgrad_f32(const float* dy, int lddy, const float* w, float* 
         return conv_fwd_mfma(dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cout, Cin, k, /*dgrad=*/1, nullptr, nullptr, ws, ws_bytes, st);
     if (conv_gather_dgrad_supported(N, D, H, W, Cin, Cout, k, stride, pad, lddy, lddx) && ((uintptr_t)dy % 16) == 0)
         return conv_gather_dgrad_mfma(dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, k, stride, pad, ws, ws_bytes, st);
+    if (headk_supported(Cin, Cout, k, stride, pad, lddy, lddx, true) && ((uintptr_t)dy % 8) == 0 && ((uintptr_t)dx % 16) == 0)
+        return headk_conv(true, dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cin, k, ws, ws_bytes, st);
     if (head_supported(Cin, Cout, k, stride, pad, lddx))
         return head_dgrad(dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, st);
     return conv_dgrad_generic(dy, lddy, w, dx, lddx, g, ws, ws_bytes, st);
@@ -424,6 +433,8 @@ int mi355seg_conv3d_wgrad_f32(const float* dy, int lddy, const float* x, int ldx
         return stem_wgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, st);
     if (head_supported(Cin, Cout, k, stride, pad, ldx))
         return head_wgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, st);
+    if (headk_wgrad_supported(Cin, Cout, k, stride, pad, ldx, lddy) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 8) == 0)
+        return headk_wgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, k, accumulate, ws, ws_bytes, st);
     if (smallcin_wgrad_supported(Cin, Cout, k))
         return smallcin_wgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, stride, pad, accumulate, ws, ws_bytes, st);
     if (smallcout_wgrad_supported(Cin, Cout, k, ldx) && ((uintptr_t)x % 16) == 0)

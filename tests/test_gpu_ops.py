@@ -68,6 +68,9 @@ CONV_CASES = [
     (2, 8, 8, 16, 1, 16, 5, 1, 2),         # V-Net in_tr: small-Cin direct wgrad, k5
     (1, 8, 8, 16, 32, 2, 5, 1, 2),         # V-Net out_tr.conv1: small-Cout direct wgrad, k5
     (2, 8, 8, 8, 2, 2, 1, 1, 0),           # V-Net out_tr.conv2: 2 -> 2, k1
+    (1, 37, 11, 45, 32, 2, 5, 1, 2),       # z-marching head kernels: two z segments, ragged x / y tiles, 2 channel passes
+    (2, 9, 10, 33, 16, 2, 3, 1, 1),        # z-marching head kernels, k3, one pass
+    (1, 6, 9, 7, 48, 2, 5, 1, 2),          # three channel passes (12 input quads -> two dgrad wave groups)
     (1, 8, 8, 8, 4, 8, 2, 2, 0),           # small-Cin strided
     (1, 8, 12, 32, 32, 64, 5, 1, 2),       # k5 on the MFMA igemm (V-Net LUConv), CK = 8
     (2, 6, 6, 6, 8, 32, 5, 1, 2),          # k5, partial tiles, single chunk
