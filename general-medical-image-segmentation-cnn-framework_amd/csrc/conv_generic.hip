@@ -353,6 +353,7 @@ size_t mi355seg_conv3d_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, i
     if (d > a) a = d;
     if (e > a) a = e;
     if (headk_supported(Cin, Cout, k, stride, pad, 4, 4, true) && headk_ws_bytes(Cin, Cout, k) > a) a = headk_ws_bytes(Cin, Cout, k);
+    if (stemk_supported(Cin, Cout, k, stride, pad, 2, 4) && headk_ws_bytes(Cout, Cin, k) > a) a = headk_ws_bytes(Cout, Cin, k);
     if (headk_wgrad_supported(Cin, Cout, k, stride, pad, 4, 2) && headk_wgrad_ws_bytes(N, D, H, W, Cin, k) > a) a = headk_wgrad_ws_bytes(N, D, H, W, Cin, k);
     return a > c ? a : c;
 }
@@ -373,6 +374,11 @@ int mi355seg_conv3d_fwd_f32(const float* x, int ldx, const float* w, const float
         return conv_gather_fwd_mfma(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, stride, pad, stats_sum, stats_sq, ws, ws_bytes, st);
     if (headk_supported(Cin, Cout, k, stride, pad, ldx, ldy, false) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 8) == 0) {
         rc = headk_conv(false, x, ldx, w, bias, y, ldy, N, D, H, W, Cin, k, ws, ws_bytes, st);
+        if (rc || !stats_sum) return rc;
+        return channel_sums(y, ldy, (long long)N * D * H * W, Cout, stats_sum, stats_sq, nullptr, 0, ws, ws_bytes, st);
+    }
+    if (stemk_supported(Cin, Cout, k, stride, pad, ldx, ldy) && ((uintptr_t)x % 8) == 0 && ((uintptr_t)y % 16) == 0) {
+        rc = stemk_fwd(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, ws, ws_bytes, st);
         if (rc || !stats_sum) return rc;
         return channel_sums(y, ldy, (long long)N * D * H * W, Cout, stats_sum, stats_sq, nullptr, 0, ws, ws_bytes, st);
     }

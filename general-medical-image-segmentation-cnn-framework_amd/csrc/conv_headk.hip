@@ -129,17 +129,19 @@ __global__ __launch_bounds__(256, 1) void headk_fwd_kernel(const float* __restri
     }
 }
 
-// ---------------------------------------------------------------- dgrad: dx[u][ci] = sum_tap sum_co dy[u + R - tap][co] w[co][ci][tap]
-// x = dy (2 channels), y = dx (Cin channels); wp[quad][tap'][co][c] holds w[co][quad*4+c][NT-1-tap'] (taps flipped)
-template <int KS>
-__global__ __launch_bounds__(512, 1) void headk_dgrad_kernel(const float* __restrict__ xin, const float* __restrict__ wpk,
-                                                             float* __restrict__ yout, HeadKArgs a) {
+// ---------------------------------------------------------------- narrow -> wide: out[u][wide c] = sum_tap sum_s in[u + tap - R][s] wp[..]
+// The narrow side has CS = 1 or 2 channels, the wide side a.Cin channels (a multiple of 4).  Two uses:
+//   dgrad of the two-channel head:  in = dy (CS = 2), out = dx, weights flipped, no bias;
+//   forward of a one/two-channel stem (V-Net in_tr, k5 1 -> 16; vnet3d.py:41-58): in = x, out = y, bias added.
+// wp[quad][tap][s][c]; the narrow ring is tiny, each of 8 waves produces one quad of wide channels.
+template <int KS, int CS>
+__global__ __launch_bounds__(512, 1) void headk_expand_kernel(const float* __restrict__ xin, const float* __restrict__ wpk,
+                                                              const float* __restrict__ bias, float* __restrict__ yout, HeadKArgs a) {
     constexpr int R = KS / 2, HY = HK_TY + 2 * R, HX = HK_TX + 2 * R, SL = 40, NT = KS * KS * KS;
-    constexpr int ITEMS = HY * HX;                                 // float2 pieces per plane
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    f32x2* ring = reinterpret_cast<f32x2*>(lds);                   // [KS][HY][SL]
+    constexpr int ITEMS = HY * HX;                                 // CS-float pieces per plane
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [KS][HY][SL][CS]
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 8 waves = 8 input-channel quads per group
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 8 waves = 8 wide-channel quads per group
     const int xq = lane & 7, yl = lane >> 3;
     int t = blockIdx.x;
     const int txi = t % a.ntx; t /= a.ntx;
@@ -149,24 +151,30 @@ __global__ __launch_bounds__(512, 1) void headk_dgrad_kernel(const float* __rest
     const int zend = min(a.D, z0 + HK_SEG);
     const int nquad = a.Cin / 4;
 
-    f32x2 stage = {0.f, 0.f};
+    float stage[CS];
     auto load_plane = [&](int z) {
         const int hx = tid % HX, hy = tid / HX;
         const int gy = y0 - R + hy, gx = x0 - R + hx;
-        f32x2 v = {0.f, 0.f};
-        if (tid < ITEMS && (unsigned)z < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
-            v = *reinterpret_cast<const f32x2*>(xin + ((((long long)n * a.D + z) * a.H + gy) * a.W + gx) * a.ldx);
-        stage = v;
+#pragma unroll
+        for (int s = 0; s < CS; ++s) stage[s] = 0.f;
+        if (tid < ITEMS && (unsigned)z < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
+            const float* src = xin + ((((long long)n * a.D + z) * a.H + gy) * a.W + gx) * a.ldx;
+            if (CS == 2) { const f32x2 v = *reinterpret_cast<const f32x2*>(src); stage[0] = v.x; stage[CS - 1] = v.y; }
+            else stage[0] = src[0];
+        }
     };
     auto store_plane = [&](int slot) {
-        if (tid < ITEMS) ring[(slot * HY + tid / HX) * SL + tid % HX] = stage;
+        if (tid < ITEMS) {
+#pragma unroll
+            for (int s = 0; s < CS; ++s) lds[((slot * HY + tid / HX) * SL + tid % HX) * CS + s] = stage[s];
+        }
     };
     static_assert(ITEMS <= 512, "one staged piece per thread");
 
     for (int qg = 0; qg < nquad; qg += 8) {
         const int quad = qg + wave;
         const bool active = quad < nquad;                          // wave-uniform
-        const float* wq = wpk + (long long)(active ? quad : 0) * NT * 8;
+        const float* wq = wpk + (long long)(active ? quad : 0) * NT * CS * 4;
         __syncthreads();
         for (int p = 0; p < KS; ++p) { load_plane(z0 - R + p); store_plane(p); }
         __syncthreads();
@@ -178,30 +186,39 @@ __global__ __launch_bounds__(512, 1) void headk_dgrad_kernel(const float* __rest
 #pragma unroll
                 for (int v = 0; v < 4; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
                 for (int dz = 0; dz < KS; ++dz) {
-                    const f32x2* pl = ring + ((i + dz) % KS) * HY * SL;
+                    const float* pl = lds + ((i + dz) % KS) * HY * SL * CS;
 #pragma unroll
                     for (int dy = 0; dy < KS; ++dy) {
-                        const f32x2* row = pl + (yl + dy) * SL + 4 * xq;
-                        f32x2 r[KS + 3];
+                        const float* row = pl + ((yl + dy) * SL + 4 * xq) * CS;
+                        float r[(KS + 3) * CS];
 #pragma unroll
-                        for (int j = 0; j < KS + 3; ++j) r[j] = row[j];
-                        const float* wr = wq + ((dz * KS + dy) * KS) * 8;
+                        for (int j = 0; j < (KS + 3) * CS / 4; ++j) {              // (KS+3)*CS is a multiple of 4 for KS = 5, 3 with CS = 2; KS = 5 with CS = 1
+                            const f32x4 q = *reinterpret_cast<const f32x4*>(row + 4 * j);
+                            r[4 * j] = q[0]; r[4 * j + 1] = q[1]; r[4 * j + 2] = q[2]; r[4 * j + 3] = q[3];
+                        }
+#pragma unroll
+                        for (int j = ((KS + 3) * CS / 4) * 4; j < (KS + 3) * CS; ++j) r[j] = row[j];
+                        const float* wr = wq + ((dz * KS + dy) * KS) * CS * 4;
 #pragma unroll
                         for (int dx = 0; dx < KS; ++dx)
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) {
-                                const float w0 = wr[dx * 8 + c], w1 = wr[dx * 8 + 4 + c];
+                            for (int s = 0; s < CS; ++s)
 #pragma unroll
-                                for (int v = 0; v < 4; ++v) acc[v][c] = fmaf(r[v + dx].y, w1, fmaf(r[v + dx].x, w0, acc[v][c]));
-                            }
+                                for (int c = 0; c < 4; ++c) {
+                                    const float wv = wr[(dx * CS + s) * 4 + c];
+#pragma unroll
+                                    for (int v = 0; v < 4; ++v) acc[v][c] = fmaf(r[(v + dx) * CS + s], wv, acc[v][c]);
+                                }
                     }
                 }
                 const int gy = y0 + yl;
+                f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+                if (bias) bq = *reinterpret_cast<const f32x4*>(bias + quad * 4);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int gx = x0 + 4 * xq + v;
                     if (gy < a.H && gx < a.W)
-                        *reinterpret_cast<f32x4*>(yout + ((((long long)n * a.D + zo) * a.H + gy) * a.W + gx) * a.ldy + quad * 4) = acc[v];
+                        *reinterpret_cast<f32x4*>(yout + ((((long long)n * a.D + zo) * a.H + gy) * a.W + gx) * a.ldy + quad * 4) = acc[v] + bq;
                 }
             }
             __syncthreads();
@@ -341,12 +358,20 @@ __global__ void headk_pack_kernel(const float* __restrict__ w, float* __restrict
             const int tap = (int)(r % NT); r /= NT;
             const int ci = (int)r * 4 + c;                         // r = pass * 4 + quad
             wp[idx] = w[((long long)co * Cin + ci) * NT + tap];
-        } else {                         // [quad][tap'][co][c], taps flipped
+        } else if (dgrad == 1) {         // [quad][tap'][co][c], taps flipped
             const int c = (int)(r % 4); r /= 4;
             const int co = (int)(r % 2); r /= 2;
             const int tap = (int)(r % NT); r /= NT;
             const int ci = (int)r * 4 + c;
             wp[idx] = w[((long long)co * Cin + ci) * NT + (NT - 1 - tap)];
+        } else {                         // stem forward, CS = dgrad - 1 narrow input channels: [quad][tap][s][c] = W[quad*4+c][s][tap]; Cin = Cout here
+            const int CS = dgrad - 1;
+            if (idx >= (long long)Cin * NT * CS) return;
+            const int c = (int)(r % 4); r /= 4;
+            const int sidx = (int)(r % CS); r /= CS;
+            const int tap = (int)(r % NT); r /= NT;
+            const int co = (int)r * 4 + c;
+            wp[idx] = w[((long long)co * CS + sidx) * NT + tap];
         }
     }
 }
@@ -372,7 +397,7 @@ static void headk_launch(bool dgrad, const float* in, const float* wp, const flo
         hipLaunchKernelGGL(headk_fwd_kernel<KS>, dim3(nwg), dim3(256), ldsb, st, in, wp, bias, out, a);
     } else {
         const size_t ldsb = (size_t)KS * HY * 40 * 8;
-        hipLaunchKernelGGL(headk_dgrad_kernel<KS>, dim3(nwg), dim3(512), ldsb, st, in, wp, out, a);
+        hipLaunchKernelGGL((headk_expand_kernel<KS, 2>), dim3(nwg), dim3(512), ldsb, st, in, wp, (const float*)nullptr, out, a);
     }
 }
 
@@ -393,6 +418,32 @@ int headk_conv(bool dgrad, const float* in, int ld_in, const float* w, const flo
     ProfScope ps(PF_DIRECT, 2.0 * vox * NT * Cin * 2, 4.0 * vox * (Cin + 2), st);
     if (k == 5) headk_launch<5>(dgrad, in, wp, bias, out, a, nwg, st);
     else headk_launch<3>(dgrad, in, wp, bias, out, a, nwg, st);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+// forward of a stem with Cin = 1 or 2 input channels (k5 "same"): the narrow -> wide kernel with unflipped weights
+bool stemk_supported(int Cin, int Cout, int k, int stride, int pad, int ldx, int ldy) {
+    return (Cin == 1 || Cin == 2) && k == 5 && stride == 1 && pad == 2 && Cout % 4 == 0 && Cout >= 4 && ldy % 4 == 0 && (Cin == 1 || ldx % 2 == 0);
+}
+
+int stemk_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W, int Cin, int Cout,
+              void* ws, size_t ws_bytes, hipStream_t st) {
+    SEG_CHECK_ARG(((uintptr_t)x % 8) == 0 && ((uintptr_t)y % 16) == 0, "stemk_fwd: x must be 8-byte and y 16-byte aligned");
+    const int NT = 125;
+    Carver cv(ws);
+    float* wp = cv.take<float>((size_t)Cout * Cin * NT);
+    SEG_CHECK_WS(cv.used(), ws_bytes);
+    const long long total = (long long)Cout * NT * 2;              // grid of the shared pack kernel; mode 2/3 trims to Cout*NT*CS
+    hipLaunchKernelGGL(headk_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, wp, Cout, NT, 1 + Cin);
+    SEG_CHECK_LAUNCH();
+    HeadKArgs a{ldx, ldy, N, D, H, W, Cout, (W + HK_TX - 1) / HK_TX, (H + HK_TY - 1) / HK_TY, (D + HK_SEG - 1) / HK_SEG};
+    const int nwg = a.ntx * a.nty * a.nseg * N;
+    const double vox = (double)N * D * H * W;
+    ProfScope ps(PF_DIRECT, 2.0 * vox * NT * Cin * Cout, 4.0 * vox * (Cin + Cout), st);
+    const size_t ldsb = (size_t)5 * (HK_TY + 4) * 40 * 4 * Cin;
+    if (Cin == 1) hipLaunchKernelGGL((headk_expand_kernel<5, 1>), dim3(nwg), dim3(512), ldsb, st, x, wp, bias, y, a);
+    else hipLaunchKernelGGL((headk_expand_kernel<5, 2>), dim3(nwg), dim3(512), ldsb, st, x, wp, bias, y, a);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }

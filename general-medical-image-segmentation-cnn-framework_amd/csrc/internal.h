@@ -35,6 +35,9 @@ bool headk_supported(int Cin, int Cout, int k, int stride, int pad, int ldx_in, 
 size_t headk_ws_bytes(int Cin, int Cout, int k);
 int headk_conv(bool dgrad, const float* in, int ld_in, const float* w, const float* bias, float* out, int ld_out,
                int N, int D, int H, int W, int Cin, int k, void* ws, size_t ws_bytes, hipStream_t st);
+bool stemk_supported(int Cin, int Cout, int k, int stride, int pad, int ldx, int ldy);
+int stemk_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W, int Cin, int Cout,
+              void* ws, size_t ws_bytes, hipStream_t st);
 bool headk_wgrad_supported(int Cin, int Cout, int k, int stride, int pad, int ldx, int lddy);
 size_t headk_wgrad_ws_bytes(int N, int D, int H, int W, int Cin, int k);
 int headk_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int k,

@@ -71,6 +71,8 @@ CONV_CASES = [
     (1, 37, 11, 45, 32, 2, 5, 1, 2),       # z-marching head kernels: two z segments, ragged x / y tiles, 2 channel passes
     (2, 9, 10, 33, 16, 2, 3, 1, 1),        # z-marching head kernels, k3, one pass
     (1, 6, 9, 7, 48, 2, 5, 1, 2),          # three channel passes (12 input quads -> two dgrad wave groups)
+    (1, 35, 9, 37, 2, 8, 5, 1, 2),         # k5 stem with two input channels on the narrow -> wide z-march kernel
+    (1, 34, 8, 32, 1, 48, 5, 1, 2),        # k5 stem, 12 output quads (two wave groups), two z segments
     (1, 8, 8, 8, 4, 8, 2, 2, 0),           # small-Cin strided
     (1, 8, 12, 32, 32, 64, 5, 1, 2),       # k5 on the MFMA igemm (V-Net LUConv), CK = 8
     (2, 6, 6, 6, 8, 32, 5, 1, 2),          # k5, partial tiles, single chunk
