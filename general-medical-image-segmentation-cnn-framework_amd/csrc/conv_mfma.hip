@@ -68,6 +68,7 @@ struct IgemmArgs {
     int Do, Ho, Wo;     // extents of the volume y points at   (output voxel = base * out_mul + child + c{z,y,x})
     int cz, cy, cx;     // fixed child offset of a strided-dgrad phase launch
     int flatn;          // != 0: N-tiles cut the flat (child tap, cout) axis, so one 32-column block may span two children
+    int by, bz;         // (y, z) tile-block shape of the M-tile walk (divisors of nty, ntz)
     signed char toff[64][4];   // per K-tap input offset (z, y, x); all zero for the stride-1 halo modes
 };
 
@@ -131,11 +132,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
     const int ks = t % a.ksplit; t /= a.ksplit;
     const int ntile = t % a.nN;
     const int mtile = t / a.nN;
+    // M-tiles are walked in (y, z) blocks of by x bz tiles (x fastest inside a block) so that the ~64 tiles an XCD works
+    // on at any moment form a compact brick whose shared halo planes stay in that XCD's L2 (by, bz divide nty, ntz)
     int mt = mtile;
+    const int per_n = a.ntx * a.nty * a.ntz;
+    const int n = mt / per_n; mt -= n * per_n;
+    const int blk = a.ntx * a.by * a.bz;
+    const int b = mt / blk; mt -= b * blk;
     const int txi = mt % a.ntx; mt /= a.ntx;
-    const int tyi = mt % a.nty; mt /= a.nty;
-    const int tzi = mt % a.ntz;
-    const int n = mt / a.ntz;
+    const int nby = a.nty / a.by;
+    const int tyi = (b % nby) * a.by + mt % a.by;
+    const int tzi = (b / nby) * a.bz + mt / a.by;
     const int x0 = txi * BX, y0 = tyi * T::TY, z0 = tzi * T::TZ;
     const int tapn = ntile / a.nNpt;                          // output child (ConvT fwd), else 0
     const int n0 = (ntile % a.nNpt) * NT;
@@ -474,7 +481,13 @@ static void dispatch_igemm_ck(const IgemmPlan& p, const IgemmArgs& a, int nwg, h
 #undef IGEMM_CASE
 }
 
-static void dispatch_igemm(const IgemmPlan& p, const IgemmArgs& a, int nwg, hipStream_t st) {
+static int tile_block(int nt) { return nt % 4 == 0 ? 4 : (nt % 2 == 0 ? 2 : 1); }
+
+static void dispatch_igemm(const IgemmPlan& p, const IgemmArgs& a_in, int nwg, hipStream_t st) {
+    IgemmArgs a = a_in;
+    static const char* flat_walk = getenv("MI355SEG_IGEMM_LINEAR_WALK");      // A/B knob: 1 = plain x, y, z tile order
+    a.by = flat_walk ? 1 : tile_block(a.nty);
+    a.bz = flat_walk ? 1 : tile_block(a.ntz);
     if (p.KS == 3) dispatch_igemm_ck<3, 16, true>(p, a, nwg, st);
     else if (p.KS == 5) dispatch_igemm_ck<5, 8, false>(p, a, nwg, st);
     else if (p.CK == 64) dispatch_igemm_ck<1, 64, true>(p, a, nwg, st);

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Reduce two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; they do not fit one pass on gfx950) of
+`bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof` into profiles/pmc_traffic.json: L2-to-fabric bytes per
+launch of the dominant kernel (conv_igemm_kernel<3,...>), FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes.
+
+Collect on the GPU box (program directly after `--`, counters in their own runs):
+  cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_f -o f -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_w -o w -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof
+then:  python tools/pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w profiles/pmc_traffic.json
+"""
+import csv
+import glob
+import json
+import sys
+
+
+def per_launch(directory, counter, match):
+    files = glob.glob(f"{directory}/**/*counter_collection.csv", recursive=True)
+    assert files, f"no counter_collection.csv under {directory}"
+    tot, n = 0.0, 0
+    for row in csv.DictReader(open(files[0])):
+        if row["Counter_Name"] == counter and match in row["Kernel_Name"]:
+            tot += float(row["Counter_Value"])
+            n += 1
+    return tot, n
+
+
+def main():
+    fdir, wdir, out = sys.argv[1:4]
+    match = "conv_igemm_kernel<3"
+    f, nf = per_launch(fdir, "FETCH_SIZE", match)
+    w, nw = per_launch(wdir, "WRITE_SIZE", match)
+    assert nf and nf == nw, (nf, nw)
+    fetch = 2.0 * f * 1024.0 / nf          # KB -> bytes, doubled (gfx950 tallies 128-byte requests at 64 bytes)
+    write = w * 1024.0 / nw
+    res = {
+        "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof",
+        "correction": "FETCH_SIZE doubled (gfx950 reports 1/2 of a wide coalesced read stream, MI355X_MICROARCH.md HBM section); WRITE_SIZE as read; unit KB*1024; "
+                      "L2-to-fabric requests: Infinity-Cache hits are included, so this is an upper bound on HBM bytes",
+        "kernel": match + ", ...> (all k3 fwd + dgrad launches)",
+        "launches_counted": nf,
+        "conv_igemm_bytes_per_launch": fetch + write,
+        "conv_igemm_fetch_bytes_per_launch_corrected": fetch,
+        "conv_igemm_write_bytes_per_launch": write,
+    }
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
