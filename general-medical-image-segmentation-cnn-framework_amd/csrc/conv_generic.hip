@@ -339,6 +339,49 @@ static int check_geom(ConvGeom* g, const char* who) {
 
 using namespace seg;
 
+// ---- patch embedding (kernel = stride, no padding; UNETR's k16 s16 conv, unetr.py:141-156) as a plain GEMM:
+// tokens x (Cin k^3) patch matrix (one strided copy) times the weight matrix in its own (Cout, Cin k^3) layout.
+namespace seg {
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, int ldx, float* __restrict__ A, int N, int D, int H, int W,
+                                                       int C, int k) {
+    const int pd = D / k, ph = H / k, pw = W / k;
+    const long long K = (long long)C * k * k * k, total = (long long)N * pd * ph * pw * K;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        long long r = idx;
+        const int dx = (int)(r % k); r /= k;
+        const int dy = (int)(r % k); r /= k;
+        const int dz = (int)(r % k); r /= k;
+        const int c = (int)(r % C); r /= C;
+        const int px = (int)(r % pw); r /= pw;
+        const int py = (int)(r % ph); r /= ph;
+        const int pz = (int)(r % pd); const int n = (int)(r / pd);
+        A[idx] = x[((((long long)n * D + pz * k + dz) * H + py * k + dy) * W + px * k + dx) * ldx + c];
+    }
+}
+static bool patch_embed_supported(int D, int H, int W, int Cin, int k, int stride, int pad) {
+    return k == stride && pad == 0 && k >= 4 && D % k == 0 && H % k == 0 && W % k == 0 && (long long)Cin * k * k * k >= 256;
+}
+static size_t patch_embed_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k) {
+    const long long M = (long long)N * (D / k) * (H / k) * (W / k), K = (long long)Cin * k * k * k;
+    size_t g1 = mi355seg_gemm_ws_bytes((int)M, Cout, (int)K, 1, 1), g2 = mi355seg_gemm_ws_bytes(Cout, (int)K, (int)M, 1, 1);
+    return align_up((size_t)M * K * sizeof(float), 256) + (g1 > g2 ? g1 : g2) + 512;
+}
+static int patch_embed_matrix(const float* x, int ldx, int N, int D, int H, int W, int Cin, int k, void* ws, size_t ws_bytes,
+                              float** A, void** rest, size_t* rest_bytes, hipStream_t st) {
+    const long long M = (long long)N * (D / k) * (H / k) * (W / k), K = (long long)Cin * k * k * k;
+    Carver cv(ws);
+    *A = cv.take<float>((size_t)M * K);
+    SEG_CHECK_WS(cv.used(), ws_bytes);
+    *rest = (char*)ws + cv.used();
+    *rest_bytes = ws_bytes - cv.used();
+    const long long blocks = (M * K + 255) / 256;
+    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, st, x, ldx, *A, N, D, H, W, Cin, k);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+}  // namespace seg
+using namespace seg;
+
 extern "C" {
 
 size_t mi355seg_conv3d_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
@@ -353,6 +396,7 @@ size_t mi355seg_conv3d_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, i
     if (d > a) a = d;
     if (e > a) a = e;
     if (headk_supported(Cin, Cout, k, stride, pad, 4, 4, true) && headk_ws_bytes(Cin, Cout, k) > a) a = headk_ws_bytes(Cin, Cout, k);
+    if (patch_embed_supported(D, H, W, Cin, k, stride, pad) && patch_embed_ws_bytes(N, D, H, W, Cin, Cout, k) > a) a = patch_embed_ws_bytes(N, D, H, W, Cin, Cout, k);
     if (stemk_supported(Cin, Cout, k, stride, pad, 2, 4) && headk_ws_bytes(Cout, Cin, k) > a) a = headk_ws_bytes(Cout, Cin, k);
     if (headk_wgrad_supported(Cin, Cout, k, stride, pad, 4, 2) && headk_wgrad_ws_bytes(N, D, H, W, Cin, k) > a) a = headk_wgrad_ws_bytes(N, D, H, W, Cin, k);
     return a > c ? a : c;
@@ -370,6 +414,15 @@ int mi355seg_conv3d_fwd_f32(const float* x, int ldx, const float* w, const float
     hipStream_t st = (hipStream_t)stream;
     if (conv_mfma_supported(N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy))
         return conv_fwd_mfma(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, /*dgrad=*/0, stats_sum, stats_sq, ws, ws_bytes, st);
+    if (patch_embed_supported(D, H, W, Cin, k, stride, pad)) {
+        float* A; void* rest; size_t rest_bytes;
+        rc = patch_embed_matrix(x, ldx, N, D, H, W, Cin, k, ws, ws_bytes, &A, &rest, &rest_bytes, st);
+        if (rc) return rc;
+        const int M = N * (D / k) * (H / k) * (W / k), K = Cin * k * k * k;
+        rc = mi355seg_gemm_f32(A, K, 1, 0, 0, w, 1, K, 0, 0, y, ldy, 0, 0, bias, M, Cout, K, 1, 1, 1.f, 0, 0, rest, rest_bytes, stream);
+        if (rc || !stats_sum) return rc;
+        return channel_sums(y, ldy, M, Cout, stats_sum, stats_sq, nullptr, 0, ws, ws_bytes, st);
+    }
     if (conv_gather_fwd_supported(N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy) && ((uintptr_t)x % 16) == 0)
         return conv_gather_fwd_mfma(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, stride, pad, stats_sum, stats_sq, ws, ws_bytes, st);
     if (headk_supported(Cin, Cout, k, stride, pad, ldx, ldy, false) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 8) == 0) {
@@ -424,6 +477,13 @@ int mi355seg_conv3d_wgrad_f32(const float* dy, int lddy, const float* x, int ldx
     if (db) {
         rc = channel_sums(dy, lddy, (long long)N * g.Do * g.Ho * g.Wo, Cout, nullptr, nullptr, db, accumulate, ws, ws_bytes, st);
         if (rc) return rc;
+    }
+    if (patch_embed_supported(D, H, W, Cin, k, stride, pad)) {          // dW[co][(ci, tap)] = sum_tokens dy[token][co] * patch[token][(ci, tap)]
+        float* A; void* rest; size_t rest_bytes;
+        rc = patch_embed_matrix(x, ldx, N, D, H, W, Cin, k, ws, ws_bytes, &A, &rest, &rest_bytes, st);
+        if (rc) return rc;
+        const int M = N * (D / k) * (H / k) * (W / k), K = Cin * k * k * k;
+        return mi355seg_gemm_f32(dy, 1, lddy, 0, 0, A, K, 1, 0, 0, dw, K, 0, 0, nullptr, Cout, K, M, 1, 1, 1.f, 0, accumulate, rest, rest_bytes, stream);
     }
     if (wgrad_mfma_supported(N, D, H, W, Cin, Cout, k, stride, pad, ldx, lddy) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0)
         return conv_wgrad_mfma(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, accumulate, ws, ws_bytes, st);
