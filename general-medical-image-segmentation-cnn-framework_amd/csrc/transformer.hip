@@ -209,19 +209,30 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __re
     for (int j = 0; j < LN_MAXJ; ++j) { const int c = lane + 64 * j; if (c < E) dx[row * E + c] = rs * (g[j] - s1 - xh[j] * s2); }
 }
 
-// dgamma[c] = sum_rows dy * xhat, dbeta[c] = sum_rows dy   (thread per column; rows is a few hundred)
+// dgamma[c] = sum_rows dy * xhat, dbeta[c] = sum_rows dy.  Block = 32 columns x 8 row groups (rows r = g, g+8, ...);
+// the eight partial sums of a column are added in group order through LDS (fixed order -> reproducible).
 __global__ __launch_bounds__(256) void layernorm_bwd_affine_kernel(const float* __restrict__ dy, const float* __restrict__ x,
         const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
         long long rows, int E) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= E) return;
+    __shared__ double sa[8][32], sb[8][32];
+    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     double a = 0.0, b = 0.0;
-    for (long long r = 0; r < rows; ++r) {
-        const float d = dy[r * E + c];
-        a += (double)(d * (x[r * E + c] - mean[r]) * rstd[r]);
-        b += (double)d;
+    if (c < E) {
+        for (long long r = g; r < rows; r += 8) {
+            const float d = dy[r * E + c];
+            a += (double)(d * (x[r * E + c] - mean[r]) * rstd[r]);
+            b += (double)d;
+        }
     }
-    dgamma[c] = (float)a; dbeta[c] = (float)b;
+    sa[g][cl] = a; sb[g][cl] = b;
+    __syncthreads();
+    if (g == 0 && c < E) {
+        double ta = 0.0, tb = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ta += sa[k][cl]; tb += sb[k][cl]; }
+        dgamma[c] = (float)ta; dbeta[c] = (float)tb;
+    }
 }
 
 // ---------------------------------------------------------------- row softmax (one wavefront per row)
@@ -306,7 +317,7 @@ int mi355seg_layernorm_bwd_f32(const float* dy, const float* x, const float* gam
     SEG_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0 && E > 0 && E <= 64 * LN_MAXJ, "layernorm_bwd: bad arguments");
     hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd, dx, rows, E);
     SEG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(layernorm_bwd_affine_kernel, dim3(cdiv(E, 256)), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, dgamma, dbeta, rows, E);
+    hipLaunchKernelGGL(layernorm_bwd_affine_kernel, dim3(cdiv(E, 32)), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, dgamma, dbeta, rows, E);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
