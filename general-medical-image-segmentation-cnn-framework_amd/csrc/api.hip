@@ -130,6 +130,15 @@ __global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, c
     for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) o[i] = a[i] * b[i];
 }
 
+__global__ __launch_bounds__(256) void add_bias_kernel(float* __restrict__ y, int ldy, const float* __restrict__ bias, long long rows, int C) {
+    const long long total = rows * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / C;
+        const int c = (int)(i - r * C);
+        y[r * ldy + c] += bias[c];
+    }
+}
+
 extern "C" {
 
 const char* mi355seg_last_error(void) { return g_err; }
@@ -205,6 +214,12 @@ int mi355seg_repeat_channels_f32(const float* x, int ldx, float* y, int ldy, lon
 int mi355seg_repeat_channels_bwd_f32(const float* dy, int lddy, float* dx, int lddx, long long rows, int C, int rep, void* stream) {
     SEG_CHECK_ARG(dy && dx && rows > 0 && C > 0 && rep > 0 && lddx >= C && lddy >= C * rep, "repeat_channels_bwd: bad arguments");
     hipLaunchKernelGGL(repeat_ch_bwd_kernel, dim3(rows_grid(rows * C)), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx, lddx, rows, C, rep);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_add_bias_f32(float* y, int ldy, const float* bias, long long rows, int C, void* stream) {
+    SEG_CHECK_ARG(y && bias && rows > 0 && C > 0 && ldy >= C, "add_bias: bad arguments");
+    hipLaunchKernelGGL(add_bias_kernel, dim3(rows_grid(rows * C)), dim3(256), 0, (hipStream_t)stream, y, ldy, bias, rows, C);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }

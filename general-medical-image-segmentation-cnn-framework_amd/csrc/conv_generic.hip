@@ -175,12 +175,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         const int col = e & 31, r = e >> 5;
         const int cil = r % CIT, tl = r / CIT;
         const int co = co0 + col, ci = ci0 + cil;
-        float s = 0.f;
+        double s = 0.0;
         if (co < Cout && ci < Cin && tl < tn) {
             const long long i = ((long long)(t0 + tl) * Cin + ci) * Cout + co;
-            for (int k = 0; k < splits; ++k) s += part[(long long)k * total + i];
+            for (int k = 0; k < splits; ++k) s += (double)part[(long long)k * total + i];
         }
-        tr[col * pitch + cil * TT + tl] = s;
+        tr[col * pitch + cil * TT + tl] = (float)s;
     }
     __syncthreads();
     const int cin_here = min(CIT, Cin - ci0);
@@ -205,18 +205,18 @@ __global__ void wgrad_reduce_flat_kernel(const float* __restrict__ part, float* 
         long long r = i / Cout;
         int ci = (int)(r % Cin);
         int t = (int)(r / Cin);
-        float s = 0.f;
+        double s = 0.0;                                    // fp64: hundreds of strips, partial sums that largely cancel
         int k = 0;
         for (; k + 8 <= splits; k += 8) {                  // 8 loads in flight, added in strip order
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = part[(long long)(k + u) * total + i];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
+            for (int u = 0; u < 8; ++u) s += (double)v[u];
         }
-        for (; k < splits; ++k) s += part[(long long)k * total + i];
+        for (; k < splits; ++k) s += (double)part[(long long)k * total + i];
         long long o = ((long long)co * Cin + ci) * T + t;
-        dw[o] = accumulate ? dw[o] + s : s;
+        dw[o] = accumulate ? dw[o] + (float)s : (float)s;
     }
 }
 

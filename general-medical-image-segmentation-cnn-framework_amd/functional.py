@@ -239,6 +239,58 @@ def conv_transpose3d_k2s2_cat(x, weight, bias, skip):
     return _ConvT3dK2S2Cat.apply(x, weight, bias, skip)
 
 
+class _ConvT3dAdjoint(Function):
+    """nn.ConvTranspose3d with kernel_size = stride = k, no padding (csrnet.py:121-137 uses k = 4), computed as the
+    adjoint of the Conv3d with the same weight tensor: forward = that conv's dgrad, input gradient = its forward,
+    weight gradient = its wgrad with the operands swapped.  (Cin, Cout, k, k, k) of the transposed conv IS the
+    (Cout_c, Cin_c, k, k, k) layout of the conv, so no repacking is involved."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, k):
+        x, ldx = cl_view(x, "conv_transpose3d input")
+        N, D, H, W, Cin = x.shape
+        if w.shape[0] != Cin or tuple(w.shape[2:]) != (k, k, k):
+            raise Mi355SegError(f"conv_transpose3d: weight {tuple(w.shape)} does not match input channels {Cin} / kernel {k}")
+        w = w.contiguous()
+        Cout = w.shape[1]
+        geom = (N, k * D, k * H, k * W, Cout, Cin, k, k, 0)             # the adjoint conv: Cout -> Cin channels, stride k
+        y = torch.empty((N, k * D, k * H, k * W, Cout), dtype=x.dtype, device=x.device)
+        L = lib()
+        ws = workspace(L.query("mi355seg_conv3d_ws_bytes", *geom), x.device)
+        L.call("mi355seg_conv3d_dgrad_f32", _p(x), ldx, _p(w), _p(y), Cout, *geom, _p(ws), ws.numel(), _stream())
+        if b is not None:
+            L.call("mi355seg_add_bias_f32", _p(y), Cout, _p(b), y.numel() // Cout, Cout, _stream())
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (geom, ldx, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        geom, ldx, has_b = ctx.cfg
+        N, D2, H2, W2, Cout, Cin, k = geom[:7]
+        dy, lddy = cl_view(dy, "conv_transpose3d grad")
+        L = lib()
+        ws = workspace(L.query("mi355seg_conv3d_ws_bytes", *geom), x.device)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+            L.call("mi355seg_conv3d_fwd_f32", _p(dy), lddy, _p(w), None, _p(dx), Cin, *geom, None, None, _p(ws), ws.numel(), _stream())
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            L.call("mi355seg_conv3d_wgrad_f32", _p(x), ldx, _p(dy), lddy, _p(dw), None, *geom, 0, _p(ws), ws.numel(), _stream())
+        if has_b and ctx.needs_input_grad[2]:
+            rows = N * D2 * H2 * W2
+            cws = workspace(L.query("mi355seg_norm_ws_bytes", rows, 1, Cout), x.device)
+            db = torch.empty(Cout, dtype=x.dtype, device=x.device)
+            L.call("mi355seg_colsum_f32", _p(dy), lddy, rows, Cout, _p(db), _p(cws), cws.numel(), _stream())
+        return dx, dw, db, None
+
+
+def conv_transpose3d_adjoint(x, weight, bias, k):
+    return _ConvT3dAdjoint.apply(x, weight, bias, int(k))
+
+
 def conv_transpose3d_k2s2(x, weight, bias=None):
     """nn.ConvTranspose3d(kernel_size=2, stride=2) on a channel-last tensor."""
     return _ConvT3dK2S2.apply(x, weight, bias)

@@ -28,13 +28,17 @@ class Conv3d(nn.Conv3d):
 
 
 class ConvTranspose3d(nn.ConvTranspose3d):
-    """nn.ConvTranspose3d(kernel_size=2, stride=2) -- the only form the U-Net family uses."""
+    """nn.ConvTranspose3d with kernel_size = stride (non-overlapping up-sampling) and no padding: k = 2 is the U-Net
+    family's form (dedicated kernels), any other k (CSRNet's 4) runs as the adjoint of the matching Conv3d."""
 
     def forward(self, x):
-        if _iso(self.kernel_size, "kernel_size") != 2 or _iso(self.stride, "stride") != 2 or \
-                _iso(self.padding, "padding") != 0 or _iso(self.output_padding, "output_padding") != 0:
-            raise NotImplementedError("ConvTranspose3d: only kernel_size=2, stride=2, padding=0 is implemented")
-        return F.conv_transpose3d_k2s2(x, self.weight, self.bias)
+        k, s = _iso(self.kernel_size, "kernel_size"), _iso(self.stride, "stride")
+        if k != s or _iso(self.padding, "padding") != 0 or _iso(self.output_padding, "output_padding") != 0 or \
+                _iso(self.dilation, "dilation") != 1 or self.groups != 1:
+            raise NotImplementedError("ConvTranspose3d: only kernel_size == stride, padding=0, output_padding=0 is implemented")
+        if k == 2:
+            return F.conv_transpose3d_k2s2(x, self.weight, self.bias)
+        return F.conv_transpose3d_adjoint(x, self.weight, self.bias, k)
 
 
 class BatchNorm3d(nn.BatchNorm3d):

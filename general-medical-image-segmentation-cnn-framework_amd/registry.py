@@ -2,8 +2,8 @@
 (train.py:324-373, predict.py:233-276).  Networks on the hot path are built from the
 MI355X drop-ins; the reference's other networks are out of scope and named as such."""
 
-IN_SCOPE = ("unet", "vnet", "res_unet", "unetr", "IS")
-OUT_OF_SCOPE = ("er_net", "re_net", "densenet", "vtnet", "densevoxelnet", "csrnet", "dunet")
+IN_SCOPE = ("unet", "vnet", "res_unet", "unetr", "IS", "csrnet")
+OUT_OF_SCOPE = ("er_net", "re_net", "densenet", "vtnet", "densevoxelnet", "dunet")
 
 
 def build_model(config):
@@ -25,6 +25,9 @@ def build_model(config):
     if network == "IS":                                     # train.py:340-343
         from .models.three_d.IS import UNet3D as ISNet
         return ISNet(in_channels=get("in_classes"), out_channels=get("out_classes"), init_features=32)
+    if network == "csrnet":                                 # train.py:362-365
+        from .models.three_d.csrnet import CSRNet
+        return CSRNet(in_channels=get("in_classes"), out_channels=get("out_classes"))
     if network in OUT_OF_SCOPE:
         raise NotImplementedError(f"network '{network}' is outside the MI355X hot-path scope (SURVEY.md section 2)")
     raise ValueError(f"unknown network '{network}'")

@@ -271,6 +271,8 @@ int mi355seg_add_rows_f32(const float* src, int ldsrc, float* dst, int lddst, lo
  * dx[r, c] = sum_j dy[r, j*C + c]. */
 int mi355seg_repeat_channels_f32(const float* x, int ldx, float* y, int ldy, long long rows, int C, int rep, void* stream);
 int mi355seg_repeat_channels_bwd_f32(const float* dy, int lddy, float* dx, int lddx, long long rows, int C, int rep, void* stream);
+/* y[r, c] += bias[c] in place (bias of a ConvTranspose3d computed as the adjoint of a bias-free convolution). */
+int mi355seg_add_bias_f32(float* y, int ldy, const float* bias, long long rows, int C, void* stream);
 /* out[i] = a[i] * b[i] (attention-probability dropout mask, unetr.py:112; out may alias a). */
 int mi355seg_mul_f32(const float* a, const float* b, float* out, long long n, void* stream);
 

@@ -8,6 +8,7 @@ Follows (reference file:line):
   * UNet3D      -- models/three_d/unet3d.py:10-48 (ctor), :50-71 (forward), :73-104 (block)
   * VNet        -- models/three_d/vnet3d.py:21-31, :41-58, :61-80, :83-104, :107-121, :124-157
   * ResUNet     -- models/three_d/residual_unet3d.py:11-80 (ctor), :82-107 (factories), :109-204 (forward)
+  * CSRNet      -- models/three_d/csrnet.py:5-45 (ctor), :46-69 (forward), :101-137 (cross-scale link blocks)
   * ISUNet3D    -- models/three_d/IS.py:10-130 (ctor: three parameter sets), :132-190 (forward: shared encoder, three decoders)
 """
 from collections import OrderedDict
@@ -64,6 +65,51 @@ class UNet3D(nn.Module):
             h = torch.cat((h, skips[lvl - 1]), dim=1)
             h = getattr(self, f"decoder{lvl}")(h)
         return self.conv(h)
+
+
+# --------------------------------------------------------------------------- CSRNet (U-Net + cross-scale residual links)
+def _link(tag, op):
+    return nn.Sequential(OrderedDict([(f"{tag}conv1", op), (f"{tag}norm1", nn.BatchNorm3d(op.out_channels)),
+                                      (f"{tag}relu1", nn.ReLU(inplace=True))]))
+
+
+class CSRNet(nn.Module):
+    """csrnet.py:5-69.  Encoder links: Conv3d k3 stride 4 (no padding) from level j to level j+2; decoder links:
+    ConvTranspose3d k4 stride 4 from the bottleneck / dec4 / dec3 to dec3 / dec2 / dec1's up-convolved input."""
+
+    def __init__(self, in_channels=1, out_channels=3, init_features=64):
+        super().__init__()
+        f = init_features
+        widths = [f, 2 * f, 4 * f, 8 * f]
+        prev = in_channels
+        for lvl, w in enumerate(widths, start=1):
+            setattr(self, f"encoder{lvl}", _double_conv(f"enc{lvl}", prev, w))
+            setattr(self, f"pool{lvl}", nn.MaxPool3d(kernel_size=2, stride=2))
+            prev = w
+        for j in (1, 2, 3):
+            setattr(self, f"encoder_r_{j}", _link(f"enc{j}_r", nn.Conv3d(widths[j - 1], 4 * widths[j - 1], kernel_size=3, stride=4)))
+        self.bottleneck = _double_conv("bottleneck", prev, 16 * f)
+        prev = 16 * f
+        for lvl in (4, 3, 2, 1):
+            w = widths[lvl - 1]
+            setattr(self, f"upconv{lvl}", nn.ConvTranspose3d(prev, w, kernel_size=2, stride=2))
+            setattr(self, f"decoder{lvl}", _double_conv(f"dec{lvl}", 2 * w, w))
+            prev = w
+        self.conv = nn.Conv3d(f, out_channels, kernel_size=1)
+        for j, cin in ((1, 16 * f), (2, 8 * f), (3, 4 * f)):
+            setattr(self, f"dncoder_r_{j}", _link(f"dnc{j}_r", nn.ConvTranspose3d(cin, cin // 4, kernel_size=4, stride=4)))
+
+    def forward(self, x):
+        e1 = self.encoder1(x)
+        e2 = self.encoder2(self.pool1(e1))
+        e3 = self.encoder3(self.pool2(e2)) + self.encoder_r_1(e1)
+        e4 = self.encoder4(self.pool3(e3)) + self.encoder_r_2(e2)
+        bn = self.bottleneck(self.pool4(e4)) + self.encoder_r_3(e3)
+        d4 = self.decoder4(torch.cat((self.upconv4(bn), e4), dim=1))
+        d3 = self.decoder3(torch.cat((self.upconv3(d4) + self.dncoder_r_1(bn), e3), dim=1))
+        d2 = self.decoder2(torch.cat((self.upconv2(d3) + self.dncoder_r_2(d4), e2), dim=1))
+        d1 = self.decoder1(torch.cat((self.upconv1(d2) + self.dncoder_r_3(d3), e1), dim=1))
+        return self.conv(d1)
 
 
 # --------------------------------------------------------------------------- IS (three-band U-Net)

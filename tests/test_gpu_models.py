@@ -294,3 +294,49 @@ def test_isnet_vs_reference_fixture(seg, golden_dir):
             assert (np.abs(bufs[k[4:]].cpu().numpy() - g[k]) / np.maximum(1.0, np.abs(g[k]))).max() < 1e-5, k
     assert n_grad == 82
     assert int(bufs["encoder1.enc1norm1.num_batches_tracked"]) == 3       # one forward = three passes of the shared encoder
+
+
+def test_csrnet_train_step_vs_reference_fixture(seg, golden_dir):
+    """CSRNet (csrnet.py): U-Net + stride-4 conv links down + k4 s4 transposed-conv links up, one train.py step.
+    Forward quantities are held to the plain 1e-4 bar against the reference fixture.  The backward of this network is
+    ill-conditioned (BatchNorm over the 16 values of the 2^3 bottleneck): the reference's OWN fp32 gradients sit
+    1e-3..3.5e-3 (relative) from an fp64 run of the same arithmetic, so every gradient is graded against that fp64
+    truth and may be no further from it than twice the reference fixture is (plus the usual 3e-4 of the scale)."""
+    from mi355seg.models.three_d.csrnet import CSRNet
+    from oracle.fill import make_input_rough
+    from oracle.nets import CSRNet as OracleCSRNet
+    g = np.load(os.path.join(golden_dir, "csrnet_f4_32.npz"))
+    x = make_input_rough((2, 1, 32, 32, 32), seed=3.0)
+    gt2 = two_channel_gt(make_labels((2, 1, 32, 32, 32)))
+    m = fill_module_(CSRNet(in_channels=1, out_channels=2, init_features=4)).cuda().train()
+    pred = m(x.cuda())
+    loss = seg.functional.bce_with_logits(pred, gt2.cuda())
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    assert np.abs(pred.detach().cpu().numpy() - g["pred"]).max() < TOL
+    mask = seg.functional.argmax_channels(pred).cpu().numpy().astype(np.uint8)
+    margin = np.abs(g["pred"][:, 1] - g["pred"][:, 0])[:, None]
+    assert np.array_equal(mask[margin > 2e-4], g["mask"][margin > 2e-4])
+    for k in g.files:
+        if k.startswith("buf/"):
+            got = dict(m.named_buffers())[k[4:]].cpu().numpy()
+            assert (np.abs(got - g[k]) / np.maximum(1.0, np.abs(g[k]))).max() < 1e-5, k
+
+    o = fill_module_(OracleCSRNet(in_channels=1, out_channels=2, init_features=4)).double().train()
+    torch.nn.functional.binary_cross_entropy_with_logits(o(x.double()), gt2.double()).backward()
+    truth = {k: p.grad for k, p in o.named_parameters()}
+    params = dict(m.named_parameters())
+    checked = 0
+    for k in g.files:
+        if not k.startswith("grad/"):
+            continue
+        t = _sample(truth[k[5:]]).astype(np.float64)
+        ref_err = np.abs(g[k] - t).max()
+        gpu_err = np.abs(_sample(params[k[5:]].grad) - t).max()
+        assert gpu_err <= 2.0 * ref_err + 3e-4 * max(1e-3, np.abs(t).max()), (k, gpu_err, ref_err)
+        checked += 1
+    assert checked == 13
+    gn_truth = np.array([float(p.grad.norm()) for p in o.parameters()])
+    gn = np.array([float(p.grad.double().norm()) for p in m.parameters()])
+    ref_gn_err = np.abs(g["gradnorm"] - gn_truth).max()
+    assert np.abs(gn - gn_truth).max() <= 2.0 * ref_gn_err + 3e-4 * gn_truth.max()

@@ -179,6 +179,28 @@ def test_conv_transpose3d_k2s2(seg, case):
     assert rel_err(bg.grad.cpu(), br.grad) < TOL
 
 
+@pytest.mark.parametrize("case", [(1, 4, 4, 8, 64, 32, 4), (2, 3, 2, 5, 8, 4, 4), (1, 3, 4, 5, 16, 32, 3), (1, 2, 2, 4, 512, 128, 4)])
+def test_conv_transpose3d_kernel_equals_stride(seg, case):
+    """nn.ConvTranspose3d(k, stride=k) (csrnet.py:121-137, k = 4) as the adjoint of the matching Conv3d: MFMA gather
+    paths when the channels allow (64 phase launches for k = 4), generic kernels otherwise."""
+    N, D, H, W, Cin, Cout, k = case
+    F = seg.functional
+    x = rnd(N, Cin, D, H, W, seed=1)
+    w = rnd(Cin, Cout, k, k, k, seed=2, scale=(2.0 / Cin) ** 0.5)
+    b = rnd(Cout, seed=3, scale=0.1)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = TF.conv_transpose3d(xr, wr, br, stride=k)
+    g = rnd(*yr.shape, seed=4)
+    yr.backward(g)
+    xg, wg, bg = cl(x).requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    yg = F.conv_transpose3d_adjoint(xg, wg, bg, k)
+    yg.backward(cl(g))
+    assert (cf(yg) - yr.detach()).abs().max() < TOL
+    assert rel_err(cf(xg.grad), xr.grad) < TOL
+    assert rel_err(wg.grad.cpu(), wr.grad) < TOL
+    assert rel_err(bg.grad.cpu(), br.grad) < TOL
+
+
 @pytest.mark.parametrize("C,act", [(32, "relu"), (16, "elu"), (2, "elu"), (64, "none"), (6, "relu")])
 def test_batchnorm_act_train(seg, C, act):
     F = seg.functional

@@ -134,3 +134,17 @@ def test_isnet_bit_identical_and_frequency_bands():
             assert torch.equal(g, outs[1][2][k]), k
     for k, v in outs[0][3].items():
         assert torch.equal(v, outs[1][3][k]), k                        # shared-encoder BN stats advanced three times
+
+
+def test_csrnet_bit_identical():
+    R = _ref("models.three_d.csrnet", "CSRNet")
+    a = fill_module_(R(1, 2, 4)).train()
+    b = fill_module_(nets.CSRNet(1, 2, 4)).train()
+    _same_keys(a, b)
+    assert list(a.state_dict()) == list(b.state_dict())
+    x = make_input((2, 1, 32, 32, 32), freq=0.23)
+    ya, ga = _fwd_bwd(a, x)
+    yb, gb = _fwd_bwd(b, x)
+    assert torch.equal(ya, yb)
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
