@@ -130,6 +130,42 @@ __global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, c
     for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) o[i] = a[i] * b[i];
 }
 
+// reverse-attention gate: thread = (row, channel quad)
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__ enc, int ldenc, const float* __restrict__ t, int ldt,
+                                                       float* __restrict__ y, int ldy, long long rows, int C) {
+    const int cw = C / 4;
+    const long long total = rows * cw;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / cw;
+        const int c = (int)(i - r * cw) * 4;
+        const float g = 2.f - 1.f / (1.f + expf(-t[r * ldt]));
+        const float4 e = *reinterpret_cast<const float4*>(enc + r * ldenc + c);
+        *reinterpret_cast<float4*>(y + r * ldy + c) = make_float4(e.x * g, e.y * g, e.z * g, e.w * g);
+    }
+}
+// one wavefront per 64 / LPV rows; LPV = lanes per row (power of two, <= 64), each lane walks its quads
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ enc, int ldenc,
+                                                       const float* __restrict__ t, int ldt, float* __restrict__ denc, int lddenc,
+                                                       float* __restrict__ dt, long long rows, int C, int LPV) {
+    const int lane = threadIdx.x & 63, sub = lane % LPV, rpw = 64 / LPV;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long r = wave * rpw + lane / LPV;
+    const bool ok = r < rows;
+    float s = 0.f, dot = 0.f;
+    if (ok) {
+        s = 1.f / (1.f + expf(-t[r * ldt]));
+        const float g = 2.f - s;
+        for (int c = sub * 4; c < C; c += LPV * 4) {
+            const float4 d = *reinterpret_cast<const float4*>(dy + r * lddy + c);
+            const float4 e = *reinterpret_cast<const float4*>(enc + r * ldenc + c);
+            dot += d.x * e.x + d.y * e.y + d.z * e.z + d.w * e.w;
+            *reinterpret_cast<float4*>(denc + r * lddenc + c) = make_float4(d.x * g, d.y * g, d.z * g, d.w * g);
+        }
+    }
+    for (int o = LPV >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    if (ok && sub == 0) dt[r] = -s * (1.f - s) * dot;
+}
+
 __global__ __launch_bounds__(256) void add_bias_kernel(float* __restrict__ y, int ldy, const float* __restrict__ bias, long long rows, int C) {
     const long long total = rows * C;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -214,6 +250,27 @@ int mi355seg_repeat_channels_f32(const float* x, int ldx, float* y, int ldy, lon
 int mi355seg_repeat_channels_bwd_f32(const float* dy, int lddy, float* dx, int lddx, long long rows, int C, int rep, void* stream) {
     SEG_CHECK_ARG(dy && dx && rows > 0 && C > 0 && rep > 0 && lddx >= C && lddy >= C * rep, "repeat_channels_bwd: bad arguments");
     hipLaunchKernelGGL(repeat_ch_bwd_kernel, dim3(rows_grid(rows * C)), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx, lddx, rows, C, rep);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_gate_fwd_f32(const float* enc, int ldenc, const float* t, int ldt, float* y, int ldy, long long rows, int C, void* stream) {
+    SEG_CHECK_ARG(enc && t && y && rows > 0 && C > 0 && C % 4 == 0 && ldenc >= C && ldy >= C && ldt >= 1 && ldenc % 4 == 0 && ldy % 4 == 0,
+                  "gate_fwd: bad arguments (C and the pitches must be multiples of 4)");
+    SEG_CHECK_ARG(((uintptr_t)enc | (uintptr_t)y) % 16 == 0, "gate_fwd: enc / y must be 16-byte aligned");
+    hipLaunchKernelGGL(gate_fwd_kernel, dim3(rows_grid(rows * C / 4)), dim3(256), 0, (hipStream_t)stream, enc, ldenc, t, ldt, y, ldy, rows, C);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_gate_bwd_f32(const float* dy, int lddy, const float* enc, int ldenc, const float* t, int ldt,
+                          float* denc, int lddenc, float* dt, long long rows, int C, void* stream) {
+    SEG_CHECK_ARG(dy && enc && t && denc && dt && rows > 0 && C > 0 && C % 4 == 0 && lddy >= C && ldenc >= C && lddenc >= C && ldt >= 1 &&
+                  lddy % 4 == 0 && ldenc % 4 == 0 && lddenc % 4 == 0, "gate_bwd: bad arguments (C and the pitches must be multiples of 4)");
+    SEG_CHECK_ARG(((uintptr_t)dy | (uintptr_t)enc | (uintptr_t)denc) % 16 == 0, "gate_bwd: dy / enc / denc must be 16-byte aligned");
+    int LPV = 1;
+    while (LPV * 2 <= C / 4 && LPV * 2 <= 64) LPV *= 2;
+    const long long waves = (rows + 64 / LPV - 1) / (64 / LPV);
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dy, lddy, enc, ldenc, t, ldt,
+                       denc, lddenc, dt, rows, C, LPV);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }

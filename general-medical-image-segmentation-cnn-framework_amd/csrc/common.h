@@ -89,6 +89,7 @@ __device__ __forceinline__ float act_apply(float z, int act, float slope) {
         case MI355SEG_ACT_RELU: return z > 0.f ? z : 0.f;
         case MI355SEG_ACT_ELU: return z > 0.f ? z : expm1f(z);
         case MI355SEG_ACT_LRELU: return z > 0.f ? z : z * slope;
+        case MI355SEG_ACT_SIGMOID: return 1.f / (1.f + expf(-z));
         default: return z;
     }
 }
@@ -97,6 +98,7 @@ __device__ __forceinline__ float act_grad(float z, int act, float slope) {
         case MI355SEG_ACT_RELU: return z > 0.f ? 1.f : 0.f;
         case MI355SEG_ACT_ELU: return z > 0.f ? 1.f : expf(z);
         case MI355SEG_ACT_LRELU: return z > 0.f ? 1.f : slope;
+        case MI355SEG_ACT_SIGMOID: { const float s = 1.f / (1.f + expf(-z)); return s * (1.f - s); }
         default: return 1.f;
     }
 }

@@ -594,7 +594,7 @@ int mi355seg_norm_act_fwd_f32(const float* x, int ldx, const float* mean, const 
                               float* y, int ldy, long long rows, int groups, int C,
                               int act, float slope, void* stream) {
     SEG_CHECK_ARG(x && y && mean && rstd && rows > 0 && groups > 0 && C > 0, "norm_act_fwd: bad arguments");
-    SEG_CHECK_ARG(act >= 0 && act <= 3, "norm_act_fwd: bad activation code %d", act);
+    SEG_CHECK_ARG(act >= 0 && act <= 4, "norm_act_fwd: bad activation code %d", act);
     hipStream_t st = (hipStream_t)stream;
     bool v = vec_ok(C, {ldx, ldy, res ? ldres : 4});
     RowMap rm = ew_map(C, v);
@@ -706,7 +706,7 @@ int mi355seg_scale_channels_f32(const float* x, int ldx, const float* scale, flo
 
 int mi355seg_act_fwd_f32(const float* x, int ldx, const float* res, int ldres, float* y, int ldy,
                          long long rows, int C, int act, float slope, void* stream) {
-    SEG_CHECK_ARG(x && y && rows > 0 && C > 0 && act >= 0 && act <= 3, "act_fwd: bad arguments");
+    SEG_CHECK_ARG(x && y && rows > 0 && C > 0 && act >= 0 && act <= 4, "act_fwd: bad arguments");
     bool v = vec_ok(C, {ldx, ldy, res ? ldres : 4});
     RowMap rm = ew_map(C, v);
     dim3 grid(row_grid(rows, rm.rpi));
@@ -722,7 +722,7 @@ int mi355seg_act_fwd_f32(const float* x, int ldx, const float* res, int ldres, f
 
 int mi355seg_act_bwd_f32(const float* dy, int lddy, const float* x, int ldx, const float* res, int ldres,
                          float* dx, int lddx, long long rows, int C, int act, float slope, void* stream) {
-    SEG_CHECK_ARG(dy && x && dx && rows > 0 && C > 0 && act >= 0 && act <= 3, "act_bwd: bad arguments");
+    SEG_CHECK_ARG(dy && x && dx && rows > 0 && C > 0 && act >= 0 && act <= 4, "act_bwd: bad arguments");
     bool v = vec_ok(C, {lddy, ldx, lddx, res ? ldres : 4});
     RowMap rm = ew_map(C, v);
     dim3 grid(row_grid(rows, rm.rpi));

@@ -13,7 +13,7 @@ from torch.autograd import Function
 
 from ._lib import lib, Mi355SegError
 
-ACT_NONE, ACT_RELU, ACT_ELU, ACT_LRELU = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_ELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 
 _WS = {}
 
@@ -756,6 +756,39 @@ class _CE3D(Function):
 
 def cross_entropy_3d(logits, labels, weight=None, size_average=True):
     return _CE3D.apply(logits, labels, weight, size_average)
+
+
+# ----------------------------------------------------------------------------- reverse-attention gate
+class _Gate(Function):
+    """enc * (2 - sigmoid(t)) with a one-channel ``t``: ``(1 - sigmoid(t)).expand(C).mul(enc) + enc`` of
+    RE_net.py:104-107 / ER_net.py in one pass (and one backward pass with the per-voxel channel reduction for dt)."""
+
+    @staticmethod
+    def forward(ctx, enc, t):
+        enc, lde = cl_view(enc, "gate features")
+        t, ldt = cl_view(t, "gate map")
+        N, D, H, W, C = enc.shape
+        if tuple(t.shape) != (N, D, H, W, 1):
+            raise Mi355SegError(f"gate: map {tuple(t.shape)} must be one channel over the voxels of {tuple(enc.shape)}")
+        y = torch.empty((N, D, H, W, C), dtype=enc.dtype, device=enc.device)
+        lib().call("mi355seg_gate_fwd_f32", _p(enc), lde, _p(t), ldt, _p(y), C, N * D * H * W, C, _stream())
+        ctx.save_for_backward(enc, t)
+        ctx.cfg = (lde, ldt, N * D * H * W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        enc, t = ctx.saved_tensors
+        lde, ldt, rows, C = ctx.cfg
+        dy, lddy = cl_view(dy, "gate grad")
+        denc = torch.empty(enc.shape, dtype=enc.dtype, device=enc.device)
+        dt = torch.empty(t.shape, dtype=t.dtype, device=t.device)
+        lib().call("mi355seg_gate_bwd_f32", _p(dy), lddy, _p(enc), lde, _p(t), ldt, _p(denc), C, _p(dt), rows, C, _stream())
+        return denc, dt
+
+
+def reverse_attention_gate(enc, t):
+    return _Gate.apply(enc, t)
 
 
 # ----------------------------------------------------------------------------- channel concat / repeat

@@ -2,8 +2,8 @@
 (train.py:324-373, predict.py:233-276).  Networks on the hot path are built from the
 MI355X drop-ins; the reference's other networks are out of scope and named as such."""
 
-IN_SCOPE = ("unet", "vnet", "res_unet", "unetr", "IS", "csrnet")
-OUT_OF_SCOPE = ("er_net", "re_net", "densenet", "vtnet", "densevoxelnet", "dunet")
+IN_SCOPE = ("unet", "vnet", "res_unet", "unetr", "IS", "csrnet", "re_net")
+OUT_OF_SCOPE = ("er_net", "densenet", "vtnet", "densevoxelnet", "dunet")
 
 
 def build_model(config):
@@ -28,6 +28,9 @@ def build_model(config):
     if network == "csrnet":                                 # train.py:362-365
         from .models.three_d.csrnet import CSRNet
         return CSRNet(in_channels=get("in_classes"), out_channels=get("out_classes"))
+    if network == "re_net":                                 # train.py:336-339
+        from .models.three_d.RE_net import RE_Net
+        return RE_Net()
     if network in OUT_OF_SCOPE:
         raise NotImplementedError(f"network '{network}' is outside the MI355X hot-path scope (SURVEY.md section 2)")
     raise ValueError(f"unknown network '{network}'")

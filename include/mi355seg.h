@@ -39,6 +39,7 @@ extern "C" {
 #define MI355SEG_ACT_RELU 1   /* nn.ReLU            (unet3d.py:89,101)            */
 #define MI355SEG_ACT_ELU 2    /* nn.ELU(alpha=1)    (vnet3d.py:14-18)             */
 #define MI355SEG_ACT_LRELU 3  /* nn.LeakyReLU(slope) (residual_unet3d.py:17)      */
+#define MI355SEG_ACT_SIGMOID 4 /* torch.sigmoid       (RE_net.py:160, ER_net.py)    */
 
 const char* mi355seg_last_error(void);
 int mi355seg_version(void);
@@ -271,6 +272,12 @@ int mi355seg_add_rows_f32(const float* src, int ldsrc, float* dst, int lddst, lo
  * dx[r, c] = sum_j dy[r, j*C + c]. */
 int mi355seg_repeat_channels_f32(const float* x, int ldx, float* y, int ldy, long long rows, int C, int rep, void* stream);
 int mi355seg_repeat_channels_bwd_f32(const float* dy, int lddy, float* dx, int lddx, long long rows, int C, int rep, void* stream);
+/* Reverse-attention gate of RE_Net / ER_Net (RE_net.py:104-107,114-117,123-126):
+ *   y[r, c] = enc[r, c] * (2 - sigmoid(t[r]))        (= (1 - sigmoid(t)).expand(C) * enc + enc; t has one channel)
+ * backward: denc[r, c] = dy[r, c] * (2 - s_r),  dt[r] = -s_r (1 - s_r) * sum_c dy[r, c] enc[r, c].   C % 4 == 0. */
+int mi355seg_gate_fwd_f32(const float* enc, int ldenc, const float* t, int ldt, float* y, int ldy, long long rows, int C, void* stream);
+int mi355seg_gate_bwd_f32(const float* dy, int lddy, const float* enc, int ldenc, const float* t, int ldt,
+                          float* denc, int lddenc, float* dt, long long rows, int C, void* stream);
 /* y[r, c] += bias[c] in place (bias of a ConvTranspose3d computed as the adjoint of a bias-free convolution). */
 int mi355seg_add_bias_f32(float* y, int ldy, const float* bias, long long rows, int C, void* stream);
 /* out[i] = a[i] * b[i] (attention-probability dropout mask, unetr.py:112; out may alias a). */

@@ -9,6 +9,7 @@ Follows (reference file:line):
   * VNet        -- models/three_d/vnet3d.py:21-31, :41-58, :61-80, :83-104, :107-121, :124-157
   * ResUNet     -- models/three_d/residual_unet3d.py:11-80 (ctor), :82-107 (factories), :109-204 (forward)
   * CSRNet      -- models/three_d/csrnet.py:5-45 (ctor), :46-69 (forward), :101-137 (cross-scale link blocks)
+  * RE_Net      -- models/three_d/RE_net.py:20-35 (ResEncoder), :36-50 (Decoder), :51-100 (ctor), :101-161 (forward)
   * ISUNet3D    -- models/three_d/IS.py:10-130 (ctor: three parameter sets), :132-190 (forward: shared encoder, three decoders)
 """
 from collections import OrderedDict
@@ -110,6 +111,72 @@ class CSRNet(nn.Module):
         d2 = self.decoder2(torch.cat((self.upconv2(d3) + self.dncoder_r_2(d4), e2), dim=1))
         d1 = self.decoder1(torch.cat((self.upconv1(d2) + self.dncoder_r_3(d3), e1), dim=1))
         return self.conv(d1)
+
+
+# --------------------------------------------------------------------------- RE_Net (residual encoders + reverse attention)
+class _ResEncoder(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv1 = nn.Conv3d(cin, cout, kernel_size=3, padding=1)
+        self.bn1 = nn.BatchNorm3d(cout)
+        self.conv2 = nn.Conv3d(cout, cout, kernel_size=3, padding=1)
+        self.bn2 = nn.BatchNorm3d(cout)
+        self.relu = nn.ReLU(inplace=False)
+        self.conv1x1 = nn.Conv3d(cin, cout, kernel_size=1)
+
+    def forward(self, x):
+        res = self.conv1x1(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        return self.relu(out + res)
+
+
+class _PlainDecoder(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv3d(cin, cout, kernel_size=3, padding=1), nn.BatchNorm3d(cout), nn.ReLU(inplace=True),
+                                  nn.Conv3d(cout, cout, kernel_size=3, padding=1), nn.BatchNorm3d(cout), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class RE_Net(nn.Module):
+    """RE_net.py:51-161.  skip_k = enc_k * (1 - sigmoid(up(conv1x1(deeper)))) + enc_k; output = sigmoid(final)."""
+
+    def __init__(self):
+        super().__init__()
+        self.encoder1, self.encoder2, self.encoder3 = _ResEncoder(1, 32), _ResEncoder(32, 64), _ResEncoder(64, 128)
+        self.bridge = _ResEncoder(128, 256)
+        self.conv1_1, self.conv2_2, self.conv3_3 = nn.Conv3d(256, 1, 1), nn.Conv3d(128, 1, 1), nn.Conv3d(64, 1, 1)
+        self.convTrans1, self.convTrans2, self.convTrans3 = (nn.ConvTranspose3d(1, 1, kernel_size=2, stride=2) for _ in range(3))
+        self.decoder3, self.decoder2, self.decoder1 = _PlainDecoder(256, 128), _PlainDecoder(128, 64), _PlainDecoder(64, 32)
+        self.down = nn.MaxPool3d(kernel_size=2, stride=2)
+        self.up3, self.up2, self.up1 = (nn.ConvTranspose3d(c, c // 2, kernel_size=2, stride=2) for c in (256, 128, 64))
+        self.final = nn.Conv3d(32, 2, kernel_size=1, padding=0)
+
+    @staticmethod
+    def _gate(enc, deeper_map):
+        rev = -1 * torch.sigmoid(deeper_map) + 1
+        return rev.expand(-1, enc.shape[1], -1, -1, -1).mul(enc) + enc
+
+    def forward(self, x):
+        # op order as upstream (pool before the 1x1x1 squeeze): it fixes the order in which autograd sums the
+        # gradients of the multiply-used encoder outputs, so the oracle stays bit-identical to the reference
+        e1 = self.encoder1(x)
+        d1 = self.down(e1)
+        e2 = self.encoder2(d1)
+        d2 = self.down(e2)
+        s1 = self._gate(e1, self.convTrans3(self.conv3_3(e2)))
+        e3 = self.encoder3(d2)
+        d3 = self.down(e3)
+        s2 = self._gate(e2, self.convTrans2(self.conv2_2(e3)))
+        br = self.bridge(d3)
+        s3 = self._gate(e3, self.convTrans1(self.conv1_1(br)))
+        h = self.decoder3(torch.cat((self.up3(br), s3), dim=1))
+        h = self.decoder2(torch.cat((self.up2(h), s2), dim=1))
+        h = self.decoder1(torch.cat((self.up1(h), s1), dim=1))
+        return torch.sigmoid(self.final(h))
 
 
 # --------------------------------------------------------------------------- IS (three-band U-Net)

@@ -340,3 +340,42 @@ def test_csrnet_train_step_vs_reference_fixture(seg, golden_dir):
     gn = np.array([float(p.grad.double().norm()) for p in m.parameters()])
     ref_gn_err = np.abs(g["gradnorm"] - gn_truth).max()
     assert np.abs(gn - gn_truth).max() <= 2.0 * ref_gn_err + 3e-4 * gn_truth.max()
+
+
+def test_renet_train_step_vs_reference_fixture(seg, golden_dir):
+    """RE_Net (RE_net.py): residual encoders, reverse-attention gates (1x1x1 conv -> 1->1 transposed conv -> enc * (2 -
+    sigmoid)), sigmoid output fed to BCEWithLogits as train.py does.  Forward held to 1e-4 against the reference
+    fixture; gradients graded against an fp64 run of the oracle relative to the reference's own fp32 distance."""
+    from mi355seg.models.three_d.RE_net import RE_Net
+    from oracle.fill import make_input_rough
+    from oracle.nets import RE_Net as OracleRENet
+    g = np.load(os.path.join(golden_dir, "renet_32.npz"))
+    x = make_input_rough((1, 1, 32, 32, 32), seed=5.0)
+    gt2 = two_channel_gt(make_labels((1, 1, 32, 32, 32)))
+    m = fill_module_(RE_Net()).cuda().train()
+    pred = m(x.cuda())
+    loss = seg.functional.bce_with_logits(pred, gt2.cuda())
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    assert np.abs(pred.detach().cpu().numpy() - g["pred"]).max() < TOL
+    mask = seg.functional.argmax_channels(pred).cpu().numpy().astype(np.uint8)
+    margin = np.abs(g["pred"][:, 1] - g["pred"][:, 0])[:, None]
+    assert np.array_equal(mask[margin > 2e-4], g["mask"][margin > 2e-4])
+    for k in g.files:
+        if k.startswith("buf/"):
+            got = dict(m.named_buffers())[k[4:]].cpu().numpy()
+            assert (np.abs(got - g[k]) / np.maximum(1.0, np.abs(g[k]))).max() < 1e-5, k
+    o = fill_module_(OracleRENet()).double().train()
+    torch.nn.functional.binary_cross_entropy_with_logits(o(x.double()), gt2.double()).backward()
+    truth = {k: p.grad for k, p in o.named_parameters()}
+    params = dict(m.named_parameters())
+    checked = 0
+    for k in g.files:
+        if not k.startswith("grad/"):
+            continue
+        t = _sample(truth[k[5:]]).astype(np.float64)
+        ref_err = np.abs(g[k] - t).max()
+        gpu_err = np.abs(_sample(params[k[5:]].grad) - t).max()
+        assert gpu_err <= 2.0 * ref_err + 3e-4 * max(1e-3, np.abs(t).max()), (k, gpu_err, ref_err)
+        checked += 1
+    assert checked == 14

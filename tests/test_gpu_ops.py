@@ -375,6 +375,30 @@ def test_gemm_batched_attention_shapes(seg, P):
     assert (out.double() - want).abs().max() < 1e-3
 
 
+@pytest.mark.parametrize("C", [32, 64, 128, 12])
+def test_reverse_attention_gate_and_sigmoid(seg, C):
+    """enc * (1 - sigmoid(t)) + enc with a one-channel map (RE_net.py:104-107) and the sigmoid output activation."""
+    F = seg.functional
+    enc, t = rnd(2, C, 4, 5, 6, seed=1), rnd(2, 1, 4, 5, 6, seed=2) * 3
+    er, tr = enc.clone().double().requires_grad_(True), t.clone().double().requires_grad_(True)
+    yr = (-1 * torch.sigmoid(tr) + 1).expand(-1, C, -1, -1, -1).mul(er) + er
+    g = rnd(*yr.shape, seed=3)
+    yr.backward(g.double())
+    eg, tg = cl(enc).requires_grad_(True), cl(t).requires_grad_(True)
+    yg = F.reverse_attention_gate(eg, tg)
+    yg.backward(cl(g))
+    assert (cf(yg).double() - yr.detach()).abs().max() < 1e-5
+    assert (cf(eg.grad).double() - er.grad).abs().max() < 1e-5
+    assert (cf(tg.grad).double() - tr.grad).abs().max() < 1e-5 * max(1.0, float(tr.grad.abs().max()))
+    xs = cl(enc).requires_grad_(True)
+    ys = F.activation(xs, F.ACT_SIGMOID)
+    ys.backward(cl(g))
+    xr = enc.clone().double().requires_grad_(True)
+    torch.sigmoid(xr).backward(g.double())
+    assert (cf(ys).double() - torch.sigmoid(enc.double())).abs().max() < 1e-6
+    assert (cf(xs.grad).double() - xr.grad).abs().max() < 1e-6
+
+
 def test_layout_roundtrip(seg):
     F = seg.functional
     x = rnd(2, 5, 4, 6, 7, seed=1)
