@@ -1,5 +1,6 @@
 // api.hip -- error state, version, layout helpers of the C-ABI.
 #include "common.h"
+#include "internal.h"
 #include <string.h>
 
 namespace seg {
@@ -130,6 +131,31 @@ __global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, c
     for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) o[i] = a[i] * b[i];
 }
 
+// ---- selective-fusion pieces (ER_net.py:36-70): per-(sample, channel) statistics and mixing of two feature maps
+__global__ __launch_bounds__(256) void mix_channels_kernel(const float* __restrict__ x1, int ld1, const float* __restrict__ a,
+        const float* __restrict__ x2, int ld2, const float* __restrict__ b, float* __restrict__ y, int ldy, long long rows, int groups, int C) {
+    const long long total = (long long)groups * rows * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / C;                       // global row (group-major)
+        const int c = (int)(i - r * C);
+        const int g = (int)(r / rows);
+        y[r * ldy + c] = x1[r * ld1 + c] * a[g * C + c] + x2[r * ld2 + c] * b[g * C + c];
+    }
+}
+__global__ __launch_bounds__(256) void broadcast_channels_kernel(const float* __restrict__ v, float alpha, float* __restrict__ y, int ldy,
+                                                                 long long rows, int groups, int C) {
+    const long long total = (long long)groups * rows * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / C;
+        const int c = (int)(i - r * C);
+        y[r * ldy + c] = alpha * v[(r / rows) * C + c];
+    }
+}
+__global__ void group_sums_finish_kernel(const double* __restrict__ s, float alpha, float* __restrict__ out, int C, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) out[c] = (accumulate ? out[c] : 0.f) + (float)((double)alpha * s[c]);
+}
+
 // reverse-attention gate: thread = (row, channel quad)
 __global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__ enc, int ldenc, const float* __restrict__ t, int ldt,
                                                        float* __restrict__ y, int ldy, long long rows, int C) {
@@ -251,6 +277,35 @@ int mi355seg_repeat_channels_bwd_f32(const float* dy, int lddy, float* dx, int l
     SEG_CHECK_ARG(dy && dx && rows > 0 && C > 0 && rep > 0 && lddx >= C && lddy >= C * rep, "repeat_channels_bwd: bad arguments");
     hipLaunchKernelGGL(repeat_ch_bwd_kernel, dim3(rows_grid(rows * C)), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx, lddx, rows, C, rep);
     SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_mix_channels_f32(const float* x1, int ld1, const float* a, const float* x2, int ld2, const float* b, float* y, int ldy,
+                              long long rows, int groups, int C, void* stream) {
+    SEG_CHECK_ARG(x1 && a && x2 && b && y && rows > 0 && groups > 0 && C > 0 && ld1 >= C && ld2 >= C && ldy >= C, "mix_channels: bad arguments");
+    hipLaunchKernelGGL(mix_channels_kernel, dim3(rows_grid(groups * rows * C)), dim3(256), 0, (hipStream_t)stream, x1, ld1, a, x2, ld2, b, y, ldy,
+                       rows, groups, C);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_broadcast_channels_f32(const float* v, float alpha, float* y, int ldy, long long rows, int groups, int C, void* stream) {
+    SEG_CHECK_ARG(v && y && rows > 0 && groups > 0 && C > 0 && ldy >= C, "broadcast_channels: bad arguments");
+    hipLaunchKernelGGL(broadcast_channels_kernel, dim3(rows_grid(groups * rows * C)), dim3(256), 0, (hipStream_t)stream, v, alpha, y, ldy, rows,
+                       groups, C);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_group_sums_f32(const float* x, int ldx, long long rows, int groups, int C, float alpha, float* out, int accumulate,
+                            void* ws, size_t ws_bytes, void* stream) {
+    SEG_CHECK_ARG(x && out && rows > 0 && groups > 0 && C > 0 && ldx >= C && ws, "group_sums: bad arguments");
+    SEG_CHECK_WS(align_up((size_t)C * sizeof(double), 256) + colsum_ws_bytes(C), ws_bytes);
+    double* ds = (double*)ws;
+    char* rest = (char*)ws + align_up((size_t)C * sizeof(double), 256);
+    for (int g = 0; g < groups; ++g) {
+        int rc = channel_sums(x + (long long)g * rows * ldx, ldx, rows, C, ds, nullptr, nullptr, 0, rest, ws_bytes - (rest - (char*)ws), (hipStream_t)stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(group_sums_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ds, alpha, out + (long long)g * C, C, accumulate);
+        SEG_CHECK_LAUNCH();
+    }
     return MI355SEG_OK;
 }
 int mi355seg_gate_fwd_f32(const float* enc, int ldenc, const float* t, int ldt, float* y, int ldy, long long rows, int C, void* stream) {

@@ -791,6 +791,105 @@ def reverse_attention_gate(enc, t):
     return _Gate.apply(enc, t)
 
 
+# ----------------------------------------------------------------------------- selective fusion (ER_Net's SFConv)
+class _SFPool(Function):
+    """(x1 + x2).mean over the voxels -> [N, C]  (``fea_U.mean(-1).mean(-1).mean(-1)`` of ER_net.py:57-58)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2):
+        x1, ld1 = cl_view(x1, "sf_pool input")
+        x2, ld2 = cl_view(x2, "sf_pool input")
+        N, D, H, W, C = x1.shape
+        if x2.shape != x1.shape:
+            raise Mi355SegError(f"sf_pool: shapes differ: {tuple(x1.shape)} vs {tuple(x2.shape)}")
+        V = D * H * W
+        s = torch.empty((N, C), dtype=x1.dtype, device=x1.device)
+        L = lib()
+        ws = workspace(L.query("mi355seg_norm_ws_bytes", V, 1, C) + 8 * C + 512, x1.device)
+        L.call("mi355seg_group_sums_f32", _p(x1), ld1, V, N, C, 1.0 / V, _p(s), 0, _p(ws), ws.numel(), _stream())
+        L.call("mi355seg_group_sums_f32", _p(x2), ld2, V, N, C, 1.0 / V, _p(s), 1, _p(ws), ws.numel(), _stream())
+        ctx.shape = (N, D, H, W, C)
+        return s
+
+    @staticmethod
+    def backward(ctx, gs):
+        N, D, H, W, C = ctx.shape
+        V = D * H * W
+        g = torch.empty((N, D, H, W, C), dtype=gs.dtype, device=gs.device)
+        lib().call("mi355seg_broadcast_channels_f32", _p(gs.contiguous()), 1.0 / V, _p(g), C, V, N, C, _stream())
+        return g, g
+
+
+class _SFMix(Function):
+    """x1 * a[n, c] + x2 * b[n, c]  (``(feas * attention_vectors).sum(dim=1)`` of ER_net.py:67-69)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, a, b):
+        x1, ld1 = cl_view(x1, "sf_mix input")
+        x2, ld2 = cl_view(x2, "sf_mix input")
+        N, D, H, W, C = x1.shape
+        a, b = a.contiguous(), b.contiguous()
+        if x2.shape != x1.shape or a.numel() != N * C or b.numel() != N * C:
+            raise Mi355SegError("sf_mix: x1 / x2 must match and the two attention vectors hold N*C values each")
+        y = torch.empty((N, D, H, W, C), dtype=x1.dtype, device=x1.device)
+        lib().call("mi355seg_mix_channels_f32", _p(x1), ld1, _p(a), _p(x2), ld2, _p(b), _p(y), C, D * H * W, N, C, _stream())
+        ctx.save_for_backward(x1, x2, a, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, a, b = ctx.saved_tensors
+        N, D, H, W, C = x1.shape
+        V = D * H * W
+        dy, lddy = cl_view(dy, "sf_mix grad")
+        L = lib()
+        dx1, dx2 = torch.empty_like(dy.contiguous()), None
+        dx2 = torch.empty_like(dx1)
+        L.call("mi355seg_scale_channels_f32", _p(dy), lddy, _p(a), _p(dx1), C, V, N, C, _stream())
+        L.call("mi355seg_scale_channels_f32", _p(dy), lddy, _p(b), _p(dx2), C, V, N, C, _stream())
+        ws = workspace(L.query("mi355seg_norm_ws_bytes", V, 1, C) + 8 * C + 512, dy.device)
+        dyc = dy.contiguous()
+        grads = []
+        for x in (x1, x2):                                   # da[n, c] = sum_v dy * x
+            prod = _mul(dyc, x.contiguous())
+            d = torch.empty((N, C), dtype=dy.dtype, device=dy.device)
+            L.call("mi355seg_group_sums_f32", _p(prod), C, V, N, C, 1.0, _p(d), 0, _p(ws), ws.numel(), _stream())
+            grads.append(d.view_as(a))
+        return dx1, dx2, grads[0], grads[1]
+
+
+class _SoftmaxLast(Function):
+    """softmax over the last dimension of a small 2-D tensor (the two-branch attention softmax, ER_net.py:66)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_cuda(x, "softmax input")
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        lib().call("mi355seg_softmax_rows_f32", _p(x), _p(y), x.shape[0], x.shape[1], _stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        lib().call("mi355seg_softmax_rows_bwd_f32", _p(y), _p(dy.contiguous()), _p(dx), y.shape[0], y.shape[1], _stream())
+        return dx
+
+
+def sf_pool(x1, x2):
+    return _SFPool.apply(x1, x2)
+
+
+def sf_mix(x1, x2, a, b):
+    return _SFMix.apply(x1, x2, a, b)
+
+
+def softmax_last(x):
+    return _SoftmaxLast.apply(x)
+
+
 # ----------------------------------------------------------------------------- channel concat / repeat
 class _CatChannels(Function):
     """torch.cat((a, b), dim=1) of the reference (vnet3d.py:101, residual_unet3d.py:183-209, unetr.py:286-293) in

@@ -2,8 +2,8 @@
 (train.py:324-373, predict.py:233-276).  Networks on the hot path are built from the
 MI355X drop-ins; the reference's other networks are out of scope and named as such."""
 
-IN_SCOPE = ("unet", "vnet", "res_unet", "unetr", "IS", "csrnet", "re_net")
-OUT_OF_SCOPE = ("er_net", "densenet", "vtnet", "densevoxelnet", "dunet")
+IN_SCOPE = ("unet", "vnet", "res_unet", "unetr", "IS", "csrnet", "re_net", "er_net")
+OUT_OF_SCOPE = ("densenet", "vtnet", "densevoxelnet", "dunet")
 
 
 def build_model(config):
@@ -31,6 +31,9 @@ def build_model(config):
     if network == "re_net":                                 # train.py:336-339
         from .models.three_d.RE_net import RE_Net
         return RE_Net()
+    if network == "er_net":                                 # train.py:332-335
+        from .models.three_d.ER_net import ER_Net
+        return ER_Net(classes=get("out_classes"), channels=get("in_classes"))
     if network in OUT_OF_SCOPE:
         raise NotImplementedError(f"network '{network}' is outside the MI355X hot-path scope (SURVEY.md section 2)")
     raise ValueError(f"unknown network '{network}'")

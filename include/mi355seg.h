@@ -278,6 +278,16 @@ int mi355seg_repeat_channels_bwd_f32(const float* dy, int lddy, float* dx, int l
 int mi355seg_gate_fwd_f32(const float* enc, int ldenc, const float* t, int ldt, float* y, int ldy, long long rows, int C, void* stream);
 int mi355seg_gate_bwd_f32(const float* dy, int lddy, const float* enc, int ldenc, const float* t, int ldt,
                           float* denc, int lddenc, float* dt, long long rows, int C, void* stream);
+/* Selective-fusion pieces of ER_Net's SFConv (ER_net.py:36-70); rows are grouped per sample (group g = rows [g*rows, (g+1)*rows)):
+ *   group_sums:         out[g, c] (+)= alpha * sum_r x[g, r, c]           (fea_U.mean over the voxels; adjoint of the mix)
+ *   mix_channels:       y[g, r, c] = x1[g, r, c] * a[g, c] + x2[g, r, c] * b[g, c]   ((feas * attention_vectors).sum(dim=1))
+ *   broadcast_channels: y[g, r, c] = alpha * v[g, c]                      (adjoint of the spatial mean)
+ * group_sums needs mi355seg_norm_ws_bytes(rows, 1, C) of workspace. */
+int mi355seg_group_sums_f32(const float* x, int ldx, long long rows, int groups, int C, float alpha, float* out, int accumulate,
+                            void* ws, size_t ws_bytes, void* stream);
+int mi355seg_mix_channels_f32(const float* x1, int ld1, const float* a, const float* x2, int ld2, const float* b, float* y, int ldy,
+                              long long rows, int groups, int C, void* stream);
+int mi355seg_broadcast_channels_f32(const float* v, float alpha, float* y, int ldy, long long rows, int groups, int C, void* stream);
 /* y[r, c] += bias[c] in place (bias of a ConvTranspose3d computed as the adjoint of a bias-free convolution). */
 int mi355seg_add_bias_f32(float* y, int ldy, const float* bias, long long rows, int C, void* stream);
 /* out[i] = a[i] * b[i] (attention-probability dropout mask, unetr.py:112; out may alias a). */

@@ -10,6 +10,7 @@ Follows (reference file:line):
   * ResUNet     -- models/three_d/residual_unet3d.py:11-80 (ctor), :82-107 (factories), :109-204 (forward)
   * CSRNet      -- models/three_d/csrnet.py:5-45 (ctor), :46-69 (forward), :101-137 (cross-scale link blocks)
   * RE_Net      -- models/three_d/RE_net.py:20-35 (ResEncoder), :36-50 (Decoder), :51-100 (ctor), :101-161 (forward)
+  * ER_Net      -- models/three_d/ER_net.py:20-35 (ResDecoder), :36-70 (SFConv), :71-81 (SF_Decoder), :98-165 (ER_Net)
   * ISUNet3D    -- models/three_d/IS.py:10-130 (ctor: three parameter sets), :132-190 (forward: shared encoder, three decoders)
 """
 from collections import OrderedDict
@@ -177,6 +178,72 @@ class RE_Net(nn.Module):
         h = self.decoder2(torch.cat((self.up2(h), s2), dim=1))
         h = self.decoder1(torch.cat((self.up1(h), s1), dim=1))
         return torch.sigmoid(self.final(h))
+
+
+# --------------------------------------------------------------------------- ER_Net (RE_Net encoder + selective-fusion decoders)
+class _ResDecoder(_ResEncoder):
+    def __init__(self, c):
+        super().__init__(c, c)
+
+
+class _SFConv(nn.Module):
+    """ER_net.py:36-70: weights = softmax over the two branches of fcs[i](fc(mean_voxels(x1 + x2))); out = sum_i w_i x_i."""
+
+    def __init__(self, features, M=2, r=4, L=32):
+        super().__init__()
+        d = max(int(features / r), L)
+        self.fc = nn.Linear(features, d)
+        self.fcs = nn.ModuleList([nn.Linear(d, features) for _ in range(M)])
+        self.softmax = nn.Softmax(dim=1)
+
+    def forward(self, x1, x2):
+        feas = torch.cat((x1.unsqueeze(dim=1), x2.unsqueeze(dim=1)), dim=1)
+        fea_s = torch.sum(feas, dim=1).mean(-1).mean(-1).mean(-1)
+        fea_z = self.fc(fea_s)
+        att = torch.cat([fc(fea_z).unsqueeze(dim=1) for fc in self.fcs], dim=1)
+        att = self.softmax(att).unsqueeze(-1).unsqueeze(-1).unsqueeze(-1)
+        return (feas * att).sum(dim=1)
+
+
+class _SFDecoder(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv1 = _SFConv(c)
+        self.bn1 = nn.BatchNorm3d(c)
+        self.relu = nn.ReLU(inplace=True)
+        self.ResDecoder = _ResDecoder(c)
+
+    def forward(self, x1, x2):
+        return self.ResDecoder(self.relu(self.bn1(self.conv1(x1, x2))))
+
+
+class ER_Net(nn.Module):
+    def __init__(self, classes, channels):
+        super().__init__()
+        self.encoder1, self.encoder2, self.encoder3 = _ResEncoder(channels, 32), _ResEncoder(32, 64), _ResEncoder(64, 128)
+        self.bridge = _ResEncoder(128, 256)
+        self.conv1_1, self.conv2_2, self.conv3_3 = nn.Conv3d(256, 1, 1), nn.Conv3d(128, 1, 1), nn.Conv3d(64, 1, 1)
+        self.convTrans1, self.convTrans2, self.convTrans3 = (nn.ConvTranspose3d(1, 1, kernel_size=2, stride=2) for _ in range(3))
+        self.decoder3, self.decoder2, self.decoder1 = _SFDecoder(128), _SFDecoder(64), _SFDecoder(32)
+        self.down = nn.MaxPool3d(kernel_size=2, stride=2)
+        self.up3, self.up2, self.up1 = (nn.ConvTranspose3d(c, c // 2, kernel_size=2, stride=2) for c in (256, 128, 64))
+        self.final = nn.Conv3d(32, classes, kernel_size=1, padding=0)
+
+    def forward(self, x):
+        e1 = self.encoder1(x)
+        d1 = self.down(e1)
+        e2 = self.encoder2(d1)
+        d2 = self.down(e2)
+        s1 = RE_Net._gate(e1, self.convTrans3(self.conv3_3(e2)))
+        e3 = self.encoder3(d2)
+        d3 = self.down(e3)
+        s2 = RE_Net._gate(e2, self.convTrans2(self.conv2_2(e3)))
+        br = self.bridge(d3)
+        s3 = RE_Net._gate(e3, self.convTrans1(self.conv1_1(br)))
+        h = self.decoder3(self.up3(br), s3)
+        h = self.decoder2(self.up2(h), s2)
+        h = self.decoder1(self.up1(h), s1)
+        return self.final(h)
 
 
 # --------------------------------------------------------------------------- IS (three-band U-Net)

@@ -49,6 +49,8 @@ def test_registry_builds_in_scope_networks_with_reference_constructors():
     assert "encoder_r_1.enc1_rconv1.weight" in m.state_dict() and m.dncoder_r_3.dnc3_rconv1.weight.shape == (256, 64, 4, 4, 4)
     m = build_model({"network": "re_net", "in_classes": 1, "out_classes": 2})
     assert sum(p.numel() for p in m.parameters()) == 5_646_560
+    m = build_model({"network": "er_net", "in_classes": 1, "out_classes": 2})
+    assert sum(p.numel() for p in m.parameters()) == 5_110_176
     with pytest.raises(NotImplementedError):
         build_model({"network": "densenet", "in_classes": 1, "out_classes": 2})
     with pytest.raises(ValueError):

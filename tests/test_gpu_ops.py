@@ -399,6 +399,33 @@ def test_reverse_attention_gate_and_sigmoid(seg, C):
     assert (cf(xs.grad).double() - xr.grad).abs().max() < 1e-6
 
 
+def test_selective_fusion_pieces(seg):
+    """SFConv's voxel mean, two-branch softmax and weighted mix (ER_net.py:52-69) with their adjoints."""
+    F = seg.functional
+    N, C, D, H, W = 2, 32, 4, 6, 8
+    x1, x2 = rnd(N, D, H, W, C, seed=1), rnd(N, D, H, W, C, seed=2)
+    a, b = rnd(N, C, seed=3).abs(), rnd(N, C, seed=4).abs()
+    g, gs = rnd(N, D, H, W, C, seed=5), rnd(N, C, seed=6)
+    leaves = [t.clone().double().requires_grad_(True) for t in (x1, x2, a, b)]
+    want_mix = leaves[0] * leaves[2][:, None, None, None, :] + leaves[1] * leaves[3][:, None, None, None, :]
+    want_pool = (leaves[0] + leaves[1]).mean(dim=(1, 2, 3))
+    ((want_mix * g.double()).sum() + (want_pool * gs.double()).sum()).backward()
+    dev = [t.cuda().requires_grad_(True) for t in (x1, x2, a, b)]
+    mix, pool = F.sf_mix(*dev), F.sf_pool(dev[0], dev[1])
+    ((mix * g.cuda()).sum() + (pool * gs.cuda()).sum()).backward()
+    assert (mix.detach().cpu().double() - want_mix.detach()).abs().max() < 1e-6
+    assert (pool.detach().cpu().double() - want_pool.detach()).abs().max() < 1e-6
+    for got, ref in zip(dev, leaves):
+        assert (got.grad.cpu().double() - ref.grad).abs().max() < 2e-5
+    logits = rnd(64, 2, seed=7)
+    lg = logits.cuda().requires_grad_(True)
+    lr = logits.clone().double().requires_grad_(True)
+    w = rnd(64, 2, seed=8)
+    (F.softmax_last(lg) * w.cuda()).sum().backward()
+    (torch.softmax(lr, dim=1) * w.double()).sum().backward()
+    assert (lg.grad.cpu().double() - lr.grad).abs().max() < 1e-6
+
+
 def test_layout_roundtrip(seg):
     F = seg.functional
     x = rnd(2, 5, 4, 6, 7, seed=1)

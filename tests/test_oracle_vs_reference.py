@@ -162,3 +162,17 @@ def test_renet_bit_identical():
     assert torch.equal(ya, yb)
     for k in ga:
         assert torch.equal(ga[k], gb[k]), k
+
+
+def test_ernet_bit_identical():
+    from oracle.fill import make_input_rough
+    R = _ref("models.three_d.ER_net", "ER_Net")
+    a = fill_module_(R(classes=2, channels=1)).train()
+    b = fill_module_(nets.ER_Net(classes=2, channels=1)).train()
+    _same_keys(a, b)
+    x = make_input_rough((1, 1, 32, 32, 32), seed=7.0)
+    ya, ga = _fwd_bwd(a, x)
+    yb, gb = _fwd_bwd(b, x)
+    assert torch.equal(ya, yb)
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
