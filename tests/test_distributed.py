@@ -91,3 +91,54 @@ def test_single_process_is_a_noop():
     D.GradAllReducer(m)(m)
     D.broadcast_buffers(m)
     assert all(torch.equal(a, p.grad) for a, p in zip(g, m.parameters()))
+
+
+def _unet_worker(rank, world, port, out):
+    """One data-parallel train step of the oracle U-Net on this rank's shard (rank-local BatchNorm statistics, as plain
+    nn.BatchNorm3d under DDP), gradients mean-all-reduced by the product's reducer."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import mi355seg
+    from mi355seg import distributed as D
+    from oracle.fill import fill_module_, make_input, make_labels
+    from oracle.losses import bce_with_logits
+    from oracle.nets import UNet3D
+    from oracle.step import two_channel_gt
+    D.init_from_env(backend="gloo")
+    torch.set_num_threads(2)
+    model = fill_module_(UNet3D(1, 2, 4)).train()
+    reducer = D.GradAllReducer(model, bucket_mb=0.05)
+    x = make_input((2, 1, 16, 16, 16), freq=0.05, phase=float(rank))
+    gt = make_labels((2, 1, 16, 16, 16), thresh=0.8 - 0.3 * rank)
+    D.broadcast_buffers(model)
+    bce_with_logits(model(x), two_channel_gt(gt).float()).backward()
+    reducer(model)
+    out[rank] = {k: p.grad.clone() for k, p in model.named_parameters()}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_gradients_equal_the_mean_of_per_shard_oracle_gradients():
+    """the CPU oracle on each rank's shard from identical weights, per-shard gradients averaged,
+    against the all-reduced gradients -- not a single batch-4 run (BatchNorm statistics would differ)."""
+    from oracle.fill import fill_module_, make_input, make_labels
+    from oracle.losses import bce_with_logits
+    from oracle.nets import UNet3D
+    from oracle.step import two_channel_gt
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_unet_worker, args=(world, port, out), nprocs=world, join=True)
+    torch.set_num_threads(2)
+    shard_grads = []
+    for rank in range(world):
+        m = fill_module_(UNet3D(1, 2, 4)).train()
+        x = make_input((2, 1, 16, 16, 16), freq=0.05, phase=float(rank))
+        gt = make_labels((2, 1, 16, 16, 16), thresh=0.8 - 0.3 * rank)
+        bce_with_logits(m(x), two_channel_gt(gt).float()).backward()
+        shard_grads.append({k: p.grad for k, p in m.named_parameters()})
+    for k, g0 in shard_grads[0].items():
+        want = (g0 + shard_grads[1][k]) / 2
+        for rank in range(world):
+            got = out[rank][k]
+            assert (got - want).abs().max() <= 1e-4 * max(1e-6, float(want.abs().max())), (k, rank)
+        assert torch.equal(out[0][k], out[1][k]), k
