@@ -128,7 +128,6 @@ def test_ddp_gradients_equal_the_mean_of_per_shard_oracle_gradients():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_unet_worker, args=(world, port, out), nprocs=world, join=True)
-    torch.set_num_threads(2)
     shard_grads = []
     for rank in range(world):
         m = fill_module_(UNet3D(1, 2, 4)).train()
