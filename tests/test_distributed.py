@@ -135,9 +135,10 @@ def test_ddp_gradients_equal_the_mean_of_per_shard_oracle_gradients():
         gt = make_labels((2, 1, 16, 16, 16), thresh=0.8 - 0.3 * rank)
         bce_with_logits(m(x), two_channel_gt(gt).float()).backward()
         shard_grads.append({k: p.grad for k, p in m.named_parameters()})
+    scale = max(float(g.abs().max()) for g in shard_grads[0].values())     # conv biases in front of BatchNorm have ~0 gradient
     for k, g0 in shard_grads[0].items():
         want = (g0 + shard_grads[1][k]) / 2
         for rank in range(world):
             got = out[rank][k]
-            assert (got - want).abs().max() <= 1e-4 * max(1e-6, float(want.abs().max())), (k, rank)
+            assert (got - want).abs().max() <= 1e-4 * max(float(want.abs().max()), 1e-3 * scale), (k, rank)
         assert torch.equal(out[0][k], out[1][k]), k
