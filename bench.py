@@ -124,6 +124,8 @@ def main():
     x = torch.randn((B, cin, Dd, Hh, Ww), generator=g).to(dev)
     gt = (torch.rand((B, 1, Dd, Hh, Ww), generator=g) > 0.9).float().to(dev)
     reducer = D.GradAllReducer(model) if world > 1 else None
+    if world > 1:
+        D.flatten_buffers(model)                    # buffer broadcast = two collectives, no copies
 
     graphed = None
     if args.hip_graph:                  # experiment: the whole step as one hipGraphLaunch (single process, no kernel timing)

@@ -91,7 +91,10 @@ class GradAllReducer:
             flat = torch.empty(total, dtype=grads[0].dtype, device=grads[0].device)
             self._flat[bi] = flat
         torch.cat([g.reshape(-1) for g in grads], out=flat)
-        self._works[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        # RCCL averages inside the collective (ReduceOp.AVG); gloo only sums, the division follows the wait
+        self._avg_in_collective = dist.get_backend() == "nccl"
+        op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
+        self._works[bi] = dist.all_reduce(flat, op=op, async_op=True)
 
     def detach(self):
         for h in self._handles:
@@ -108,18 +111,46 @@ class GradAllReducer:
         for bi, bucket in enumerate(self.buckets):
             self._works[bi].wait()
             flat = self._flat[bi]
-            if inv != 1.0:
+            if inv != 1.0 and not getattr(self, "_avg_in_collective", False):
                 flat.mul_(inv)
-            off = 0
+            off, dsts, srcs = 0, [], []
             for p in bucket:
                 n = p.numel()
+                view = flat[off:off + n].view_as(p)
                 if p.grad is None:
-                    p.grad = flat[off:off + n].view_as(p).clone()
+                    p.grad = view.clone()
                 else:
-                    p.grad.copy_(flat[off:off + n].view_as(p))
+                    dsts.append(p.grad)
+                    srcs.append(view)
                 off += n
+            if dsts:
+                torch._foreach_copy_(dsts, srcs)              # one multi-tensor launch per bucket instead of one copy per parameter
             self._works[bi] = None
             self._pending[bi] = len(bucket)
+
+
+def flatten_buffers(model):
+    """Re-seat every module buffer as a view into one flat tensor per dtype class (float / integer), so that
+    ``broadcast_buffers`` is two collectives with no gather / scatter copies around them.  The kernels update running
+    statistics through ``data_ptr()``, so views are transparent to them.  Idempotent; returns the flat tensors."""
+    if getattr(model, "_mi355seg_flat_buffers", None) is not None:
+        return model._mi355seg_flat_buffers
+    owners = [(mod, name, b) for mod in model.modules() for name, b in mod._buffers.items() if b is not None]
+    flats = []
+    for floating in (True, False):
+        group = [(m, n, b) for (m, n, b) in owners if b.is_floating_point() == floating]
+        if not group:
+            flats.append(None)
+            continue
+        flat = torch.cat([b.detach().reshape(-1) for (_, _, b) in group])
+        off = 0
+        for m, n, b in group:
+            k = b.numel()
+            m._buffers[n] = flat[off:off + k].view_as(b)
+            off += k
+        flats.append(flat)
+    model._mi355seg_flat_buffers = tuple(flats)
+    return model._mi355seg_flat_buffers
 
 
 def broadcast_buffers(model, src=0):
@@ -127,6 +158,15 @@ def broadcast_buffers(model, src=0):
     num_batches_tracked) overwrite every rank's before the forward."""
     if world_size() == 1:
         return
+    flats = getattr(model, "_mi355seg_flat_buffers", None)
+    if flats is not None:
+        live = {b.untyped_storage().data_ptr() for b in model.buffers()}
+        if live <= {f.untyped_storage().data_ptr() for f in flats if f is not None}:
+            for flat in flats:
+                if flat is not None:
+                    dist.broadcast(flat, src=src)
+            return
+        model._mi355seg_flat_buffers = None           # the module was moved / re-created since: fall back to gather + scatter
     bufs = [b for b in model.buffers()]
     if not bufs:
         return

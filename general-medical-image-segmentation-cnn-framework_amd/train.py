@@ -64,6 +64,8 @@ def train(config, model, logger):
     scalars = open(os.path.join(config.hydra_path, "scalars.jsonl"), "a") if rank == 0 else None
     loader = make_loader(config, device, config.in_classes, seed=1234 + rank)
     reducer = D.GradAllReducer(model) if world > 1 else None
+    if world > 1:
+        D.flatten_buffers(model)                    # buffer broadcast = two collectives, no copies
     epochs = config.epochs - elapsed_epochs
     iteration = elapsed_epochs * len(loader)
     loss_meter, dice_meter = AverageMeter(), AverageMeter()

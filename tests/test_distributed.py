@@ -35,10 +35,21 @@ def _worker(rank, world, port, out):
     if rank == 1:
         for b in model.buffers():
             b.add_(1)
-    D.broadcast_buffers(model)
+    D.broadcast_buffers(model)                                 # gather / broadcast / scatter path
     ref = _make_model()
     for a, b in zip(model.buffers(), ref.buffers()):
         assert torch.equal(a, b)
+    if rank == 1:
+        for b in model.buffers():
+            b.add_(2)
+    flats = D.flatten_buffers(model)                           # buffers become views of two flat tensors
+    assert flats[0] is not None and flats[1] is not None and D.flatten_buffers(model) is flats
+    D.broadcast_buffers(model)                                 # two collectives, no copies
+    for (k, a), b in zip(model.named_buffers(), ref.buffers()):
+        assert torch.equal(a, b), k
+    model.train()(torch.zeros(2, 1, 4, 4, 4))                  # BatchNorm keeps updating the (view) buffers in place
+    assert int(model[1].num_batches_tracked) == 1 and flats[1].sum() == 1
+    model[1].reset_running_stats()
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.randn(2, 1, 4, 4, 4, generator=g)
     hooked = D.GradAllReducer(model, bucket_mb=0.0001)         # tiny buckets -> several collectives, launched from hooks
