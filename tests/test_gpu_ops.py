@@ -426,6 +426,36 @@ def test_selective_fusion_pieces(seg):
     assert (lg.grad.cpu().double() - lr.grad).abs().max() < 1e-6
 
 
+def test_c_abi_rejects_bad_arguments(seg):
+    """Error behaviour of the boundary: invalid geometry, pitches below the channel count, null pointers and short
+    workspaces come back as error codes with a message (raised as Mi355SegError by the binding), never as a launch."""
+    from mi355seg._lib import Mi355SegError
+    L = seg.lib()
+    x = torch.zeros(1, 4, 4, 4, 16, device="cuda")
+    w = torch.zeros(32, 16, 3, 3, 3, device="cuda")
+    y = torch.zeros(1, 4, 4, 4, 32, device="cuda")
+    ws = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    ok = (x.data_ptr(), 16, w.data_ptr(), None, y.data_ptr(), 32, 1, 4, 4, 4, 16, 32, 3, 1, 1, None, None, ws.data_ptr(), ws.numel(), st)
+    L.call("mi355seg_conv3d_fwd_f32", *ok)
+    bad = {
+        "pitch below channels": ok[:1] + (8,) + ok[2:],
+        "null input": (None,) + ok[1:],
+        "zero depth": ok[:7] + (0,) + ok[8:],
+        "kernel larger than the padded input": ok[:12] + (11,) + ok[13:],
+        "short workspace": ok[:18] + (64,) + ok[19:],
+    }
+    for what, args in bad.items():
+        with pytest.raises(Mi355SegError) as err:
+            L.call("mi355seg_conv3d_fwd_f32", *args)
+        assert "conv" in str(err.value) or "workspace" in str(err.value), what
+    with pytest.raises(Mi355SegError):
+        seg.functional.conv3d(x.cpu(), w, None, 1, 1)                      # CPU tensor: no fallback
+    with pytest.raises(Mi355SegError):
+        seg.functional.conv3d(x.double(), w, None, 1, 1)                   # fp32 only
+    torch.cuda.synchronize()
+
+
 def test_layout_roundtrip(seg):
     F = seg.functional
     x = rnd(2, 5, 4, 6, 7, seed=1)
