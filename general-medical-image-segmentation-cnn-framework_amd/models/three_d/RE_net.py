@@ -15,6 +15,9 @@ from ... import functional as F
 from ...layers import BatchNorm3d, Conv3d, ConvTranspose3d, MaxPool3d, ReLU
 
 
+_WIDTHS = (32, 64, 128, 256)            # encoder1..3 + bridge
+
+
 def downsample():
     return MaxPool3d(kernel_size=2, stride=2)
 
@@ -24,24 +27,29 @@ def deconv(in_channels, out_channels):
 
 
 def initialize_weights(*models):
-    for model in models:
-        for m in model.modules():
-            if isinstance(m, (nn.Conv3d, nn.Linear)):
-                nn.init.kaiming_normal_(m.weight)
-                if m.bias is not None:
-                    m.bias.data.zero_()
-            elif isinstance(m, nn.BatchNorm3d):
-                m.weight.data.fill_(1)
-                m.bias.data.zero_()
+    """RE_net.py:10-19: kaiming-normal Conv3d / Linear weights, zero biases, BatchNorm (1, 0); ConvTranspose3d untouched."""
+    for net in models:
+        for mod in net.modules():
+            if isinstance(mod, nn.BatchNorm3d):
+                mod.weight.data.fill_(1)
+                mod.bias.data.zero_()
+            elif isinstance(mod, (nn.Conv3d, nn.Linear)):
+                nn.init.kaiming_normal_(mod.weight)
+                if mod.bias is not None:
+                    mod.bias.data.zero_()
+
+
+def _k3(cin, cout):
+    return Conv3d(cin, cout, kernel_size=3, padding=1)
 
 
 class ResEncoder(nn.Module):
+    """relu(relu(bn2(conv2(relu(bn1(conv1 x))))) + conv1x1(x))  (RE_net.py:20-35); both conv+BN+ReLU pairs are fused nodes."""
+
     def __init__(self, in_channels, out_channels):
         super().__init__()
-        self.conv1 = Conv3d(in_channels, out_channels, kernel_size=3, padding=1)
-        self.bn1 = BatchNorm3d(out_channels)
-        self.conv2 = Conv3d(out_channels, out_channels, kernel_size=3, padding=1)
-        self.bn2 = BatchNorm3d(out_channels)
+        self.conv1, self.bn1 = _k3(in_channels, out_channels), BatchNorm3d(out_channels)
+        self.conv2, self.bn2 = _k3(out_channels, out_channels), BatchNorm3d(out_channels)
         self.relu = ReLU(inplace=False)
         self.conv1x1 = Conv3d(in_channels, out_channels, kernel_size=1)
 
@@ -53,11 +61,14 @@ class ResEncoder(nn.Module):
 
 
 class Decoder(nn.Module):
+    """(conv k3 -> BN -> ReLU) x 2 held in ``self.conv`` with indices 0..5  (RE_net.py:36-50)."""
+
     def __init__(self, in_channels, out_channels):
         super().__init__()
-        self.conv = nn.Sequential(
-            Conv3d(in_channels, out_channels, kernel_size=3, padding=1), BatchNorm3d(out_channels), ReLU(inplace=True),
-            Conv3d(out_channels, out_channels, kernel_size=3, padding=1), BatchNorm3d(out_channels), ReLU(inplace=True))
+        stages = []
+        for cin in (in_channels, out_channels):
+            stages += [_k3(cin, out_channels), BatchNorm3d(out_channels), ReLU(inplace=True)]
+        self.conv = nn.Sequential(*stages)
 
     def forward(self, x):
         c1, b1, _, c2, b2, _ = self.conv.children()
@@ -67,35 +78,35 @@ class Decoder(nn.Module):
 class RE_Net(nn.Module):
     def __init__(self):
         super().__init__()
-        self.encoder1 = ResEncoder(1, 32)
-        self.encoder2 = ResEncoder(32, 64)
-        self.encoder3 = ResEncoder(64, 128)
-        self.bridge = ResEncoder(128, 256)
-        self.conv1_1 = Conv3d(256, 1, kernel_size=1)
-        self.conv2_2 = Conv3d(128, 1, kernel_size=1)
-        self.conv3_3 = Conv3d(64, 1, kernel_size=1)
-        self.convTrans1 = ConvTranspose3d(1, 1, kernel_size=2, stride=2)
-        self.convTrans2 = ConvTranspose3d(1, 1, kernel_size=2, stride=2)
-        self.convTrans3 = ConvTranspose3d(1, 1, kernel_size=2, stride=2)
-        self.decoder3 = Decoder(256, 128)
-        self.decoder2 = Decoder(128, 64)
-        self.decoder1 = Decoder(64, 32)
+        cin = 1
+        for name, width in zip(("encoder1", "encoder2", "encoder3", "bridge"), _WIDTHS):
+            setattr(self, name, ResEncoder(cin, width))
+            cin = width
+        for k, width in zip((1, 2, 3), reversed(_WIDTHS[1:])):          # conv1_1: 256 -> 1, conv2_2: 128 -> 1, conv3_3: 64 -> 1
+            setattr(self, f"conv{k}_{k}", Conv3d(width, 1, kernel_size=1))
+        for k in (1, 2, 3):
+            setattr(self, f"convTrans{k}", ConvTranspose3d(1, 1, kernel_size=2, stride=2))
+        for k, width in zip((3, 2, 1), reversed(_WIDTHS[1:])):          # decoder3: 256 -> 128, decoder2: 128 -> 64, decoder1: 64 -> 32
+            setattr(self, f"decoder{k}", Decoder(width, width // 2))
         self.down = downsample()
-        self.up3 = deconv(256, 128)
-        self.up2 = deconv(128, 64)
-        self.up1 = deconv(64, 32)
-        self.final = Conv3d(32, 2, kernel_size=1, padding=0)
+        for k, width in zip((3, 2, 1), reversed(_WIDTHS[1:])):
+            setattr(self, f"up{k}", deconv(width, width // 2))
+        self.final = Conv3d(_WIDTHS[0], 2, kernel_size=1, padding=0)
         initialize_weights(self)
+
+    def _skip(self, enc, deeper, k):
+        """enc * (1 - sigmoid(up(squeeze(deeper)))) + enc  (RE_net.py:101-127)."""
+        squeezed = getattr(self, f"conv{k}_{k}")(deeper)
+        return F.reverse_attention_gate(enc, getattr(self, f"convTrans{k}")(squeezed))
 
     def forward(self, x):
         enc1 = self.encoder1(F.to_channels_last(x))
         enc2 = self.encoder2(self.down(enc1))
-        skip1 = F.reverse_attention_gate(enc1, self.convTrans3(self.conv3_3(enc2)))
+        skip1 = self._skip(enc1, enc2, 3)
         enc3 = self.encoder3(self.down(enc2))
-        skip2 = F.reverse_attention_gate(enc2, self.convTrans2(self.conv2_2(enc3)))
-        bridge = self.bridge(self.down(enc3))
-        skip3 = F.reverse_attention_gate(enc3, self.convTrans1(self.conv1_1(bridge)))
-        h = self.decoder3(F.cat_channels(self.up3(bridge), skip3))
-        h = self.decoder2(F.cat_channels(self.up2(h), skip2))
-        h = self.decoder1(F.cat_channels(self.up1(h), skip1))
+        skip2 = self._skip(enc2, enc3, 2)
+        h = self.bridge(self.down(enc3))
+        skip3 = self._skip(enc3, h, 1)
+        for k, skip in ((3, skip3), (2, skip2), (1, skip1)):
+            h = getattr(self, f"decoder{k}")(F.cat_channels(getattr(self, f"up{k}")(h), skip))
         return F.to_channels_first(F.activation(self.final(h), F.ACT_SIGMOID))
