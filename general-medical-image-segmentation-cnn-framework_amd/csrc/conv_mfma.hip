@@ -133,16 +133,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
     const int ntile = t % a.nN;
     const int mtile = t / a.nN;
     // M-tiles are walked in (y, z) blocks of by x bz tiles (x fastest inside a block) so that the ~64 tiles an XCD works
-    // on at any moment form a compact brick whose shared halo planes stay in that XCD's L2 (by, bz divide nty, ntz)
+    // on at any moment form a compact brick whose shared halo planes stay in that XCD's L2 (by divides nty; the last
+    // z-row of bricks may be shorter than bz)
     int mt = mtile;
     const int per_n = a.ntx * a.nty * a.ntz;
     const int n = mt / per_n; mt -= n * per_n;
-    const int blk = a.ntx * a.by * a.bz;
+    const int nby = a.nty / a.by;
+    const int zfull = a.ntz / a.bz;                           // full z-rows of bricks; a ragged last row holds the remaining slabs
+    const int rowtiles = a.ntx * a.nty * a.bz;                // tiles per full z-row
+    int zrow = mt / rowtiles, bzz = a.bz;
+    if (zrow >= zfull) { zrow = zfull; bzz = a.ntz - zfull * a.bz; }
+    mt -= zrow * rowtiles;
+    const int blk = a.ntx * a.by * bzz;
     const int b = mt / blk; mt -= b * blk;
     const int txi = mt % a.ntx; mt /= a.ntx;
-    const int nby = a.nty / a.by;
-    const int tyi = (b % nby) * a.by + mt % a.by;
-    const int tzi = (b / nby) * a.bz + mt / a.by;
+    const int tyi = b * a.by + mt % a.by;
+    const int tzi = zrow * a.bz + mt / a.by;
     const int x0 = txi * BX, y0 = tyi * T::TY, z0 = tzi * T::TZ;
     const int tapn = ntile / a.nNpt;                          // output child (ConvT fwd), else 0
     const int n0 = (ntile % a.nNpt) * NT;
@@ -493,7 +499,7 @@ static void dispatch_igemm(const IgemmPlan& p, const IgemmArgs& a_in, int nwg, h
     IgemmArgs a = a_in;
     static const char* flat_walk = getenv("MI355SEG_IGEMM_LINEAR_WALK");      // A/B knob: 1 = plain x, y, z tile order
     a.by = flat_walk ? 1 : tile_block(a.nty);
-    a.bz = flat_walk ? 1 : tile_block(a.ntz);
+    a.bz = flat_walk ? 1 : (a.ntz >= 4 ? 4 : tile_block(a.ntz));      // z may be ragged (last brick row shorter), y must divide
     if (p.KS == 3) dispatch_igemm_ck<3, 16, true>(p, a, nwg, st);
     else if (p.KS == 5) dispatch_igemm_ck<5, 8, false>(p, a, nwg, st);
     else if (p.CK == 64) dispatch_igemm_ck<1, 64, true>(p, a, nwg, st);
