@@ -37,6 +37,12 @@ WORKLOADS = {
 }
 
 
+# MI355SEG_CONV_MATH=bf16 is an opt-in reduced-precision experiment (bf16 MFMA operands in the k3 conv fwd/dgrad); the graded
+# configuration is the default: exact fp32 everywhere
+DTYPE = "f32" if not os.environ.get("MI355SEG_CONV_MATH", "").startswith("b") else \
+    "f32 tensors + fp32 accumulate, bf16 MFMA operands in conv fwd/dgrad (opt-in experiment, NOT the graded configuration)"
+
+
 def usable_cores():
     """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box
     exposes all 256 hardware threads but grants a share of them; oversubscribing 256 threads on that share is
@@ -177,7 +183,7 @@ def main():
     res = {
         "metric": "train voxels/sec (128^3 patches) 3D U-Net", "value": vox_per_step * args.steps / dt, "unit": "voxels/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": f"{args.workload}: UNet3D(1,2,32) fwd+BCE+bwd+Adam+Dice, x=[{B},{cin},{Dd},{Hh},{Ww}] fp32 per GPU, "
                                "random-init (kaiming) weights, data-parallel replicas with RCCL gradient all-reduce",
                    "global_batch": B * world, "patch": [Dd, Hh, Ww], "parallelism": f"dp{world}"},

@@ -339,6 +339,8 @@ static int check_geom(ConvGeom* g, const char* who) {
 
 using namespace seg;
 
+static bool conv_math_bf16() { static const char* e = getenv("MI355SEG_CONV_MATH"); return e && e[0] == 'b'; }
+
 // ---- patch embedding (kernel = stride, no padding; UNETR's k16 s16 conv, unetr.py:141-156) as a plain GEMM:
 // tokens x (Cin k^3) patch matrix (one strided copy) times the weight matrix in its own (Cout, Cin k^3) layout.
 namespace seg {
@@ -412,6 +414,12 @@ int mi355seg_conv3d_fwd_f32(const float* x, int ldx, const float* w, const float
     SEG_CHECK_ARG(x && w && y && ldx >= Cin && ldy >= Cout, "conv3d_fwd: null pointer or pitch < channels");
     SEG_CHECK_ARG((stats_sum == nullptr) == (stats_sq == nullptr), "conv3d_fwd: stats_sum/stats_sq must come together");
     hipStream_t st = (hipStream_t)stream;
+    if (conv_math_bf16() && k == 3 && stride == 1 && pad == 1 && Cin % 16 == 0 && Cout % 32 == 0 && W >= 8 && ldx % 4 == 0 && ((uintptr_t)x % 16) == 0) {
+        // opt-in reduced-precision mode (MI355SEG_CONV_MATH=bf16): bf16 MFMA operands, fp32 accumulate; never the default
+        rc = mi355seg_conv3d_bf16mma_f32(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, stream);
+        if (rc || !stats_sum) return rc;
+        return channel_sums(y, ldy, (long long)N * D * H * W, Cout, stats_sum, stats_sq, nullptr, 0, ws, ws_bytes, st);
+    }
     if (conv_mfma_supported(N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy))
         return conv_fwd_mfma(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, /*dgrad=*/0, stats_sum, stats_sq, ws, ws_bytes, st);
     if (patch_embed_supported(D, H, W, Cin, k, stride, pad)) {
@@ -454,6 +462,8 @@ int mi355seg_conv3d_dgrad_f32(const float* dy, int lddy, const float* w, float* 
     SEG_CHECK_ARG(dy && w && dx && lddy >= Cout && lddx >= Cin, "conv3d_dgrad: null pointer or pitch < channels");
     hipStream_t st = (hipStream_t)stream;
     // k3 s1 p1: dgrad is the same convolution with flipped taps and Cin<->Cout swapped
+    if (conv_math_bf16() && k == 3 && stride == 1 && pad == 1 && Cout % 16 == 0 && Cin % 32 == 0 && W >= 8 && lddy % 4 == 0 && ((uintptr_t)dy % 16) == 0)
+        return mi355seg_conv3d_bf16mma_f32(dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cin, Cout, 1, ws, ws_bytes, stream);
     if (conv_mfma_supported(N, D, H, W, Cout, Cin, k, stride, pad, lddy, lddx))
         return conv_fwd_mfma(dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cout, Cin, k, /*dgrad=*/1, nullptr, nullptr, ws, ws_bytes, st);
     if (conv_gather_dgrad_supported(N, D, H, W, Cin, Cout, k, stride, pad, lddy, lddx) && ((uintptr_t)dy % 16) == 0)

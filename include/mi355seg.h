@@ -60,6 +60,13 @@ int mi355seg_conv3d_fwd_f32(const float* x, int ldx, const float* w, const float
                             int k, int stride, int pad, double* stats_sum, double* stats_sq,
                             void* ws, size_t ws_bytes, void* stream);
 
+/* EXPERIMENTAL, opt-in (not used by the parity-graded paths): Conv3d k3 s1 p1 forward (dgrad = 0) or input gradient (dgrad != 0; then
+ * x is dy with Cout channels and y is dx with Cin channels) with bf16 MFMA operands -- activations rounded to bf16 while staged,
+ * weights packed as bf16, fp32 accumulation, fp32 tensors in HBM.  GEMM-K channels % 16 == 0, GEMM-N channels % 32 == 0, W >= 8. */
+size_t mi355seg_conv3d_bf16mma_ws_bytes(int Cin, int Cout);
+int mi355seg_conv3d_bf16mma_f32(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
+                                int N, int D, int H, int W, int Cin, int Cout, int dgrad, void* ws, size_t ws_bytes, void* stream);
+
 /* dx = conv_backward_input(dy, w).  D,H,W are the INPUT extents (of x/dx). */
 int mi355seg_conv3d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
                               int N, int D, int H, int W, int Cin, int Cout,

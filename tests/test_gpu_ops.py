@@ -456,6 +456,31 @@ def test_c_abi_rejects_bad_arguments(seg):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("case", [(1, 8, 8, 32, 32, 64), (2, 6, 9, 40, 16, 32), (1, 12, 12, 16, 64, 32)])
+def test_experimental_bf16_operand_conv(seg, case):
+    """The opt-in bf16-operand MFMA conv (k3 s1 p1): equals an fp64 convolution of the bf16-ROUNDED activations and
+    weights up to fp32 accumulation order -- i.e. the only deviation from the fp32 path is the operand rounding."""
+    N, D, H, W, Cin, Cout = case
+    L = seg.lib()
+    x, w, b = rnd(N, Cin, D, H, W, seed=1), rnd(Cout, Cin, 3, 3, 3, seed=2, scale=(2.0 / (27 * Cin)) ** 0.5), rnd(Cout, seed=3, scale=0.1)
+    xb, wb = x.bfloat16().double(), w.bfloat16().double()
+    want = TF.conv3d(xb, wb, b.double(), padding=1)
+    xg, wg = cl(x), w.cuda()
+    y = torch.empty(N, D, H, W, Cout, device="cuda")
+    ws = torch.empty(L.query("mi355seg_conv3d_bf16mma_ws_bytes", Cin, Cout), dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    L.call("mi355seg_conv3d_bf16mma_f32", xg.data_ptr(), Cin, wg.data_ptr(), b.cuda().data_ptr(), y.data_ptr(), Cout, N, D, H, W, Cin, Cout, 0,
+           ws.data_ptr(), ws.numel(), st)
+    assert (cf(y).double() - want).abs().max() < 2e-5 * max(1.0, float(want.abs().max()))
+    if Cin % 32 == 0:                                                    # dgrad: dx = conv_transpose(dy, w) on bf16-rounded operands
+        g = rnd(N, Cout, D, H, W, seed=4)
+        want_dx = TF.conv_transpose3d(g.bfloat16().double(), wb, padding=1)
+        dx = torch.empty(N, D, H, W, Cin, device="cuda")
+        L.call("mi355seg_conv3d_bf16mma_f32", cl(g).data_ptr(), Cout, wg.data_ptr(), None, dx.data_ptr(), Cin, N, D, H, W, Cin, Cout, 1,
+               ws.data_ptr(), ws.numel(), st)
+        assert (cf(dx).double() - want_dx).abs().max() < 2e-5 * max(1.0, float(want_dx.abs().max()))
+
+
 def test_layout_roundtrip(seg):
     F = seg.functional
     x = rnd(2, 5, 4, 6, 7, seed=1)
