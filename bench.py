@@ -39,8 +39,11 @@ WORKLOADS = {
 
 # MI355SEG_CONV_MATH=bf16 is an opt-in reduced-precision experiment (bf16 MFMA operands in the k3 conv fwd/dgrad); the graded
 # configuration is the default: exact fp32 everywhere
-DTYPE = "f32" if not os.environ.get("MI355SEG_CONV_MATH", "").startswith("b") else \
-    "f32 tensors + fp32 accumulate, bf16 MFMA operands in conv fwd/dgrad (opt-in experiment, NOT the graded configuration)"
+_MATH = os.environ.get("MI355SEG_CONV_MATH", "")
+DTYPE = "f32" if not _MATH.startswith("b") else (
+    "f32 via bf16x6 split MFMA in conv fwd/dgrad (three bf16 parts per operand, six products, fp32 accumulate; opt-in experiment, NOT the graded configuration)"
+    if "x6" in _MATH else
+    "f32 tensors + fp32 accumulate, bf16 MFMA operands in conv fwd/dgrad (opt-in experiment, NOT the graded configuration)")
 
 
 def usable_cores():

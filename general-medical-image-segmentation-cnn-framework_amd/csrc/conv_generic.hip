@@ -6,6 +6,7 @@
 // and packed-weight reads are fully coalesced.
 #include "common.h"
 #include "internal.h"
+#include <string.h>
 
 namespace seg {
 
@@ -339,7 +340,19 @@ static int check_geom(ConvGeom* g, const char* who) {
 
 using namespace seg;
 
-static bool conv_math_bf16() { static const char* e = getenv("MI355SEG_CONV_MATH"); return e && e[0] == 'b'; }
+// MI355SEG_CONV_MATH = "bf16" (reduced precision) or "bf16x6" (fp32-accurate split); unset = exact fp32 MFMA (the default)
+static int conv_math_mode() {
+    static const char* e = getenv("MI355SEG_CONV_MATH");
+    if (!e || e[0] != 'b') return 0;
+    return strstr(e, "x6") ? 2 : 1;
+}
+static bool conv_math_bf16() { return conv_math_mode() != 0; }
+static int conv_math_call(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W, int Cin,
+                          int Cout, int dgrad, void* ws, size_t ws_bytes, void* stream) {
+    if (conv_math_mode() == 2 && mi355seg_conv3d_bf16x6_ws_bytes(Cin, Cout) <= ws_bytes)
+        return mi355seg_conv3d_bf16x6_f32(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, dgrad, ws, ws_bytes, stream);
+    return mi355seg_conv3d_bf16mma_f32(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, dgrad, ws, ws_bytes, stream);
+}
 
 // ---- patch embedding (kernel = stride, no padding; UNETR's k16 s16 conv, unetr.py:141-156) as a plain GEMM:
 // tokens x (Cin k^3) patch matrix (one strided copy) times the weight matrix in its own (Cout, Cin k^3) layout.
@@ -397,6 +410,7 @@ size_t mi355seg_conv3d_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, i
     if (b > a) a = b;
     if (d > a) a = d;
     if (e > a) a = e;
+    if (k == 3 && stride == 1 && pad == 1 && mi355seg_conv3d_bf16x6_ws_bytes(Cin, Cout) > a) a = mi355seg_conv3d_bf16x6_ws_bytes(Cin, Cout);
     if (headk_supported(Cin, Cout, k, stride, pad, 4, 4, true) && headk_ws_bytes(Cin, Cout, k) > a) a = headk_ws_bytes(Cin, Cout, k);
     if (patch_embed_supported(D, H, W, Cin, k, stride, pad) && patch_embed_ws_bytes(N, D, H, W, Cin, Cout, k) > a) a = patch_embed_ws_bytes(N, D, H, W, Cin, Cout, k);
     if (stemk_supported(Cin, Cout, k, stride, pad, 2, 4) && headk_ws_bytes(Cout, Cin, k) > a) a = headk_ws_bytes(Cout, Cin, k);
@@ -416,7 +430,7 @@ int mi355seg_conv3d_fwd_f32(const float* x, int ldx, const float* w, const float
     hipStream_t st = (hipStream_t)stream;
     if (conv_math_bf16() && k == 3 && stride == 1 && pad == 1 && Cin % 16 == 0 && Cout % 32 == 0 && W >= 8 && ldx % 4 == 0 && ((uintptr_t)x % 16) == 0) {
         // opt-in reduced-precision mode (MI355SEG_CONV_MATH=bf16): bf16 MFMA operands, fp32 accumulate; never the default
-        rc = mi355seg_conv3d_bf16mma_f32(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, stream);
+        rc = conv_math_call(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, stream);
         if (rc || !stats_sum) return rc;
         return channel_sums(y, ldy, (long long)N * D * H * W, Cout, stats_sum, stats_sq, nullptr, 0, ws, ws_bytes, st);
     }
@@ -463,7 +477,7 @@ int mi355seg_conv3d_dgrad_f32(const float* dy, int lddy, const float* w, float* 
     hipStream_t st = (hipStream_t)stream;
     // k3 s1 p1: dgrad is the same convolution with flipped taps and Cin<->Cout swapped
     if (conv_math_bf16() && k == 3 && stride == 1 && pad == 1 && Cout % 16 == 0 && Cin % 32 == 0 && W >= 8 && lddy % 4 == 0 && ((uintptr_t)dy % 16) == 0)
-        return mi355seg_conv3d_bf16mma_f32(dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cin, Cout, 1, ws, ws_bytes, stream);
+        return conv_math_call(dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cin, Cout, 1, ws, ws_bytes, stream);
     if (conv_mfma_supported(N, D, H, W, Cout, Cin, k, stride, pad, lddy, lddx))
         return conv_fwd_mfma(dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cout, Cin, k, /*dgrad=*/1, nullptr, nullptr, ws, ws_bytes, st);
     if (conv_gather_dgrad_supported(N, D, H, W, Cin, Cout, k, stride, pad, lddy, lddx) && ((uintptr_t)dy % 16) == 0)

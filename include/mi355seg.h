@@ -67,6 +67,12 @@ size_t mi355seg_conv3d_bf16mma_ws_bytes(int Cin, int Cout);
 int mi355seg_conv3d_bf16mma_f32(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
                                 int N, int D, int H, int W, int Cin, int Cout, int dgrad, void* ws, size_t ws_bytes, void* stream);
 
+/* EXPERIMENTAL, opt-in: same contract, but every fp32 operand is split into three bf16 parts (x = h + m + l) and six bf16 MFMAs
+ * (hh, hm, mh, mm, hl, lh) form each product: fp32-level accuracy at 2.7x the fp32 matrix rate. */
+size_t mi355seg_conv3d_bf16x6_ws_bytes(int Cin, int Cout);
+int mi355seg_conv3d_bf16x6_f32(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
+                               int N, int D, int H, int W, int Cin, int Cout, int dgrad, void* ws, size_t ws_bytes, void* stream);
+
 /* dx = conv_backward_input(dy, w).  D,H,W are the INPUT extents (of x/dx). */
 int mi355seg_conv3d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
                               int N, int D, int H, int W, int Cin, int Cout,

@@ -481,6 +481,33 @@ def test_experimental_bf16_operand_conv(seg, case):
         assert (cf(dx).double() - want_dx).abs().max() < 2e-5 * max(1.0, float(want_dx.abs().max()))
 
 
+@pytest.mark.parametrize("case", [(1, 8, 8, 32, 32, 64), (2, 6, 9, 40, 32, 32), (1, 12, 12, 16, 64, 32)])
+def test_experimental_bf16x6_split_conv_is_fp32_accurate(seg, case):
+    """The opt-in split-precision conv (three bf16 parts per operand, six MFMAs per product) against an fp64 convolution of
+    the UNROUNDED fp32 tensors: it must be as close to the truth as the exact-fp32 MFMA path is (same 1e-6-level error)."""
+    N, D, H, W, Cin, Cout = case
+    L = seg.lib()
+    F = seg.functional
+    x, w, b = rnd(N, Cin, D, H, W, seed=1), rnd(Cout, Cin, 3, 3, 3, seed=2, scale=(2.0 / (27 * Cin)) ** 0.5), rnd(Cout, seed=3, scale=0.1)
+    want = TF.conv3d(x.double(), w.double(), b.double(), padding=1)
+    xg, wg = cl(x), w.cuda()
+    y = torch.empty(N, D, H, W, Cout, device="cuda")
+    ws = torch.empty(L.query("mi355seg_conv3d_bf16x6_ws_bytes", Cin, Cout), dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    L.call("mi355seg_conv3d_bf16x6_f32", xg.data_ptr(), Cin, wg.data_ptr(), b.cuda().data_ptr(), y.data_ptr(), Cout, N, D, H, W, Cin, Cout, 0,
+           ws.data_ptr(), ws.numel(), st)
+    err6 = (cf(y).double() - want).abs().max().item()
+    err32 = (cf(F.conv3d(xg, wg, b.cuda(), 1, 1)).double() - want).abs().max().item()
+    scale = float(want.abs().max())
+    assert err6 < 2e-6 * max(1.0, scale) and err6 < 4.0 * err32 + 1e-7
+    g = rnd(N, Cout, D, H, W, seed=4)
+    want_dx = TF.conv_transpose3d(g.double(), w.double(), padding=1)
+    dx = torch.empty(N, D, H, W, Cin, device="cuda")
+    L.call("mi355seg_conv3d_bf16x6_f32", cl(g).data_ptr(), Cout, wg.data_ptr(), None, dx.data_ptr(), Cin, N, D, H, W, Cin, Cout, 1,
+           ws.data_ptr(), ws.numel(), st)
+    assert (cf(dx).double() - want_dx).abs().max() < 2e-6 * max(1.0, float(want_dx.abs().max()))
+
+
 def test_layout_roundtrip(seg):
     F = seg.functional
     x = rnd(2, 5, 4, 6, 7, seed=1)

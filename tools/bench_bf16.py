@@ -24,4 +24,6 @@ def run(name, fn):
     ms = e0.elapsed_time(e1) / reps
     print(f"{name:10s} {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s (fp32-equivalent)")
 run("fp32 mfma", lambda: L.call("mi355seg_conv3d_fwd_f32", x.data_ptr(), Cin, w.data_ptr(), None, y.data_ptr(), Cout, N, D, H, W, Cin, Cout, 3, 1, 1, None, None, ws.data_ptr(), ws.numel(), st))
+ws6 = torch.empty(L.query("mi355seg_conv3d_bf16x6_ws_bytes", Cin, Cout), dtype=torch.uint8, device="cuda")
+run("bf16x6", lambda: L.call("mi355seg_conv3d_bf16x6_f32", x.data_ptr(), Cin, w.data_ptr(), None, y.data_ptr(), Cout, N, D, H, W, Cin, Cout, 0, ws6.data_ptr(), ws6.numel(), st))
 run("bf16 mfma", lambda: L.call("mi355seg_conv3d_bf16mma_f32", x.data_ptr(), Cin, w.data_ptr(), None, y.data_ptr(), Cout, N, D, H, W, Cin, Cout, 0, ws.data_ptr(), ws.numel(), st))
