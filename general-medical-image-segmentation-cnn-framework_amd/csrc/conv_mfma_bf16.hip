@@ -351,6 +351,165 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16x6_kernel(Bf16x6Args a)
     }
 }
 
+// Variant with the three bf16 planes of the halo tile in LDS (split once at staging time, three 16-byte A reads per tap and no
+// VALU work in the MFMA loop).  112 B per voxel: the 16-wide tile (648 halo voxels, 72.6 KB) still fits twice per CU.
+template <int BX, int MB, int NBW>
+__global__ __launch_bounds__(256, 2) void conv_igemm_bf16x6p_kernel(Bf16x6Args a) {
+    constexpr int PITCH = 56;                                    // bf16 per voxel: three 16-channel planes (h, m, l) + 8 pad = 112 B (7 slots)
+    constexpr int LPB = 32 / BX, LINES = 4 * MB * LPB, TY = 4, TZ = LINES / TY;
+    constexpr int HX = BX + 2, HY = TY + 2, HZ = TZ + 2, NVOX = HX * HY * HZ;
+    constexpr int NPIECE = NVOX * 4, NITER = (NPIECE + 255) / 256;
+    constexpr int NT = 32 * NBW;
+    constexpr int PLANE = 2 * NT * 8, STEP = 3 * PLANE, CHUNK = 27 * STEP;
+    extern __shared__ __attribute__((aligned(16))) __bf16 ldsp[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, i = lane & 31;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int ntile = t % a.nN;
+    int mt = t / a.nN;
+    const int per_n = a.ntx * a.nty * a.ntz;
+    const int n = mt / per_n; mt -= n * per_n;
+    const int zfull = a.ntz / a.bz, rowtiles = a.ntx * a.nty * a.bz;
+    int zrow = mt / rowtiles, bzz = a.bz;
+    if (zrow >= zfull) { zrow = zfull; bzz = a.ntz - zfull * a.bz; }
+    mt -= zrow * rowtiles;
+    const int blk = a.ntx * a.by * bzz;
+    const int b = mt / blk; mt -= b * blk;
+    const int txi = mt % a.ntx; mt /= a.ntx;
+    const int tyi = b * a.by + mt % a.by, tzi = zrow * a.bz + mt / a.by;
+    const int x0 = txi * BX, y0 = tyi * TY, z0 = tzi * TZ, n0 = ntile * NT;
+
+    f32x16 acc[MB][NBW];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[mb][nb][v] = 0.f;
+    int abase[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int m = wave * MB + mb;
+        const int line = m * LPB + i / BX, xx = i % BX;
+        abase[mb] = (((line / TY) * HY + (line % TY)) * HX + xx) * PITCH + 8 * h;
+    }
+    const __bf16* wlane = a.wq + (long long)ntile * a.nchunks * CHUNK + (h * NT + i) * 8;
+
+    f32x4 stage[NITER];
+    auto load_stage = [&](int chunk) {
+#pragma unroll
+        for (int it = 0; it < NITER; ++it) {
+            const int p = it * 256 + tid;
+            const int vox = p >> 2, part = p & 3;
+            const int hz = vox / (HY * HX), rem = vox % (HY * HX);
+            const int hy = rem / HX, hx = rem % HX;
+            const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (p < NPIECE && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+                v = *reinterpret_cast<const f32x4*>(a.x + ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.ldx + chunk * 16 + part * 4);
+            stage[it] = v;
+        }
+    };
+    auto write_stage = [&]() {
+#pragma unroll
+        for (int it = 0; it < NITER; ++it) {
+            const int p = it * 256 + tid;
+            if (p < NPIECE) {                                    // split once per staged value (the register variant splits per tap)
+                bf16x4 qh, qm, ql;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = stage[it][e];
+                    const __bf16 bh = (__bf16)v;
+                    const float r1 = v - (float)bh;
+                    const __bf16 bm = (__bf16)r1;
+                    qh[e] = bh; qm[e] = bm; ql[e] = (__bf16)(r1 - (float)bm);
+                }
+                __bf16* dst = ldsp + (p >> 2) * PITCH + (p & 3) * 4;
+                *reinterpret_cast<bf16x4*>(dst) = qh;
+                *reinterpret_cast<bf16x4*>(dst + 16) = qm;
+                *reinterpret_cast<bf16x4*>(dst + 32) = ql;
+            }
+        }
+    };
+
+    load_stage(0);
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        const __bf16* wp = wlane + (long long)chunk * CHUNK;
+        constexpr int PFD = 2;
+        bf16x8 bq[PFD + 1][NBW][3];
+#pragma unroll
+        for (int d = 0; d < PFD; ++d)
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bq[d][nb][pl] = *reinterpret_cast<const bf16x8*>(wp + d * STEP + pl * PLANE + nb * 256);
+        __syncthreads();
+        write_stage();
+        __syncthreads();
+        if (chunk + 1 < a.nchunks) load_stage(chunk + 1);
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+            const int tapoff = ((dz * HY + dy) * HX + dx) * PITCH;
+            const int cur = tap % (PFD + 1), fill = (tap + PFD) % (PFD + 1);
+            if (tap + PFD < 27) {
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        bq[fill][nb][pl] = *reinterpret_cast<const bf16x8*>(wp + (tap + PFD) * STEP + pl * PLANE + nb * 256);
+            }
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ldsp + abase[mb] + tapoff);
+                const bf16x8 am = *reinterpret_cast<const bf16x8*>(ldsp + abase[mb] + tapoff + 16);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(ldsp + abase[mb] + tapoff + 32);
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) {
+                    f32x16 c = acc[mb][nb];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bq[cur][nb][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[cur][nb][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bq[cur][nb][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bq[cur][nb][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[cur][nb][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[cur][nb][0], c, 0, 0, 0);
+                    acc[mb][nb] = c;
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+        const int col = n0 + nb * 32 + i;
+        const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int m = wave * MB + mb;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int r = (v & 3) + 8 * (v >> 2) + 4 * h;
+                const int line = m * LPB + r / BX, xx = r % BX;
+                const int gz = z0 + line / TY, gy = y0 + line % TY, gx = x0 + xx;
+                if (gz < a.D && gy < a.H && gx < a.W)
+                    a.y[((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.ldy + col] = acc[mb][nb][v] + bv;
+            }
+        }
+    }
+}
+
+template <int BX, int MB, int NBW>
+static void launch_bf16x6p(const Bf16x6Args& a, int nwg, hipStream_t st) {
+    constexpr int LINES = 4 * MB * (32 / BX), TZ = LINES / 4;
+    constexpr int LDSB = (BX + 2) * 6 * (TZ + 2) * 56 * 2;
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute((const void*)conv_igemm_bf16x6p_kernel<BX, MB, NBW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); set = true; }
+    hipLaunchKernelGGL((conv_igemm_bf16x6p_kernel<BX, MB, NBW>), dim3(nwg), dim3(256), LDSB, st, a);
+}
+
 template <int BX, int MB, int NBW>
 static void launch_bf16x6(const Bf16x6Args& a, int nwg, hipStream_t st) {
     constexpr int LINES = 4 * MB * (32 / BX), TZ = LINES / 4;
@@ -412,7 +571,9 @@ int mi355seg_conv3d_bf16x6_f32(const float* x, int ldx, const float* w, const fl
     SEG_CHECK_WS(mi355seg_conv3d_bf16x6_ws_bytes(Cin, Cout), ws_bytes);
     hipStream_t st = (hipStream_t)stream;
     __bf16* wq = (__bf16*)ws;
-    const int BX = (W % 32 == 0 || W > 48) ? 32 : 16;
+    static const char* regsplit_env = getenv("MI355SEG_BF16X6_REGSPLIT");
+    const bool planes = !(regsplit_env && regsplit_env[0] == '1');
+    const int BX = (planes && W % 16 == 0) ? 16 : ((W % 32 == 0 || W > 48) ? 32 : 16);
     const int NBW = Nc % 64 == 0 ? 2 : 1, NT = 32 * NBW, MB = 2;
     const int TZ = (4 * MB * (32 / BX)) / 4;
     const long long total = (long long)27 * Cin * Cout;
@@ -425,7 +586,9 @@ int mi355seg_conv3d_bf16x6_f32(const float* x, int ldx, const float* w, const fl
     const int nwg = N * a.ntx * a.nty * a.ntz * a.nN;
     const double vox = (double)N * D * H * W;
     ProfScope ps(PF_IGEMM, 2.0 * vox * 27 * Cin * Cout, 4.0 * (vox * (Cin + Cout) + 27.0 * Cin * Cout), st);
-    if (BX == 32) { if (NBW == 2) launch_bf16x6<32, 2, 2>(a, nwg, st); else launch_bf16x6<32, 2, 1>(a, nwg, st); }
+    static const char* regsplit = getenv("MI355SEG_BF16X6_REGSPLIT");        // A/B knob: 1 = split in registers per tap (fp32 tile in LDS)
+    if (BX == 16 && !(regsplit && regsplit[0] == '1')) { if (NBW == 2) launch_bf16x6p<16, 2, 2>(a, nwg, st); else launch_bf16x6p<16, 2, 1>(a, nwg, st); }
+    else if (BX == 32) { if (NBW == 2) launch_bf16x6<32, 2, 2>(a, nwg, st); else launch_bf16x6<32, 2, 1>(a, nwg, st); }
     else { if (NBW == 2) launch_bf16x6<16, 2, 2>(a, nwg, st); else launch_bf16x6<16, 2, 1>(a, nwg, st); }
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
