@@ -2,21 +2,23 @@
 """bench.py -- train voxels/sec of the 3D U-Net hot path on N MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
 
-A "step" is one full iteration of the reference's train loop (train.py:187-221) on one
-synthetic batch already resident in HBM: zero_grad, 2-channel gt, forward, argmax,
-BCE-with-logits, backward, (gradient all-reduce), Adam step, Dice counters.
-Workload = BASELINE.json configs[1]: UNet3D(1,2,32), x = fp32 [2,1,128,128,128] per GPU.
+N > 1 without a launcher (WORLD_SIZE unset): bench.py starts the N ranks itself (one child process per GPU,
+torchrun's environment contract, RCCL over xGMI) BEFORE any GPU call and only waits for them; under
+``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`` it is one of the ranks.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel family = the fp32-MFMA
-implicit-GEMM conv kernel, timed live with HIP events on the launch stream) and
-`cpu_baseline` (the CPU oracle == the reference's PyTorch-CPU arithmetic, timed on this
-box's host cores on a bounded sample).
+A "step" is one full iteration of the reference's train loop (train.py:187-221) on one synthetic batch already
+resident in HBM: zero_grad, 2-channel gt, forward, argmax, BCE-with-logits, backward, (gradient all-reduce),
+Adam step, Dice counters.  Workload = BASELINE.json configs[1]: UNet3D(1,2,32), x = fp32 [2,1,128,128,128] per GPU.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel family = the implicit-GEMM conv kernel, timed live
+with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle == the reference's PyTorch-CPU arithmetic,
+timed in a child process on this box's host cores, started before the first GPU call and overlapped with the GPU run).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,10 +26,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
-
-PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 matrix peak (spec, no sparsity)
+PEAK_BF16X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0   # fp32-equivalent peak of the split-precision path: six bf16 MFMAs per product
 PEAK_HBM_TBS = 8.0               # HBM3E spec peak
 
 WORKLOADS = {
@@ -36,14 +37,11 @@ WORKLOADS = {
     "unet3d_f32_1x64": (1, 2, 32, 1, 64, 64, 64, 1359168.0, 5376.0),         # BASELINE configs[0] size
 }
 
-
-# MI355SEG_CONV_MATH=bf16 is an opt-in reduced-precision experiment (bf16 MFMA operands in the k3 conv fwd/dgrad); the graded
-# configuration is the default: exact fp32 everywhere
-_MATH = os.environ.get("MI355SEG_CONV_MATH", "")
-DTYPE = "f32" if not _MATH.startswith("b") else (
-    "f32 via bf16x6 split MFMA in conv fwd/dgrad (three bf16 parts per operand, six products, fp32 accumulate; opt-in experiment, NOT the graded configuration)"
-    if "x6" in _MATH else
-    "f32 tensors + fp32 accumulate, bf16 MFMA operands in conv fwd/dgrad (opt-in experiment, NOT the graded configuration)")
+MATH_DTYPE = {
+    "fp32": "f32",
+    "bf16x6": "f32 (bf16x6 split MFMA: every fp32 conv operand = three bf16 parts, six bf16 products per fp32 product, fp32 accumulate)",
+    "bf16": "f32 tensors, bf16 MFMA operands in conv fwd/dgrad (reduced precision, opt-in experiment, NOT a graded configuration)",
+}
 
 
 def usable_cores():
@@ -66,11 +64,24 @@ def usable_cores():
     return min(n, 64)           # ATen CPU conv scaling is flat beyond a few dozen threads
 
 
-def cpu_baseline(sample_shape, steps=1):
-    """Oracle (== reference arithmetic on ATen CPU) train step timed on the host cores."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sample_shape, steps=1, reserve=2):
+    """Oracle (== reference arithmetic on ATen CPU) train step timed on the host cores.  Runs in a child process
+    of its own (``--cpu-baseline-child``) that never touches the GPU; ``reserve`` cores are left to the GPU
+    process's launch thread, which runs at the same time."""
+    import torch
     from oracle.nets import UNet3D as OracleUNet
     from oracle.step import train_step as oracle_step, weights_init_normal
-    cores = usable_cores()
+    cores = max(1, usable_cores() - reserve)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     m = OracleUNet(1, 2, 32)
@@ -80,61 +91,142 @@ def cpu_baseline(sample_shape, steps=1):
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(sample_shape, generator=g)
     gt = (torch.rand(sample_shape, generator=g) > 0.9).float()
-    oracle_step(m, opt, x, gt)                     # warm-up (oneDNN primitive creation)
+    # the warm-up (oneDNN primitive creation, first-touch of ~20 GB of activations) uses a half batch to stay inside the budget
+    oracle_step(m, opt, x[:1], gt[:1])
     t0 = time.perf_counter()
     for _ in range(steps):
         oracle_step(m, opt, x, gt)
     dt = (time.perf_counter() - t0) / steps
     vox = x.numel()
-    return {"value": vox / dt, "unit": "voxels/s", "cores": cores, "kind": "port",
-            "sample": f"1 warm-up + {steps} timed train step(s) of the CPU oracle (reference arithmetic, anomaly mode off) "
-                      f"on x={list(sample_shape)} fp32, {dt:.2f} s/step"}
+    return {"value": vox / dt, "unit": "voxels/s", "cores": cores, "cpu": cpu_model_name(), "kind": "port",
+            "sample": f"1 warm-up (batch 1) + {steps} timed train step(s) of the CPU oracle (reference arithmetic on ATen-CPU, anomaly mode off) "
+                      f"on x={list(sample_shape)} fp32 (cfg 2's full batch), {dt:.2f} s/step, {cores} threads "
+                      f"({reserve} of the box's share left to the concurrently running GPU process)"}
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="unet3d_f32_2x128", choices=sorted(WORKLOADS))
+    ap.add_argument("--conv-math", default=os.environ.get("MI355SEG_CONV_MATH") or "bf16x6", choices=["fp32", "bf16x6", "bf16"],
+                    help="arithmetic of the k3/k5 MFMA convolutions: bf16x6 (default; fp32-accurate split on the bf16 matrix cores) "
+                         "or fp32 (exact fp32 MFMA)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="1,1,128,128,128")
+    ap.add_argument("--cpu-sample", default="2,1,128,128,128")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-exact-leg", action="store_true", help="skip the untimed exact-fp32 steps reported beside the headline")
     ap.add_argument("--no-prof", action="store_true", help="skip the in-library HIP-event kernel timing")
     ap.add_argument("--prof-all", action="store_true", help="HIP-event timing of every kernel family (adds ~1 %% to the step)")
     ap.add_argument("--hip-graph", action="store_true", help="experiment: replay the whole train step as one captured HIP graph (N=1, implies --no-prof)")
     ap.add_argument("--dump-launches", default=None, help="write per-launch (family, ms, GFLOP, TFLOP/s) of the LAST timed step to this file")
-    args = ap.parse_args()
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="plumbing rehearsal without a GPU (tests only): the launch / rendezvous / reducer / barrier / JSON path on a "
+                         "toy torch.nn model over gloo; the line is marked rehearsal and is NOT a measurement")
+    return ap.parse_args()
 
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py), used
+    only when the stamp says they were taken on an ancestor of the code being run with the same conv math."""
+    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(tf))
+    except Exception:
+        return None, "no profiles/pmc_traffic.json"
+    stamp = rec.get("git_head")
+    if not stamp:
+        return None, "profiles/pmc_traffic.json carries no git stamp"
+    try:
+        rc = subprocess.run(["git", "-C", ROOT, "merge-base", "--is-ancestor", stamp, "HEAD"], capture_output=True, timeout=20).returncode
+    except Exception:
+        rc = None
+    if rc is None or rc > 1:
+        # not a git checkout (the GPU box gets a snapshot without .git): trust the stamped kernel source hash instead
+        import hashlib
+        h = hashlib.sha256()
+        for f in rec.get("kernel_sources", []):
+            try:
+                h.update(open(os.path.join(ROOT, f), "rb").read())
+            except Exception:
+                return None, f"stamped kernel source {f} is missing"
+        if h.hexdigest()[:16] != rec.get("kernel_sources_sha16"):
+            return None, "kernel sources changed since the PMC passes were taken (stale stamp)"
+        return rec, "offline rocprofv3 --pmc (kernel sources match the stamp)"
+    if rc == 1:
+        return None, f"PMC stamp {stamp[:10]} is not an ancestor of HEAD"
+    return rec, f"offline rocprofv3 --pmc at {stamp[:10]}"
+
+
+def main():
+    args = parse_args()
+    if args.cpu_baseline_child:
+        shape = tuple(int(v) for v in args.cpu_sample.split(","))
+        print(json.dumps(cpu_baseline(shape, steps=1)))
+        return 0
+
+    # ---- start the ranks ourselves when nobody else did (no GPU call has happened in this process)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        from importlib import import_module
+        sys.path.insert(0, ROOT)
+        import_module("mi355seg")
+        from mi355seg.distributed import self_launch
+        return self_launch(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:])
+
+    rank_env, world_env = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    cpu_child = None
+    if rank_env == 0 and world_env == 1 and not args.no_cpu_baseline and not args.rehearse_cpu:
+        # CPU baseline in its own process, started BEFORE the first GPU call and running beside the GPU work
+        cpu_child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--cpu-sample", args.cpu_sample],
+                                     stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+
+    import torch
+    import torch.distributed as dist
     import mi355seg
     from mi355seg import distributed as D
-    from mi355seg.engine import train_step, weights_init_normal
-    from mi355seg.models.three_d.unet3d import UNet3D
 
     # MI355SEG_DIST_BACKEND=gloo lets the N > 1 path be rehearsed on a one-GPU box (ranks share cuda:0); the
     # driver's real runs use the default: nccl == RCCL over xGMI, one rank per GPU
-    rank, world, local = D.init_from_env(backend=os.environ.get("MI355SEG_DIST_BACKEND"))
+    backend = os.environ.get("MI355SEG_DIST_BACKEND") or ("gloo" if args.rehearse_cpu else None)
+    rank, world, local = D.init_from_env(backend=backend)
     if args.gpus != world:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but the launcher formed WORLD_SIZE={world}; reporting {world}", file=sys.stderr)
         args.gpus = world
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the product path)"
-    local = local % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    L = mi355seg.lib()
 
     cin, ncls, width, B, Dd, Hh, Ww, flop_per_vox, bytes_per_vox = WORKLOADS[args.workload]
-    torch.manual_seed(0)
-    model = UNet3D(in_channels=cin, out_channels=ncls, init_features=width)
-    model.apply(weights_init_normal("kaiming"))
-    model = model.to(dev).train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=bool(args.hip_graph))
+    if args.rehearse_cpu:
+        dev = torch.device("cpu")
+        L = None
+        B, Dd, Hh, Ww = 2, 8, 8, 8
+        torch.manual_seed(100 + rank)                # different initial weights per rank: setup_replica must equalise them
+        model = torch.nn.Sequential(torch.nn.Conv3d(1, 4, 3, padding=1), torch.nn.BatchNorm3d(4), torch.nn.ReLU(), torch.nn.Conv3d(4, 2, 1)).train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        args.no_prof = True
+    else:
+        assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the product path)"
+        from mi355seg.engine import train_step, weights_init_normal
+        from mi355seg.models.three_d.unet3d import UNet3D
+        local = local % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        L = mi355seg.lib()
+        mi355seg.set_conv_math(args.conv_math)
+        torch.manual_seed(0)
+        model = UNet3D(in_channels=cin, out_channels=ncls, init_features=width)
+        model.apply(weights_init_normal("kaiming"))
+        model = model.to(dev).train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=bool(args.hip_graph))
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     x = torch.randn((B, cin, Dd, Hh, Ww), generator=g).to(dev)
     gt = (torch.rand((B, 1, Dd, Hh, Ww), generator=g) > 0.9).float().to(dev)
-    reducer = D.GradAllReducer(model) if world > 1 else None
+    reducer = D.setup_replica(model)                # world > 1: rank 0's parameters / buffers everywhere + bucketed gradient reducer
+    rank_devices = [str(dev)]
     if world > 1:
-        D.flatten_buffers(model)                    # buffer broadcast = two collectives, no copies
+        gathered = [None] * world
+        dist.all_gather_object(gathered, f"rank{rank}:{dev}")
+        rank_devices = gathered
 
     graphed = None
     if args.hip_graph:                  # experiment: the whole step as one hipGraphLaunch (single process, no kernel timing)
@@ -143,31 +235,51 @@ def main():
         args.no_prof = True
         graphed = GraphedTrainStep(model, opt, x, gt, warmup=3)
 
+    def rehearsal_step():
+        D.broadcast_buffers(model)
+        opt.zero_grad(set_to_none=True)
+        pred = model(x)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(pred, torch.cat([(gt == 0).float(), gt], 1))
+        loss.backward()
+        if reducer is not None:
+            reducer(model)
+        opt.step()
+        m = pred.argmax(1, keepdim=True)
+        c = torch.stack([gt.long().sum(), m.sum(), ((gt.long() & m) != 0).sum(), ((gt.long() | m) != 0).sum()])
+        return {"loss": loss.detach(), "counts": c}
+
     def step():
+        if args.rehearse_cpu:
+            return rehearsal_step()
         if graphed is not None:
             return graphed(x, gt, sync_metric=False)
         if world > 1:
             D.broadcast_buffers(model)
         return train_step(model, opt, x, gt, sync_metric=False, grad_hook=reducer)
 
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+
     for _ in range(args.warmup):
         out = step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
     if not args.no_prof:
         L.call("mi355seg_prof_reset")
         # default: bracket only the two MFMA conv families (51 launches per step); --prof-all brackets all ~400
         L.call("mi355seg_prof_enable", 1 if args.prof_all else 2 * 0b11)
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    L.call("mi355seg_prof_enable", 0)
+    if L is not None:
+        L.call("mi355seg_prof_enable", 0)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -176,8 +288,9 @@ def main():
 
     if rank != 0:
         if world > 1:
+            dist.barrier()
             dist.destroy_process_group()
-        return
+        return 0
 
     from mi355seg.utils.metric import metric_from_counts
     jac, dice = metric_from_counts(counts.cpu().tolist())
@@ -186,12 +299,22 @@ def main():
     res = {
         "metric": "train voxels/sec (128^3 patches) 3D U-Net", "value": vox_per_step * args.steps / dt, "unit": "voxels/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": MATH_DTYPE[args.conv_math], "data": "synthetic",
         "config": {"workload": f"{args.workload}: UNet3D(1,2,32) fwd+BCE+bwd+Adam+Dice, x=[{B},{cin},{Dd},{Hh},{Ww}] fp32 per GPU, "
-                               "random-init (kaiming) weights, data-parallel replicas with RCCL gradient all-reduce",
-                   "global_batch": B * world, "patch": [Dd, Hh, Ww], "parallelism": f"dp{world}"},
+                               f"random-init (kaiming) weights, data-parallel replicas with RCCL gradient all-reduce, conv math {args.conv_math}",
+                   "global_batch": B * world, "patch": [Dd, Hh, Ww], "parallelism": f"dp{world}", "conv_math": args.conv_math},
+        "rccl_ranks": world, "dist_backend": (dist.get_backend() if world > 1 else None), "rank_devices": rank_devices,
         "loss": float(loss.item()), "dice": dice,
     }
+    if args.rehearse_cpu:
+        res["rehearsal"] = "CPU plumbing rehearsal on a toy torch.nn model (tests/test_bench_launch.py); not a measurement"
+        res["data"] = "rehearsal"
+        print(json.dumps(res), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
+
     if not args.no_prof:
         import ctypes
         buf = (ctypes.c_double * 32)()
@@ -218,29 +341,57 @@ def main():
         n, tms, fl, by = buf[0], buf[1], buf[2], buf[3]
         if n > 0 and tms > 0:
             ach = fl / (tms * 1e-3) / 1e12
+            peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16x6": PEAK_BF16X6_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS}[args.conv_math]
+            rec, note = pmc_traffic()
             traffic = None
-            tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tf):
-                try:
-                    traffic = json.load(open(tf)).get("conv_igemm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                               "kernel": "conv_igemm_kernel (Conv3d k3 fwd+dgrad, fp32 MFMA 32x32x2)",
-                               "launches": int(n), "avg_launch_ms": tms / n,
+            if rec is not None and rec.get("conv_math", "fp32") == args.conv_math:
+                traffic = rec.get("conv_igemm_bytes_per_launch")
+            elif rec is not None:
+                note = f"PMC passes were taken with conv math {rec.get('conv_math', 'fp32')}, this run uses {args.conv_math}"
+            kern = {"fp32": "conv_igemm_kernel<F32> (Conv3d k3 fwd+dgrad, v_mfma_f32_32x32x2_f32)",
+                    "bf16x6": "conv_igemm_kernel<BF16X3> (Conv3d k3 fwd+dgrad, six v_mfma_f32_32x32x16_bf16 per fp32 product)",
+                    "bf16": "conv_igemm_kernel<BF16> (Conv3d k3 fwd+dgrad, v_mfma_f32_32x32x16_bf16)"}[args.conv_math]
+            res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                               "frac": ach / peak, "traffic": traffic, "traffic_source": note,
+                               "kernel": kern, "launches": int(n), "avg_launch_ms": tms / n,
+                               "peak_basis": {"fp32": "fp32 MFMA 157.3 TFLOP/s", "bf16x6": "bf16 MFMA 2500 TFLOP/s / 6 products = 416.7 fp32-equivalent TFLOP/s",
+                                              "bf16": "bf16 MFMA 2500 TFLOP/s"}[args.conv_math],
+                               "achieved_counts": "algorithmic fp32 FLOPs (2 x voxels x 27 x Cin x Cout per launch), not MFMA issue slots",
                                "algorithmic_gflop_per_launch": fl / n / 1e9, "hbm_algorithmic_gbs": by / (tms * 1e-3) / 1e9}
-    t_mfma = flop_per_vox * B * Dd * Hh * Ww / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e3
+    peak_step = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16x6": PEAK_BF16X6_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS}[args.conv_math]
+    t_mfma = flop_per_vox * B * Dd * Hh * Ww / (peak_step * 1e12) * 1e3
     t_hbm = bytes_per_vox * B * Dd * Hh * Ww / (PEAK_HBM_TBS * 1e12) * 1e3
     res["step_roofline"] = {"conv_t_mfma_ms": t_mfma, "conv_t_hbm_ms": t_hbm, "frac_of_mfma_bound": t_mfma / ms, "frac_of_hbm_bound": t_hbm / ms}
-    if world == 1 and not args.no_cpu_baseline:
-        shape = tuple(int(v) for v in args.cpu_sample.split(","))
-        res["cpu_baseline"] = cpu_baseline(shape, steps=3)
-        res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
-    print(json.dumps(res))
+
+    if args.conv_math != "fp32" and not args.no_exact_leg and graphed is None and world == 1:
+        # the same step with the exact-fp32 MFMA convolutions, reported beside the headline (outside the timed region)
+        mi355seg.set_conv_math("fp32")
+        for _ in range(2):
+            step()
+        sync()
+        t1 = time.perf_counter()
+        nx = max(3, min(args.steps, 5))
+        for _ in range(nx):
+            step()
+        sync()
+        res["exact_fp32_ms_per_step"] = (time.perf_counter() - t1) / nx * 1e3
+        mi355seg.set_conv_math(args.conv_math)
+
+    if cpu_child is not None:
+        try:
+            txt, _ = cpu_child.communicate(timeout=600)
+            res["cpu_baseline"] = json.loads(txt.strip().splitlines()[-1])
+            res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+        except Exception as e:          # the GPU numbers stand on their own; say why the CPU leg is missing
+            cpu_child.kill()
+            res["cpu_baseline"] = None
+            res["cpu_baseline_error"] = repr(e)
+    print(json.dumps(res), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -4,4 +4,20 @@ forward/backward, losses and Dice metric as hand-written gfx950 kernels behind a
 from . import functional
 from ._lib import LIB_PATH, Mi355SegError, lib
 
-__all__ = ["functional", "lib", "LIB_PATH", "Mi355SegError"]
+_MATH = {"fp32": 0, "bf16": 1, "bf16x6": 2}
+
+
+def set_conv_math(mode):
+    """Arithmetic of the MFMA convolutions on fp32 tensors: "fp32" (exact fp32 MFMA), "bf16x6" (fp32-accurate split on
+    the bf16 matrix cores) or "bf16" (reduced precision, experiments only).  See include/mi355seg.h."""
+    if mode not in _MATH:
+        raise ValueError(f"conv math must be one of {sorted(_MATH)}, got {mode!r}")
+    lib().call("mi355seg_set_conv_math", _MATH[mode])
+
+
+def get_conv_math():
+    code = lib().query("mi355seg_get_conv_math")
+    return next(k for k, v in _MATH.items() if v == code)
+
+
+__all__ = ["functional", "lib", "LIB_PATH", "Mi355SegError", "set_conv_math", "get_conv_math"]

@@ -340,16 +340,25 @@ static int check_geom(ConvGeom* g, const char* who) {
 
 using namespace seg;
 
-// MI355SEG_CONV_MATH = "bf16" (reduced precision) or "bf16x6" (fp32-accurate split); unset = exact fp32 MFMA (the default)
-static int conv_math_mode() {
-    static const char* e = getenv("MI355SEG_CONV_MATH");
-    if (!e || e[0] != 'b') return 0;
-    return strstr(e, "x6") ? 2 : 1;
+// Arithmetic of the MFMA convolutions on fp32 tensors (mi355seg_set_conv_math; initial value from MI355SEG_CONV_MATH):
+// MI355SEG_MATH_FP32 exact fp32 MFMA, MI355SEG_MATH_BF16X6 fp32-accurate split on the bf16 matrix cores, MI355SEG_MATH_BF16
+// reduced precision (bf16 operands).
+static int conv_math_from_env() {
+    const char* e = getenv("MI355SEG_CONV_MATH");
+    if (!e || !e[0]) return MI355SEG_MATH_DEFAULT;
+    if (!strcmp(e, "fp32") || !strcmp(e, "f32")) return MI355SEG_MATH_FP32;
+    if (!strcmp(e, "bf16x6")) return MI355SEG_MATH_BF16X6;
+    if (!strcmp(e, "bf16")) return MI355SEG_MATH_BF16;
+    fprintf(stderr, "libmi355seg: MI355SEG_CONV_MATH=%s is not one of fp32 / bf16x6 / bf16; using the default\n", e);
+    return MI355SEG_MATH_DEFAULT;
 }
-static bool conv_math_bf16() { return conv_math_mode() != 0; }
+static int g_conv_math = conv_math_from_env();
+static int conv_math_mode() { return g_conv_math; }
+static bool conv_math_bf16() { return conv_math_mode() != MI355SEG_MATH_FP32; }
 static int conv_math_call(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W, int Cin,
                           int Cout, int dgrad, void* ws, size_t ws_bytes, void* stream) {
-    if (conv_math_mode() == 2 && mi355seg_conv3d_bf16x6_ws_bytes(Cin, Cout) <= ws_bytes)
+    // never a silent precision downgrade: a workspace that cannot hold the split weights is an error (EWORKSPACE)
+    if (conv_math_mode() == MI355SEG_MATH_BF16X6)
         return mi355seg_conv3d_bf16x6_f32(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, dgrad, ws, ws_bytes, stream);
     return mi355seg_conv3d_bf16mma_f32(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, dgrad, ws, ws_bytes, stream);
 }
@@ -398,6 +407,13 @@ static int patch_embed_matrix(const float* x, int ldx, int N, int D, int H, int 
 using namespace seg;
 
 extern "C" {
+
+int mi355seg_set_conv_math(int mode) {
+    SEG_CHECK_ARG(mode == MI355SEG_MATH_FP32 || mode == MI355SEG_MATH_BF16 || mode == MI355SEG_MATH_BF16X6, "set_conv_math: unknown mode %d", mode);
+    g_conv_math = mode;
+    return MI355SEG_OK;
+}
+int mi355seg_get_conv_math(void) { return g_conv_math; }
 
 size_t mi355seg_conv3d_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
     size_t a = conv_generic_ws_bytes(N, D, H, W, Cin, Cout, k, stride, pad);

@@ -25,6 +25,14 @@
 
 namespace seg {
 
+// Timing-experiment switches (ablations of the main loop, tile-shape overrides) exist only in a -DMI355SEG_TUNE build
+// (make TUNE=1); the shipped kernels carry none of them.
+#ifdef MI355SEG_TUNE
+#define SEG_DBG(a, bit) ((a).dbg & (bit))
+#else
+#define SEG_DBG(a, bit) 0
+#endif
+
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
@@ -62,7 +70,7 @@ struct IgemmArgs {
     int nM;             // M-tiles
     int ksplit, cps;    // K-splits and chunks per split (nchunks == ksplit * cps)
     long long split_stride;   // floats between the output slabs of consecutive K-splits
-    int dbg;            // timing experiments only (MI355SEG_DBG): 1 no re-staging, 2 B loaded once per chunk, 4 no stores
+    int dbg;            // -DMI355SEG_TUNE builds only (MI355SEG_DBG): 1 no re-staging, 2 B loaded once per chunk, 4 no stores; else 0 and unread
     // ---- gather / scatter generalisation (strided Conv3d fwd + per-phase dgrad, ConvT with narrow Cout)
     int Di, Hi, Wi;     // extents of the volume x points at   (input voxel = base * in_mul + toff[tap])
     int Do, Ho, Wo;     // extents of the volume y points at   (output voxel = base * out_mul + child + c{z,y,x})
@@ -217,12 +225,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
         for (int d = 0; d < PFD; ++d)
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb) bq[d][nb] = *reinterpret_cast<const f32x4*>(wp + d * STEP_FLOATS + nb * 128);
-        if (!(a.dbg & 1) || chunk == c0) {
+        if (!SEG_DBG(a, 1) || chunk == c0) {
         __syncthreads();                 // every wave is done reading the previous chunk
         write_stage();
         __syncthreads();
         }
-        if (chunk + 1 < c1 && !(a.dbg & 1)) load_stage(chunk + 1);
+        if (chunk + 1 < c1 && !SEG_DBG(a, 1)) load_stage(chunk + 1);
 #pragma unroll
         for (int tap = 0; tap < NTAP; ++tap) {
             const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
             for (int kk = 0; kk < CK / 8; ++kk) {
                 const int step = tap * (CK / 8) + kk;
                 const int cur = step % (PFD + 1), fill = (step + PFD) % (PFD + 1);
-                if (step + PFD < NSTEP && !(a.dbg & 2)) {
+                if (step + PFD < NSTEP && !SEG_DBG(a, 2)) {
 #pragma unroll
                     for (int nb = 0; nb < NBW; ++nb)
                         bq[fill][nb] = *reinterpret_cast<const f32x4*>(wp + (step + PFD) * STEP_FLOATS + nb * 128);
@@ -239,7 +247,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
                 f32x4 av[MB];
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) av[mb] = *reinterpret_cast<const f32x4*>(lds + abase[mb] + tapoff + kk * 8);
-                if (a.dbg & 8) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -247,7 +254,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
 #pragma unroll
                         for (int nb = 0; nb < NBW; ++nb)
                             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb][s], bq[cur][nb][s], acc[mb][nb], 0, 0, 0);
-                if (a.dbg & 8) __builtin_amdgcn_s_setprio(0);
             }
         }
     }
@@ -276,8 +282,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
                 // partial tiles (extents that are not tile multiples): rows outside the volume are dropped
                 const bool inside = (z0 + line / T::TY) < a.D && (y0 + line % T::TY) < a.H && (x0 + xx) < a.W &&
                                     gz < a.Do && gy < a.Ho && gx < a.Wo;
+#ifdef MI355SEG_TUNE
                 if (inside && (!(a.dbg & 4) || val == 12345.678f))
-                yout[((((long long)n * a.Do + gz) * a.Ho + gy) * a.Wo + gx) * a.ldy + col] = val;
+#else
+                if (inside)
+#endif
+                    yout[((((long long)n * a.Do + gz) * a.Ho + gy) * a.Wo + gx) * a.ldy + col] = val;
                 if (inside) { s1 += val; s2 += val * val; }
             }
         }
@@ -423,7 +433,11 @@ static bool igemm_plan(int KS, int N, int D, int H, int W, int Kc, int Nc, int n
     long long m2 = tiles(2, &tz2), m1 = tiles(1, &tz1);
     (void)m1;
     int MB;
+#ifdef MI355SEG_TUNE
     static const char* force = getenv("MI355SEG_IGEMM_MB");          // tuning knob: 1 / 2 force that M-block count
+#else
+    constexpr const char* force = nullptr;
+#endif
     int tz3;
     const long long m3 = tiles(3, &tz3);
     if (KS == 5) MB = 1;                                             // the 5^3 halo of a 2-block tile does not fit twice per CU
@@ -497,7 +511,11 @@ static int tile_block(int nt) { return nt % 4 == 0 ? 4 : (nt % 2 == 0 ? 2 : 1); 
 
 static void dispatch_igemm(const IgemmPlan& p, const IgemmArgs& a_in, int nwg, hipStream_t st) {
     IgemmArgs a = a_in;
+#ifdef MI355SEG_TUNE
     static const char* flat_walk = getenv("MI355SEG_IGEMM_LINEAR_WALK");      // A/B knob: 1 = plain x, y, z tile order
+#else
+    constexpr const char* flat_walk = nullptr;
+#endif
     a.by = flat_walk ? 1 : tile_block(a.nty);
     a.bz = flat_walk ? 1 : (a.ntz >= 4 ? 4 : tile_block(a.ntz));      // z may be ragged (last brick row shorter), y must divide
     if (p.KS == 3) dispatch_igemm_ck<3, 16, true>(p, a, nwg, st);
@@ -506,7 +524,11 @@ static void dispatch_igemm(const IgemmPlan& p, const IgemmArgs& a_in, int nwg, h
     else dispatch_igemm_ck<1, 16, true>(p, a, nwg, st);
 }
 
+#ifdef MI355SEG_TUNE
 static int dbg_flags() { static const char* e = getenv("MI355SEG_DBG"); return e ? atoi(e) : 0; }
+#else
+static constexpr int dbg_flags() { return 0; }
+#endif
 static int pack_grid(long long total) { return (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256); }
 
 // K-split factor for layers with too few tiles to fill 2 x 256 workgroup slots

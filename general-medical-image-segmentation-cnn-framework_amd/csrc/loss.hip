@@ -127,6 +127,17 @@ __global__ __launch_bounds__(256) void counts_finalize_kernel(const long long* _
     if (threadIdx.x == 0) for (int j = 0; j < 4; ++j) counts[j] = acc[j];
 }
 
+// train.py:190-193: gt_back = (gt == 0); gt = cat([gt_back, gt], dim=1) as float, one pass
+__global__ __launch_bounds__(256) void two_channel_gt_kernel(const float* __restrict__ gt, float* __restrict__ out, long long N, long long S) {
+    const long long total = N * S;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / S, s = i - n * S;
+        const float v = gt[i];
+        out[(2 * n) * S + s] = v == 0.f ? 1.f : 0.f;
+        out[(2 * n + 1) * S + s] = v;
+    }
+}
+
 // one pass over logits + one-hot targets: BCE sum, argmax(pred), argmax(gt), Dice counters
 __global__ __launch_bounds__(kLossThreads) void bce_argmax_dice_kernel(const float* __restrict__ x, const float* __restrict__ t,
         long long N, int K, long long S, int64_t* __restrict__ mask, double* __restrict__ lpart, long long* __restrict__ cpart) {
@@ -307,6 +318,13 @@ int mi355seg_dice_counts_i64(const int64_t* gt, const int64_t* pred, long long n
     hipLaunchKernelGGL(dice_counts_kernel, dim3(nblk), dim3(kLossThreads), 0, st, gt, pred, numel, (long long*)ws);
     SEG_CHECK_LAUNCH();
     hipLaunchKernelGGL(counts_finalize_kernel, dim3(1), dim3(256), 0, st, (const long long*)ws, nblk, counts);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+int mi355seg_two_channel_gt_f32(const float* gt, float* out, long long N, long long S, void* stream) {
+    SEG_CHECK_ARG(gt && out && N > 0 && S > 0, "two_channel_gt: bad arguments");
+    hipLaunchKernelGGL(two_channel_gt_kernel, dim3(loss_grid(N * S) * 2), dim3(256), 0, (hipStream_t)stream, gt, out, N, S);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }

@@ -32,6 +32,48 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def self_launch(nproc, argv, env=None):
+    """Start ``nproc`` ranks of the running script (``argv`` = [script, args...]) as child processes, one per GPU, with
+    the torchrun environment contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), wait for them and
+    return the worst exit code.  This is what ``accelerate launch`` does for the reference (train.py:167-169 runs under
+    it).  The parent never touches the GPU (a process that has initialised HIP must not exec or fork workers), it only
+    waits; the children inherit stdout / stderr, so rank 0's output is the job's output."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(nproc):
+        e = dict(os.environ if env is None else env)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), LOCAL_WORLD_SIZE=str(nproc),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this driver
+        e.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // nproc)))
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=e))
+    import time
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            for p in procs:
+                if p.poll() not in (None, 0) and not rc:         # one rank died: the others would hang in a collective
+                    rc = p.returncode
+                    for q in procs:
+                        if q.poll() is None:
+                            q.terminate()
+            time.sleep(0.05)
+        for p in procs:
+            rc = rc or p.returncode
+    except KeyboardInterrupt:
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        raise
+    return rc
+
+
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -127,6 +169,40 @@ class GradAllReducer:
                 torch._foreach_copy_(dsts, srcs)              # one multi-tensor launch per bucket instead of one copy per parameter
             self._works[bi] = None
             self._pending[bi] = len(bucket)
+
+
+def broadcast_parameters(model, src=0):
+    """DDP's wrap-time parameter broadcast (accelerator.prepare -> DistributedDataParallel.__init__, reference
+    train.py:167-169): every rank starts from rank ``src``'s parameters, whatever its own random init drew.  One flat
+    collective per dtype; a no-op for a single process.  Returns the number of parameters sent."""
+    if world_size() == 1:
+        return 0
+    params = [p for p in model.parameters()]
+    sent = 0
+    for dtype in sorted({p.dtype for p in params}, key=str):
+        group = [p for p in params if p.dtype == dtype]
+        flat = torch.cat([p.detach().reshape(-1) for p in group])
+        dist.broadcast(flat, src=src)
+        off = 0
+        with torch.no_grad():
+            for p in group:
+                n = p.numel()
+                p.copy_(flat[off:off + n].view_as(p))
+                off += n
+        sent += off
+    return sent
+
+
+def setup_replica(model, bucket_mb=32.0, overlap=True):
+    """Everything ``accelerator.prepare(model)`` does for the data-parallel replicas (train.py:167-169): rank 0's
+    parameters and buffers overwrite every rank's, the buffers are flattened for the per-step broadcast, and the
+    bucketed gradient reducer is armed.  Returns the reducer (None for a single process)."""
+    if world_size() == 1:
+        return None
+    broadcast_parameters(model)
+    flatten_buffers(model)
+    broadcast_buffers(model)
+    return GradAllReducer(model, bucket_mb=bucket_mb, overlap=overlap)
 
 
 def flatten_buffers(model):

@@ -11,9 +11,8 @@ from .utils.metric import metric_from_counts
 
 
 def two_channel_gt(gt):
-    """train.py:190-193: gt_back = (gt == 0); gt = cat([gt_back, gt], dim=1) as float."""
-    gt = gt.to(torch.float32)
-    return torch.cat([(gt == 0).to(torch.float32), gt], dim=1)
+    """train.py:190-193: gt_back = (gt == 0); gt = cat([gt_back, gt], dim=1) as float (one kernel, no torch.cat)."""
+    return F.two_channel_gt(gt)
 
 
 def train_step(model, optimizer, x, gt, criterion=None, sync_metric=True, grad_hook=None):
@@ -32,13 +31,14 @@ def train_step(model, optimizer, x, gt, criterion=None, sync_metric=True, grad_h
     else:
         pred = model(x)
     if criterion is None:
-        loss = F.bce_with_logits(pred, gt2)
+        # nn.BCEWithLogitsLoss + pred.argmax + gt.argmax + the Dice counters in one pass over the logits
+        loss, mask, counts = F.bce_argmax_dice(pred, gt2)
     else:
         loss = criterion(pred, gt2)
-    with torch.no_grad():
-        mask = F.argmax_channels(pred)
-        gt_lab = F.argmax_channels(gt2)
-        counts = F.dice_counts(gt_lab, mask)
+        with torch.no_grad():
+            mask = F.argmax_channels(pred)
+            gt_lab = F.argmax_channels(gt2)
+            counts = F.dice_counts(gt_lab, mask)
     loss.backward()
     if grad_hook is not None:
         grad_hook(model)

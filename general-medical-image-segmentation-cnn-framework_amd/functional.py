@@ -643,21 +643,56 @@ def dice_counts(gt, pred):
     return out
 
 
+class _BCEArgmaxDice(Function):
+    """train.py:204,209,221 in ONE pass over the logits: BCE-with-logits mean loss (differentiable w.r.t. the logits),
+    pred.argmax(1, keepdim) and the four integer Dice counters of metric(gt.argmax, mask)."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        _require_cuda(logits, "bce_argmax_dice input")
+        logits, target = logits.contiguous(), target.contiguous().to(torch.float32)
+        if logits.shape != target.shape:
+            raise ValueError(f"Target size ({tuple(target.shape)}) must be the same as input size ({tuple(logits.shape)})")
+        N, K = logits.shape[0], logits.shape[1]
+        S = logits[0, 0].numel()
+        L = lib()
+        ws = workspace(L.query("mi355seg_loss_ws_bytes", logits.numel()), logits.device)
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        mask = torch.empty((N, 1) + tuple(logits.shape[2:]), dtype=torch.int64, device=logits.device)
+        counts = torch.empty(4, dtype=torch.int64, device=logits.device)
+        L.call("mi355seg_bce_argmax_dice_f32", _p(logits), _p(target), N, K, S, _p(loss), _p(mask), _p(counts),
+               _p(ws), ws.numel(), _stream())
+        ctx.save_for_backward(logits, target)
+        ctx.mark_non_differentiable(mask, counts)
+        return loss, mask, counts
+
+    @staticmethod
+    def backward(ctx, g, _gmask, _gcounts):
+        logits, target = ctx.saved_tensors
+        g = g.contiguous().to(torch.float32)
+        d = torch.empty_like(logits)
+        lib().call("mi355seg_bce_logits_bwd_f32", _p(logits), _p(target), _p(g), logits.numel(), _p(d), _stream())
+        return d, None
+
+
 def bce_argmax_dice(logits, target):
-    """Fused tail of the train step: (loss, mask int64 [N,1,...], counts int64[4]).
-    Forward only (use bce_with_logits for the differentiable loss)."""
-    _require_cuda(logits, "bce_argmax_dice input")
-    logits, target = logits.contiguous(), target.contiguous().to(torch.float32)
-    N, K = logits.shape[0], logits.shape[1]
-    S = logits[0, 0].numel()
-    L = lib()
-    ws = workspace(L.query("mi355seg_loss_ws_bytes", logits.numel()), logits.device)
-    loss = torch.empty((), dtype=torch.float32, device=logits.device)
-    mask = torch.empty((N, 1) + tuple(logits.shape[2:]), dtype=torch.int64, device=logits.device)
-    counts = torch.empty(4, dtype=torch.int64, device=logits.device)
-    L.call("mi355seg_bce_argmax_dice_f32", _p(logits), _p(target), N, K, S, _p(loss), _p(mask), _p(counts),
-           _p(ws), ws.numel(), _stream())
-    return loss, mask, counts
+    """Fused tail of the train step: (loss, mask int64 [N,1,...], counts int64[4]); the loss carries the autograd
+    edge of nn.BCEWithLogitsLoss()."""
+    return _BCEArgmaxDice.apply(logits, target)
+
+
+def two_channel_gt(gt):
+    """train.py:190-193 as one kernel: cat([(gt == 0), gt], dim=1) as float for a single-channel label volume."""
+    if not gt.is_cuda:
+        raise Mi355SegError(f"two_channel_gt input: expected a tensor on an MI355X (cuda/HIP) device, got {gt.device}")
+    gt = gt.contiguous().to(torch.float32)
+    if gt.dim() < 3 or gt.shape[1] != 1:
+        raise Mi355SegError(f"two_channel_gt: expected [N,1,...], got {tuple(gt.shape)}")
+    N = gt.shape[0]
+    S = gt[0].numel()
+    out = torch.empty((N, 2) + tuple(gt.shape[2:]), dtype=torch.float32, device=gt.device)
+    lib().call("mi355seg_two_channel_gt_f32", _p(gt), _p(out), N, S, _stream())
+    return out
 
 
 def dice_sums(x, t, apply_sigmoid=False):

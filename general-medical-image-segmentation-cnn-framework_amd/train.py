@@ -63,9 +63,9 @@ def train(config, model, logger):
     model.train()
     scalars = open(os.path.join(config.hydra_path, "scalars.jsonl"), "a") if rank == 0 else None
     loader = make_loader(config, device, config.in_classes, seed=1234 + rank)
-    reducer = D.GradAllReducer(model) if world > 1 else None
-    if world > 1:
-        D.flatten_buffers(model)                    # buffer broadcast = two collectives, no copies
+    # accelerator.prepare (train.py:167-169): rank 0's parameters / buffers everywhere (after the optional checkpoint
+    # load, so a resumed rank 0 wins), flat buffers for the per-step broadcast, bucketed gradient reducer
+    reducer = D.setup_replica(model)
     epochs = config.epochs - elapsed_epochs
     iteration = elapsed_epochs * len(loader)
     loss_meter, dice_meter = AverageMeter(), AverageMeter()
@@ -104,6 +104,15 @@ def main(argv=None, conf_dir=None):
     conf_dir = conf_dir or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "conf")
     config = compose(conf_dir, argv, job_name="train")
     parse_patch_size(config)
+    # ``accelerate launch --num_processes N train.py`` of the reference: ``config.gpus=N`` (or MI355SEG_GPUS=N) starts the N
+    # ranks from here when no launcher did (WORLD_SIZE unset) -- before this process has made any GPU call -- and waits
+    gpus = int(config.get("gpus", os.environ.get("MI355SEG_GPUS", 1)) or 1)
+    if gpus > 1 and "WORLD_SIZE" not in os.environ:
+        script = os.path.abspath(sys.argv[0]) if sys.argv and sys.argv[0].endswith(".py") else os.path.abspath(__file__)
+        rc = D.self_launch(gpus, [script] + argv)
+        if rc:
+            raise SystemExit(rc)
+        return config, None
     model = build_model(config)                          # train.py:324-373
     model.apply(weights_init_normal(config.init_type))   # train.py:374
     logger = get_logger(config)

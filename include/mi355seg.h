@@ -44,6 +44,21 @@ extern "C" {
 const char* mi355seg_last_error(void);
 int mi355seg_version(void);
 
+/* Arithmetic of the MFMA convolutions (k3 / k5 Conv3d forward, input gradient and weight gradient) on fp32 tensors.  The
+ * reference's arithmetic for these is ATen fp32 (unet3d.py:80-98 through nn.Conv3d); all three modes accumulate in fp32:
+ *   FP32   -- v_mfma_f32_32x32x2_f32, exact fp32 products;
+ *   BF16X6 -- every fp32 operand is split into three bf16 parts (x = h + m + l, 24 mantissa bits) and six
+ *             v_mfma_f32_32x32x16_bf16 (hh, hm, mh, mm, hl, lh) form each product: fp32-level accuracy (the dropped
+ *             terms are below 2^-23 of a product) at 2.7x the fp32 matrix rate;
+ *   BF16   -- operands rounded to bf16 (reduced precision; never selected implicitly).
+ * Process-wide, read at each launch.  Initial value: environment MI355SEG_CONV_MATH = fp32 | bf16x6 | bf16, else the default. */
+#define MI355SEG_MATH_FP32 0
+#define MI355SEG_MATH_BF16 1
+#define MI355SEG_MATH_BF16X6 2
+#define MI355SEG_MATH_DEFAULT MI355SEG_MATH_FP32
+int mi355seg_set_conv_math(int mode);
+int mi355seg_get_conv_math(void);
+
 /* ------------------------------------------------------------------ Conv3d
  * Replaces nn.Conv3d forward/backward (ATen convolution / convolution_backward):
  * unet3d.py:80-98 (k3 s1 p1), :46-48 (k1 head); vnet3d.py:25,47,111 (k5 p2), :65 (k2 s2);
@@ -202,6 +217,9 @@ int mi355seg_argmax_ch_f32(const float* logits, long long N, int K, long long S,
  * counts[0]=sum(gt) counts[1]=sum(pred) counts[2]=nnz(gt&pred) counts[3]=nnz(gt|pred). */
 int mi355seg_dice_counts_i64(const int64_t* gt, const int64_t* pred, long long numel,
                              int64_t* counts, void* ws, size_t ws_bytes, void* stream);
+
+/* The 2-channel target of the live loop (train.py:190-193): out[n][0] = (gt[n] == 0), out[n][1] = gt[n], float [N,2,S]. */
+int mi355seg_two_channel_gt_f32(const float* gt, float* out, long long N, long long S, void* stream);
 
 /* Fused train-step tail (train.py:204,209,221 in one pass over the logits):
  * BCE mean loss, argmax mask (int64), gt.argmax and the four Dice counters.

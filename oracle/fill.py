@@ -40,6 +40,51 @@ def fill_module_(module: torch.nn.Module) -> torch.nn.Module:
     return module
 
 
+# the three 1x1 output heads of the Residual U-Net (residual_unet3d.py:73-79) are summed by the deep supervision: a quarter
+# of the kaiming scale keeps the summed logits O(1) (abs max 3.7) in the well-conditioned 96^3 fixture
+RESUNET96_HEAD_SCALE = {"ds2_1x1_conv3d": 0.25, "ds3_1x1_conv3d": 0.25, "conv3d_l4": 0.25}
+
+
+def _hash_uniform(n: int, seed: float) -> np.ndarray:
+    """Closed-form white-noise-like values in [-1, 1): frac(sin(12.9898 i + seed) * 43758.5453) * 2 - 1 (float64)."""
+    i = np.arange(n, dtype=np.float64)
+    v = np.sin(12.9898 * i + seed) * 43758.5453
+    return (v - np.floor(v)) * 2.0 - 1.0
+
+
+@torch.no_grad()
+def fill_module_hash_(module: torch.nn.Module, scale_by_name=None) -> torch.nn.Module:
+    """Like fill_module_, but the conv / linear weights are decorrelated (hash-uniform) with the variance 2 / fan_in of
+    kaiming_normal_ (the reference's init policy, train.py:50-51): every layer then roughly preserves the activation
+    scale, so a following InstanceNorm does not multiply rounding noise by a large 1 / std -- the WELL-CONDITIONED
+    fixture of the Residual U-Net uses it.  ``scale_by_name`` = {substring: factor} rescales the matching weights
+    (the three 1x1 output heads, so that the summed deep-supervision logits stay O(1))."""
+    scale_by_name = scale_by_name or {}
+    for name, t in module.state_dict().items():
+        if name.endswith("num_batches_tracked"):
+            t.zero_()
+            continue
+        n = t.numel()
+        ph = _phase(name)
+        idx = np.arange(n, dtype=np.float64)
+        if name.endswith("running_mean"):
+            v = 0.05 * np.sin(0.37 * idx + ph)
+        elif name.endswith("running_var"):
+            v = 1.0 + 0.1 * np.cos(0.23 * idx + ph)
+        elif t.dim() == 1 and ("norm" in name or "bn" in name) and name.endswith("weight"):
+            v = 1.0 + 0.1 * np.sin(0.61 * idx + ph)
+        elif t.dim() == 1:
+            v = 0.05 * np.sin(0.71 * idx + ph)
+        else:
+            fan_in = n // t.shape[0] if "upconv" not in name and "up_conv" not in name else n // t.shape[1]
+            v = _hash_uniform(n, ph) * np.sqrt(6.0 / max(fan_in, 1))        # uniform on [-a, a) has variance a^2 / 3
+        for key, f in scale_by_name.items():
+            if key in name:
+                v = v * f
+        t.copy_(torch.from_numpy(v.astype(np.float32)).reshape(t.shape))
+    return module
+
+
 def make_input(shape, freq=0.01, phase=0.0) -> torch.Tensor:
     """Smooth closed-form volume ``sin(freq*i + phase) + 0.5*sin(0.0037*i)``, fp32."""
     n = int(np.prod(shape))

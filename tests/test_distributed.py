@@ -153,3 +153,46 @@ def test_ddp_gradients_equal_the_mean_of_per_shard_oracle_gradients():
             got = out[rank][k]
             assert (got - want).abs().max() <= 1e-4 * max(float(want.abs().max()), 1e-3 * scale), (k, rank)
         assert torch.equal(out[0][k], out[1][k]), k
+
+
+def _init_worker(rank, world, port, out):
+    """Ranks that drew DIFFERENT random initial weights (train.py applies weights_init_normal with no seed) must hold
+    rank 0's parameters and buffers after setup_replica -- DDP's wrap-time broadcast, reference train.py:167-169."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import mi355seg
+    from mi355seg import distributed as D
+    D.init_from_env(backend="gloo")
+    torch.manual_seed(1000 + rank)
+    model = torch.nn.Sequential(torch.nn.Conv3d(1, 4, 3, padding=1), torch.nn.BatchNorm3d(4), torch.nn.ReLU(), torch.nn.Conv3d(4, 2, 1)).train()
+    with torch.no_grad():
+        model[1].running_mean.add_(rank)
+    before = [p.detach().clone() for p in model.parameters()]
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    reducer = D.setup_replica(model, bucket_mb=0.0001)
+    after_setup = [p.detach().clone() for p in model.parameters()]
+    g = torch.Generator().manual_seed(7 + rank)               # each rank its own shard
+    x = torch.randn(2, 1, 4, 4, 4, generator=g)
+    D.broadcast_buffers(model)
+    opt.zero_grad(set_to_none=True)
+    model(x).square().mean().backward()
+    reducer(model)
+    opt.step()
+    out[rank] = (before, after_setup, [p.detach().clone() for p in model.parameters()], [b.clone() for b in model.buffers()])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicas_start_from_rank0_parameters_and_stay_identical():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_init_worker, args=(world, port, out), nprocs=world, join=True)
+    b0, s0, a0, buf0 = out[0]
+    b1, s1, a1, buf1 = out[1]
+    assert any(not torch.equal(x, y) for x, y in zip(b0, b1))          # the ranks really started apart
+    for x, y, z in zip(b0, s0, s1):
+        assert torch.equal(x, y) and torch.equal(x, z)                  # rank 0's values everywhere, bit for bit
+    for x, y in zip(a0, a1):
+        assert torch.equal(x, y)                                        # and still one model after a step on different shards
+    assert any(not torch.equal(x, y) for x, y in zip(s0, a0))          # the step did move the parameters
+    # (running statistics are rank-local between two forwards, as under DDP: rank 0's are re-broadcast at the next one)

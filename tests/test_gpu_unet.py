@@ -65,6 +65,22 @@ def test_unet3d_train_step_vs_reference_fixture(seg, golden_dir):
     for k, b in m.named_buffers():
         if k.endswith("num_batches_tracked"):
             assert int(b) == 1
+    # parameters after the Adam step (train.py:109,213).  Step 1 of Adam moves every weight by -lr * g / (|g| + eps):
+    # -+lr wherever the gradient is decisive, so there the post-step samples must agree to a small fraction of lr;
+    # where |g| is within a few orders of eps = 1e-8 the step is rounding-sensitive and only the 2 * lr envelope holds.
+    lr, checked = 1e-3, 0
+    for k in g.files:
+        if not k.startswith("post/"):
+            continue
+        ref_post, ref_grad = g[k].astype(np.float64), g["grad/" + k[5:]].astype(np.float64)
+        got_post = _sample(params[k[5:]]).astype(np.float64)
+        d = np.abs(got_post - ref_post)
+        decisive = np.abs(ref_grad) > 1e-4
+        assert d.max() <= 2 * lr + 1e-7, (k, d.max())
+        if decisive.any():
+            assert d[decisive].max() < 0.01 * lr, (k, d[decisive].max(), int(decisive.sum()))
+            checked += int(decisive.sum())
+    assert checked > 1000, checked
     m.eval()
     with torch.no_grad():
         pe = m(x).cpu().numpy()

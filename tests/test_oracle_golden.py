@@ -113,3 +113,20 @@ def test_vnet_and_resunet_oracle_match_reference_fixtures(golden_dir):
     torch.manual_seed(11)
     d = np.abs(smp(m(x)) - g["pred"])
     assert d.mean() < 1e-5 and d.max() < 2e-3
+
+
+def test_resunet_oracle_matches_the_well_conditioned_fixture(golden_dir):
+    """resunet_f4_96.npz (kaiming-variance hash weights, 96^3: deepest InstanceNorm over 216 voxels): the oracle must sit
+    within the PLAIN 1e-4 of the reference on every sampled voxel (the reference itself moves 8.6e-6 with the thread count)."""
+    from oracle.fill import RESUNET96_HEAD_SCALE, fill_module_hash_, make_input_rough
+    from oracle.nets import ResUNet
+    g = np.load(os.path.join(golden_dir, "resunet_f4_96.npz"))
+    assert float(g["thread_spread"]) < 2e-5
+    m = fill_module_hash_(ResUNet(in_channels=4, n_classes=4, base_n_filter=4), RESUNET96_HEAD_SCALE).eval()
+    x = make_input_rough((1, 4, 96, 96, 96), seed=2.0)
+    with torch.no_grad():
+        f = m(x).reshape(-1)
+    K = 1 << 18
+    got = f[::max(1, f.numel() // K)][:K].numpy()
+    d = np.abs(got - g["pred_eval"])
+    assert d.max() < TOL, d.max()
