@@ -40,7 +40,6 @@ WORKLOADS = {
 MATH_DTYPE = {
     "fp32": "f32",
     "bf16x6": "f32 (bf16x6 split MFMA: every fp32 conv operand = three bf16 parts, six bf16 products per fp32 product, fp32 accumulate)",
-    "bf16": "f32 tensors, bf16 MFMA operands in conv fwd/dgrad (reduced precision, opt-in experiment, NOT a graded configuration)",
 }
 
 
@@ -110,7 +109,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="unet3d_f32_2x128", choices=sorted(WORKLOADS))
-    ap.add_argument("--conv-math", default=os.environ.get("MI355SEG_CONV_MATH") or "bf16x6", choices=["fp32", "bf16x6", "bf16"],
+    ap.add_argument("--conv-math", default=os.environ.get("MI355SEG_CONV_MATH") or "bf16x6", choices=["fp32", "bf16x6"],
                     help="arithmetic of the k3/k5 MFMA convolutions: bf16x6 (default; fp32-accurate split on the bf16 matrix cores) "
                          "or fp32 (exact fp32 MFMA)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -341,24 +340,23 @@ def main():
         n, tms, fl, by = buf[0], buf[1], buf[2], buf[3]
         if n > 0 and tms > 0:
             ach = fl / (tms * 1e-3) / 1e12
-            peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16x6": PEAK_BF16X6_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS}[args.conv_math]
+            peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16x6": PEAK_BF16X6_TFLOPS}[args.conv_math]
             rec, note = pmc_traffic()
             traffic = None
             if rec is not None and rec.get("conv_math", "fp32") == args.conv_math:
                 traffic = rec.get("conv_igemm_bytes_per_launch")
             elif rec is not None:
                 note = f"PMC passes were taken with conv math {rec.get('conv_math', 'fp32')}, this run uses {args.conv_math}"
-            kern = {"fp32": "conv_igemm_kernel<F32> (Conv3d k3 fwd+dgrad, v_mfma_f32_32x32x2_f32)",
-                    "bf16x6": "conv_igemm_kernel<BF16X3> (Conv3d k3 fwd+dgrad, six v_mfma_f32_32x32x16_bf16 per fp32 product)",
-                    "bf16": "conv_igemm_kernel<BF16> (Conv3d k3 fwd+dgrad, v_mfma_f32_32x32x16_bf16)"}[args.conv_math]
+            kern = {"fp32": "conv_igemm_kernel<MATH_F32> (Conv3d k3 fwd+dgrad, v_mfma_f32_32x32x2_f32)",
+                    "bf16x6": "conv_igemm_kernel<MATH_X3> (Conv3d k3 fwd+dgrad, six v_mfma_f32_32x32x16_bf16 per fp32 product)"}[args.conv_math]
             res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                                "frac": ach / peak, "traffic": traffic, "traffic_source": note,
                                "kernel": kern, "launches": int(n), "avg_launch_ms": tms / n,
-                               "peak_basis": {"fp32": "fp32 MFMA 157.3 TFLOP/s", "bf16x6": "bf16 MFMA 2500 TFLOP/s / 6 products = 416.7 fp32-equivalent TFLOP/s",
-                                              "bf16": "bf16 MFMA 2500 TFLOP/s"}[args.conv_math],
+                               "peak_basis": {"fp32": "fp32 MFMA 157.3 TFLOP/s",
+                                              "bf16x6": "bf16 MFMA 2500 TFLOP/s / 6 products = 416.7 fp32-equivalent TFLOP/s"}[args.conv_math],
                                "achieved_counts": "algorithmic fp32 FLOPs (2 x voxels x 27 x Cin x Cout per launch), not MFMA issue slots",
                                "algorithmic_gflop_per_launch": fl / n / 1e9, "hbm_algorithmic_gbs": by / (tms * 1e-3) / 1e9}
-    peak_step = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16x6": PEAK_BF16X6_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS}[args.conv_math]
+    peak_step = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16x6": PEAK_BF16X6_TFLOPS}[args.conv_math]
     t_mfma = flop_per_vox * B * Dd * Hh * Ww / (peak_step * 1e12) * 1e3
     t_hbm = bytes_per_vox * B * Dd * Hh * Ww / (PEAK_HBM_TBS * 1e12) * 1e3
     res["step_roofline"] = {"conv_t_mfma_ms": t_mfma, "conv_t_hbm_ms": t_hbm, "frac_of_mfma_bound": t_mfma / ms, "frac_of_hbm_bound": t_hbm / ms}

@@ -4,12 +4,13 @@ forward/backward, losses and Dice metric as hand-written gfx950 kernels behind a
 from . import functional
 from ._lib import LIB_PATH, Mi355SegError, lib
 
-_MATH = {"fp32": 0, "bf16": 1, "bf16x6": 2}
+_MATH = {"fp32": 0, "bf16x6": 2}
+DEFAULT_CONV_MATH = "bf16x6"
 
 
 def set_conv_math(mode):
-    """Arithmetic of the MFMA convolutions on fp32 tensors: "fp32" (exact fp32 MFMA), "bf16x6" (fp32-accurate split on
-    the bf16 matrix cores) or "bf16" (reduced precision, experiments only).  See include/mi355seg.h."""
+    """Arithmetic of the MFMA convolutions on fp32 tensors: "fp32" (exact fp32 MFMA), or "bf16x6" (the default: fp32-accurate
+    split on the bf16 matrix cores).  See include/mi355seg.h."""
     if mode not in _MATH:
         raise ValueError(f"conv math must be one of {sorted(_MATH)}, got {mode!r}")
     lib().call("mi355seg_set_conv_math", _MATH[mode])

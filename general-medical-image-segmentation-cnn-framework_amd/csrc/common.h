@@ -55,6 +55,40 @@ struct Carver {
 
 constexpr int kWave = 64;
 
+// arithmetic policies of the matrix-core convolution kernels (igemm_kernel.h, conv_wgrad_mfma.hip)
+enum { MATH_F32 = 0, MATH_X3 = 1, MATH_B16 = 2 };
+
+// ---- storage-type helpers: every tensor is fp32 or bf16 in HBM, every kernel computes in fp32 registers.
+// ld4 / st4 move four consecutive elements (16 bytes of fp32, 8 bytes of bf16; the pointer must be aligned to that).
+typedef __bf16 bf16;
+using f32x4_t = __attribute__((ext_vector_type(4))) float;
+using f32x2_t = __attribute__((ext_vector_type(2))) float;
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4_t ld4(const float* p) { return *reinterpret_cast<const f32x4_t*>(p); }
+__device__ __forceinline__ f32x4_t ld4(const bf16* p) {
+    const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(p);
+    return f32x4_t{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void st4(float* p, f32x4_t v) { *reinterpret_cast<f32x4_t*>(p) = v; }
+__device__ __forceinline__ void st4(bf16* p, f32x4_t v) {
+    bf16x4_t q;
+    q[0] = (bf16)v[0]; q[1] = (bf16)v[1]; q[2] = (bf16)v[2]; q[3] = (bf16)v[3];
+    *reinterpret_cast<bf16x4_t*>(p) = q;
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16* p) { return (float)*p; }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16* p, float v) { *p = (bf16)v; }
+// x = h + m + l with three bf16 parts (24 mantissa bits): the operand split of the bf16x6 convolutions
+__device__ __forceinline__ void split3(float v, bf16& h, bf16& m, bf16& l) {
+    h = (bf16)v;
+    const float r1 = v - (float)h;
+    m = (bf16)r1;
+    l = (bf16)(r1 - (float)m);
+}
+
 // ---- optional per-family kernel timing (api.hip) ----
 enum ProfFamily { PF_IGEMM = 0, PF_WGRAD = 1, PF_GENERIC = 2, PF_CONVT = 3, PF_NORM = 4, PF_POOL = 5, PF_LOSS = 6, PF_DIRECT = 7 };
 extern unsigned g_prof_mask;     // bit f set: launches of ProfFamily f are bracketed by HIP events

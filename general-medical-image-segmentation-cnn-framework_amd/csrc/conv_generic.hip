@@ -341,26 +341,19 @@ static int check_geom(ConvGeom* g, const char* who) {
 using namespace seg;
 
 // Arithmetic of the MFMA convolutions on fp32 tensors (mi355seg_set_conv_math; initial value from MI355SEG_CONV_MATH):
-// MI355SEG_MATH_FP32 exact fp32 MFMA, MI355SEG_MATH_BF16X6 fp32-accurate split on the bf16 matrix cores, MI355SEG_MATH_BF16
-// reduced precision (bf16 operands).
+// MI355SEG_MATH_FP32 exact fp32 MFMA, MI355SEG_MATH_BF16X6 fp32-accurate split on the bf16 matrix cores.
 static int conv_math_from_env() {
     const char* e = getenv("MI355SEG_CONV_MATH");
     if (!e || !e[0]) return MI355SEG_MATH_DEFAULT;
     if (!strcmp(e, "fp32") || !strcmp(e, "f32")) return MI355SEG_MATH_FP32;
     if (!strcmp(e, "bf16x6")) return MI355SEG_MATH_BF16X6;
-    if (!strcmp(e, "bf16")) return MI355SEG_MATH_BF16;
-    fprintf(stderr, "libmi355seg: MI355SEG_CONV_MATH=%s is not one of fp32 / bf16x6 / bf16; using the default\n", e);
+    fprintf(stderr, "libmi355seg: MI355SEG_CONV_MATH=%s is not one of fp32 / bf16x6; using the default\n", e);
     return MI355SEG_MATH_DEFAULT;
 }
 static int g_conv_math = conv_math_from_env();
-static int conv_math_mode() { return g_conv_math; }
-static bool conv_math_bf16() { return conv_math_mode() != MI355SEG_MATH_FP32; }
-static int conv_math_call(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W, int Cin,
-                          int Cout, int dgrad, void* ws, size_t ws_bytes, void* stream) {
-    // never a silent precision downgrade: a workspace that cannot hold the split weights is an error (EWORKSPACE)
-    if (conv_math_mode() == MI355SEG_MATH_BF16X6)
-        return mi355seg_conv3d_bf16x6_f32(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, dgrad, ws, ws_bytes, stream);
-    return mi355seg_conv3d_bf16mma_f32(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, dgrad, ws, ws_bytes, stream);
+namespace seg {
+// policy for a convolution on fp32 tensors: the split-precision kernels where the selected math asks for them
+int f32_conv_policy() { return g_conv_math == MI355SEG_MATH_BF16X6 ? MATH_X3 : MATH_F32; }
 }
 
 // ---- patch embedding (kernel = stride, no padding; UNETR's k16 s16 conv, unetr.py:141-156) as a plain GEMM:
@@ -409,7 +402,7 @@ using namespace seg;
 extern "C" {
 
 int mi355seg_set_conv_math(int mode) {
-    SEG_CHECK_ARG(mode == MI355SEG_MATH_FP32 || mode == MI355SEG_MATH_BF16 || mode == MI355SEG_MATH_BF16X6, "set_conv_math: unknown mode %d", mode);
+    SEG_CHECK_ARG(mode == MI355SEG_MATH_FP32 || mode == MI355SEG_MATH_BF16X6, "set_conv_math: unknown mode %d", mode);
     g_conv_math = mode;
     return MI355SEG_OK;
 }
@@ -426,7 +419,6 @@ size_t mi355seg_conv3d_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, i
     if (b > a) a = b;
     if (d > a) a = d;
     if (e > a) a = e;
-    if (k == 3 && stride == 1 && pad == 1 && mi355seg_conv3d_bf16x6_ws_bytes(Cin, Cout) > a) a = mi355seg_conv3d_bf16x6_ws_bytes(Cin, Cout);
     if (headk_supported(Cin, Cout, k, stride, pad, 4, 4, true) && headk_ws_bytes(Cin, Cout, k) > a) a = headk_ws_bytes(Cin, Cout, k);
     if (patch_embed_supported(D, H, W, Cin, k, stride, pad) && patch_embed_ws_bytes(N, D, H, W, Cin, Cout, k) > a) a = patch_embed_ws_bytes(N, D, H, W, Cin, Cout, k);
     if (stemk_supported(Cin, Cout, k, stride, pad, 2, 4) && headk_ws_bytes(Cout, Cin, k) > a) a = headk_ws_bytes(Cout, Cin, k);
@@ -444,14 +436,11 @@ int mi355seg_conv3d_fwd_f32(const float* x, int ldx, const float* w, const float
     SEG_CHECK_ARG(x && w && y && ldx >= Cin && ldy >= Cout, "conv3d_fwd: null pointer or pitch < channels");
     SEG_CHECK_ARG((stats_sum == nullptr) == (stats_sq == nullptr), "conv3d_fwd: stats_sum/stats_sq must come together");
     hipStream_t st = (hipStream_t)stream;
-    if (conv_math_bf16() && k == 3 && stride == 1 && pad == 1 && Cin % 16 == 0 && Cout % 32 == 0 && W >= 8 && ldx % 4 == 0 && ((uintptr_t)x % 16) == 0) {
-        // opt-in reduced-precision mode (MI355SEG_CONV_MATH=bf16): bf16 MFMA operands, fp32 accumulate; never the default
-        rc = conv_math_call(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, stream);
-        if (rc || !stats_sum) return rc;
-        return channel_sums(y, ldy, (long long)N * D * H * W, Cout, stats_sum, stats_sq, nullptr, 0, ws, ws_bytes, st);
-    }
-    if (conv_mfma_supported(N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy))
-        return conv_fwd_mfma(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, /*dgrad=*/0, stats_sum, stats_sq, ws, ws_bytes, st);
+    const int pol = f32_conv_policy();
+    if (pol != MATH_F32 && conv_mfma_supported(pol, N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy))
+        return conv_fwd_mfma(pol, x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, /*dgrad=*/0, stats_sum, stats_sq, ws, ws_bytes, st);
+    if (conv_mfma_supported(MATH_F32, N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy))
+        return conv_fwd_mfma(MATH_F32, x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, /*dgrad=*/0, stats_sum, stats_sq, ws, ws_bytes, st);
     if (patch_embed_supported(D, H, W, Cin, k, stride, pad)) {
         float* A; void* rest; size_t rest_bytes;
         rc = patch_embed_matrix(x, ldx, N, D, H, W, Cin, k, ws, ws_bytes, &A, &rest, &rest_bytes, st);
@@ -461,8 +450,8 @@ int mi355seg_conv3d_fwd_f32(const float* x, int ldx, const float* w, const float
         if (rc || !stats_sum) return rc;
         return channel_sums(y, ldy, M, Cout, stats_sum, stats_sq, nullptr, 0, ws, ws_bytes, st);
     }
-    if (conv_gather_fwd_supported(N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy) && ((uintptr_t)x % 16) == 0)
-        return conv_gather_fwd_mfma(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, stride, pad, stats_sum, stats_sq, ws, ws_bytes, st);
+    if (conv_gather_fwd_supported(MATH_F32, N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy) && ((uintptr_t)x % 16) == 0)
+        return conv_gather_fwd_mfma(MATH_F32, x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, stride, pad, stats_sum, stats_sq, ws, ws_bytes, st);
     if (headk_supported(Cin, Cout, k, stride, pad, ldx, ldy, false) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 8) == 0) {
         rc = headk_conv(false, x, ldx, w, bias, y, ldy, N, D, H, W, Cin, k, ws, ws_bytes, st);
         if (rc || !stats_sum) return rc;
@@ -492,12 +481,13 @@ int mi355seg_conv3d_dgrad_f32(const float* dy, int lddy, const float* w, float* 
     SEG_CHECK_ARG(dy && w && dx && lddy >= Cout && lddx >= Cin, "conv3d_dgrad: null pointer or pitch < channels");
     hipStream_t st = (hipStream_t)stream;
     // k3 s1 p1: dgrad is the same convolution with flipped taps and Cin<->Cout swapped
-    if (conv_math_bf16() && k == 3 && stride == 1 && pad == 1 && Cout % 16 == 0 && Cin % 32 == 0 && W >= 8 && lddy % 4 == 0 && ((uintptr_t)dy % 16) == 0)
-        return conv_math_call(dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cin, Cout, 1, ws, ws_bytes, stream);
-    if (conv_mfma_supported(N, D, H, W, Cout, Cin, k, stride, pad, lddy, lddx))
-        return conv_fwd_mfma(dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cout, Cin, k, /*dgrad=*/1, nullptr, nullptr, ws, ws_bytes, st);
-    if (conv_gather_dgrad_supported(N, D, H, W, Cin, Cout, k, stride, pad, lddy, lddx) && ((uintptr_t)dy % 16) == 0)
-        return conv_gather_dgrad_mfma(dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, k, stride, pad, ws, ws_bytes, st);
+    const int pol = f32_conv_policy();
+    if (pol != MATH_F32 && conv_mfma_supported(pol, N, D, H, W, Cout, Cin, k, stride, pad, lddy, lddx))
+        return conv_fwd_mfma(pol, dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cout, Cin, k, /*dgrad=*/1, nullptr, nullptr, ws, ws_bytes, st);
+    if (conv_mfma_supported(MATH_F32, N, D, H, W, Cout, Cin, k, stride, pad, lddy, lddx))
+        return conv_fwd_mfma(MATH_F32, dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cout, Cin, k, /*dgrad=*/1, nullptr, nullptr, ws, ws_bytes, st);
+    if (conv_gather_dgrad_supported(MATH_F32, N, D, H, W, Cin, Cout, k, stride, pad, lddy, lddx) && ((uintptr_t)dy % 16) == 0)
+        return conv_gather_dgrad_mfma(MATH_F32, dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, k, stride, pad, ws, ws_bytes, st);
     if (headk_supported(Cin, Cout, k, stride, pad, lddy, lddx, true) && ((uintptr_t)dy % 8) == 0 && ((uintptr_t)dx % 16) == 0)
         return headk_conv(true, dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cin, k, ws, ws_bytes, st);
     if (head_supported(Cin, Cout, k, stride, pad, lddx))
@@ -525,6 +515,9 @@ int mi355seg_conv3d_wgrad_f32(const float* dy, int lddy, const float* x, int ldx
         const int M = N * (D / k) * (H / k) * (W / k), K = Cin * k * k * k;
         return mi355seg_gemm_f32(dy, 1, lddy, 0, 0, A, K, 1, 0, 0, dw, K, 0, 0, nullptr, Cout, K, M, 1, 1, 1.f, 0, accumulate, rest, rest_bytes, stream);
     }
+    if (f32_conv_policy() == MATH_X3 && wgrad_lowp_supported(MATH_X3, N, D, H, W, Cin, Cout, k, stride, pad, ldx, lddy) &&
+        ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0)
+        return conv_wgrad_lowp(MATH_X3, dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, accumulate, ws, ws_bytes, st);
     if (wgrad_mfma_supported(N, D, H, W, Cin, Cout, k, stride, pad, ldx, lddy) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0)
         return conv_wgrad_mfma(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, accumulate, ws, ws_bytes, st);
     if (k == 1 && stride == 1 && pad == 0 && pw_wgrad_supported((long long)N * D * H * W, Cin, Cout, 1, ldx, lddy)) {

@@ -1,0 +1,345 @@
+// conv_wgrad_lowp.hip -- weight gradient of Conv3d k3 s1 p1 / k5 s1 p2 on the bf16 matrix cores.
+//
+//   dW[tap][ci][co] = sum over voxels v of  x[v + tap][ci] * dy[v][co]
+//
+// i.e. one GEMM per tap with M = Cin, N = Cout and K = all output voxels, on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation.  Two arithmetic policies (common.h):
+//   MATH_X3  fp32 tensors ("bf16x6"): x and dy are split once, while they are staged, into three bf16 planes each
+//            (v = h + m + l, 24 mantissa bits) and six MFMAs (lh, hl, mm, mh, hm, hh) form each product -- fp32-level
+//            accuracy at 2.7x the fp32 matrix rate;
+//   MATH_B16 bf16 tensors: one plane, one MFMA per k-step.
+//
+// K runs over voxels, but NDHWC keeps the CHANNELS of a voxel contiguous, so both MFMA operands are k-strided in memory.
+// The tiles are therefore stored in LDS exactly as they arrive ([voxel][32 channels], 64-byte rows, planes interleaved
+// per voxel) and read with gfx950's transposing LDS load ds_read_b64_tr_b16: per 16-lane group it fetches a block of
+// 4 voxels x 16 channels and hands lane i the 4 voxels of channel i -- two of them are the 8 consecutive k of one lane's
+// MFMA fragment.  Row stride 64 * NP bytes puts the 4 rows of a block on disjoint 16-bank spans: conflict-free.
+//
+// A workgroup (8 waves, two per SIMD) owns one 32(ci) x 32(co) block pair and a strip of spatial tiles; its 27 (k5: the
+// 25 of one dz plane) tap-tiles are dealt to the eight waves, so the whole slab stays in accumulators while the workgroup
+// walks its strip; the dy fragment of a k-step is shared by the wave's tap-tiles.  The next tile is prefetched into
+// registers during the MFMAs (issue early / write late).  Each workgroup writes its slab once; the fixed-order second
+// stage (wgrad_reduce) sums the strips and emits the PyTorch (Cout,Cin,k,k,k) layout -> bitwise reproducible, no atomics.
+#include "common.h"
+#include "internal.h"
+#include <initializer_list>
+#include <type_traits>
+
+namespace seg {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+constexpr int LW_WAVES = 8;
+constexpr int LW_THREADS = LW_WAVES * 64;
+constexpr int LW_TPW = 4;                    // tap-tiles per wave (27 or 25 taps over 8 waves; the last waves own one fewer)
+
+template <int BX, int KS, int NP>
+struct LTile {
+    static constexpr int HALO = KS / 2;
+    static constexpr int NTAPS = KS == 3 ? 27 : KS * KS;          // taps per workgroup (k5: one dz plane)
+    static constexpr int PLANES = KS == 3 ? 1 : KS;
+    static constexpr int VOX = NP == 3 ? 128 : 256;               // output voxels per tile (three planes per operand: half the tile)
+    static constexpr int TY = BX == 8 ? 8 : 4;
+    static constexpr int LINES = VOX / BX;
+    static constexpr int TZ = LINES / TY;
+    static constexpr int HX = BX + 2 * HALO, HY = TY + 2 * HALO, HZ = KS == 3 ? TZ + 2 : TZ;
+    static constexpr int NVOX = HX * HY * HZ;
+    static constexpr int ROW = 64 * NP;                           // bytes per voxel row: NP planes of 32 bf16 channels
+    static constexpr int KSTEPS = VOX / 16;
+    static constexpr int X_BYTES = NVOX * ROW, D_BYTES = VOX * ROW;
+    static constexpr int LDS_BYTES = X_BYTES + D_BYTES;
+    static_assert(TZ >= 1 && LINES % TY == 0, "tile lines must fill whole y-rows");
+    static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the LDS");
+};
+
+struct LWgradArgs {
+    const void* x; const void* dy; float* part;
+    int ldx, lddy, N, D, H, W, Cin, Cout;
+    int ntx, nty, ntz, ntiles, nstrips, npairs, ncob, ntaps_total;
+};
+
+__device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* lds, int off0, int off1) {
+    // two transposing reads = the 8 consecutive k (voxels) of this lane's channel
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + off0));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + off1));
+    const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int BX, int KS, int NP, typename IN_T>
+__global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradArgs a) {
+    using T = LTile<BX, KS, NP>;
+    constexpr int EPP = std::is_same<IN_T, float>::value ? 4 : 8;            // elements per staged 16-byte piece
+    constexpr int PPV = 32 / EPP;                                             // pieces per voxel (32 channels)
+    constexpr int XPIECES = T::NVOX * PPV, DPIECES = T::VOX * PPV;
+    constexpr int XITER = (XPIECES + LW_THREADS - 1) / LW_THREADS, DITER = DPIECES / LW_THREADS;
+    static_assert(DPIECES % LW_THREADS == 0, "dy tile must split evenly over the workgroup");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* xs = lds;
+    unsigned char* ds = lds + T::X_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, i = lane & 31;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int plane = t % T::PLANES, tp = t / T::PLANES;          // k5: which dz plane of taps this workgroup owns
+    const int pair = tp % a.npairs, strip = tp / a.npairs;
+    const int cib = pair / a.ncob, cob = pair % a.ncob;
+    const int ci0 = cib * 32, co0 = cob * 32;
+    const IN_T* __restrict__ xin = reinterpret_cast<const IN_T*>(a.x);
+    const IN_T* __restrict__ din = reinterpret_cast<const IN_T*>(a.dy);
+
+    // transposing-read lane geometry: lane 4q+p of a 16-lane group addresses voxel row q, channels 4p..4p+3 of the group's
+    // 16-channel half; group (h, cg) covers k = 8h .. 8h+7 (two reads of 4) and channels 16cg .. 16cg+15
+    const int li = lane & 15, q = li >> 2, p = li & 3, cg = (lane >> 4) & 1;
+    const int chan_off = (16 * cg + 4 * p) * 2;
+    const int kq_x = (BX >= 16 ? 8 * h + q : h * T::HX + q);    // BX = 8: the two halves of a k-step are two x-lines
+    const int lane_x = kq_x * T::ROW + chan_off;
+    const int lane_d = (8 * h + q) * T::ROW + chan_off;
+
+    // the taps of this wave: wave, wave + 8, wave + 16 (, wave + 24 for the first waves)
+    const bool has_last = wave + LW_WAVES * (LW_TPW - 1) <= T::NTAPS - 1;       // wave-uniform
+    int abase[LW_TPW];
+#pragma unroll
+    for (int tt = 0; tt < LW_TPW; ++tt) {
+        int tap = wave + LW_WAVES * tt;
+        if (tap > T::NTAPS - 1) tap = T::NTAPS - 1;
+        const int dz = KS == 3 ? tap / 9 : 0, dy = KS == 3 ? (tap / 3) % 3 : tap / KS, dx = tap % KS;
+        abase[tt] = ((dz * T::HY + dy) * T::HX + dx) * T::ROW + lane_x;
+    }
+
+    f32x16 acc[LW_TPW];
+#pragma unroll
+    for (int tt = 0; tt < LW_TPW; ++tt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[tt][v] = 0.f;
+
+    using stage_t = typename std::conditional<EPP == 4, f32x4, bf16x8_t>::type;
+    stage_t sx[XITER], sd[DITER];
+    auto load_stage = [&](int tile) {
+        int mt = tile;
+        const int txi = mt % a.ntx; mt /= a.ntx;
+        const int tyi = mt % a.nty; mt /= a.nty;
+        const int tzi = mt % a.ntz;
+        const int n = mt / a.ntz;
+        const int x0 = txi * BX, y0 = tyi * T::TY, z0 = tzi * T::TZ;
+#pragma unroll
+        for (int it = 0; it < XITER; ++it) {
+            const int pc = it * LW_THREADS + tid;
+            const int vox = pc / PPV, part = pc % PPV;
+            const int hz = vox / (T::HY * T::HX), rem = vox % (T::HY * T::HX);
+            const int hy = rem / T::HX, hx = rem % T::HX;
+            const int gz = z0 + hz + (KS == 3 ? -1 : plane - T::HALO), gy = y0 - T::HALO + hy, gx = x0 - T::HALO + hx;
+            const bool ok = (pc < XPIECES) && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            stage_t v = {};
+            if (ok) v = *reinterpret_cast<const stage_t*>(xin + ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.ldx + ci0 + part * EPP);
+            sx[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < DITER; ++it) {
+            const int pc = it * LW_THREADS + tid;
+            const int vox = pc / PPV, part = pc % PPV;
+            const int line = vox / BX, xx = vox % BX;
+            const int gz = z0 + line / T::TY, gy = y0 + line % T::TY, gx = x0 + xx;
+            stage_t dv = {};                          // partial tiles: voxels outside the volume contribute nothing
+            if (gz < a.D && gy < a.H && gx < a.W)
+                dv = *reinterpret_cast<const stage_t*>(din + ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.lddy + co0 + part * EPP);
+            sd[it] = dv;
+        }
+    };
+    auto put = [&](unsigned char* base, int pc, const stage_t& v) {
+        unsigned char* dst = base + (pc / PPV) * T::ROW + (pc % PPV) * (EPP * 2);
+        if constexpr (EPP == 4) {
+            if constexpr (NP == 3) {                  // split once per staged value: planes h | m | l of the voxel row
+                bf16x4_t qh, qm, ql;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bf16 bh, bm, bl; split3(v[e], bh, bm, bl); qh[e] = bh; qm[e] = bm; ql[e] = bl; }
+                *reinterpret_cast<bf16x4_t*>(dst) = qh;
+                *reinterpret_cast<bf16x4_t*>(dst + 64) = qm;
+                *reinterpret_cast<bf16x4_t*>(dst + 128) = ql;
+            } else {
+                bf16x4_t qh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qh[e] = (bf16)v[e];
+                *reinterpret_cast<bf16x4_t*>(dst) = qh;
+            }
+        } else {
+            *reinterpret_cast<bf16x8_t*>(dst) = v;
+        }
+    };
+    auto write_stage = [&]() {
+#pragma unroll
+        for (int it = 0; it < XITER; ++it) {
+            const int pc = it * LW_THREADS + tid;
+            if (pc < XPIECES) put(xs, pc, sx[it]);
+        }
+#pragma unroll
+        for (int it = 0; it < DITER; ++it) put(ds, it * LW_THREADS + tid, sd[it]);
+    };
+
+    // byte offset of k-step ks, half-read t inside the x halo / the dy tile (lane part excluded)
+    auto xoff = [](int ks, int t) {
+        if constexpr (BX >= 16) {
+            const int line = ks / (BX / 16), xp = ks % (BX / 16);
+            return ((((line / T::TY) * T::HY + (line % T::TY)) * T::HX) + xp * 16 + 4 * t) * T::ROW;
+        } else {
+            const int line = 2 * ks;
+            return ((((line / T::TY) * T::HY + (line % T::TY)) * T::HX) + 4 * t) * T::ROW;
+        }
+    };
+    auto doff = [](int ks, int t) { return (ks * 16 + 4 * t) * T::ROW; };
+
+    auto tile_mfma = [&](auto ntc) {
+        constexpr int NTT = decltype(ntc)::value;
+        bf16x8_t ac[NTT][NP], bc[NP];
+#pragma unroll
+        for (int ks = 0; ks < T::KSTEPS; ++ks) {
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) bc[pl] = tr_frag(ds, lane_d + doff(ks, 0) + pl * 64, lane_d + doff(ks, 1) + pl * 64);
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) ac[tt][pl] = tr_frag(xs, abase[tt] + xoff(ks, 0) + pl * 64, abase[tt] + xoff(ks, 1) + pl * 64);
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) {
+                f32x16 c = acc[tt];
+                if constexpr (NP == 3) {                // planes 0 / 1 / 2 = h / m / l; the small cross terms go in first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[tt][2], bc[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[tt][0], bc[2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[tt][1], bc[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[tt][1], bc[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[tt][0], bc[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[tt][0], bc[0], c, 0, 0, 0);
+                } else {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[tt][0], bc[0], c, 0, 0, 0);
+                }
+                acc[tt] = c;
+            }
+        }
+    };
+
+    int tile = strip;
+    if (tile < a.ntiles) load_stage(tile);
+    for (; tile < a.ntiles; tile += a.nstrips) {
+        __syncthreads();
+        write_stage();
+        __syncthreads();
+        if (tile + a.nstrips < a.ntiles) load_stage(tile + a.nstrips);
+        // every lane of every wave runs the transposing reads (they need EXEC all ones); a wave without a fourth tap
+        // simply issues one tap-tile fewer
+        if (has_last) tile_mfma(std::integral_constant<int, LW_TPW>{});
+        else tile_mfma(std::integral_constant<int, LW_TPW - 1>{});
+    }
+
+    // slab store: part[strip][tap][ci][co]; rows of the 32x32 tile = ci, lanes (cols) = co
+#pragma unroll
+    for (int tt = 0; tt < LW_TPW; ++tt) {
+        const int tap = wave + LW_WAVES * tt;
+        if (tap > T::NTAPS - 1) break;
+        float* dst = a.part + (((long long)strip * a.ntaps_total + plane * T::NTAPS + tap) * a.Cin + ci0) * a.Cout + co0 + i;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int r = (v & 3) + 8 * (v >> 2) + 4 * h;
+            dst[(long long)r * a.Cout] = acc[tt][v];
+        }
+    }
+}
+
+struct LWgradPlan { int KS, BX, ntx, nty, ntz, ntiles, nstrips, npairs, taps, planes; };
+
+static bool lwgrad_plan(int math, int KS, int N, int D, int H, int W, int Cin, int Cout, LWgradPlan* p) {
+    if ((KS != 3 && KS != 5) || Cin % 32 || Cout % 32 || W < 4) return false;
+    const int vox = math == MATH_X3 ? 128 : 256;
+    int BX = 0; long long best = -1;
+    for (int bx : {32, 16, 8}) {
+        if (math == MATH_X3 && bx == 32) continue;          // 128-voxel tiles: the 16-wide tile has the smaller halo
+        long long padded = (long long)((W + bx - 1) / bx) * bx;
+        if (best < 0 || padded < best) { best = padded; BX = bx; }
+    }
+    const int TY = BX == 8 ? 8 : 4, TZ = (vox / BX) / TY;
+    p->KS = KS; p->BX = BX; p->ntx = (W + BX - 1) / BX; p->nty = (H + TY - 1) / TY; p->ntz = (D + TZ - 1) / TZ;
+    p->ntiles = N * p->ntz * p->nty * p->ntx;
+    p->npairs = (Cin / 32) * (Cout / 32);
+    p->taps = KS * KS * KS; p->planes = KS == 3 ? 1 : KS;
+    const int per_strip = p->npairs * p->planes;
+    int want = 256 / per_strip;                             // one 8-wave workgroup per CU: never more than 256 in all
+    long long cap = (long long)(160u << 20) / ((long long)p->taps * Cin * Cout * 4);   // keep the slab workspace <= 160 MB
+    if (cap < 1) cap = 1;
+    if (want > cap) want = (int)cap;
+    if (want > p->ntiles) want = p->ntiles;
+    if (want < 1) want = 1;
+    p->nstrips = want;
+    return true;
+}
+
+bool wgrad_lowp_supported(int math, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int lddy) {
+    const int al = math == MATH_B16 ? 8 : 4;
+    if (!((k == 3 && pad == 1) || (k == 5 && pad == 2)) || stride != 1 || (ldx % al) || (lddy % al)) return false;
+    LWgradPlan p;
+    return lwgrad_plan(math, k, N, D, H, W, Cin, Cout, &p);
+}
+
+size_t wgrad_lowp_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k) {
+    size_t best = 0;
+    for (int math : {MATH_X3, MATH_B16}) {
+        LWgradPlan p;
+        if (!lwgrad_plan(math, k, N, D, H, W, Cin, Cout, &p)) continue;
+        const size_t need = align_up((size_t)p.nstrips * p.taps * Cin * Cout * sizeof(float), 256) + 1024;
+        if (need > best) best = need;
+    }
+    return best;
+}
+
+template <int BX, int KS, int NP, typename IN_T>
+static void launch_lwgrad(const LWgradArgs& a, int nwg, hipStream_t st) {
+    using T = LTile<BX, KS, NP>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_lowp_kernel<BX, KS, NP, IN_T>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_lowp_kernel<BX, KS, NP, IN_T>), dim3(nwg), dim3(LW_THREADS), T::LDS_BYTES, st, a);
+}
+
+template <int KS>
+static void dispatch_lwgrad(int math, const LWgradPlan& p, const LWgradArgs& a, int nwg, hipStream_t st) {
+    if (math == MATH_X3) {
+        if (p.BX == 16) launch_lwgrad<16, KS, 3, float>(a, nwg, st);
+        else launch_lwgrad<8, KS, 3, float>(a, nwg, st);
+    } else {
+        if (p.BX == 32) launch_lwgrad<32, KS, 1, bf16>(a, nwg, st);
+        else if (p.BX == 16) launch_lwgrad<16, KS, 1, bf16>(a, nwg, st);
+        else launch_lwgrad<8, KS, 1, bf16>(a, nwg, st);
+    }
+}
+
+int conv_wgrad_lowp(int math, const void* dy, int lddy, const void* x, int ldx, float* dw, int N, int D, int H, int W, int Cin,
+                    int Cout, int k, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+    LWgradPlan p;
+    SEG_CHECK_ARG(lwgrad_plan(math, k, N, D, H, W, Cin, Cout, &p), "conv_wgrad_lowp: unsupported shape");
+    SEG_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, "conv_wgrad_lowp: pointers must be 16-byte aligned");
+    Carver cv(ws);
+    float* part = cv.take<float>((size_t)p.nstrips * p.taps * Cin * Cout);
+    SEG_CHECK_WS(cv.used(), ws_bytes);
+    LWgradArgs a{x, dy, part, ldx, lddy, N, D, H, W, Cin, Cout, p.ntx, p.nty, p.ntz, p.ntiles, p.nstrips, p.npairs, Cout / 32, p.taps};
+    const int nwg = p.nstrips * p.npairs * p.planes;
+    const double vox = (double)N * D * H * W;
+    {
+        ProfScope ps(PF_WGRAD, 2.0 * vox * p.taps * Cin * Cout, (math == MATH_B16 ? 2.0 : 4.0) * vox * (Cin + Cout) + 4.0 * p.taps * Cin * Cout, st);
+        if (k == 3) dispatch_lwgrad<3>(math, p, a, nwg, st);
+        else dispatch_lwgrad<5>(math, p, a, nwg, st);
+        SEG_CHECK_LAUNCH();
+    }
+    wgrad_reduce(part, dw, p.nstrips, p.taps, Cin, Cout, accumulate, st);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+}  // namespace seg

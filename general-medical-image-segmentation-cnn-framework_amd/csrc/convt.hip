@@ -134,8 +134,8 @@ int mi355seg_convt3d_k2s2_fwd_f32(const float* x, int ldx, const float* w, const
     SEG_CHECK_ARG(x && w && y && N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ldx >= Cin && ldy >= Cout,
                   "convt3d_k2s2_fwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (convt_mfma_supported(N, D, H, W, Cin, Cout, ldx, ldy) && ((uintptr_t)x % 16) == 0)
-        return convt_fwd_mfma(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, ws, ws_bytes, st);
+    if (convt_mfma_supported(MATH_F32, N, D, H, W, Cin, Cout, ldx, ldy) && ((uintptr_t)x % 16) == 0)
+        return convt_fwd_mfma(MATH_F32, x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, ws, ws_bytes, st);
     Carver cv(ws);
     float* wp = cv.take<float>((size_t)8 * Cin * Cout);
     SEG_CHECK_WS(cv.used(), ws_bytes);
@@ -153,8 +153,8 @@ int mi355seg_convt3d_k2s2_dgrad_f32(const float* dy, int lddy, const float* w, f
     SEG_CHECK_ARG(dy && w && dx && N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && lddy >= Cout && lddx >= Cin,
                   "convt3d_k2s2_dgrad: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (convt_mfma_supported(N, D, H, W, Cin, Cout, lddx, lddy) && ((uintptr_t)dy % 16) == 0)
-        return convt_dgrad_mfma(dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, ws, ws_bytes, st);
+    if (convt_mfma_supported(MATH_F32, N, D, H, W, Cin, Cout, lddx, lddy) && ((uintptr_t)dy % 16) == 0)
+        return convt_dgrad_mfma(MATH_F32, dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, ws, ws_bytes, st);
     Carver cv(ws);
     float* wd = cv.take<float>((size_t)8 * Cin * Cout);
     SEG_CHECK_WS(cv.used(), ws_bytes);

@@ -1,0 +1,441 @@
+// igemm_kernel.h -- the implicit-GEMM convolution kernel (Conv3d k1 / k3 / k5 forward + input gradient, gather mode for
+// strided / even kernels, ConvTranspose3d k2 s2) with three arithmetic policies behind ONE kernel body:
+//
+//   MATH_F32  fp32 tensors, fp32 halo tile in LDS, v_mfma_f32_32x32x2_f32 (exact fp32 products);
+//   MATH_X3   fp32 tensors, "bf16x6": every staged value is split once into three bf16 parts (x = h + m + l, 24 mantissa
+//             bits) kept as three planes of the LDS tile, the weights are split by the pack kernel, and six
+//             v_mfma_f32_32x32x16_bf16 (hh, hm, mh, mm, hl, lh; fp32 accumulate; small terms first) form each product:
+//             fp32-level accuracy at 2.7x the fp32 matrix rate;
+//   MATH_B16  bf16 tensors in HBM (activations in, activations out), one bf16 plane in LDS, one bf16 MFMA per
+//             16-channel k-step, fp32 accumulate, fp32 bias / BatchNorm statistics in the epilogue.
+//
+//   M = output voxels, N = output channels, K = taps x Cin.
+//
+// Workgroup = 4 waves (256 threads); each wave owns MB M-blocks of 32 voxels and all NT = 32*NBW output channels of
+// the tile, i.e. the tile is (128*MB voxels) x NT.  The input halo tile ((TZ+2h) x (TY+2h) x (BX+2h) voxels x CK input
+// channels, NDHWC) is staged in LDS once per CK-channel chunk and re-read by all taps as shifted ds_read_b128 (the shift
+// is an immediate offset; the voxel pitch is an odd number of 16-byte slots, so the reads are bank-conflict free).
+// Weights are pre-packed so that the B operand of a k-step is ONE coalesced 16-byte global load per lane (L2-resident,
+// software-prefetched through a register ring); the next chunk's halo is prefetched into registers before the MFMAs of the
+// current chunk and written to LDS after them (issue-early / write-late).  Epilogue: bias add, NDHWC store, optional
+// per-channel (sum, M2, n) partials for the BatchNorm that follows (deterministic two-stage).
+#pragma once
+#include "common.h"
+#include <type_traits>
+
+namespace seg {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// Timing-experiment switches (ablations of the main loop, tile-shape overrides) exist only in a -DMI355SEG_TUNE build
+// (make TUNE=1); the shipped kernels carry none of them.
+#ifdef MI355SEG_TUNE
+#define SEG_DBG(a, bit) ((a).dbg & (bit))
+#else
+#define SEG_DBG(a, bit) 0
+#endif
+
+template <int MATH> struct MathTraits;
+template <> struct MathTraits<MATH_F32> { using in_t = float; using out_t = float; static constexpr int NP = 1, EPP = 4, LDS_ELEM = 4, KGRAN = 8; };
+template <> struct MathTraits<MATH_X3> { using in_t = float; using out_t = float; static constexpr int NP = 3, EPP = 4, LDS_ELEM = 2, KGRAN = 16; };
+template <> struct MathTraits<MATH_B16> { using in_t = bf16; using out_t = bf16; static constexpr int NP = 1, EPP = 8, LDS_ELEM = 2, KGRAN = 16; };
+
+// CK = input channels per LDS chunk: 16 for k3 (two workgroups per CU), 8 for fp32 k5 (the 5^3 halo is 4x larger), 64 for
+// k1 / ConvTranspose where there is no halo and few MFMAs per chunk otherwise.
+// PITCH (in LDS elements) = NP planes of CK channels + 16 bytes of padding -> an odd number of 16-byte slots per voxel.
+template <int MATH, int KS, int BX, int MB, int CK>
+struct Tile {
+    using MT = MathTraits<MATH>;
+    static constexpr int PITCH = MT::NP * CK + 16 / MT::LDS_ELEM;
+    static constexpr int HALO = KS / 2;
+    static constexpr int NTAP = KS * KS * KS;
+    static constexpr int LPB = 32 / BX;           // x-lines per 32-voxel M-block
+    static constexpr int LINES = 4 * MB * LPB;    // x-lines per workgroup tile
+    static constexpr int TY = 4;
+    static constexpr int TZ = LINES / TY;
+    static constexpr int HX = BX + 2 * HALO, HY = TY + 2 * HALO, HZ = TZ + 2 * HALO;
+    static constexpr int NVOX = HX * HY * HZ;
+    static constexpr int PPV = CK / MT::EPP;                  // staged pieces (one global load each) per voxel
+    static constexpr int NPIECE = NVOX * PPV;
+    static constexpr int NITER = (NPIECE + 255) / 256;
+    static constexpr int LDS_BYTES = NVOX * PITCH * MT::LDS_ELEM;
+    static_assert(LINES % TY == 0, "tile lines must fill whole y-rows");
+    static_assert(CK % MT::KGRAN == 0, "chunk must hold whole MFMA k-steps");
+    static_assert(((PITCH * MT::LDS_ELEM / 16) & 1) == 1, "voxel pitch must be an odd number of 16-byte slots");
+};
+
+// The M space is always the "base grid" (N, D, H, W).  in_mul / out_mul = 2 turn the same kernel into
+// ConvTranspose3d k2 s2: forward scatters N-tile (tap, cout-tile) to child voxel 2*v + tap of the
+// (2D,2H,2W) output; dgrad gathers K-chunk (tap, cout-chunk) from child voxel 2*v + tap of the input.
+// x / wq / y are float or bf16 arrays as the arithmetic policy of the launch says; ldx / ldy count elements.
+struct IgemmArgs {
+    const void* x; const void* wq; const float* bias; void* y; float* spart;
+    int ldx, ldy, N, D, H, W, Cout;
+    int ntx, nty, ntz, nN;
+    int nchunks;        // total K chunks of CK channels (taps of a ConvT dgrad included)
+    int cpt;            // chunks per input tap  (== nchunks when in_mul == 1)
+    int nNpt;           // N-tiles per output tap (== nN when out_mul == 1)
+    int in_mul, out_mul;
+    int nM;             // M-tiles
+    int ksplit, cps;    // K-splits and chunks per split (nchunks == ksplit * cps); ksplit > 1: y is an fp32 slab array
+    long long split_stride;   // floats between the output slabs of consecutive K-splits
+    int dbg;            // -DMI355SEG_TUNE builds only (MI355SEG_DBG): 1 no re-staging, 2 B loaded once per chunk, 4 no stores; else 0 and unread
+    // ---- gather / scatter generalisation (strided Conv3d fwd + per-phase dgrad, ConvT with narrow Cout)
+    int Di, Hi, Wi;     // extents of the volume x points at   (input voxel = base * in_mul + toff[tap])
+    int Do, Ho, Wo;     // extents of the volume y points at   (output voxel = base * out_mul + child + c{z,y,x})
+    int cz, cy, cx;     // fixed child offset of a strided-dgrad phase launch
+    int flatn;          // != 0: N-tiles cut the flat (child tap, cout) axis, so one 32-column block may span two children
+    int by, bz;         // (y, z) tile-block shape of the M-tile walk (divisors of nty, ntz)
+    signed char toff[64][4];   // per K-tap input offset (z, y, x); all zero for the stride-1 halo modes
+};
+
+struct TapList { unsigned char t[64]; };
+struct IgemmPlan { int KS, CK, BX, MB, NBW, TZ, nM, nN, ntx, nty, ntz, flat; };
+
+// ---------------------------------------------------------------- the kernel
+// One virtual tile = (M-tile, N-tile, K-split) per workgroup; up to two workgroups share a CU and the
+// hardware dispatcher staggers them, so one stages its halo while the other issues MFMAs (a persistent
+// variant was measured 8-10 % slower on the large layers: co-resident workgroups fall into lockstep).
+// With ksplit > 1 (few-tile deep layers) every split writes raw fp32 partial sums to its own slab and a
+// tiny second kernel adds them in fixed order.
+template <int MATH, int KS, int BX, int MB, int NBW, int CK>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
+    using T = Tile<MATH, KS, BX, MB, CK>;
+    using MT = MathTraits<MATH>;
+    using in_t = typename MT::in_t;
+    using out_t = typename MT::out_t;
+    constexpr int PITCH = T::PITCH;
+    constexpr int PPV = T::PPV;
+    constexpr int NT = 32 * NBW;
+    constexpr int NTAP = T::NTAP;
+    constexpr int NP = MT::NP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, i = lane & 31;
+
+    // XCD-aware block -> tile map: blocks dealt round-robin to the 8 XCDs get contiguous tile ranges,
+    // so halo-sharing neighbours and the N-tiles / K-splits of one M-tile share an L2 (bijective).
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int ks = t % a.ksplit; t /= a.ksplit;
+    const int ntile = t % a.nN;
+    const int mtile = t / a.nN;
+    // M-tiles are walked in (y, z) blocks of by x bz tiles (x fastest inside a block) so that the ~64 tiles an XCD works
+    // on at any moment form a compact brick whose shared halo planes stay in that XCD's L2 (by divides nty; the last
+    // z-row of bricks may be shorter than bz)
+    int mt = mtile;
+    const int per_n = a.ntx * a.nty * a.ntz;
+    const int n = mt / per_n; mt -= n * per_n;
+    const int zfull = a.ntz / a.bz;                           // full z-rows of bricks; a ragged last row holds the remaining slabs
+    const int rowtiles = a.ntx * a.nty * a.bz;                // tiles per full z-row
+    int zrow = mt / rowtiles, bzz = a.bz;
+    if (zrow >= zfull) { zrow = zfull; bzz = a.ntz - zfull * a.bz; }
+    mt -= zrow * rowtiles;
+    const int blk = a.ntx * a.by * bzz;
+    const int b = mt / blk; mt -= b * blk;
+    const int txi = mt % a.ntx; mt /= a.ntx;
+    const int tyi = b * a.by + mt % a.by;
+    const int tzi = zrow * a.bz + mt / a.by;
+    const int x0 = txi * BX, y0 = tyi * T::TY, z0 = tzi * T::TZ;
+    const int tapn = ntile / a.nNpt;                          // output child (ConvT fwd), else 0
+    const int n0 = (ntile % a.nNpt) * NT;
+    const int Di = a.Di, Hi = a.Hi, Wi = a.Wi;
+    const in_t* __restrict__ xin = reinterpret_cast<const in_t*>(a.x);
+
+    f32x16 acc[MB][NBW];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[mb][nb][v] = 0.f;
+
+    // per-lane LDS base (LDS elements) of the A fragment for each M-block: lane (i, h) reads voxel i of the block and the
+    // h-th half of a k-step's channels (4 floats / 8 bf16 = 16 bytes)
+    int abase[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int m = wave * MB + mb;
+        const int line = m * T::LPB + i / BX, xx = i % BX;
+        abase[mb] = (((line / T::TY) * T::HY + (line % T::TY)) * T::HX + xx) * PITCH + (16 / MT::LDS_ELEM) * h;
+    }
+
+    const int c0 = ks * a.cps, c1 = c0 + a.cps;             // this split's chunk range
+
+    // ---- halo staging: global -> registers (issue early) -> LDS (write late)
+    using stage_t = typename std::conditional<MATH == MATH_B16, bf16x8_t, f32x4>::type;
+    stage_t stage[T::NITER];
+    auto load_stage = [&](int chunk) {
+#pragma unroll
+        for (int it = 0; it < T::NITER; ++it) {
+            const int p = it * 256 + tid;
+            const int vox = p / PPV, part = p % PPV;
+            const int hz = vox / (T::HY * T::HX), rem = vox % (T::HY * T::HX);
+            const int hy = rem / T::HX, hx = rem % T::HX;
+            const int tapk = chunk / a.cpt, cch = chunk - tapk * a.cpt;     // input child (ConvT dgrad), else 0
+            const int gz = (z0 - T::HALO + hz) * a.in_mul + a.toff[tapk][0];
+            const int gy = (y0 - T::HALO + hy) * a.in_mul + a.toff[tapk][1];
+            const int gx = (x0 - T::HALO + hx) * a.in_mul + a.toff[tapk][2];
+            const bool ok = (p < T::NPIECE) && (unsigned)gz < (unsigned)Di && (unsigned)gy < (unsigned)Hi && (unsigned)gx < (unsigned)Wi;
+            stage_t v = {};
+            if (ok) {
+                const long long off = ((((long long)n * Di + gz) * Hi + gy) * Wi + gx) * a.ldx + cch * CK + part * MT::EPP;
+                v = *reinterpret_cast<const stage_t*>(xin + off);
+            }
+            stage[it] = v;
+        }
+    };
+    auto write_stage = [&]() {
+#pragma unroll
+        for (int it = 0; it < T::NITER; ++it) {
+            const int p = it * 256 + tid;
+            if (p < T::NPIECE) {
+                if constexpr (MATH == MATH_F32) {
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(lds_raw) + (p / PPV) * PITCH + (p % PPV) * 4) = stage[it];
+                } else if constexpr (MATH == MATH_X3) {          // split once per staged value: planes h | m | l of the voxel
+                    bf16x4_t qh, qm, ql;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bf16 bh, bm, bl; split3(stage[it][e], bh, bm, bl); qh[e] = bh; qm[e] = bm; ql[e] = bl; }
+                    bf16* dst = reinterpret_cast<bf16*>(lds_raw) + (p / PPV) * PITCH + (p % PPV) * 4;
+                    *reinterpret_cast<bf16x4_t*>(dst) = qh;
+                    *reinterpret_cast<bf16x4_t*>(dst + CK) = qm;
+                    *reinterpret_cast<bf16x4_t*>(dst + 2 * CK) = ql;
+                } else {
+                    *reinterpret_cast<bf16x8_t*>(reinterpret_cast<bf16*>(lds_raw) + (p / PPV) * PITCH + (p % PPV) * 8) = stage[it];
+                }
+            }
+        }
+    };
+
+    load_stage(c0);
+    if constexpr (MATH == MATH_F32) {
+        constexpr int STEP_FLOATS = 2 * NT * 4;                 // packed weights consumed per (tap, kk) step
+        constexpr int CHUNK_FLOATS = NTAP * (CK / 8) * STEP_FLOATS;
+        const float* lds = reinterpret_cast<const float*>(lds_raw);
+        const float* wlane = reinterpret_cast<const float*>(a.wq) + (long long)ntile * a.nchunks * CHUNK_FLOATS + (h * NT + i) * 4;
+        for (int chunk = c0; chunk < c1; ++chunk) {
+            const float* wp = wlane + (long long)chunk * CHUNK_FLOATS;
+            // B fragments run PFD steps ahead of the MFMAs that consume them (register ring, static indices).
+            // The ring's first PFD loads are issued BEFORE the next chunk's halo prefetch: vmcnt retires in
+            // order, so a B load queued behind 13 halo loads (possible HBM misses) would stall the first MFMAs.
+            constexpr int NSTEP = NTAP * (CK / 8);
+            constexpr int PFD = NSTEP > 4 ? 4 : 1;
+            f32x4 bq[PFD + 1][NBW];
+#pragma unroll
+            for (int d = 0; d < PFD; ++d)
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) bq[d][nb] = *reinterpret_cast<const f32x4*>(wp + d * STEP_FLOATS + nb * 128);
+            if (!SEG_DBG(a, 1) || chunk == c0) {
+                __syncthreads();                 // every wave is done reading the previous chunk
+                write_stage();
+                __syncthreads();
+            }
+            if (chunk + 1 < c1 && !SEG_DBG(a, 1)) load_stage(chunk + 1);
+#pragma unroll
+            for (int tap = 0; tap < NTAP; ++tap) {
+                const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
+                const int tapoff = ((dz * T::HY + dy) * T::HX + dx) * PITCH;
+#pragma unroll
+                for (int kk = 0; kk < CK / 8; ++kk) {
+                    const int step = tap * (CK / 8) + kk;
+                    const int cur = step % (PFD + 1), fill = (step + PFD) % (PFD + 1);
+                    if (step + PFD < NSTEP && !SEG_DBG(a, 2)) {
+#pragma unroll
+                        for (int nb = 0; nb < NBW; ++nb)
+                            bq[fill][nb] = *reinterpret_cast<const f32x4*>(wp + (step + PFD) * STEP_FLOATS + nb * 128);
+                    }
+                    f32x4 av[MB];
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) av[mb] = *reinterpret_cast<const f32x4*>(lds + abase[mb] + tapoff + kk * 8);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                            for (int nb = 0; nb < NBW; ++nb)
+                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb][s], bq[cur][nb][s], acc[mb][nb], 0, 0, 0);
+                }
+            }
+        }
+    } else {
+        // bf16 matrix cores: one k-step = 16 channels; lane (i, h) holds channels 8h .. 8h+7 of its voxel / output column.
+        // wq[nt][chunk][tap][kstep][plane][h][j][8]
+        constexpr int KSTEPS = CK / 16;
+        constexpr int PLANE = 2 * NT * 8;                        // bf16 elements of one plane of one k-step
+        constexpr int STEP = NP * PLANE;
+        constexpr int NSTEP = NTAP * KSTEPS;
+        constexpr int CHUNK = NSTEP * STEP;
+        const bf16* lds = reinterpret_cast<const bf16*>(lds_raw);
+        const bf16* wlane = reinterpret_cast<const bf16*>(a.wq) + (long long)ntile * a.nchunks * CHUNK + (h * NT + i) * 8;
+        for (int chunk = c0; chunk < c1; ++chunk) {
+            const bf16* wp = wlane + (long long)chunk * CHUNK;
+            constexpr int PFD = NSTEP > 4 ? (NP == 3 ? 2 : 4) : 1;
+            bf16x8_t bq[PFD + 1][NBW][NP];
+#pragma unroll
+            for (int d = 0; d < PFD; ++d)
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) bq[d][nb][pl] = *reinterpret_cast<const bf16x8_t*>(wp + d * STEP + pl * PLANE + nb * 256);
+            __syncthreads();                 // every wave is done reading the previous chunk
+            write_stage();
+            __syncthreads();
+            if (chunk + 1 < c1) load_stage(chunk + 1);
+#pragma unroll
+            for (int tap = 0; tap < NTAP; ++tap) {
+                const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
+                const int tapoff = ((dz * T::HY + dy) * T::HX + dx) * PITCH;
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk) {
+                    const int step = tap * KSTEPS + kk;
+                    const int cur = step % (PFD + 1), fill = (step + PFD) % (PFD + 1);
+                    if (step + PFD < NSTEP) {
+#pragma unroll
+                        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                            for (int pl = 0; pl < NP; ++pl)
+                                bq[fill][nb][pl] = *reinterpret_cast<const bf16x8_t*>(wp + (step + PFD) * STEP + pl * PLANE + nb * 256);
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        bf16x8_t av[NP];
+#pragma unroll
+                        for (int pl = 0; pl < NP; ++pl) av[pl] = *reinterpret_cast<const bf16x8_t*>(lds + abase[mb] + tapoff + pl * CK + kk * 16);
+#pragma unroll
+                        for (int nb = 0; nb < NBW; ++nb) {
+                            f32x16 c = acc[mb][nb];
+                            if constexpr (NP == 3) {            // planes 0 / 1 / 2 = h / m / l; the small cross terms go in first
+                                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2], bq[cur][nb][0], c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bq[cur][nb][2], c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bq[cur][nb][1], c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bq[cur][nb][0], c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bq[cur][nb][1], c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bq[cur][nb][0], c, 0, 0, 0);
+                            } else {
+                                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bq[cur][nb][0], c, 0, 0, 0);
+                            }
+                            acc[mb][nb] = c;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: bias, store, optional BatchNorm partial statistics
+    float* yslab = reinterpret_cast<float*>(a.y) + (long long)ks * a.split_stride;     // ksplit > 1: raw fp32 partial sums
+    out_t* yout = reinterpret_cast<out_t*>(a.y);
+    const bool slab = a.ksplit > 1;
+    float ssum[NBW];
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+        int col = n0 + nb * 32 + i, child = tapn;
+        if (a.flatn) { const int nf = ntile * NT + nb * 32 + i; child = nf / a.Cout; col = nf - child * a.Cout; }   // per-lane child
+        const int oz = ((child >> 2) & 1) + a.cz, oy = ((child >> 1) & 1) + a.cy, ox = (child & 1) + a.cx;
+        const float bv = a.bias ? a.bias[col] : 0.f;
+        float s1 = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int m = wave * MB + mb;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int r = (v & 3) + 8 * (v >> 2) + 4 * h;      // row of the 32x32 tile held in register v
+                const int line = m * T::LPB + r / BX, xx = r % BX;
+                const int gz = (z0 + line / T::TY) * a.out_mul + oz;
+                const int gy = (y0 + line % T::TY) * a.out_mul + oy;
+                const int gx = (x0 + xx) * a.out_mul + ox;
+                const float val = acc[mb][nb][v] + bv;
+                // partial tiles (extents that are not tile multiples): rows outside the volume are dropped
+                const bool inside = (z0 + line / T::TY) < a.D && (y0 + line % T::TY) < a.H && (x0 + xx) < a.W &&
+                                    gz < a.Do && gy < a.Ho && gx < a.Wo;
+#ifdef MI355SEG_TUNE
+                if (inside && (!(a.dbg & 4) || val == 12345.678f))
+#else
+                if (inside)
+#endif
+                {
+                    const long long off = ((((long long)n * a.Do + gz) * a.Ho + gy) * a.Wo + gx) * a.ldy + col;
+                    if constexpr (MATH == MATH_B16) {
+                        if (slab) yslab[off] = val; else yout[off] = (out_t)val;
+                    } else {
+                        yslab[off] = val;                           // ks == 0 and split_stride == 0 when there is one split
+                    }
+                }
+                if (inside) s1 += val;
+            }
+        }
+        ssum[nb] = s1;
+    }
+    if (a.spart) {
+        // BatchNorm batch statistics of this tile, cancellation-free: per channel the tile sum, then the tile
+        // mean, then M2 = sum (y - tile_mean)^2 from the accumulators still in registers; the second stage
+        // combines (n, sum, M2) of all tiles in fp64 (Chan et al.).  spart[mtile][c] = {sum, M2, n}.
+        float* lds = reinterpret_cast<float*>(lds_raw);
+        __syncthreads();                 // LDS halo no longer needed
+        float cnt = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            float s1 = ssum[nb] + __shfl_xor(ssum[nb], 32, 64);
+            if (h == 0) lds[wave * NT + nb * 32 + i] = s1;
+        }
+        {   // valid rows of this tile (same for every channel)
+            const int vz = min(T::TZ, a.D - z0), vy = min(T::TY, a.H - y0), vx = min(BX, a.W - x0);
+            cnt = (float)(vz * vy * vx);
+        }
+        __syncthreads();
+        float tmean[NBW];
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            const int c = nb * 32 + i;
+            tmean[nb] = (lds[c] + lds[NT + c] + lds[2 * NT + c] + lds[3 * NT + c]) / cnt;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            const float bv = a.bias ? a.bias[n0 + nb * 32 + i] : 0.f;
+            float m2 = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int m = wave * MB + mb;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int r = (v & 3) + 8 * (v >> 2) + 4 * h;
+                    const int line = m * T::LPB + r / BX, xx = r % BX;
+                    const bool inside = (z0 + line / T::TY) < a.D && (y0 + line % T::TY) < a.H && (x0 + xx) < a.W;
+                    const float d = acc[mb][nb][v] + bv - tmean[nb];
+                    if (inside) m2 += d * d;
+                }
+            }
+            m2 += __shfl_xor(m2, 32, 64);
+            if (h == 0) lds[4 * NT + wave * NT + nb * 32 + i] = m2;
+        }
+        __syncthreads();
+        if (tid < NT) {
+            const float s1 = lds[tid] + lds[NT + tid] + lds[2 * NT + tid] + lds[3 * NT + tid];
+            const float m2 = lds[4 * NT + tid] + lds[5 * NT + tid] + lds[6 * NT + tid] + lds[7 * NT + tid];
+            float* dst = a.spart + ((long long)mtile * a.Cout + n0 + tid) * 3;
+            dst[0] = s1; dst[1] = m2; dst[2] = cnt;
+        }
+    }
+}
+
+template <int MATH, int KS, int BX, int MB, int NBW, int CK>
+static void launch_igemm(const IgemmArgs& a, int nwg, hipStream_t st) {
+    using T = Tile<MATH, KS, BX, MB, CK>;
+    constexpr int LDSB = T::LDS_BYTES < 8 * 64 * 4 ? 8 * 64 * 4 : T::LDS_BYTES;      // the statistics epilogue needs 8 x NT floats
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<MATH, KS, BX, MB, NBW, CK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_kernel<MATH, KS, BX, MB, NBW, CK>), dim3(nwg), dim3(256), LDSB, st, a);
+}
+
+// conv_igemm_lowp.hip: the MATH_X3 / MATH_B16 instantiations (their own translation unit: they compile in parallel)
+void dispatch_igemm_lowp(int math, const IgemmPlan& p, const IgemmArgs& a, int nwg, hipStream_t st);
+bool igemm_lowp_has(int math, int KS, int CK, int BX, int MB);
+
+}  // namespace seg

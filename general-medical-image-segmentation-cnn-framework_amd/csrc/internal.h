@@ -8,6 +8,8 @@ namespace seg {
 size_t colsum_ws_bytes(int C);
 int channel_sums(const float* x, int ldx, long long rows, int C, double* sum, double* sq, float* fsum, int accumulate,
                  void* ws, size_t ws_bytes, hipStream_t st);
+int channel_sums(const bf16* x, int ldx, long long rows, int C, double* sum, double* sq, float* fsum, int accumulate,
+                 void* ws, size_t ws_bytes, hipStream_t st);
 
 int finalize_channel_partials(const float* part, int nblk, int C, double* sum, double* sq, hipStream_t st);
 
@@ -46,28 +48,32 @@ int head_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, in
                int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 
 // conv_generic.hip
+int f32_conv_policy();     // MATH_X3 when the bf16x6 conv math is selected, else MATH_F32
 void pack_w_fwd(const float* w, float* wp, int Cout, int Cin, int T, hipStream_t st);
 void pack_w_dgrad(const float* w, float* wd, int Cout, int Cin, int T, int flip, hipStream_t st);
 void wgrad_reduce(const float* part, float* dw, int splits, int T, int Cin, int Cout, int accumulate, hipStream_t st);
 
-// conv_mfma.hip -- fp32-MFMA implicit-GEMM Conv3d k3 s1 p1
+// conv_mfma.hip / igemm_kernel.h -- implicit-GEMM Conv3d / ConvTranspose3d on the matrix cores.  `math` is the arithmetic
+// policy of igemm_kernel.h: MATH_F32 (0: fp32 tensors, fp32 MFMA), MATH_X3 (1: fp32 tensors, bf16x6 split) or MATH_B16
+// (2: bf16 tensors, bf16 MFMA); x / y / dy / dx point at fp32 or bf16 NDHWC arrays accordingly, weights are always the
+// fp32 masters in their PyTorch layout.
 size_t conv_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad);
-bool conv_mfma_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int ldy);
+bool conv_mfma_supported(int math, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int ldy);
 // dgrad != 0: `w` is still the (Cfwd_out=Cin_here ... ) torch weight of the FORWARD conv, i.e. shape (Cin, Cout, 27)
 // seen from this call's Cin/Cout; taps are flipped while packing.
-bool conv_gather_fwd_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int ldy);
-bool conv_gather_dgrad_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int lddy, int lddx);
+bool conv_gather_fwd_supported(int math, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int ldy);
+bool conv_gather_dgrad_supported(int math, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int lddy, int lddx);
 size_t conv_gather_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad);
-int conv_gather_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W,
+int conv_gather_fwd_mfma(int math, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int N, int D, int H, int W,
                          int Cin, int Cout, int k, int stride, int pad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st);
-int conv_gather_dgrad_mfma(const float* dy, int lddy, const float* w, float* dx, int lddx, int N, int D, int H, int W,
+int conv_gather_dgrad_mfma(int math, const void* dy, int lddy, const float* w, void* dx, int lddx, int N, int D, int H, int W,
                            int Cin, int Cout, int k, int stride, int pad, void* ws, size_t ws_bytes, hipStream_t st);
-int conv_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W,
+int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int N, int D, int H, int W,
                   int Cin, int Cout, int k, int dgrad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st);
-bool convt_mfma_supported(int N, int D, int H, int W, int Cin, int Cout, int ldx, int ldy);
-int convt_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W,
+bool convt_mfma_supported(int math, int N, int D, int H, int W, int Cin, int Cout, int ldx, int ldy);
+int convt_fwd_mfma(int math, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int N, int D, int H, int W,
                    int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t st);
-int convt_dgrad_mfma(const float* dy, int lddy, const float* w, float* dx, int lddx, int N, int D, int H, int W,
+int convt_dgrad_mfma(int math, const void* dy, int lddy, const float* w, void* dx, int lddx, int N, int D, int H, int W,
                      int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t st);
 // conv_gwgrad.hip -- MFMA gather-wgrad for any cubic kernel / stride / padding
 size_t gwgrad_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad);
@@ -79,6 +85,11 @@ size_t pw_wgrad_ws_bytes(long long nvox, int Cin, int Cout, int T);
 bool pw_wgrad_supported(long long nvox, int Cin, int Cout, int T, int ldx, int lddy);
 int pw_wgrad_mfma(const float* dy, int lddy, const float* x, int ldx, int N, int D, int H, int W, int Cin, int Cout, int T,
                   float** part_out, int* nstrips_out, void* ws, size_t ws_bytes, hipStream_t st);
+// conv_wgrad_lowp.hip -- k3 / k5 wgrad on the bf16 matrix cores (MATH_X3: fp32 tensors, bf16x6 split; MATH_B16: bf16 tensors)
+bool wgrad_lowp_supported(int math, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int lddy);
+size_t wgrad_lowp_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k);
+int conv_wgrad_lowp(int math, const void* dy, int lddy, const void* x, int ldx, float* dw, int N, int D, int H, int W, int Cin,
+                    int Cout, int k, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 size_t wgrad_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k);
 bool wgrad_mfma_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int lddy);
 int conv_wgrad_mfma(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin,

@@ -531,6 +531,13 @@ int channel_sums(const float* x, int ldx, long long rows, int C, double* sum, do
     return MI355SEG_OK;
 }
 
+// TEMPORARY until the bf16 storage instantiation of this file lands
+int channel_sums(const bf16* x, int ldx, long long rows, int C, double* sum, double* sq, float* fsum, int accumulate,
+                 void* ws, size_t ws_bytes, hipStream_t st) {
+    set_error("channel_sums: bf16 storage is not built yet");
+    return MI355SEG_EINVAL;
+}
+
 static int channel_sums_chunk(const float* x, int ldx, long long rows, int C, double* sum, double* sq, float* fsum, int accumulate,
                               void* ws, size_t ws_bytes, hipStream_t st) {
     SEG_CHECK_WS(colsum_ws_bytes(C), ws_bytes);

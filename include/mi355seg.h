@@ -45,17 +45,16 @@ const char* mi355seg_last_error(void);
 int mi355seg_version(void);
 
 /* Arithmetic of the MFMA convolutions (k3 / k5 Conv3d forward, input gradient and weight gradient) on fp32 tensors.  The
- * reference's arithmetic for these is ATen fp32 (unet3d.py:80-98 through nn.Conv3d); all three modes accumulate in fp32:
+ * reference's arithmetic for these is ATen fp32 (unet3d.py:80-98 through nn.Conv3d); both modes accumulate in fp32:
  *   FP32   -- v_mfma_f32_32x32x2_f32, exact fp32 products;
  *   BF16X6 -- every fp32 operand is split into three bf16 parts (x = h + m + l, 24 mantissa bits) and six
  *             v_mfma_f32_32x32x16_bf16 (hh, hm, mh, mm, hl, lh) form each product: fp32-level accuracy (the dropped
  *             terms are below 2^-23 of a product) at 2.7x the fp32 matrix rate;
- *   BF16   -- operands rounded to bf16 (reduced precision; never selected implicitly).
- * Process-wide, read at each launch.  Initial value: environment MI355SEG_CONV_MATH = fp32 | bf16x6 | bf16, else the default. */
+ * (bf16 TENSORS have their own entry points, *_bf16: there the products are plain bf16 MFMAs.)
+ * Process-wide, read at each launch.  Initial value: environment MI355SEG_CONV_MATH = fp32 | bf16x6, else the default. */
 #define MI355SEG_MATH_FP32 0
-#define MI355SEG_MATH_BF16 1
 #define MI355SEG_MATH_BF16X6 2
-#define MI355SEG_MATH_DEFAULT MI355SEG_MATH_FP32
+#define MI355SEG_MATH_DEFAULT MI355SEG_MATH_BF16X6
 int mi355seg_set_conv_math(int mode);
 int mi355seg_get_conv_math(void);
 
@@ -74,19 +73,6 @@ int mi355seg_conv3d_fwd_f32(const float* x, int ldx, const float* w, const float
                             float* y, int ldy, int N, int D, int H, int W, int Cin, int Cout,
                             int k, int stride, int pad, double* stats_sum, double* stats_sq,
                             void* ws, size_t ws_bytes, void* stream);
-
-/* EXPERIMENTAL, opt-in (not used by the parity-graded paths): Conv3d k3 s1 p1 forward (dgrad = 0) or input gradient (dgrad != 0; then
- * x is dy with Cout channels and y is dx with Cin channels) with bf16 MFMA operands -- activations rounded to bf16 while staged,
- * weights packed as bf16, fp32 accumulation, fp32 tensors in HBM.  GEMM-K channels % 16 == 0, GEMM-N channels % 32 == 0, W >= 8. */
-size_t mi355seg_conv3d_bf16mma_ws_bytes(int Cin, int Cout);
-int mi355seg_conv3d_bf16mma_f32(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
-                                int N, int D, int H, int W, int Cin, int Cout, int dgrad, void* ws, size_t ws_bytes, void* stream);
-
-/* EXPERIMENTAL, opt-in: same contract, but every fp32 operand is split into three bf16 parts (x = h + m + l) and six bf16 MFMAs
- * (hh, hm, mh, mm, hl, lh) form each product: fp32-level accuracy at 2.7x the fp32 matrix rate. */
-size_t mi355seg_conv3d_bf16x6_ws_bytes(int Cin, int Cout);
-int mi355seg_conv3d_bf16x6_f32(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
-                               int N, int D, int H, int W, int Cin, int Cout, int dgrad, void* ws, size_t ws_bytes, void* stream);
 
 /* dx = conv_backward_input(dy, w).  D,H,W are the INPUT extents (of x/dx). */
 int mi355seg_conv3d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,

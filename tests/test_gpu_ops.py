@@ -10,6 +10,7 @@ import torch.nn.functional as TF
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
+DEFAULT_MATH = "bf16x6"        # the library default (include/mi355seg.h, MI355SEG_MATH_DEFAULT)
 
 
 @pytest.fixture(scope="module")
@@ -456,56 +457,38 @@ def test_c_abi_rejects_bad_arguments(seg):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("case", [(1, 8, 8, 32, 32, 64), (2, 6, 9, 40, 16, 32), (1, 12, 12, 16, 64, 32)])
-def test_experimental_bf16_operand_conv(seg, case):
-    """The opt-in bf16-operand MFMA conv (k3 s1 p1): equals an fp64 convolution of the bf16-ROUNDED activations and
-    weights up to fp32 accumulation order -- i.e. the only deviation from the fp32 path is the operand rounding."""
-    N, D, H, W, Cin, Cout = case
-    L = seg.lib()
-    x, w, b = rnd(N, Cin, D, H, W, seed=1), rnd(Cout, Cin, 3, 3, 3, seed=2, scale=(2.0 / (27 * Cin)) ** 0.5), rnd(Cout, seed=3, scale=0.1)
-    xb, wb = x.bfloat16().double(), w.bfloat16().double()
-    want = TF.conv3d(xb, wb, b.double(), padding=1)
-    xg, wg = cl(x), w.cuda()
-    y = torch.empty(N, D, H, W, Cout, device="cuda")
-    ws = torch.empty(L.query("mi355seg_conv3d_bf16mma_ws_bytes", Cin, Cout), dtype=torch.uint8, device="cuda")
-    st = torch.cuda.current_stream().cuda_stream
-    L.call("mi355seg_conv3d_bf16mma_f32", xg.data_ptr(), Cin, wg.data_ptr(), b.cuda().data_ptr(), y.data_ptr(), Cout, N, D, H, W, Cin, Cout, 0,
-           ws.data_ptr(), ws.numel(), st)
-    assert (cf(y).double() - want).abs().max() < 2e-5 * max(1.0, float(want.abs().max()))
-    if Cin % 32 == 0:                                                    # dgrad: dx = conv_transpose(dy, w) on bf16-rounded operands
-        g = rnd(N, Cout, D, H, W, seed=4)
-        want_dx = TF.conv_transpose3d(g.bfloat16().double(), wb, padding=1)
-        dx = torch.empty(N, D, H, W, Cin, device="cuda")
-        L.call("mi355seg_conv3d_bf16mma_f32", cl(g).data_ptr(), Cout, wg.data_ptr(), None, dx.data_ptr(), Cin, N, D, H, W, Cin, Cout, 1,
-               ws.data_ptr(), ws.numel(), st)
-        assert (cf(dx).double() - want_dx).abs().max() < 2e-5 * max(1.0, float(want_dx.abs().max()))
-
-
-@pytest.mark.parametrize("case", [(1, 8, 8, 32, 32, 64), (2, 6, 9, 40, 32, 32), (1, 12, 12, 16, 64, 32)])
-def test_experimental_bf16x6_split_conv_is_fp32_accurate(seg, case):
-    """The opt-in split-precision conv (three bf16 parts per operand, six MFMAs per product) against an fp64 convolution of
-    the UNROUNDED fp32 tensors: it must be as close to the truth as the exact-fp32 MFMA path is (same 1e-6-level error)."""
-    N, D, H, W, Cin, Cout = case
-    L = seg.lib()
+@pytest.mark.parametrize("case", [(1, 8, 8, 32, 32, 64, 3), (2, 6, 9, 40, 32, 32, 3), (1, 12, 12, 16, 64, 32, 3), (2, 8, 8, 8, 128, 128, 3),
+                                  (1, 4, 4, 4, 256, 512, 3), (1, 5, 7, 13, 32, 64, 3), (1, 10, 12, 16, 32, 32, 5)])
+def test_split_precision_conv_is_fp32_accurate(seg, case):
+    """Conv math "bf16x6" (three bf16 parts per fp32 operand, six bf16 MFMAs per product, fp32 accumulate) against an fp64
+    convolution of the UNROUNDED fp32 tensors, for the forward, the input gradient and the weight gradient: it must be as
+    close to the truth as the exact-fp32 MFMA path is (the same 1e-6-level error), through the ordinary entry points."""
+    N, D, H, W, Cin, Cout, k = case
     F = seg.functional
-    x, w, b = rnd(N, Cin, D, H, W, seed=1), rnd(Cout, Cin, 3, 3, 3, seed=2, scale=(2.0 / (27 * Cin)) ** 0.5), rnd(Cout, seed=3, scale=0.1)
-    want = TF.conv3d(x.double(), w.double(), b.double(), padding=1)
-    xg, wg = cl(x), w.cuda()
-    y = torch.empty(N, D, H, W, Cout, device="cuda")
-    ws = torch.empty(L.query("mi355seg_conv3d_bf16x6_ws_bytes", Cin, Cout), dtype=torch.uint8, device="cuda")
-    st = torch.cuda.current_stream().cuda_stream
-    L.call("mi355seg_conv3d_bf16x6_f32", xg.data_ptr(), Cin, wg.data_ptr(), b.cuda().data_ptr(), y.data_ptr(), Cout, N, D, H, W, Cin, Cout, 0,
-           ws.data_ptr(), ws.numel(), st)
-    err6 = (cf(y).double() - want).abs().max().item()
-    err32 = (cf(F.conv3d(xg, wg, b.cuda(), 1, 1)).double() - want).abs().max().item()
-    scale = float(want.abs().max())
-    assert err6 < 2e-6 * max(1.0, scale) and err6 < 4.0 * err32 + 1e-7
+    pad = k // 2
+    x, w, b = rnd(N, Cin, D, H, W, seed=1), rnd(Cout, Cin, k, k, k, seed=2, scale=(2.0 / (k ** 3 * Cin)) ** 0.5), rnd(Cout, seed=3, scale=0.1)
     g = rnd(N, Cout, D, H, W, seed=4)
-    want_dx = TF.conv_transpose3d(g.double(), w.double(), padding=1)
-    dx = torch.empty(N, D, H, W, Cin, device="cuda")
-    L.call("mi355seg_conv3d_bf16x6_f32", cl(g).data_ptr(), Cout, wg.data_ptr(), None, dx.data_ptr(), Cin, N, D, H, W, Cin, Cout, 1,
-           ws.data_ptr(), ws.numel(), st)
-    assert (cf(dx).double() - want_dx).abs().max() < 2e-6 * max(1.0, float(want_dx.abs().max()))
+    xd = x.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    want = TF.conv3d(xd, wd, b.double(), padding=pad)
+    want.backward(g.double())
+    errs = {}
+    try:
+        for math in ("fp32", "bf16x6"):
+            seg.set_conv_math(math)
+            assert seg.get_conv_math() == math
+            xg = cl(x).requires_grad_(True)
+            wg = w.cuda().requires_grad_(True)
+            y = F.conv3d(xg, wg, b.cuda(), 1, pad)
+            y.backward(cl(g))
+            errs[math] = ((cf(y).double() - want.detach()).abs().max().item(), (cf(xg.grad).double() - xd.grad).abs().max().item(),
+                          (wg.grad.cpu().double() - wd.grad).abs().max().item())
+    finally:
+        seg.set_conv_math(DEFAULT_MATH)
+    scales = (float(want.abs().max()), float(xd.grad.abs().max()), float(wd.grad.abs().max()))
+    for what, e6, e32, sc in zip(("fwd", "dgrad", "wgrad"), errs["bf16x6"], errs["fp32"], scales):
+        assert e6 < 3e-6 * max(1.0, sc), (what, e6, e32, sc)
+        assert e6 < 4.0 * e32 + 2e-7 * max(1.0, sc), (what, e6, e32, sc)
 
 
 def test_layout_roundtrip(seg):

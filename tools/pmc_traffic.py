@@ -23,8 +23,9 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ["general-medical-image-segmentation-cnn-framework_amd/csrc/conv_mfma.hip",
-                  "general-medical-image-segmentation-cnn-framework_amd/csrc/conv_mfma_bf16.hip"]
+KERNEL_SOURCES = ["general-medical-image-segmentation-cnn-framework_amd/csrc/igemm_kernel.h",
+                  "general-medical-image-segmentation-cnn-framework_amd/csrc/conv_mfma.hip",
+                  "general-medical-image-segmentation-cnn-framework_amd/csrc/conv_igemm_lowp.hip"]
 
 
 def per_launch(directory, counter, match):
