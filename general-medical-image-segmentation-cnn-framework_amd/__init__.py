@@ -2,6 +2,7 @@
 forward/backward, losses and Dice metric as hand-written gfx950 kernels behind a C-ABI
 (include/mi355seg.h), exposed with the reference framework's own module interface."""
 from . import functional
+from .functional import autocast
 from ._lib import LIB_PATH, Mi355SegError, lib
 
 _MATH = {"fp32": 0, "bf16x6": 2}
@@ -21,4 +22,4 @@ def get_conv_math():
     return next(k for k, v in _MATH.items() if v == code)
 
 
-__all__ = ["functional", "lib", "LIB_PATH", "Mi355SegError", "set_conv_math", "get_conv_math"]
+__all__ = ["functional", "autocast", "lib", "LIB_PATH", "Mi355SegError", "set_conv_math", "get_conv_math"]

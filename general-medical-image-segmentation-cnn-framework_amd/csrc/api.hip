@@ -39,7 +39,8 @@ void prof_end(hipStream_t st) {
 }
 
 // [N,C,S] -> [N,S,ld] (channel-last) through a 32x33 LDS tile so both sides stay coalesced
-__global__ __launch_bounds__(256) void ncs_to_nsc_kernel(const float* __restrict__ src, float* __restrict__ dst, int ld,
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void ncs_to_nsc_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int ld,
                                                           int C, long long S) {
     __shared__ float tile[32][33];
     const long long s0 = (long long)blockIdx.x * 32;
@@ -48,15 +49,16 @@ __global__ __launch_bounds__(256) void ncs_to_nsc_kernel(const float* __restrict
     const int tx = threadIdx.x % 32, ty = threadIdx.x / 32;   // 32 x 8
     for (int j = ty; j < 32; j += 8) {
         int c = c0 + j; long long s = s0 + tx;
-        tile[j][tx] = (c < C && s < S) ? src[(n * C + c) * S + s] : 0.f;
+        tile[j][tx] = (c < C && s < S) ? ld1(src + (n * C + c) * S + s) : 0.f;
     }
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
         long long s = s0 + j; int c = c0 + tx;
-        if (c < C && s < S) dst[(n * S + s) * ld + c] = tile[tx][j];
+        if (c < C && s < S) st1(dst + (n * S + s) * ld + c, tile[tx][j]);
     }
 }
-__global__ __launch_bounds__(256) void nsc_to_ncs_kernel(const float* __restrict__ src, int ld, float* __restrict__ dst,
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void nsc_to_ncs_kernel(const TS* __restrict__ src, int ld, TD* __restrict__ dst,
                                                           int C, long long S) {
     __shared__ float tile[32][33];
     const long long s0 = (long long)blockIdx.x * 32;
@@ -65,33 +67,33 @@ __global__ __launch_bounds__(256) void nsc_to_ncs_kernel(const float* __restrict
     const int tx = threadIdx.x % 32, ty = threadIdx.x / 32;
     for (int j = ty; j < 32; j += 8) {
         long long s = s0 + j; int c = c0 + tx;
-        tile[j][tx] = (c < C && s < S) ? src[(n * S + s) * ld + c] : 0.f;
+        tile[j][tx] = (c < C && s < S) ? ld1(src + (n * S + s) * ld + c) : 0.f;
     }
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
         int c = c0 + j; long long s = s0 + tx;
-        if (c < C && s < S) dst[(n * C + c) * S + s] = tile[tx][j];
+        if (c < C && s < S) st1(dst + (n * C + c) * S + s, tile[tx][j]);
     }
 }
 
-template <bool ADD>
-__global__ __launch_bounds__(256) void rows_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd,
+template <typename T, bool ADD>
+__global__ __launch_bounds__(256) void rows_kernel(const T* __restrict__ src, int lds, T* __restrict__ dst, int ldd,
                                                     long long rows, int C) {
-    const bool v = (C % 4 == 0) && (lds % 4 == 0) && (ldd % 4 == 0) && (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
+    const bool v = (C % 4 == 0) && (lds % 4 == 0) && (ldd % 4 == 0) && (((uintptr_t)src | (uintptr_t)dst) % (4 * sizeof(T)) == 0);
     const int cw = v ? C / 4 : C;
     const long long total = rows * cw;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         long long r = i / cw;
         int c = (int)(i % cw);
         if (v) {
-            float4 a = *reinterpret_cast<const float4*>(src + r * lds + c * 4);
-            float4* d = reinterpret_cast<float4*>(dst + r * ldd + c * 4);
-            if (ADD) { float4 b = *d; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
-            *d = a;
+            float4 a = ldf4(src + r * lds + c * 4);
+            T* d = dst + r * ldd + c * 4;
+            if (ADD) { float4 b = ldf4(d); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+            stf4(d, a);
         } else {
-            float a = src[r * lds + c];
-            if (ADD) a += dst[r * ldd + c];
-            dst[r * ldd + c] = a;
+            float a = ld1(src + r * lds + c);
+            if (ADD) a += ld1(dst + r * ldd + c);
+            st1(dst + r * ldd + c, a);
         }
     }
 }
@@ -100,25 +102,27 @@ __global__ __launch_bounds__(256) void rows_kernel(const float* __restrict__ src
 using namespace seg;
 
 // y[r, j*C + c] = x[r, c] (j < rep) and its adjoint dx[r, c] = sum_j dy[r, j*C + c]; C*rep is small (V-Net: 16).
-__global__ __launch_bounds__(256) void repeat_ch_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+template <typename T>
+__global__ __launch_bounds__(256) void repeat_ch_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
                                                         long long rows, int C, int rep) {
     const int CR = C * rep;
     const long long total = rows * CR;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long r = i / CR;
         const int c = (int)(i - r * CR);
-        y[r * ldy + c] = x[r * ldx + c % C];
+        y[r * ldy + c] = x[r * ldx + c % C];          // a copy: no conversion either way
     }
 }
-__global__ __launch_bounds__(256) void repeat_ch_bwd_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx,
+template <typename T>
+__global__ __launch_bounds__(256) void repeat_ch_bwd_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dx, int lddx,
                                                             long long rows, int C, int rep) {
     const long long total = rows * C;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long r = i / C;
         const int c = (int)(i - r * C);
         float s = 0.f;
-        for (int j = 0; j < rep; ++j) s += dy[r * lddy + j * C + c];
-        dx[r * lddx + c] = s;
+        for (int j = 0; j < rep; ++j) s += ld1(dy + r * lddy + j * C + c);
+        st1(dx + r * lddx + c, s);
     }
 }
 __global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o,
@@ -192,12 +196,13 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
     if (ok && sub == 0) dt[r] = -s * (1.f - s) * dot;
 }
 
-__global__ __launch_bounds__(256) void add_bias_kernel(float* __restrict__ y, int ldy, const float* __restrict__ bias, long long rows, int C) {
+template <typename T>
+__global__ __launch_bounds__(256) void add_bias_kernel(T* __restrict__ y, int ldy, const float* __restrict__ bias, long long rows, int C) {
     const long long total = rows * C;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long r = i / C;
         const int c = (int)(i - r * C);
-        y[r * ldy + c] += bias[c];
+        st1(y + r * ldy + c, ld1(y + r * ldy + c) + bias[c]);
     }
 }
 
@@ -237,14 +242,28 @@ int mi355seg_prof_read(double* out, int n) {
 int mi355seg_ncdhw_to_ndhwc_f32(const float* src, float* dst, int lddst, long long N, int C, long long S, void* stream) {
     SEG_CHECK_ARG(src && dst && N > 0 && C > 0 && S > 0 && lddst >= C && N < 65536, "ncdhw_to_ndhwc: bad arguments");
     dim3 grid((unsigned)((S + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N);
-    hipLaunchKernelGGL(ncs_to_nsc_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, lddst, C, S);
+    hipLaunchKernelGGL((ncs_to_nsc_kernel<float, float>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, lddst, C, S);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_ncdhw_f32_to_ndhwc_bf16(const float* src, mi355seg_bf16* dst, int lddst, long long N, int C, long long S, void* stream) {
+    SEG_CHECK_ARG(src && dst && N > 0 && C > 0 && S > 0 && lddst >= C && N < 65536, "ncdhw_f32_to_ndhwc_bf16: bad arguments");
+    dim3 grid((unsigned)((S + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N);
+    hipLaunchKernelGGL((ncs_to_nsc_kernel<float, bf16>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, lddst, C, S);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
 int mi355seg_ndhwc_to_ncdhw_f32(const float* src, int ldsrc, float* dst, long long N, int C, long long S, void* stream) {
     SEG_CHECK_ARG(src && dst && N > 0 && C > 0 && S > 0 && ldsrc >= C && N < 65536, "ndhwc_to_ncdhw: bad arguments");
     dim3 grid((unsigned)((S + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N);
-    hipLaunchKernelGGL(nsc_to_ncs_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ldsrc, dst, C, S);
+    hipLaunchKernelGGL((nsc_to_ncs_kernel<float, float>), grid, dim3(256), 0, (hipStream_t)stream, src, ldsrc, dst, C, S);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_ndhwc_bf16_to_ncdhw_f32(const mi355seg_bf16* src, int ldsrc, float* dst, long long N, int C, long long S, void* stream) {
+    SEG_CHECK_ARG(src && dst && N > 0 && C > 0 && S > 0 && ldsrc >= C && N < 65536, "ndhwc_bf16_to_ncdhw_f32: bad arguments");
+    dim3 grid((unsigned)((S + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N);
+    hipLaunchKernelGGL((nsc_to_ncs_kernel<bf16, float>), grid, dim3(256), 0, (hipStream_t)stream, src, ldsrc, dst, C, S);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
@@ -254,14 +273,28 @@ static int rows_grid(long long total) {
 }
 int mi355seg_copy_rows_f32(const float* src, int ldsrc, float* dst, int lddst, long long rows, int C, void* stream) {
     SEG_CHECK_ARG(src && dst && rows > 0 && C > 0 && ldsrc >= C && lddst >= C, "copy_rows: bad arguments");
-    hipLaunchKernelGGL((rows_kernel<false>), dim3(rows_grid(rows * C / 4 + 1)), dim3(256), 0, (hipStream_t)stream, src, ldsrc,
+    hipLaunchKernelGGL((rows_kernel<float, false>), dim3(rows_grid(rows * C / 4 + 1)), dim3(256), 0, (hipStream_t)stream, src, ldsrc,
+                       dst, lddst, rows, C);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_copy_rows_bf16(const mi355seg_bf16* src, int ldsrc, mi355seg_bf16* dst, int lddst, long long rows, int C, void* stream) {
+    SEG_CHECK_ARG(src && dst && rows > 0 && C > 0 && ldsrc >= C && lddst >= C, "copy_rows: bad arguments");
+    hipLaunchKernelGGL((rows_kernel<bf16, false>), dim3(rows_grid(rows * C / 4 + 1)), dim3(256), 0, (hipStream_t)stream, src, ldsrc,
                        dst, lddst, rows, C);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
 int mi355seg_add_rows_f32(const float* src, int ldsrc, float* dst, int lddst, long long rows, int C, void* stream) {
     SEG_CHECK_ARG(src && dst && rows > 0 && C > 0 && ldsrc >= C && lddst >= C, "add_rows: bad arguments");
-    hipLaunchKernelGGL((rows_kernel<true>), dim3(rows_grid(rows * C / 4 + 1)), dim3(256), 0, (hipStream_t)stream, src, ldsrc,
+    hipLaunchKernelGGL((rows_kernel<float, true>), dim3(rows_grid(rows * C / 4 + 1)), dim3(256), 0, (hipStream_t)stream, src, ldsrc,
+                       dst, lddst, rows, C);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_add_rows_bf16(const mi355seg_bf16* src, int ldsrc, mi355seg_bf16* dst, int lddst, long long rows, int C, void* stream) {
+    SEG_CHECK_ARG(src && dst && rows > 0 && C > 0 && ldsrc >= C && lddst >= C, "add_rows: bad arguments");
+    hipLaunchKernelGGL((rows_kernel<bf16, true>), dim3(rows_grid(rows * C / 4 + 1)), dim3(256), 0, (hipStream_t)stream, src, ldsrc,
                        dst, lddst, rows, C);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
@@ -269,13 +302,25 @@ int mi355seg_add_rows_f32(const float* src, int ldsrc, float* dst, int lddst, lo
 
 int mi355seg_repeat_channels_f32(const float* x, int ldx, float* y, int ldy, long long rows, int C, int rep, void* stream) {
     SEG_CHECK_ARG(x && y && rows > 0 && C > 0 && rep > 0 && ldx >= C && ldy >= C * rep, "repeat_channels: bad arguments");
-    hipLaunchKernelGGL(repeat_ch_kernel, dim3(rows_grid(rows * C * rep)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, C, rep);
+    hipLaunchKernelGGL(repeat_ch_kernel<float>, dim3(rows_grid(rows * C * rep)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, C, rep);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_repeat_channels_bf16(const mi355seg_bf16* x, int ldx, mi355seg_bf16* y, int ldy, long long rows, int C, int rep, void* stream) {
+    SEG_CHECK_ARG(x && y && rows > 0 && C > 0 && rep > 0 && ldx >= C && ldy >= C * rep, "repeat_channels: bad arguments");
+    hipLaunchKernelGGL(repeat_ch_kernel<bf16>, dim3(rows_grid(rows * C * rep)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, C, rep);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
 int mi355seg_repeat_channels_bwd_f32(const float* dy, int lddy, float* dx, int lddx, long long rows, int C, int rep, void* stream) {
     SEG_CHECK_ARG(dy && dx && rows > 0 && C > 0 && rep > 0 && lddx >= C && lddy >= C * rep, "repeat_channels_bwd: bad arguments");
-    hipLaunchKernelGGL(repeat_ch_bwd_kernel, dim3(rows_grid(rows * C)), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx, lddx, rows, C, rep);
+    hipLaunchKernelGGL(repeat_ch_bwd_kernel<float>, dim3(rows_grid(rows * C)), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx, lddx, rows, C, rep);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_repeat_channels_bwd_bf16(const mi355seg_bf16* dy, int lddy, mi355seg_bf16* dx, int lddx, long long rows, int C, int rep, void* stream) {
+    SEG_CHECK_ARG(dy && dx && rows > 0 && C > 0 && rep > 0 && lddx >= C && lddy >= C * rep, "repeat_channels_bwd: bad arguments");
+    hipLaunchKernelGGL(repeat_ch_bwd_kernel<bf16>, dim3(rows_grid(rows * C)), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx, lddx, rows, C, rep);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
@@ -331,7 +376,13 @@ int mi355seg_gate_bwd_f32(const float* dy, int lddy, const float* enc, int ldenc
 }
 int mi355seg_add_bias_f32(float* y, int ldy, const float* bias, long long rows, int C, void* stream) {
     SEG_CHECK_ARG(y && bias && rows > 0 && C > 0 && ldy >= C, "add_bias: bad arguments");
-    hipLaunchKernelGGL(add_bias_kernel, dim3(rows_grid(rows * C)), dim3(256), 0, (hipStream_t)stream, y, ldy, bias, rows, C);
+    hipLaunchKernelGGL(add_bias_kernel<float>, dim3(rows_grid(rows * C)), dim3(256), 0, (hipStream_t)stream, y, ldy, bias, rows, C);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_add_bias_bf16(mi355seg_bf16* y, int ldy, const float* bias, long long rows, int C, void* stream) {
+    SEG_CHECK_ARG(y && bias && rows > 0 && C > 0 && ldy >= C, "add_bias: bad arguments");
+    hipLaunchKernelGGL(add_bias_kernel<bf16>, dim3(rows_grid(rows * C)), dim3(256), 0, (hipStream_t)stream, y, ldy, bias, rows, C);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }

@@ -77,6 +77,18 @@ __device__ __forceinline__ void st4(bf16* p, f32x4_t v) {
     q[0] = (bf16)v[0]; q[1] = (bf16)v[1]; q[2] = (bf16)v[2]; q[3] = (bf16)v[3];
     *reinterpret_cast<bf16x4_t*>(p) = q;
 }
+// the same for HIP's float4 struct (.x .y .z .w), which the streaming kernels are written in
+__device__ __forceinline__ float4 ldf4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ldf4(const bf16* p) {
+    const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void stf4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void stf4(bf16* p, float4 v) {
+    bf16x4_t q;
+    q[0] = (bf16)v.x; q[1] = (bf16)v.y; q[2] = (bf16)v.z; q[3] = (bf16)v.w;
+    *reinterpret_cast<bf16x4_t*>(p) = q;
+}
 __device__ __forceinline__ float ld1(const float* p) { return *p; }
 __device__ __forceinline__ float ld1(const bf16* p) { return (float)*p; }
 __device__ __forceinline__ void st1(float* p, float v) { *p = v; }

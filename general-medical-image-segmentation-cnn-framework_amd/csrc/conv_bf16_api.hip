@@ -1,0 +1,204 @@
+// conv_bf16_api.hip -- Conv3d forward / input gradient / weight gradient on bf16 NDHWC tensors (the bf16 configurations:
+// V-Net vnet3d.py:21-121, Residual U-Net residual_unet3d.py:22-107, UNETR decoder unetr.py:8-51).  Activations and
+// activation gradients are bf16 in HBM, weights / bias / weight gradients stay fp32 masters (what torch autocast does for
+// the reference), every product is a bf16 MFMA with fp32 accumulation.
+//
+// Native bf16 kernels: the implicit-GEMM kernel (k1 / k3 / k5 stride 1, gather mode for strided / even kernels), the
+// transposing-read wgrad (k3 / k5), the K = voxels wgrads (k1, any-geometry gather wgrad: bf16 loads, fp32 MFMA) and the
+// HBM-bound small-channel stems / heads.  Any other shape (V-Net's two-channel k5 head and one-channel k5 stem, tiny
+// or ragged channel counts) runs through the fp32 entry point on fp32 copies made in the workspace: one extra read +
+// write of tensors that are a few channels wide -- correct for every geometry, never the hot layers.
+#include "common.h"
+#include "internal.h"
+
+namespace seg {
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_rows_kernel(const TS* __restrict__ src, int lds, TD* __restrict__ dst, int ldd, long long rows, int C) {
+    const bool v = (C % 4 == 0) && (lds % 4 == 0) && (ldd % 4 == 0) && ((uintptr_t)src % (4 * sizeof(TS)) == 0) && ((uintptr_t)dst % (4 * sizeof(TD)) == 0);
+    const int cw = v ? C / 4 : C;
+    const long long total = rows * cw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / cw;
+        const int c = (int)(i - r * cw);
+        if (v) st4(dst + r * ldd + c * 4, ld4(src + r * lds + c * 4));
+        else st1(dst + r * ldd + c, ld1(src + r * lds + c));
+    }
+}
+
+template <typename TS, typename TD>
+static void cast_rows(const TS* src, int lds, TD* dst, int ldd, long long rows, int C, hipStream_t st) {
+    long long b = (rows * C / 4 + 255) / 256;
+    const int grid = (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+    hipLaunchKernelGGL((cast_rows_kernel<TS, TD>), dim3(grid), dim3(256), 0, st, src, lds, dst, ldd, rows, C);
+}
+
+static int oext(int n, int k, int s, int p) { return (n + 2 * p - k) / s + 1; }
+
+// which native bf16 kernel serves a shape (0 = none: fp32 fallback)
+enum { NB_NONE = 0, NB_IGEMM, NB_GATHER, NB_STEM, NB_HEAD, NB_LOWP, NB_PW, NB_SMALLCIN, NB_SMALLCOUT, NB_GW };
+static int native_fwd(int N, int D, int H, int W, int Cin, int Cout, int k, int s, int p, int ldx, int ldy) {
+    if (conv_mfma_supported(MATH_B16, N, D, H, W, Cin, Cout, k, s, p, ldx, ldy)) return NB_IGEMM;
+    if (conv_gather_fwd_supported(MATH_B16, N, D, H, W, Cin, Cout, k, s, p, ldx, ldy)) return NB_GATHER;
+    if (stem_supported(Cin, Cout, k, s, p, ldy)) return NB_STEM;
+    if (head_supported(Cin, Cout, k, s, p, ldx)) return NB_HEAD;
+    return NB_NONE;
+}
+static int native_dgrad(int N, int D, int H, int W, int Cin, int Cout, int k, int s, int p, int lddy, int lddx) {
+    if (conv_mfma_supported(MATH_B16, N, D, H, W, Cout, Cin, k, s, p, lddy, lddx)) return NB_IGEMM;
+    if (conv_gather_dgrad_supported(MATH_B16, N, D, H, W, Cin, Cout, k, s, p, lddy, lddx)) return NB_GATHER;
+    if (head_supported(Cin, Cout, k, s, p, lddx)) return NB_HEAD;
+    return NB_NONE;
+}
+static int native_wgrad(int N, int D, int H, int W, int Cin, int Cout, int k, int s, int p, int ldx, int lddy) {
+    if (wgrad_lowp_supported(MATH_B16, N, D, H, W, Cin, Cout, k, s, p, ldx, lddy)) return NB_LOWP;
+    if (k == 1 && s == 1 && p == 0 && pw_wgrad_supported((long long)N * D * H * W, Cin, Cout, 1, ldx, lddy)) return NB_PW;
+    if (stem_supported(Cin, Cout, k, s, p, lddy)) return NB_STEM;
+    if (head_supported(Cin, Cout, k, s, p, ldx)) return NB_HEAD;
+    if (smallcin_wgrad_supported(Cin, Cout, k)) return NB_SMALLCIN;
+    if (smallcout_wgrad_supported(Cin, Cout, k, ldx)) return NB_SMALLCOUT;
+    if (gwgrad_supported(N, D, H, W, Cin, Cout, k, s, p, ldx, lddy)) return NB_GW;
+    return NB_NONE;
+}
+
+}  // namespace seg
+
+using namespace seg;
+
+extern "C" {
+
+// workspace of the three bf16 Conv3d entry points for one layer geometry (contiguous tensors assumed for the fallback test)
+size_t mi355seg_conv3d_ws_bytes_bf16(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
+    size_t base = mi355seg_conv3d_ws_bytes(N, D, H, W, Cin, Cout, k, stride, pad);
+    if (D + 2 * pad < k || H + 2 * pad < k || W + 2 * pad < k) return base;
+    const int Do = oext(D, k, stride, pad), Ho = oext(H, k, stride, pad), Wo = oext(W, k, stride, pad);
+    const bool fb = !native_fwd(N, D, H, W, Cin, Cout, k, stride, pad, Cin, Cout) || !native_dgrad(N, D, H, W, Cin, Cout, k, stride, pad, Cout, Cin) ||
+                    !native_wgrad(N, D, H, W, Cin, Cout, k, stride, pad, Cin, Cout);
+    if (fb) base += align_up((size_t)N * D * H * W * Cin * 4, 256) + align_up((size_t)N * Do * Ho * Wo * Cout * 4, 256) + 512;
+    return base;
+}
+
+int mi355seg_conv3d_fwd_bf16(const mi355seg_bf16* x, int ldx, const float* w, const float* bias, mi355seg_bf16* y, int ldy,
+                             int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                             double* stats_sum, double* stats_sq, void* ws, size_t ws_bytes, void* stream) {
+    SEG_CHECK_ARG(x && w && y && N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ldx >= Cin && ldy >= Cout, "conv3d_fwd_bf16: bad arguments");
+    SEG_CHECK_ARG(k >= 1 && k <= 16 && stride >= 1 && pad >= 0 && D + 2 * pad >= k && H + 2 * pad >= k && W + 2 * pad >= k,
+                  "conv3d_fwd_bf16: bad k/stride/pad %d/%d/%d", k, stride, pad);
+    SEG_CHECK_ARG((stats_sum == nullptr) == (stats_sq == nullptr), "conv3d_fwd_bf16: stats_sum/stats_sq must come together");
+    hipStream_t st = (hipStream_t)stream;
+    const int Do = oext(D, k, stride, pad), Ho = oext(H, k, stride, pad), Wo = oext(W, k, stride, pad);
+    const long long vout = (long long)N * Do * Ho * Wo;
+    const bool al = ((uintptr_t)x % 16) == 0;
+    const int nb = native_fwd(N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy);
+    if (nb == NB_IGEMM && al)
+        return conv_fwd_mfma(MATH_B16, x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, /*dgrad=*/0, stats_sum, stats_sq, ws, ws_bytes, st);
+    if (nb == NB_GATHER && al)
+        return conv_gather_fwd_mfma(MATH_B16, x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, stride, pad, stats_sum, stats_sq, ws, ws_bytes, st);
+    if (nb == NB_STEM && ((uintptr_t)y % 8) == 0)
+        return stem_fwd(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, stats_sum, stats_sq, ws, ws_bytes, st);
+    if (nb == NB_HEAD && ((uintptr_t)x % 8) == 0) {
+        int rc = head_fwd(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, st);
+        if (rc || !stats_sum) return rc;
+        return channel_sums(y, ldy, vout, Cout, stats_sum, stats_sq, nullptr, 0, ws, ws_bytes, st);
+    }
+    // fp32 fallback
+    Carver cv(ws);
+    float* xf = cv.take<float>((size_t)N * D * H * W * Cin);
+    float* yf = cv.take<float>((size_t)vout * Cout);
+    const size_t used = cv.used();
+    SEG_CHECK_WS(used + mi355seg_conv3d_ws_bytes(N, D, H, W, Cin, Cout, k, stride, pad), ws_bytes);
+    cast_rows(x, ldx, xf, Cin, (long long)N * D * H * W, Cin, st);
+    SEG_CHECK_LAUNCH();
+    int rc = mi355seg_conv3d_fwd_f32(xf, Cin, w, bias, yf, Cout, N, D, H, W, Cin, Cout, k, stride, pad, stats_sum, stats_sq, (char*)ws + used, ws_bytes - used, stream);
+    if (rc) return rc;
+    cast_rows(yf, Cout, y, ldy, vout, Cout, st);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+int mi355seg_conv3d_dgrad_bf16(const mi355seg_bf16* dy, int lddy, const float* w, mi355seg_bf16* dx, int lddx,
+                               int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                               void* ws, size_t ws_bytes, void* stream) {
+    SEG_CHECK_ARG(dy && w && dx && N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && lddy >= Cout && lddx >= Cin, "conv3d_dgrad_bf16: bad arguments");
+    SEG_CHECK_ARG(k >= 1 && k <= 16 && stride >= 1 && pad >= 0 && D + 2 * pad >= k && H + 2 * pad >= k && W + 2 * pad >= k,
+                  "conv3d_dgrad_bf16: bad k/stride/pad %d/%d/%d", k, stride, pad);
+    hipStream_t st = (hipStream_t)stream;
+    const int Do = oext(D, k, stride, pad), Ho = oext(H, k, stride, pad), Wo = oext(W, k, stride, pad);
+    const long long vout = (long long)N * Do * Ho * Wo, vin = (long long)N * D * H * W;
+    const bool al = ((uintptr_t)dy % 16) == 0;
+    const int nb = native_dgrad(N, D, H, W, Cin, Cout, k, stride, pad, lddy, lddx);
+    if (nb == NB_IGEMM && al)
+        return conv_fwd_mfma(MATH_B16, dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cout, Cin, k, /*dgrad=*/1, nullptr, nullptr, ws, ws_bytes, st);
+    if (nb == NB_GATHER && al)
+        return conv_gather_dgrad_mfma(MATH_B16, dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, k, stride, pad, ws, ws_bytes, st);
+    if (nb == NB_HEAD && ((uintptr_t)dx % 8) == 0)
+        return head_dgrad(dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, st);
+    Carver cv(ws);
+    float* dxf = cv.take<float>((size_t)vin * Cin);
+    float* dyf = cv.take<float>((size_t)vout * Cout);
+    const size_t used = cv.used();
+    SEG_CHECK_WS(used + mi355seg_conv3d_ws_bytes(N, D, H, W, Cin, Cout, k, stride, pad), ws_bytes);
+    cast_rows(dy, lddy, dyf, Cout, vout, Cout, st);
+    SEG_CHECK_LAUNCH();
+    int rc = mi355seg_conv3d_dgrad_f32(dyf, Cout, w, dxf, Cin, N, D, H, W, Cin, Cout, k, stride, pad, (char*)ws + used, ws_bytes - used, stream);
+    if (rc) return rc;
+    cast_rows(dxf, Cin, dx, lddx, vin, Cin, st);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+int mi355seg_conv3d_wgrad_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, float* dw, float* db,
+                               int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int accumulate,
+                               void* ws, size_t ws_bytes, void* stream) {
+    SEG_CHECK_ARG(dy && x && dw && N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && lddy >= Cout && ldx >= Cin, "conv3d_wgrad_bf16: bad arguments");
+    SEG_CHECK_ARG(k >= 1 && k <= 16 && stride >= 1 && pad >= 0 && D + 2 * pad >= k && H + 2 * pad >= k && W + 2 * pad >= k,
+                  "conv3d_wgrad_bf16: bad k/stride/pad %d/%d/%d", k, stride, pad);
+    hipStream_t st = (hipStream_t)stream;
+    const int Do = oext(D, k, stride, pad), Ho = oext(H, k, stride, pad), Wo = oext(W, k, stride, pad);
+    const long long vout = (long long)N * Do * Ho * Wo, vin = (long long)N * D * H * W;
+    if (db) {
+        int rc = channel_sums(dy, lddy, vout, Cout, nullptr, nullptr, db, accumulate, ws, ws_bytes, st);
+        if (rc) return rc;
+    }
+    const bool al16 = ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, al8 = ((uintptr_t)x % 8) == 0 && ((uintptr_t)dy % 8) == 0;
+    const int nb = native_wgrad(N, D, H, W, Cin, Cout, k, stride, pad, ldx, lddy);
+    if (nb == NB_LOWP && al16) return conv_wgrad_lowp(MATH_B16, dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, accumulate, ws, ws_bytes, st);
+    if (nb == NB_PW && al8) {
+        float* part; int nstrips;
+        int rc = pw_wgrad_mfma(dy, lddy, x, ldx, N, D, H, W, Cin, Cout, 1, &part, &nstrips, ws, ws_bytes, st);
+        if (rc) return rc;
+        wgrad_reduce(part, dw, nstrips, 1, Cin, Cout, accumulate, st);
+        SEG_CHECK_LAUNCH();
+        return MI355SEG_OK;
+    }
+    if (nb == NB_STEM && al8) return stem_wgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, st);
+    if (nb == NB_HEAD && al8) return head_wgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, st);
+    if (nb == NB_SMALLCIN && al8) return smallcin_wgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, stride, pad, accumulate, ws, ws_bytes, st);
+    if (nb == NB_SMALLCOUT && al8) return smallcout_wgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, stride, pad, accumulate, ws, ws_bytes, st);
+    if (nb == NB_GW && al8) return conv_gwgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, stride, pad, accumulate, ws, ws_bytes, st);
+    Carver cv(ws);
+    float* xf = cv.take<float>((size_t)vin * Cin);
+    float* dyf = cv.take<float>((size_t)vout * Cout);
+    const size_t used = cv.used();
+    SEG_CHECK_WS(used + mi355seg_conv3d_ws_bytes(N, D, H, W, Cin, Cout, k, stride, pad), ws_bytes);
+    cast_rows(x, ldx, xf, Cin, vin, Cin, st);
+    cast_rows(dy, lddy, dyf, Cout, vout, Cout, st);
+    SEG_CHECK_LAUNCH();
+    return mi355seg_conv3d_wgrad_f32(dyf, Cout, xf, Cin, dw, nullptr, N, D, H, W, Cin, Cout, k, stride, pad, accumulate, (char*)ws + used, ws_bytes - used, stream);
+}
+
+// dtype casts of [rows, C] matrices with row pitches (autocast boundaries: fp32 <-> bf16 activations)
+int mi355seg_cast_f32_to_bf16(const float* src, int ldsrc, mi355seg_bf16* dst, int lddst, long long rows, int C, void* stream) {
+    SEG_CHECK_ARG(src && dst && rows > 0 && C > 0 && ldsrc >= C && lddst >= C, "cast_f32_to_bf16: bad arguments");
+    cast_rows(src, ldsrc, dst, lddst, rows, C, (hipStream_t)stream);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_cast_bf16_to_f32(const mi355seg_bf16* src, int ldsrc, float* dst, int lddst, long long rows, int C, void* stream) {
+    SEG_CHECK_ARG(src && dst && rows > 0 && C > 0 && ldsrc >= C && lddst >= C, "cast_bf16_to_f32: bad arguments");
+    cast_rows(src, ldsrc, dst, lddst, rows, C, (hipStream_t)stream);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+}  // extern "C"

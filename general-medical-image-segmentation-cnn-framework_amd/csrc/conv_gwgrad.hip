@@ -17,7 +17,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 struct GwArgs {
-    const float* x; const float* dy; float* part;
+    const void* x; const void* dy; float* part;      // x / dy: fp32 or bf16 (the kernel's IN_T), staged into LDS as fp32
     int ldx, lddy, N, D, H, W, Do, Ho, Wo, Cin, Cout, k, stride, pad, T;
     int ntiles, nstrips, npairs, ncob, ngroups;
 };
@@ -26,7 +26,10 @@ constexpr int GW_V = 64, GW_TG = 8;
 constexpr int GW_XIT = GW_TG * GW_V * 8 / 256, GW_DIT = GW_V * 8 / 256;
 constexpr int GW_LDS = (GW_V * 32 + GW_TG * GW_V * 32) * 4;
 
+template <typename IN_T>
 __global__ __launch_bounds__(256, 2) void conv_gwgrad_kernel(GwArgs a) {
+    const IN_T* __restrict__ xin = reinterpret_cast<const IN_T*>(a.x);
+    const IN_T* __restrict__ dyin = reinterpret_cast<const IN_T*>(a.dy);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* ds = lds;                       // [V][32]
     float* xs = lds + GW_V * 32;           // [TG][V][32]
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void conv_gwgrad_kernel(GwArgs a) {
             const int p = it * 256 + tid;
             const int part = p & 7, vl = p >> 3;
             f32x4 dv = {0.f, 0.f, 0.f, 0.f};
-            if (v0 + vl < nvox && co0 + part * 4 < a.Cout) dv = *reinterpret_cast<const f32x4*>(a.dy + (v0 + vl) * a.lddy + co0 + part * 4);
+            if (v0 + vl < nvox && co0 + part * 4 < a.Cout) dv = ld4(dyin + (v0 + vl) * a.lddy + co0 + part * 4);
             sd[it] = dv;
         }
 #pragma unroll
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void conv_gwgrad_kernel(GwArgs a) {
                 const int kw = tap % a.k, kh = (tap / a.k) % a.k, kd = tap / (a.k * a.k);
                 const int iz = od * a.stride - a.pad + kd, iy = oh * a.stride - a.pad + kh, ix = ow * a.stride - a.pad + kw;
                 if ((unsigned)iz < (unsigned)a.D && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                    xv = *reinterpret_cast<const f32x4*>(a.x + ((((long long)n * a.D + iz) * a.H + iy) * a.W + ix) * a.ldx + ci0 + part * 4);
+                    xv = ld4(xin + ((((long long)n * a.D + iz) * a.H + iy) * a.W + ix) * a.ldx + ci0 + part * 4);
             }
             sx[it] = xv;
         }
@@ -150,12 +153,13 @@ bool gwgrad_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int 
     return (ldx % 4) == 0 && (lddy % 4) == 0 && k <= 7 && gw_plan(N, Do, Ho, Wo, Cin, Cout, k, &p);
 }
 
-int conv_gwgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
+template <typename IN_T>
+int conv_gwgrad(const IN_T* dy, int lddy, const IN_T* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
                 int k, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
     GwPlan p;
     const int Do = (D + 2 * pad - k) / stride + 1, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     SEG_CHECK_ARG(gw_plan(N, Do, Ho, Wo, Cin, Cout, k, &p), "conv_gwgrad: unsupported shape");
-    SEG_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, "conv_gwgrad: pointers must be 16-byte aligned");
+    SEG_CHECK_ARG(((uintptr_t)x % (4 * sizeof(IN_T))) == 0 && ((uintptr_t)dy % (4 * sizeof(IN_T))) == 0, "conv_gwgrad: pointers must be aligned to four elements");
     Carver cv(ws);
     float* part = cv.take<float>((size_t)p.nstrips * p.T * Cin * Cout);
     SEG_CHECK_WS(cv.used(), ws_bytes);
@@ -164,15 +168,18 @@ int conv_gwgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, i
     const int nwg = p.nstrips * p.npairs * p.ngroups;
     const double vox = (double)N * Do * Ho * Wo;
     {
-        ProfScope ps(PF_WGRAD, 2.0 * vox * p.T * Cin * Cout, 4.0 * (vox * ((double)p.T * Cin + Cout) + (double)p.T * Cin * Cout), st);
+        ProfScope ps(PF_WGRAD, 2.0 * vox * p.T * Cin * Cout, (double)sizeof(IN_T) * vox * ((double)p.T * Cin + Cout) + 4.0 * p.T * Cin * Cout, st);
         static bool set = false;
-        if (!set) { (void)hipFuncSetAttribute((const void*)conv_gwgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS); set = true; }
-        hipLaunchKernelGGL(conv_gwgrad_kernel, dim3(nwg), dim3(256), GW_LDS, st, a);
+        if (!set) { (void)hipFuncSetAttribute((const void*)conv_gwgrad_kernel<IN_T>, hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS); set = true; }
+        hipLaunchKernelGGL(conv_gwgrad_kernel<IN_T>, dim3(nwg), dim3(256), GW_LDS, st, a);
         SEG_CHECK_LAUNCH();
     }
     wgrad_reduce(part, dw, p.nstrips, p.T, Cin, Cout, accumulate, st);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
+
+template int conv_gwgrad<float>(const float*, int, const float*, int, float*, int, int, int, int, int, int, int, int, int, int, void*, size_t, hipStream_t);
+template int conv_gwgrad<bf16>(const bf16*, int, const bf16*, int, float*, int, int, int, int, int, int, int, int, int, int, void*, size_t, hipStream_t);
 
 }  // namespace seg

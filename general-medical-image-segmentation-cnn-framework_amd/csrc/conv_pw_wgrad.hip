@@ -16,7 +16,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 struct PwArgs {
-    const float* x; const float* dy; float* part;
+    const void* x; const void* dy; float* part;      // x / dy: fp32 or bf16 (the kernel's IN_T), staged into LDS as fp32
     int ldx, lddy, N, D, H, W, Cin, Cout;
     int ntiles, nstrips, npairs, ncob;
 };
@@ -32,9 +32,11 @@ struct PwCfg {
     static constexpr int LDS_BYTES = (V * 32 + T * V * 32) * 4;
 };
 
-template <int T>
+template <int T, typename IN_T>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(PwArgs a) {
     using C = PwCfg<T>;
+    const IN_T* __restrict__ xin = reinterpret_cast<const IN_T*>(a.x);
+    const IN_T* __restrict__ dyin = reinterpret_cast<const IN_T*>(a.dy);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;
     float* ds = lds + C::X_FLOATS;
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(PwArgs a) {
         for (int it = 0; it < C::XIT; ++it) {
             const int p = it * 256 + tid;
             f32x4 xv = {0.f, 0.f, 0.f, 0.f};
-            if (v0 + (p >> 3) < nvox && ci0 + (p & 7) * 4 < a.Cin) xv = *reinterpret_cast<const f32x4*>(a.x + (v0 + (p >> 3)) * a.ldx + ci0 + (p & 7) * 4);
+            if (v0 + (p >> 3) < nvox && ci0 + (p & 7) * 4 < a.Cin) xv = ld4(xin + (v0 + (p >> 3)) * a.ldx + ci0 + (p & 7) * 4);
             sx[it] = xv;
         }
 #pragma unroll
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(PwArgs a) {
                 ov = v0 + vl;
             }
             f32x4 dv = {0.f, 0.f, 0.f, 0.f};
-            if (v0 + vl < nvox && co0 + part * 4 < a.Cout) dv = *reinterpret_cast<const f32x4*>(a.dy + ov * a.lddy + co0 + part * 4);
+            if (v0 + vl < nvox && co0 + part * 4 < a.Cout) dv = ld4(dyin + ov * a.lddy + co0 + part * 4);
             sd[it] = dv;
         }
     };
@@ -165,30 +167,33 @@ bool pw_wgrad_supported(long long nvox, int Cin, int Cout, int T, int ldx, int l
 }
 
 // returns the slab pointer/strip count through *part_out / *nstrips_out; the caller runs the layout-specific reduce
-int pw_wgrad_mfma(const float* dy, int lddy, const float* x, int ldx, int N, int D, int H, int W, int Cin, int Cout, int T,
+template <typename IN_T>
+int pw_wgrad_mfma(const IN_T* dy, int lddy, const IN_T* x, int ldx, int N, int D, int H, int W, int Cin, int Cout, int T,
                   float** part_out, int* nstrips_out, void* ws, size_t ws_bytes, hipStream_t st) {
     PwPlan p;
     const long long nvox = (long long)N * D * H * W;
     SEG_CHECK_ARG(pw_plan(nvox, Cin, Cout, T, &p), "pw_wgrad_mfma: unsupported shape");
-    SEG_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, "pw_wgrad_mfma: pointers must be 16-byte aligned");
+    SEG_CHECK_ARG(((uintptr_t)x % (4 * sizeof(IN_T))) == 0 && ((uintptr_t)dy % (4 * sizeof(IN_T))) == 0, "pw_wgrad_mfma: pointers must be aligned to four elements");
     Carver cv(ws);
     float* part = cv.take<float>((size_t)p.nstrips * T * Cin * Cout);
     SEG_CHECK_WS(cv.used(), ws_bytes);
     PwArgs a{x, dy, part, ldx, lddy, N, D, H, W, Cin, Cout, p.ntiles, p.nstrips, p.npairs, (Cout + 31) / 32};
     const int nwg = p.nstrips * p.npairs;
-    ProfScope ps(T == 8 ? PF_CONVT : PF_WGRAD, 2.0 * nvox * T * Cin * Cout, 4.0 * (nvox * (Cin + (double)T * Cout) + (double)T * Cin * Cout), st);
+    ProfScope ps(T == 8 ? PF_CONVT : PF_WGRAD, 2.0 * nvox * T * Cin * Cout, (double)sizeof(IN_T) * nvox * (Cin + (double)T * Cout) + 4.0 * T * Cin * Cout, st);
     if (T == 8) {
         static bool set8 = false;
-        if (!set8) { (void)hipFuncSetAttribute((const void*)pw_wgrad_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, PwCfg<8>::LDS_BYTES); set8 = true; }
-        hipLaunchKernelGGL((pw_wgrad_kernel<8>), dim3(nwg), dim3(256), PwCfg<8>::LDS_BYTES, st, a);
+        if (!set8) { (void)hipFuncSetAttribute((const void*)pw_wgrad_kernel<8, IN_T>, hipFuncAttributeMaxDynamicSharedMemorySize, PwCfg<8>::LDS_BYTES); set8 = true; }
+        hipLaunchKernelGGL((pw_wgrad_kernel<8, IN_T>), dim3(nwg), dim3(256), PwCfg<8>::LDS_BYTES, st, a);
     } else {
         static bool set1 = false;
-        if (!set1) { (void)hipFuncSetAttribute((const void*)pw_wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, PwCfg<1>::LDS_BYTES); set1 = true; }
-        hipLaunchKernelGGL((pw_wgrad_kernel<1>), dim3(nwg), dim3(256), PwCfg<1>::LDS_BYTES, st, a);
+        if (!set1) { (void)hipFuncSetAttribute((const void*)pw_wgrad_kernel<1, IN_T>, hipFuncAttributeMaxDynamicSharedMemorySize, PwCfg<1>::LDS_BYTES); set1 = true; }
+        hipLaunchKernelGGL((pw_wgrad_kernel<1, IN_T>), dim3(nwg), dim3(256), PwCfg<1>::LDS_BYTES, st, a);
     }
     SEG_CHECK_LAUNCH();
     *part_out = part; *nstrips_out = p.nstrips;
     return MI355SEG_OK;
 }
+template int pw_wgrad_mfma<float>(const float*, int, const float*, int, int, int, int, int, int, int, int, float**, int*, void*, size_t, hipStream_t);
+template int pw_wgrad_mfma<bf16>(const bf16*, int, const bf16*, int, int, int, int, int, int, int, int, float**, int*, void*, size_t, hipStream_t);
 
 }  // namespace seg

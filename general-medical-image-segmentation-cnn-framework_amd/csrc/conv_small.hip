@@ -16,9 +16,9 @@ struct SmallGeom { int N, D, H, W, Cin, Cout, ldx, ldy; };
 
 // ---------------------------------------------------------------- stem forward
 // thread = (voxel, output-channel quad); LPV = Cout/4 lanes per voxel
-template <int CIN>
-__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-        const float* __restrict__ bias, float* __restrict__ y, float* __restrict__ spart, SmallGeom g) {
+template <typename T, int CIN>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+        const float* __restrict__ bias, T* __restrict__ y, float* __restrict__ spart, SmallGeom g) {
     extern __shared__ __attribute__((aligned(16))) float sw[];      // [27][CIN][Cout] then reduction scratch
     const int Cout = g.Cout, LPV = Cout / 4;
     for (int i = threadIdx.x; i < 27 * CIN * Cout; i += 256) {
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     const int cq = threadIdx.x % LPV, vl = threadIdx.x / LPV, VPB = 256 / LPV;
     const long long nvox = (long long)g.N * g.D * g.H * g.W;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + cq * 4);
+    if (bias) bv = ld4(bias + cq * 4);
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
     for (long long v = (long long)blockIdx.x * VPB + vl; v < nvox; v += (long long)gridDim.x * VPB) {
         int xw = (int)(v % g.W); long long r = v / g.W;
@@ -41,16 +41,16 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
             const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
             const int iz = zd + dz, iy = yh + dy, ix = xw + dx;
             if ((unsigned)iz < (unsigned)g.D && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W) {
-                const float* xp = x + ((((long long)n * g.D + iz) * g.H + iy) * g.W + ix) * g.ldx;
+                const T* xp = x + ((((long long)n * g.D + iz) * g.H + iy) * g.W + ix) * g.ldx;
 #pragma unroll
                 for (int ci = 0; ci < CIN; ++ci) {
                     const float xv = xp[ci];
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(sw + (tap * CIN + ci) * Cout + cq * 4);
+                    const f32x4 wv = ld4(sw + (tap * CIN + ci) * Cout + cq * 4);
                     acc += xv * wv;
                 }
             }
         }
-        *reinterpret_cast<f32x4*>(y + v * g.ldy + cq * 4) = acc;
+        st4(y + v * g.ldy + cq * 4, acc);
         s1 += acc; s2 += acc * acc;
     }
     if (spart) {          // per-channel sum / sum of squares of this block (BatchNorm statistics)
@@ -71,8 +71,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 // ---------------------------------------------------------------- stem wgrad
 // grid = (blocks, CIN).  thread = (voxel, cout quad) keeps 27 x 4 accumulators:
 // acc[tap][j] += x[v + tap][ci] * dy[v][cq*4 + j].  part[blk][tap][ci][co].
-template <int DUMMY>
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename T, int DUMMY>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
         float* __restrict__ part, SmallGeom g, int lddy) {
     extern __shared__ __attribute__((aligned(16))) float sred[];
     const int Cout = g.Cout, LPV = Cout / 4, VPB = 256 / LPV;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
         int xw = (int)(v % g.W); long long r = v / g.W;
         int yh = (int)(r % g.H); r /= g.H;
         int zd = (int)(r % g.D); int n = (int)(r / g.D);
-        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + v * lddy + cq * 4);
+        const f32x4 d = ld4(dy + v * lddy + cq * 4);
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
             const int dz = tap / 9 - 1, dyy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     }
     if (lane < LPV) {
 #pragma unroll
-        for (int t = 0; t < 27; ++t) *reinterpret_cast<f32x4*>(sred + ((wave * 27 + t) * LPV + lane) * 4) = acc[t];
+        for (int t = 0; t < 27; ++t) st4(sred + ((wave * 27 + t) * LPV + lane) * 4, acc[t]);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 27 * Cout; i += 256) {
@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 // tile's 8 x-lines.  TX = 256 / (Cout/4).
 constexpr int S1_TZ = 2, S1_TY = 4;
 
-__device__ __forceinline__ void s1_stage(float* tile, const float* __restrict__ x, int ldx, int n, int z0, int y0, int x0, int TX,
+template <typename T>
+__device__ __forceinline__ void s1_stage(float* tile, const T* __restrict__ x, int ldx, int n, int z0, int y0, int x0, int TX,
                                          int D, int H, int W) {
     const int HX = TX + 2, HY = S1_TY + 2, HZ = S1_TZ + 2;
     for (int p = threadIdx.x; p < HX * HY * HZ; p += 256) {
@@ -136,13 +137,14 @@ __device__ __forceinline__ void s1_stage(float* tile, const float* __restrict__ 
         const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
         float v = 0.f;
         if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-            v = x[((((long long)n * D + gz) * H + gy) * W + gx) * ldx];
+            v = ld1(x + ((((long long)n * D + gz) * H + gy) * W + gx) * ldx);
         tile[p] = v;
     }
 }
 
-__global__ __launch_bounds__(256) void stem1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-        const float* __restrict__ bias, float* __restrict__ y, float* __restrict__ spart, SmallGeom g, int ntiles) {
+template <typename T>
+__global__ __launch_bounds__(256) void stem1_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+        const float* __restrict__ bias, T* __restrict__ y, float* __restrict__ spart, SmallGeom g, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Cout = g.Cout, LPV = Cout / 4, TX = 256 / LPV, HX = TX + 2, HY = S1_TY + 2;
     const int cq = threadIdx.x % LPV, xs = threadIdx.x / LPV;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256) void stem1_fwd_kernel(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; ++j) wr[t][j] = w[(long long)(cq * 4 + j) * 27 + t];
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + cq * 4);
+    if (bias) bv = ld4(bias + cq * 4);
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
     const int ntx = g.W / TX, nty = g.H / S1_TY, ntz = g.D / S1_TZ;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256) void stem1_fwd_kernel(const float* __restrict_
                 acc += tp[(dz * HY + dy) * HX + dx] * wr[t];
             }
             const long long v = (((long long)n * g.D + z0 + lz) * g.H + y0 + ly) * g.W + x0 + xs;
-            *reinterpret_cast<f32x4*>(y + v * g.ldy + cq * 4) = acc;
+            st4(y + v * g.ldy + cq * 4, acc);
             s1 += acc; s2 += acc * acc;
         }
     }
@@ -194,7 +196,8 @@ __global__ __launch_bounds__(256) void stem1_fwd_kernel(const float* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void stem1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename T>
+__global__ __launch_bounds__(256) void stem1_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
         float* __restrict__ part, SmallGeom g, int lddy, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Cout = g.Cout, LPV = Cout / 4, TX = 256 / LPV, HX = TX + 2, HY = S1_TY + 2;
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(256) void stem1_wgrad_kernel(const float* __restric
         for (int line = 0; line < S1_TZ * S1_TY; ++line) {
             const int lz = line / S1_TY, ly = line % S1_TY;
             const long long v = (((long long)n * g.D + z0 + lz) * g.H + y0 + ly) * g.W + x0 + xs;
-            dreg[line] = *reinterpret_cast<const f32x4*>(dy + v * lddy + cq * 4);
+            dreg[line] = ld4(dy + v * lddy + cq * 4);
         }
         __syncthreads();
         s1_stage(sm, x, g.ldx, n, z0, y0, x0, TX, g.D, g.H, g.W);
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(256) void stem1_wgrad_kernel(const float* __restric
     __syncthreads();
     if (lane < LPV) {
 #pragma unroll
-        for (int t = 0; t < 27; ++t) *reinterpret_cast<f32x4*>(sm + ((wave * 27 + t) * LPV + lane) * 4) = acc[t];
+        for (int t = 0; t < 27; ++t) st4(sm + ((wave * 27 + t) * LPV + lane) * 4, acc[t]);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 27 * Cout; i += 256) {
@@ -270,17 +273,17 @@ static size_t stem1_lds(int Cout) {
 
 // ---------------------------------------------------------------- pointwise (k1) small-Cout head
 // thread = (voxel, input-channel quad); LPV = Cin/4 lanes per voxel (<= 64)
-template <int COUT>
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-        const float* __restrict__ bias, float* __restrict__ y, SmallGeom g) {
+template <typename T, int COUT>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+        const float* __restrict__ bias, T* __restrict__ y, SmallGeom g) {
     const int LPV = g.Cin / 4, VPB = 256 / LPV;
     const int c4 = threadIdx.x % LPV, vl = threadIdx.x / LPV;
     const long long nvox = (long long)g.N * g.D * g.H * g.W;
     f32x4 wr[COUT];
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) wr[co] = *reinterpret_cast<const f32x4*>(w + (long long)co * g.Cin + c4 * 4);
+    for (int co = 0; co < COUT; ++co) wr[co] = ld4(w + (long long)co * g.Cin + c4 * 4);
     for (long long v = (long long)blockIdx.x * VPB + vl; v < nvox; v += (long long)gridDim.x * VPB) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + v * g.ldx + c4 * 4);
+        const f32x4 xv = ld4(x + v * g.ldx + c4 * 4);
         float o[COUT];
 #pragma unroll
         for (int co = 0; co < COUT; ++co) {
@@ -295,26 +298,26 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     }
 }
 
-template <int COUT>
-__global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ w,
-        float* __restrict__ dx, SmallGeom g) {
+template <typename T, int COUT>
+__global__ __launch_bounds__(256) void head_dgrad_kernel(const T* __restrict__ dy, int lddy, const float* __restrict__ w,
+        T* __restrict__ dx, SmallGeom g) {
     const int LPV = g.Cin / 4, VPB = 256 / LPV;
     const int c4 = threadIdx.x % LPV, vl = threadIdx.x / LPV;
     const long long nvox = (long long)g.N * g.D * g.H * g.W;
     f32x4 wr[COUT];
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) wr[co] = *reinterpret_cast<const f32x4*>(w + (long long)co * g.Cin + c4 * 4);
+    for (int co = 0; co < COUT; ++co) wr[co] = ld4(w + (long long)co * g.Cin + c4 * 4);
     for (long long v = (long long)blockIdx.x * VPB + vl; v < nvox; v += (long long)gridDim.x * VPB) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int co = 0; co < COUT; ++co) acc += dy[v * lddy + co] * wr[co];
-        *reinterpret_cast<f32x4*>(dx + v * g.ldx + c4 * 4) = acc;
+        st4(dx + v * g.ldx + c4 * 4, acc);
     }
 }
 
 // part[blk][0][ci][co] = sum over the block's voxels of x[v][ci] * dy[v][co]
-template <int COUT>
-__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int lddy,
+template <typename T, int COUT>
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, int lddy,
         float* __restrict__ part, SmallGeom g) {
     __shared__ float sred[4 * 64 * COUT * 4];
     const int LPV = g.Cin / 4, VPB = 256 / LPV;
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
 #pragma unroll
     for (int co = 0; co < COUT; ++co) acc[co] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (long long v = (long long)blockIdx.x * VPB + vl; v < nvox; v += (long long)gridDim.x * VPB) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + v * g.ldx + c4 * 4);
+        const f32x4 xv = ld4(x + v * g.ldx + c4 * 4);
 #pragma unroll
         for (int co = 0; co < COUT; ++co) acc[co] += dy[v * lddy + co] * xv;
     }
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
     const int nl = LPV < 64 ? LPV : 64;
     if (lane < nl) {
 #pragma unroll
-        for (int co = 0; co < COUT; ++co) *reinterpret_cast<f32x4*>(sred + ((wave * 64 + lane) * COUT + co) * 4) = acc[co];
+        for (int co = 0; co < COUT; ++co) st4(sred + ((wave * 64 + lane) * COUT + co) * 4, acc[co]);
     }
     __syncthreads();
     // when LPV == 64 a wave covers exactly one voxel row of quads; waves then hold different voxels of the same quads
@@ -364,8 +367,8 @@ struct SmallConv { int N, D, H, W, Do, Ho, Wo, Cin, Cout, k, stride, pad, T, ldx
 
 // (A) few input channels: thread = (output voxel, VW output channels); grid = (blocks, Cin, tap groups);
 //     acc[tap of the group][VW] += x[in(v, tap)][ci] * dy[v][co..co+VW).  part[blk][tap][ci][co]
-template <int TPG, int VW>
-__global__ __launch_bounds__(256) void smallcin_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename T, int TPG, int VW>
+__global__ __launch_bounds__(256) void smallcin_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
         float* __restrict__ part, SmallConv g) {
     extern __shared__ __attribute__((aligned(16))) float sred[];
     const int LPV = g.Cout / VW, VPB = 256 / LPV;
@@ -423,8 +426,8 @@ __global__ __launch_bounds__(256) void smallcin_wgrad_kernel(const float* __rest
 
 // (B) few output channels: thread = (output voxel, input-channel quad); grid = (blocks, tap groups);
 //     acc[tap][co] (f32x4 over the quad) += dy[v][co] * x[in(v, tap)][c4*4 .. +3].  part[blk][tap][ci][co]
-template <int COUT, int TPG>
-__global__ __launch_bounds__(256) void smallcout_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename T, int COUT, int TPG>
+__global__ __launch_bounds__(256) void smallcout_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
         float* __restrict__ part, SmallConv g) {
     extern __shared__ __attribute__((aligned(16))) float sred[];
     const int LPV = g.Cin / 4, VPB = 256 / LPV;
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(256) void smallcout_wgrad_kernel(const float* __res
             const int iz = od * g.stride - g.pad + kd, iy = oh * g.stride - g.pad + kh, ix = ow * g.stride - g.pad + kw;
             f32x4 xv = {0.f, 0.f, 0.f, 0.f};
             if (tap < g.T && (unsigned)iz < (unsigned)g.D && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
-                xv = *reinterpret_cast<const f32x4*>(x + ((((long long)n * g.D + iz) * g.H + iy) * g.W + ix) * g.ldx + c4 * 4);
+                xv = ld4(x + ((((long long)n * g.D + iz) * g.H + iy) * g.W + ix) * g.ldx + c4 * 4);
 #pragma unroll
             for (int co = 0; co < COUT; ++co) acc[t][co] += d[co] * xv;
         }
@@ -498,7 +501,8 @@ size_t small_wgrad_ws_bytes(int Cin, int Cout, int k) {
     return align_up((size_t)512 * k * k * k * Cin * Cout * sizeof(float), 256) + 1024;
 }
 
-int smallcin_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
+template <typename T>
+int smallcin_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
                    int k, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
     SmallConv g{N, D, H, W, (D + 2 * pad - k) / stride + 1, (H + 2 * pad - k) / stride + 1, (W + 2 * pad - k) / stride + 1,
                 Cin, Cout, k, stride, pad, k * k * k, ldx, lddy};
@@ -513,8 +517,8 @@ int smallcin_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw
     size_t lds = (size_t)4 * TPG * Cout * 4;
     {
         ProfScope ps(PF_DIRECT, 2.0 * nvox * g.T * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
-        if (vw == 4) hipLaunchKernelGGL((smallcin_wgrad_kernel<25, 4>), grid, dim3(256), lds, st, x, dy, part, g);
-        else hipLaunchKernelGGL((smallcin_wgrad_kernel<25, 1>), grid, dim3(256), lds, st, x, dy, part, g);
+        if (vw == 4) hipLaunchKernelGGL((smallcin_wgrad_kernel<T, 25, 4>), grid, dim3(256), lds, st, x, dy, part, g);
+        else hipLaunchKernelGGL((smallcin_wgrad_kernel<T, 25, 1>), grid, dim3(256), lds, st, x, dy, part, g);
         SEG_CHECK_LAUNCH();
     }
     wgrad_reduce(part, dw, nblk, g.T, Cin, Cout, accumulate, st);
@@ -522,7 +526,8 @@ int smallcin_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw
     return MI355SEG_OK;
 }
 
-int smallcout_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
+template <typename T>
+int smallcout_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
                     int k, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
     SmallConv g{N, D, H, W, (D + 2 * pad - k) / stride + 1, (H + 2 * pad - k) / stride + 1, (W + 2 * pad - k) / stride + 1,
                 Cin, Cout, k, stride, pad, k * k * k, ldx, lddy};
@@ -536,11 +541,11 @@ int smallcout_wgrad(const float* dy, int lddy, const float* x, int ldx, float* d
         if (Cout == 2) {
             constexpr int TPG = 25;
             dim3 grid(nblk, (g.T + TPG - 1) / TPG);
-            hipLaunchKernelGGL((smallcout_wgrad_kernel<2, TPG>), grid, dim3(256), (size_t)4 * TPG * 2 * (Cin / 4) * 16, st, x, dy, part, g);
+            hipLaunchKernelGGL((smallcout_wgrad_kernel<T, 2, TPG>), grid, dim3(256), (size_t)4 * TPG * 2 * (Cin / 4) * 16, st, x, dy, part, g);
         } else {
             constexpr int TPG = 13;
             dim3 grid(nblk, (g.T + TPG - 1) / TPG);
-            hipLaunchKernelGGL((smallcout_wgrad_kernel<4, TPG>), grid, dim3(256), (size_t)4 * TPG * 4 * (Cin / 4) * 16, st, x, dy, part, g);
+            hipLaunchKernelGGL((smallcout_wgrad_kernel<T, 4, TPG>), grid, dim3(256), (size_t)4 * TPG * 4 * (Cin / 4) * 16, st, x, dy, part, g);
         }
         SEG_CHECK_LAUNCH();
     }
@@ -565,7 +570,8 @@ size_t small_ws_bytes(int Cin, int Cout, int k) {
     return align_up((size_t)1024 * T * Cin * Cout * sizeof(float), 256) + colsum_ws_bytes(Cout) + 1024;
 }
 
-int stem_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W, int Cin,
+template <typename T>
+int stem_fwd(const T* x, int ldx, const float* w, const float* bias, T* y, int ldy, int N, int D, int H, int W, int Cin,
              int Cout, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st) {
     SmallGeom g{N, D, H, W, Cin, Cout, ldx, ldy};
     const long long nvox = (long long)N * D * H * W;
@@ -580,7 +586,7 @@ int stem_fwd(const float* x, int ldx, const float* w, const float* bias, float* 
         int nb = ntiles < 1024 ? ntiles : 1024;
         {
             ProfScope ps(PF_DIRECT, 2.0 * nvox * 27.0 * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
-            hipLaunchKernelGGL(stem1_fwd_kernel, dim3(nb), dim3(256), stem1_lds(Cout), st, x, w, bias, y, spart, g, ntiles);
+            hipLaunchKernelGGL(stem1_fwd_kernel<T>, dim3(nb), dim3(256), stem1_lds(Cout), st, x, w, bias, y, spart, g, ntiles);
             SEG_CHECK_LAUNCH();
         }
         if (ssum) return channel_sums(y, ldy, nvox, Cout, ssum, ssq, nullptr, 0, ws, ws_bytes, st);
@@ -588,16 +594,17 @@ int stem_fwd(const float* x, int ldx, const float* w, const float* bias, float* 
     }
     {
         ProfScope ps(PF_DIRECT, 2.0 * nvox * 27.0 * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
-        if (Cin == 1) hipLaunchKernelGGL((stem_fwd_kernel<1>), dim3(nblk), dim3(256), lds, st, x, w, bias, y, spart, g);
-        else if (Cin == 2) hipLaunchKernelGGL((stem_fwd_kernel<2>), dim3(nblk), dim3(256), lds, st, x, w, bias, y, spart, g);
-        else hipLaunchKernelGGL((stem_fwd_kernel<4>), dim3(nblk), dim3(256), lds, st, x, w, bias, y, spart, g);
+        if (Cin == 1) hipLaunchKernelGGL((stem_fwd_kernel<T, 1>), dim3(nblk), dim3(256), lds, st, x, w, bias, y, spart, g);
+        else if (Cin == 2) hipLaunchKernelGGL((stem_fwd_kernel<T, 2>), dim3(nblk), dim3(256), lds, st, x, w, bias, y, spart, g);
+        else hipLaunchKernelGGL((stem_fwd_kernel<T, 4>), dim3(nblk), dim3(256), lds, st, x, w, bias, y, spart, g);
         SEG_CHECK_LAUNCH();
     }
     if (ssum) return channel_sums(y, ldy, nvox, Cout, ssum, ssq, nullptr, 0, ws, ws_bytes, st);
     return MI355SEG_OK;
 }
 
-int stem_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
+template <typename T>
+int stem_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
                int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
     SmallGeom g{N, D, H, W, Cin, Cout, ldx, 0};
     const long long nvox = (long long)N * D * H * W;
@@ -612,7 +619,7 @@ int stem_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, in
         int nb = ntiles < 512 ? ntiles : 512;
         {
             ProfScope ps(PF_DIRECT, 2.0 * nvox * 27.0 * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
-            hipLaunchKernelGGL(stem1_wgrad_kernel, dim3(nb), dim3(256), stem1_lds(Cout), st, x, dy, part, g, lddy, ntiles);
+            hipLaunchKernelGGL(stem1_wgrad_kernel<T>, dim3(nb), dim3(256), stem1_lds(Cout), st, x, dy, part, g, lddy, ntiles);
             SEG_CHECK_LAUNCH();
         }
         wgrad_reduce(part, dw, nb, 27, Cin, Cout, accumulate, st);
@@ -621,7 +628,7 @@ int stem_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, in
     }
     {
         ProfScope ps(PF_DIRECT, 2.0 * nvox * 27.0 * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
-        hipLaunchKernelGGL((stem_wgrad_kernel<0>), dim3(nblk, Cin), dim3(256), lds, st, x, dy, part, g, lddy);
+        hipLaunchKernelGGL((stem_wgrad_kernel<T, 0>), dim3(nblk, Cin), dim3(256), lds, st, x, dy, part, g, lddy);
         SEG_CHECK_LAUNCH();
     }
     wgrad_reduce(part, dw, nblk, 27, Cin, Cout, accumulate, st);
@@ -629,31 +636,34 @@ int stem_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, in
     return MI355SEG_OK;
 }
 
-int head_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W, int Cin,
+template <typename T>
+int head_fwd(const T* x, int ldx, const float* w, const float* bias, T* y, int ldy, int N, int D, int H, int W, int Cin,
              int Cout, hipStream_t st) {
     SmallGeom g{N, D, H, W, Cin, Cout, ldx, ldy};
     const long long nvox = (long long)N * D * H * W;
     const int nblk = small_grid(nvox, 256 / (Cin / 4)) * 2;
     ProfScope ps(PF_DIRECT, 2.0 * nvox * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
-    if (Cout == 2) hipLaunchKernelGGL((head_fwd_kernel<2>), dim3(nblk), dim3(256), 0, st, x, w, bias, y, g);
-    else hipLaunchKernelGGL((head_fwd_kernel<4>), dim3(nblk), dim3(256), 0, st, x, w, bias, y, g);
+    if (Cout == 2) hipLaunchKernelGGL((head_fwd_kernel<T, 2>), dim3(nblk), dim3(256), 0, st, x, w, bias, y, g);
+    else hipLaunchKernelGGL((head_fwd_kernel<T, 4>), dim3(nblk), dim3(256), 0, st, x, w, bias, y, g);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
 
-int head_dgrad(const float* dy, int lddy, const float* w, float* dx, int lddx, int N, int D, int H, int W, int Cin, int Cout,
+template <typename T>
+int head_dgrad(const T* dy, int lddy, const float* w, T* dx, int lddx, int N, int D, int H, int W, int Cin, int Cout,
                hipStream_t st) {
     SmallGeom g{N, D, H, W, Cin, Cout, lddx, 0};
     const long long nvox = (long long)N * D * H * W;
     const int nblk = small_grid(nvox, 256 / (Cin / 4)) * 2;
     ProfScope ps(PF_DIRECT, 2.0 * nvox * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
-    if (Cout == 2) hipLaunchKernelGGL((head_dgrad_kernel<2>), dim3(nblk), dim3(256), 0, st, dy, lddy, w, dx, g);
-    else hipLaunchKernelGGL((head_dgrad_kernel<4>), dim3(nblk), dim3(256), 0, st, dy, lddy, w, dx, g);
+    if (Cout == 2) hipLaunchKernelGGL((head_dgrad_kernel<T, 2>), dim3(nblk), dim3(256), 0, st, dy, lddy, w, dx, g);
+    else hipLaunchKernelGGL((head_dgrad_kernel<T, 4>), dim3(nblk), dim3(256), 0, st, dy, lddy, w, dx, g);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
 
-int head_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
+template <typename T>
+int head_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
                int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
     SmallGeom g{N, D, H, W, Cin, Cout, ldx, 0};
     const long long nvox = (long long)N * D * H * W;
@@ -663,13 +673,26 @@ int head_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, in
     float* part = (float*)ws;
     {
         ProfScope ps(PF_DIRECT, 2.0 * nvox * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
-        if (Cout == 2) hipLaunchKernelGGL((head_wgrad_kernel<2>), dim3(nblk), dim3(256), 0, st, x, dy, lddy, part, g);
-        else hipLaunchKernelGGL((head_wgrad_kernel<4>), dim3(nblk), dim3(256), 0, st, x, dy, lddy, part, g);
+        if (Cout == 2) hipLaunchKernelGGL((head_wgrad_kernel<T, 2>), dim3(nblk), dim3(256), 0, st, x, dy, lddy, part, g);
+        else hipLaunchKernelGGL((head_wgrad_kernel<T, 4>), dim3(nblk), dim3(256), 0, st, x, dy, lddy, part, g);
         SEG_CHECK_LAUNCH();
     }
     wgrad_reduce(part, dw, nblk, 1, Cin, Cout, accumulate, st);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
+
+// explicit instantiations for the two storage types (declared as templates in internal.h)
+#define SEG_INST(T) \
+    template int smallcin_wgrad<T>(const T*, int, const T*, int, float*, int, int, int, int, int, int, int, int, int, int, void*, size_t, hipStream_t); \
+    template int smallcout_wgrad<T>(const T*, int, const T*, int, float*, int, int, int, int, int, int, int, int, int, int, void*, size_t, hipStream_t); \
+    template int stem_fwd<T>(const T*, int, const float*, const float*, T*, int, int, int, int, int, int, int, double*, double*, void*, size_t, hipStream_t); \
+    template int stem_wgrad<T>(const T*, int, const T*, int, float*, int, int, int, int, int, int, int, void*, size_t, hipStream_t); \
+    template int head_fwd<T>(const T*, int, const float*, const float*, T*, int, int, int, int, int, int, int, hipStream_t); \
+    template int head_dgrad<T>(const T*, int, const float*, T*, int, int, int, int, int, int, int, hipStream_t); \
+    template int head_wgrad<T>(const T*, int, const T*, int, float*, int, int, int, int, int, int, int, void*, size_t, hipStream_t);
+SEG_INST(float)
+SEG_INST(bf16)
+#undef SEG_INST
 
 }  // namespace seg

@@ -21,8 +21,9 @@ __global__ void convt_pack_kernel(const float* __restrict__ w, float* __restrict
 }
 
 // thread per (output voxel, cout)
-__global__ __launch_bounds__(256) void convt_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ wp,
-        const float* __restrict__ bias, float* __restrict__ y, int ldy, int N, int D, int H, int W, int Cin, int Cout) {
+template <typename T>
+__global__ __launch_bounds__(256) void convt_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ wp,
+        const float* __restrict__ bias, T* __restrict__ y, int ldy, int N, int D, int H, int W, int Cin, int Cout) {
     const int D2 = 2 * D, H2 = 2 * H, W2 = 2 * W;
     const long long total = (long long)N * D2 * H2 * W2 * Cout;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(256) void convt_fwd_kernel(const float* __restrict_
         int oh = (int)(r % H2); r /= H2;
         int od = (int)(r % D2); int n = (int)(r / D2);
         int t = ((od & 1) << 2) | ((oh & 1) << 1) | (ow & 1);
-        const float* xp = x + ((((long long)n * D + (od >> 1)) * H + (oh >> 1)) * W + (ow >> 1)) * ldx;
+        const T* xp = x + ((((long long)n * D + (od >> 1)) * H + (oh >> 1)) * W + (ow >> 1)) * ldx;
         const float* wq = wp + (long long)t * Cin * Cout + co;
         float acc = bias ? bias[co] : 0.f;
         int ci = 0;
@@ -47,8 +48,9 @@ __global__ __launch_bounds__(256) void convt_fwd_kernel(const float* __restrict_
 }
 
 // thread per (input voxel, cin): dx = sum_{t,co} dy[child t, co] * w[ci][co][t]
-__global__ __launch_bounds__(256) void convt_dgrad_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ wd,
-        float* __restrict__ dx, int lddx, int N, int D, int H, int W, int Cin, int Cout) {
+template <typename T>
+__global__ __launch_bounds__(256) void convt_dgrad_kernel(const T* __restrict__ dy, int lddy, const float* __restrict__ wd,
+        T* __restrict__ dx, int lddx, int N, int D, int H, int W, int Cin, int Cout) {
     const int H2 = 2 * H, W2 = 2 * W, D2 = 2 * D;
     const long long total = (long long)N * D * H * W * Cin;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void convt_dgrad_kernel(const float* __restric
         float acc = 0.f;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            const float* dp = dy + ((((long long)n * D2 + 2 * id + (t >> 2)) * H2 + 2 * ih + ((t >> 1) & 1)) * W2 + 2 * iw + (t & 1)) * lddy;
+            const T* dp = dy + ((((long long)n * D2 + 2 * id + (t >> 2)) * H2 + 2 * ih + ((t >> 1) & 1)) * W2 + 2 * iw + (t & 1)) * lddy;
             const float* wq = wd + (long long)t * Cout * Cin + ci;
             for (int co = 0; co < Cout; ++co) acc = fmaf(dp[co], wq[(long long)co * Cin], acc);
         }
@@ -68,7 +70,8 @@ __global__ __launch_bounds__(256) void convt_dgrad_kernel(const float* __restric
 }
 
 // grid = (pair blocks, 8 taps, splits); thread = (ci, co); partial[split][t][ci][co]
-__global__ __launch_bounds__(256) void convt_wgrad_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
+template <typename T>
+__global__ __launch_bounds__(256) void convt_wgrad_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx,
         float* __restrict__ part, int N, int D, int H, int W, int Cin, int Cout, long long vps) {
     const int pair = blockIdx.x * blockDim.x + threadIdx.x;
     const int t = blockIdx.y, split = blockIdx.z;
@@ -119,6 +122,7 @@ using namespace seg;
 
 extern "C" {
 
+
 size_t mi355seg_convt3d_k2s2_ws_bytes(int N, int D, int H, int W, int Cin, int Cout) {
     size_t wb = align_up((size_t)8 * Cin * Cout * sizeof(float), 256);
     size_t part = align_up((size_t)convt_splits((long long)N * D * H * W, Cin, Cout) * 8 * Cin * Cout * sizeof(float), 256);
@@ -128,74 +132,20 @@ size_t mi355seg_convt3d_k2s2_ws_bytes(int N, int D, int H, int W, int Cin, int C
     return wb + (part > red ? part : red) + 1024;
 }
 
-int mi355seg_convt3d_k2s2_fwd_f32(const float* x, int ldx, const float* w, const float* bias,
-                                  float* y, int ldy, int N, int D, int H, int W, int Cin, int Cout,
-                                  void* ws, size_t ws_bytes, void* stream) {
-    SEG_CHECK_ARG(x && w && y && N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ldx >= Cin && ldy >= Cout,
-                  "convt3d_k2s2_fwd: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
-    if (convt_mfma_supported(MATH_F32, N, D, H, W, Cin, Cout, ldx, ldy) && ((uintptr_t)x % 16) == 0)
-        return convt_fwd_mfma(MATH_F32, x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, ws, ws_bytes, st);
-    Carver cv(ws);
-    float* wp = cv.take<float>((size_t)8 * Cin * Cout);
-    SEG_CHECK_WS(cv.used(), ws_bytes);
-    hipLaunchKernelGGL(convt_pack_kernel, dim3(tgrid((long long)8 * Cin * Cout)), dim3(256), 0, st, w, wp, (float*)nullptr, Cin, Cout);
-    SEG_CHECK_LAUNCH();
-    long long total = (long long)N * D * H * W * 8 * Cout;
-    hipLaunchKernelGGL(convt_fwd_kernel, dim3(tgrid(total)), dim3(256), 0, st, x, ldx, wp, bias, y, ldy, N, D, H, W, Cin, Cout);
-    SEG_CHECK_LAUNCH();
-    return MI355SEG_OK;
-}
 
-int mi355seg_convt3d_k2s2_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
-                                    int N, int D, int H, int W, int Cin, int Cout,
-                                    void* ws, size_t ws_bytes, void* stream) {
-    SEG_CHECK_ARG(dy && w && dx && N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && lddy >= Cout && lddx >= Cin,
-                  "convt3d_k2s2_dgrad: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
-    if (convt_mfma_supported(MATH_F32, N, D, H, W, Cin, Cout, lddx, lddy) && ((uintptr_t)dy % 16) == 0)
-        return convt_dgrad_mfma(MATH_F32, dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, ws, ws_bytes, st);
-    Carver cv(ws);
-    float* wd = cv.take<float>((size_t)8 * Cin * Cout);
-    SEG_CHECK_WS(cv.used(), ws_bytes);
-    hipLaunchKernelGGL(convt_pack_kernel, dim3(tgrid((long long)8 * Cin * Cout)), dim3(256), 0, st, w, (float*)nullptr, wd, Cin, Cout);
-    SEG_CHECK_LAUNCH();
-    long long total = (long long)N * D * H * W * Cin;
-    hipLaunchKernelGGL(convt_dgrad_kernel, dim3(tgrid(total)), dim3(256), 0, st, dy, lddy, wd, dx, lddx, N, D, H, W, Cin, Cout);
-    SEG_CHECK_LAUNCH();
-    return MI355SEG_OK;
-}
-
-int mi355seg_convt3d_k2s2_wgrad_f32(const float* dy, int lddy, const float* x, int ldx,
-                                    float* dw, float* db, int N, int D, int H, int W, int Cin, int Cout,
-                                    void* ws, size_t ws_bytes, void* stream) {
-    SEG_CHECK_ARG(dy && x && dw && N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && lddy >= Cout && ldx >= Cin,
-                  "convt3d_k2s2_wgrad: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
-    const long long nvox = (long long)N * D * H * W;
-    if (db) {
-        int rc = channel_sums(dy, lddy, nvox * 8, Cout, nullptr, nullptr, db, 0, ws, ws_bytes, st);
-        if (rc) return rc;
-    }
-    if (pw_wgrad_supported(nvox, Cin, Cout, 8, ldx, lddy) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0) {
-        float* part; int nstrips;
-        int rc = pw_wgrad_mfma(dy, lddy, x, ldx, N, D, H, W, Cin, Cout, 8, &part, &nstrips, ws, ws_bytes, st);
-        if (rc) return rc;
-        hipLaunchKernelGGL(convt_wgrad_reduce_kernel, dim3(tgrid((long long)8 * Cin * Cout)), dim3(256), 0, st, part, dw, nstrips, Cin, Cout);
-        SEG_CHECK_LAUNCH();
-        return MI355SEG_OK;
-    }
-    const int splits = convt_splits(nvox, Cin, Cout);
-    Carver cv(ws);
-    float* part = cv.take<float>((size_t)splits * 8 * Cin * Cout);
-    SEG_CHECK_WS(cv.used(), ws_bytes);
-    long long vps = (nvox + splits - 1) / splits;
-    dim3 grid(cdiv((long long)Cin * Cout, 256), 8, splits);
-    hipLaunchKernelGGL(convt_wgrad_kernel, grid, dim3(256), 0, st, dy, lddy, x, ldx, part, N, D, H, W, Cin, Cout, vps);
-    SEG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(convt_wgrad_reduce_kernel, dim3(tgrid((long long)8 * Cin * Cout)), dim3(256), 0, st, part, dw, splits, Cin, Cout);
-    SEG_CHECK_LAUNCH();
-    return MI355SEG_OK;
-}
+#define TT float
+#define TT_MATH MATH_F32
+#define FN(name) mi355seg_##name##_f32
+#include "convt_api.inc"
+#undef TT
+#undef TT_MATH
+#undef FN
+#define TT bf16
+#define TT_MATH MATH_B16
+#define FN(name) mi355seg_##name##_bf16
+#include "convt_api.inc"
+#undef TT
+#undef TT_MATH
+#undef FN
 
 }  // extern "C"

@@ -17,20 +17,20 @@ int finalize_channel_partials(const float* part, int nblk, int C, double* sum, d
 bool stem_supported(int Cin, int Cout, int k, int stride, int pad, int ldy);
 bool head_supported(int Cin, int Cout, int k, int stride, int pad, int ldx);
 size_t small_ws_bytes(int Cin, int Cout, int k);
-int stem_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W, int Cin,
+template <typename T> int stem_fwd(const T* x, int ldx, const float* w, const float* bias, T* y, int ldy, int N, int D, int H, int W, int Cin,
              int Cout, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st);
-int stem_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
+template <typename T> int stem_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
                int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
-int head_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W, int Cin,
+template <typename T> int head_fwd(const T* x, int ldx, const float* w, const float* bias, T* y, int ldy, int N, int D, int H, int W, int Cin,
              int Cout, hipStream_t st);
-int head_dgrad(const float* dy, int lddy, const float* w, float* dx, int lddx, int N, int D, int H, int W, int Cin, int Cout,
+template <typename T> int head_dgrad(const T* dy, int lddy, const float* w, T* dx, int lddx, int N, int D, int H, int W, int Cin, int Cout,
                hipStream_t st);
 bool smallcin_wgrad_supported(int Cin, int Cout, int k);
 bool smallcout_wgrad_supported(int Cin, int Cout, int k, int ldx);
 size_t small_wgrad_ws_bytes(int Cin, int Cout, int k);
-int smallcin_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
+template <typename T> int smallcin_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
                    int k, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
-int smallcout_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
+template <typename T> int smallcout_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
                     int k, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 // conv_headk.hip -- odd-kernel "same" convolutions with two output channels (V-Net head), z-marching VALU kernels
 bool headk_supported(int Cin, int Cout, int k, int stride, int pad, int ldx_in, int ld_out, bool dgrad);
@@ -44,7 +44,7 @@ bool headk_wgrad_supported(int Cin, int Cout, int k, int stride, int pad, int ld
 size_t headk_wgrad_ws_bytes(int N, int D, int H, int W, int Cin, int k);
 int headk_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int k,
                 int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
-int head_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
+template <typename T> int head_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
                int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 
 // conv_generic.hip
@@ -78,12 +78,12 @@ int convt_dgrad_mfma(int math, const void* dy, int lddy, const float* w, void* d
 // conv_gwgrad.hip -- MFMA gather-wgrad for any cubic kernel / stride / padding
 size_t gwgrad_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad);
 bool gwgrad_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int lddy);
-int conv_gwgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
+template <typename T> int conv_gwgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
                 int k, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 // conv_pw_wgrad.hip -- K = voxels GEMM wgrads (T = 1: Conv3d k1, T = 8: ConvTranspose3d k2 s2)
 size_t pw_wgrad_ws_bytes(long long nvox, int Cin, int Cout, int T);
 bool pw_wgrad_supported(long long nvox, int Cin, int Cout, int T, int ldx, int lddy);
-int pw_wgrad_mfma(const float* dy, int lddy, const float* x, int ldx, int N, int D, int H, int W, int Cin, int Cout, int T,
+template <typename IN_T> int pw_wgrad_mfma(const IN_T* dy, int lddy, const IN_T* x, int ldx, int N, int D, int H, int W, int Cin, int Cout, int T,
                   float** part_out, int* nstrips_out, void* ws, size_t ws_bytes, hipStream_t st);
 // conv_wgrad_lowp.hip -- k3 / k5 wgrad on the bf16 matrix cores (MATH_X3: fp32 tensors, bf16x6 split; MATH_B16: bf16 tensors)
 bool wgrad_lowp_supported(int math, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int lddy);

@@ -46,15 +46,17 @@ static bool red_plan(long long rows, int C, int ld, RedPlan* p) {
 // ---------------------------------------------------------------------------------------
 // pivot of channel c in group g: the mean of 8 samples spread over the group's rows.  Sums are taken of
 // (x - pivot), so var = E[(x-p)^2] - E[x-p]^2 does not cancel when |mean| >> std (nearly constant channels).
-__device__ __forceinline__ float stats_pivot(const float* __restrict__ x, int ldx, long long rbase, long long rows, int c) {
+template <typename T>
+__device__ __forceinline__ float stats_pivot(const T* __restrict__ x, int ldx, long long rbase, long long rows, int c) {
     float p = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) p += x[(rbase + (rows * k) / 8) * ldx + c];
+    for (int k = 0; k < 8; ++k) p += ld1(x + (rbase + (rows * k) / 8) * ldx + c);
     return p * 0.125f;
 }
 
+template <typename T>
 struct StatsF {     // sum (x - pivot), sum (x - pivot)^2 ; pivots fetched once per thread
-    const float* x; int ldx; long long rows;
+    const T* x; int ldx; long long rows;
     struct State { float p[4]; };
     __device__ __forceinline__ State prepC(int g, int c, int nj, int C) const { return prep(g, c, nj); }
     __device__ __forceinline__ State prep(int g, int c, int nj) const {
@@ -63,19 +65,20 @@ struct StatsF {     // sum (x - pivot), sum (x - pivot)^2 ; pivots fetched once 
         return s;
     }
     __device__ __forceinline__ void eval(const State& st, long long r, int g, int c, int C, float& a, float& b) const {
-        float v = x[r * ldx + c] - st.p[0];
+        float v = ld1(x + r * ldx + c) - st.p[0];
         a = v; b = v * v;
     }
     __device__ __forceinline__ void eval4(const State& st, long long r, int g, int c, int C, float4& a, float4& b) const {
-        float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        float4 v = ldf4(x + r * ldx + c);
         v.x -= st.p[0]; v.y -= st.p[1]; v.z -= st.p[2]; v.w -= st.p[3];
         a = v; b = make_float4(v.x * v.x, v.y * v.y, v.z * v.z, v.w * v.w);
     }
 };
 
+template <typename T>
 struct BwdF {       // sum dz, sum dz*xhat  with dz = dy*act'(z), z = xhat*gamma+beta (+res)
-    const float* dy; int lddy; const float* x; int ldx; const float* mean; const float* rstd;
-    const float* gamma; const float* beta; const float* res; int ldres; int act; float slope;
+    const T* dy; int lddy; const T* x; int ldx; const float* mean; const float* rstd;
+    const float* gamma; const float* beta; const T* res; int ldres; int act; float slope;
     struct State { float m[4], rs[4], ga[4], be[4]; };
     __device__ __forceinline__ State prep(int g, int c, int nj) const { return State(); }
     __device__ __forceinline__ State prepC(int g, int c, int nj, int C) const {
@@ -94,12 +97,12 @@ struct BwdF {       // sum dz, sum dz*xhat  with dz = dy*act'(z), z = xhat*gamma
         a = dz; b = dz * xh;
     }
     __device__ __forceinline__ void eval(const State& st, long long r, int g, int c, int C, float& a, float& b) const {
-        one(st, 0, dy[r * lddy + c], x[r * ldx + c], res ? res[r * ldres + c] : 0.f, a, b);
+        one(st, 0, ld1(dy + r * lddy + c), ld1(x + r * ldx + c), res ? ld1(res + r * ldres + c) : 0.f, a, b);
     }
     __device__ __forceinline__ void eval4(const State& st, long long r, int g, int c, int C, float4& a, float4& b) const {
-        float4 d = *reinterpret_cast<const float4*>(dy + r * lddy + c);
-        float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
-        float4 rr = res ? *reinterpret_cast<const float4*>(res + r * ldres + c) : make_float4(0, 0, 0, 0);
+        float4 d = ldf4(dy + r * lddy + c);
+        float4 v = ldf4(x + r * ldx + c);
+        float4 rr = res ? ldf4(res + r * ldres + c) : make_float4(0, 0, 0, 0);
         one(st, 0, d.x, v.x, rr.x, a.x, b.x);
         one(st, 1, d.y, v.y, rr.y, a.y, b.y);
         one(st, 2, d.z, v.z, rr.z, a.z, b.z);
@@ -185,10 +188,11 @@ static int launch_colreduce2(const F& f, long long rows, int groups, int C, int 
 
 // finalise: one wavefront per (group, channel); lanes stride over the per-block partials, fp64
 // shuffle reduction -> fixed summation order (deterministic).
+template <typename T>
 __global__ __launch_bounds__(64) void stats_finalize_kernel(const float* __restrict__ part, int nblk, int C, int groups, double rows,
                                       float eps, float* __restrict__ mean, float* __restrict__ rstd,
                                       float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
-                                      const float* __restrict__ x, int ldx) {
+                                      const T* __restrict__ x, int ldx) {
     const int i = blockIdx.x;
     const int g = i / C, c = i % C;
     double s = 0.0, q = 0.0;
@@ -255,10 +259,10 @@ struct RowMap {
     int lanes, rpi;     // threads across channels, rows per block iteration
 };
 
-template <bool VEC>
-__global__ __launch_bounds__(256) void norm_act_fwd_kernel(const float* __restrict__ x, int ldx,
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void norm_act_fwd_kernel(const T* __restrict__ x, int ldx,
         const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
-        const float* __restrict__ beta, const float* __restrict__ res, int ldres, float* __restrict__ y, int ldy,
+        const float* __restrict__ beta, const T* __restrict__ res, int ldres, T* __restrict__ y, int ldy,
         long long rows, int C, int lanes, int rpi, int act, float slope) {
     constexpr int NJ = VEC ? 4 : 1;
     const int g = blockIdx.y;
@@ -277,28 +281,28 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const float* __restri
         for (long long r = (long long)blockIdx.x * rpi + rsub; r < rows; r += (long long)gridDim.x * rpi) {
             const long long row = rbase + r;
             if (VEC) {
-                float4 v = *reinterpret_cast<const float4*>(x + row * ldx + c);
-                float4 rr = res ? *reinterpret_cast<const float4*>(res + row * ldres + c) : make_float4(0, 0, 0, 0);
+                float4 v = ldf4(x + row * ldx + c);
+                float4 rr = res ? ldf4(res + row * ldres + c) : make_float4(0, 0, 0, 0);
                 float4 o;
                 o.x = act_apply(fmaf(v.x, al[0], be[0]) + rr.x, act, slope);
                 o.y = act_apply(fmaf(v.y, al[NJ > 1 ? 1 : 0], be[NJ > 1 ? 1 : 0]) + rr.y, act, slope);
                 o.z = act_apply(fmaf(v.z, al[NJ > 1 ? 2 : 0], be[NJ > 1 ? 2 : 0]) + rr.z, act, slope);
                 o.w = act_apply(fmaf(v.w, al[NJ > 1 ? 3 : 0], be[NJ > 1 ? 3 : 0]) + rr.w, act, slope);
-                *reinterpret_cast<float4*>(y + row * ldy + c) = o;
+                stf4(y + row * ldy + c, o);
             } else {
-                const float rv = res ? res[row * ldres + c] : 0.f;
-                y[row * ldy + c] = act_apply(fmaf(x[row * ldx + c], al[0], be[0]) + rv, act, slope);
+                const float rv = res ? ld1(res + row * ldres + c) : 0.f;
+                st1(y + row * ldy + c, act_apply(fmaf(ld1(x + row * ldx + c), al[0], be[0]) + rv, act, slope));
             }
         }
     }
 }
 
-template <bool VEC>
-__global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(const float* __restrict__ dy, int lddy,
-        const float* __restrict__ x, int ldx, const float* __restrict__ mean, const float* __restrict__ rstd,
-        const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ res, int ldres,
-        const float* __restrict__ s1, const float* __restrict__ s2, float* __restrict__ dx, int lddx,
-        float* __restrict__ dres, int lddres, long long rows, int C, int lanes, int rpi, int act, float slope,
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(const T* __restrict__ dy, int lddy,
+        const T* __restrict__ x, int ldx, const float* __restrict__ mean, const float* __restrict__ rstd,
+        const float* __restrict__ gamma, const float* __restrict__ beta, const T* __restrict__ res, int ldres,
+        const float* __restrict__ s1, const float* __restrict__ s2, T* __restrict__ dx, int lddx,
+        T* __restrict__ dres, int lddres, long long rows, int C, int lanes, int rpi, int act, float slope,
         float* __restrict__ dxpart) {
     constexpr int NJ = VEC ? 4 : 1;
     __shared__ float shs[256 * 4];
@@ -325,16 +329,16 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(const float* __
             const long long row = rbase + r;
             float dv[NJ], xv[NJ], rv[NJ], od[NJ], oz[NJ];
             if (VEC) {
-                float4 d = *reinterpret_cast<const float4*>(dy + row * lddy + c);
-                float4 v = *reinterpret_cast<const float4*>(x + row * ldx + c);
+                float4 d = ldf4(dy + row * lddy + c);
+                float4 v = ldf4(x + row * ldx + c);
                 dv[0] = d.x; xv[0] = v.x;
                 if (NJ > 1) { dv[1] = d.y; dv[2] = d.z; dv[3] = d.w; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w; }
-                float4 q = res ? *reinterpret_cast<const float4*>(res + row * ldres + c) : make_float4(0, 0, 0, 0);
+                float4 q = res ? ldf4(res + row * ldres + c) : make_float4(0, 0, 0, 0);
                 rv[0] = q.x;
                 if (NJ > 1) { rv[1] = q.y; rv[2] = q.z; rv[3] = q.w; }
             } else {
-                dv[0] = dy[row * lddy + c]; xv[0] = x[row * ldx + c];
-                rv[0] = res ? res[row * ldres + c] : 0.f;
+                dv[0] = ld1(dy + row * lddy + c); xv[0] = ld1(x + row * ldx + c);
+                rv[0] = res ? ld1(res + row * ldres + c) : 0.f;
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -346,11 +350,11 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(const float* __
                 colsum[j] += od[j];
             }
             if (VEC) {
-                *reinterpret_cast<float4*>(dx + row * lddx + c) = make_float4(od[0], od[NJ > 1 ? 1 : 0], od[NJ > 1 ? 2 : 0], od[NJ > 1 ? 3 : 0]);
-                if (dres) *reinterpret_cast<float4*>(dres + row * lddres + c) = make_float4(oz[0], oz[NJ > 1 ? 1 : 0], oz[NJ > 1 ? 2 : 0], oz[NJ > 1 ? 3 : 0]);
+                stf4(dx + row * lddx + c, make_float4(od[0], od[NJ > 1 ? 1 : 0], od[NJ > 1 ? 2 : 0], od[NJ > 1 ? 3 : 0]));
+                if (dres) stf4(dres + row * lddres + c, make_float4(oz[0], oz[NJ > 1 ? 1 : 0], oz[NJ > 1 ? 2 : 0], oz[NJ > 1 ? 3 : 0]));
             } else {
-                dx[row * lddx + c] = od[0];
-                if (dres) dres[row * lddres + c] = oz[0];
+                st1(dx + row * lddx + c, od[0]);
+                if (dres) st1(dres + row * lddres + c, oz[0]);
             }
         }
     }
@@ -373,9 +377,9 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(const float* __
     }
 }
 
-template <bool VEC, bool BWD>
-__global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
-        const float* __restrict__ res, int ldres, float* __restrict__ out, int ldo, long long rows, int C, int lanes, int rpi,
+template <typename T, bool VEC, bool BWD>
+__global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx,
+        const T* __restrict__ res, int ldres, T* __restrict__ out, int ldo, long long rows, int C, int lanes, int rpi,
         int act, float slope) {
     const int cw = VEC ? C / 4 : C;
     const int rsub = threadIdx.x / lanes;
@@ -384,32 +388,32 @@ __global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ dy, 
         const int c = cc * (VEC ? 4 : 1);
         for (long long r = (long long)blockIdx.x * rpi + rsub; r < rows; r += (long long)gridDim.x * rpi) {
             if (VEC) {
-                float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+                float4 v = ldf4(x + r * ldx + c);
                 if (res) {
-                    float4 q = *reinterpret_cast<const float4*>(res + r * ldres + c);
+                    float4 q = ldf4(res + r * ldres + c);
                     v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
                 }
                 float4 o;
                 if (BWD) {
-                    float4 d = *reinterpret_cast<const float4*>(dy + r * lddy + c);
+                    float4 d = ldf4(dy + r * lddy + c);
                     o = make_float4(d.x * act_grad(v.x, act, slope), d.y * act_grad(v.y, act, slope),
                                     d.z * act_grad(v.z, act, slope), d.w * act_grad(v.w, act, slope));
                 } else {
                     o = make_float4(act_apply(v.x, act, slope), act_apply(v.y, act, slope),
                                     act_apply(v.z, act, slope), act_apply(v.w, act, slope));
                 }
-                *reinterpret_cast<float4*>(out + r * ldo + c) = o;
+                stf4(out + r * ldo + c, o);
             } else {
-                float v = x[r * ldx + c] + (res ? res[r * ldres + c] : 0.f);
-                out[r * ldo + c] = BWD ? dy[r * lddy + c] * act_grad(v, act, slope) : act_apply(v, act, slope);
+                float v = ld1(x + r * ldx + c) + (res ? ld1(res + r * ldres + c) : 0.f);
+                st1(out + r * ldo + c, BWD ? ld1(dy + r * lddy + c) * act_grad(v, act, slope) : act_apply(v, act, slope));
             }
         }
     }
 }
 
-template <bool VEC>
-__global__ __launch_bounds__(256) void scale_channels_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
-        float* __restrict__ y, int ldy, long long rows, int C, int lanes, int rpi) {
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void scale_channels_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ scale,
+        T* __restrict__ y, int ldy, long long rows, int C, int lanes, int rpi) {
     const int g = blockIdx.y;
     const int cw = VEC ? C / 4 : C;
     const int rsub = threadIdx.x / lanes;
@@ -422,10 +426,10 @@ __global__ __launch_bounds__(256) void scale_channels_kernel(const float* __rest
         for (long long r = (long long)blockIdx.x * rpi + rsub; r < rows; r += (long long)gridDim.x * rpi) {
             const long long row = rbase + r;
             if (VEC) {
-                float4 v = *reinterpret_cast<const float4*>(x + row * ldx + c);
-                *reinterpret_cast<float4*>(y + row * ldy + c) = make_float4(v.x * sc.x, v.y * sc.y, v.z * sc.z, v.w * sc.w);
+                float4 v = ldf4(x + row * ldx + c);
+                stf4(y + row * ldy + c, make_float4(v.x * sc.x, v.y * sc.y, v.z * sc.z, v.w * sc.w));
             } else {
-                y[row * ldy + c] = x[row * ldx + c] * sc.x;
+                st1(y + row * ldy + c, ld1(x + row * ldx + c) * sc.x);
             }
         }
     }
@@ -459,8 +463,9 @@ static bool vec_ok(int C, std::initializer_list<int> lds) {
 
 // channel sums of a [rows, C] matrix as doubles (used for dbias and conv-epilogue stats
 // on the generic path).  part must hold nblk*C*2 floats.
+template <typename T>
 struct SumF {        // sums of (x - pivot) and (x - pivot)^2; pivot = 0 when only the plain sum is wanted
-    const float* x; int ldx; long long rows; int use_pivot;
+    const T* x; int ldx; long long rows; int use_pivot;
     struct State { float p[4]; };
     __device__ __forceinline__ State prepC(int g, int c, int nj, int C) const {
         State s;
@@ -468,18 +473,19 @@ struct SumF {        // sums of (x - pivot) and (x - pivot)^2; pivot = 0 when on
         return s;
     }
     __device__ __forceinline__ void eval(const State& st, long long r, int g, int c, int C, float& a, float& b) const {
-        float v = x[r * ldx + c] - st.p[0]; a = v; b = v * v;
+        float v = ld1(x + r * ldx + c) - st.p[0]; a = v; b = v * v;
     }
     __device__ __forceinline__ void eval4(const State& st, long long r, int g, int c, int C, float4& a, float4& b) const {
-        float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        float4 v = ldf4(x + r * ldx + c);
         v.x -= st.p[0]; v.y -= st.p[1]; v.z -= st.p[2]; v.w -= st.p[3];
         a = v; b = make_float4(v.x * v.x, v.y * v.y, v.z * v.z, v.w * v.w);
     }
 };
 
+template <typename T>
 __global__ __launch_bounds__(64) void sums_finalize_kernel(const float* __restrict__ part, int nblk, int C, double* __restrict__ sum,
                                      double* __restrict__ sq, float* __restrict__ fsum, int accumulate,
-                                     const float* __restrict__ x, int ldx, long long rows, int use_pivot) {
+                                     const T* __restrict__ x, int ldx, long long rows, int use_pivot) {
     const int c = blockIdx.x;
     double a = 0.0, b = 0.0;
     for (int k = threadIdx.x; k < nblk; k += 64) {
@@ -501,23 +507,36 @@ __global__ __launch_bounds__(64) void sums_finalize_kernel(const float* __restri
 size_t colsum_ws_bytes(int C) { return align_up((size_t)kMaxRedBlocks * C * 2 * sizeof(float), 256); }
 
 int finalize_channel_partials(const float* part, int nblk, int C, double* sum, double* sq, hipStream_t st) {
-    hipLaunchKernelGGL(sums_finalize_kernel, dim3(C), dim3(64), 0, st, part, nblk, C, sum, sq, (float*)nullptr, 0,
+    hipLaunchKernelGGL(sums_finalize_kernel<float>, dim3(C), dim3(64), 0, st, part, nblk, C, sum, sq, (float*)nullptr, 0,
                        (const float*)nullptr, 0, 0LL, 0);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
 
-static int channel_sums_chunk(const float* x, int ldx, long long rows, int C, double* sum, double* sq, float* fsum, int accumulate,
-                              void* ws, size_t ws_bytes, hipStream_t st);
+template <typename T>
+static int channel_sums_chunk(const T* x, int ldx, long long rows, int C, double* sum, double* sq, float* fsum, int accumulate,
+                              void* ws, size_t ws_bytes, hipStream_t st) {
+    SEG_CHECK_WS(colsum_ws_bytes(C), ws_bytes);
+    float* part = (float*)ws;
+    RedPlan p;
+    const int use_pivot = sq != nullptr;          // second moments: shift by a data pivot against cancellation
+    SumF<T> f{x, ldx, rows, use_pivot};
+    int rc = launch_colreduce2(f, rows, 1, C, ldx, part, &p, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sums_finalize_kernel<T>, dim3(C), dim3(64), 0, st, part, p.nblk, C, sum, sq, fsum, accumulate, x, ldx, rows, use_pivot);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
 
-// exported to the other translation units.  The reducer handles power-of-two widths up to 1024 (16 B per lane) or
+// exported to the other translation units.  The reducer handles power-of-two widths up to 1024 (4 elements per lane) or
 // any width up to 256, so wider / ragged channel counts are walked in such chunks (e.g. 768 = 512 + 256).
-int channel_sums(const float* x, int ldx, long long rows, int C, double* sum, double* sq, float* fsum, int accumulate,
-                 void* ws, size_t ws_bytes, hipStream_t st) {
+template <typename T>
+static int channel_sums_t(const T* x, int ldx, long long rows, int C, double* sum, double* sq, float* fsum, int accumulate,
+                          void* ws, size_t ws_bytes, hipStream_t st) {
     int c0 = 0;
     while (c0 < C) {
         int rem = C - c0, take;
-        if (rem >= 4 && (ldx % 4) == 0 && (c0 % 4) == 0 && ((uintptr_t)x % 16) == 0) {
+        if (rem >= 4 && (ldx % 4) == 0 && (c0 % 4) == 0 && ((uintptr_t)x % (4 * sizeof(T))) == 0) {
             take = 4;
             while (take * 2 <= rem && take * 2 <= 1024) take *= 2;
         } else {
@@ -530,26 +549,13 @@ int channel_sums(const float* x, int ldx, long long rows, int C, double* sum, do
     }
     return MI355SEG_OK;
 }
-
-// TEMPORARY until the bf16 storage instantiation of this file lands
+int channel_sums(const float* x, int ldx, long long rows, int C, double* sum, double* sq, float* fsum, int accumulate,
+                 void* ws, size_t ws_bytes, hipStream_t st) {
+    return channel_sums_t(x, ldx, rows, C, sum, sq, fsum, accumulate, ws, ws_bytes, st);
+}
 int channel_sums(const bf16* x, int ldx, long long rows, int C, double* sum, double* sq, float* fsum, int accumulate,
                  void* ws, size_t ws_bytes, hipStream_t st) {
-    set_error("channel_sums: bf16 storage is not built yet");
-    return MI355SEG_EINVAL;
-}
-
-static int channel_sums_chunk(const float* x, int ldx, long long rows, int C, double* sum, double* sq, float* fsum, int accumulate,
-                              void* ws, size_t ws_bytes, hipStream_t st) {
-    SEG_CHECK_WS(colsum_ws_bytes(C), ws_bytes);
-    float* part = (float*)ws;
-    RedPlan p;
-    const int use_pivot = sq != nullptr;          // second moments: shift by a data pivot against cancellation
-    SumF f{x, ldx, rows, use_pivot};
-    int rc = launch_colreduce2(f, rows, 1, C, ldx, part, &p, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(sums_finalize_kernel, dim3(C), dim3(64), 0, st, part, p.nblk, C, sum, sq, fsum, accumulate, x, ldx, rows, use_pivot);
-    SEG_CHECK_LAUNCH();
-    return MI355SEG_OK;
+    return channel_sums_t(x, ldx, rows, C, sum, sq, fsum, accumulate, ws, ws_bytes, st);
 }
 
 }  // namespace seg
@@ -557,33 +563,11 @@ static int channel_sums_chunk(const float* x, int ldx, long long rows, int C, do
 using namespace seg;
 
 extern "C" {
-
 size_t mi355seg_norm_ws_bytes(long long rows, int groups, int C) {
     (void)rows;
     size_t g = (size_t)(groups < 1 ? 1 : groups);
     return align_up(g * kMaxRedBlocks * (size_t)C * 2 * sizeof(float), 256) + 2 * align_up(g * C * sizeof(float), 256) +
            align_up((size_t)8192 * C * 2 * sizeof(float), 256) + 1024;
-}
-
-int mi355seg_norm_stats_f32(const float* x, int ldx, long long rows, int groups, int C, float eps,
-                            float* mean, float* rstd, float* running_mean, float* running_var,
-                            float momentum, void* ws, size_t ws_bytes, void* stream) {
-    SEG_CHECK_ARG(x && mean && rstd && rows > 0 && groups > 0 && C > 0 && ldx >= C, "norm_stats: bad arguments");
-    SEG_CHECK_ARG(!(running_mean && groups != 1), "norm_stats: running stats need groups == 1");
-    SEG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "norm_stats: running_mean/var must come together");
-    RedPlan p;
-    SEG_CHECK_ARG(red_plan(rows, C, ldx, &p), "norm_stats: unsupported channel count C=%d", C);
-    size_t need = (size_t)groups * p.nblk * C * 2 * sizeof(float);
-    SEG_CHECK_WS(need, ws_bytes);
-    float* part = (float*)ws;
-    hipStream_t st = (hipStream_t)stream;
-    StatsF f{x, ldx, rows};
-    int rc = launch_colreduce2(f, rows, groups, C, ldx, part, &p, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(groups * C), dim3(64), 0, st, part, p.nblk, C,
-                       groups, (double)rows, eps, mean, rstd, running_mean, running_var, momentum, x, ldx);
-    SEG_CHECK_LAUNCH();
-    return MI355SEG_OK;
 }
 
 int mi355seg_norm_stats_from_sums_f32(const double* sum, const double* sq, long long rows, int C, float eps,
@@ -596,102 +580,6 @@ int mi355seg_norm_stats_from_sums_f32(const double* sum, const double* sq, long 
     return MI355SEG_OK;
 }
 
-int mi355seg_norm_act_fwd_f32(const float* x, int ldx, const float* mean, const float* rstd,
-                              const float* gamma, const float* beta, const float* res, int ldres,
-                              float* y, int ldy, long long rows, int groups, int C,
-                              int act, float slope, void* stream) {
-    SEG_CHECK_ARG(x && y && mean && rstd && rows > 0 && groups > 0 && C > 0, "norm_act_fwd: bad arguments");
-    SEG_CHECK_ARG(act >= 0 && act <= 4, "norm_act_fwd: bad activation code %d", act);
-    hipStream_t st = (hipStream_t)stream;
-    bool v = vec_ok(C, {ldx, ldy, res ? ldres : 4});
-    RowMap rm = ew_map(C, v);
-    dim3 grid(row_grid(rows, rm.rpi), groups);
-    ProfScope ps(PF_NORM, 0.0, 4.0 * rows * groups * C * (res ? 3.0 : 2.0), st);
-    if (v)
-        hipLaunchKernelGGL((norm_act_fwd_kernel<true>), grid, dim3(256), 0, st, x, ldx, mean, rstd, gamma,
-                           beta, res, ldres, y, ldy, rows, C, rm.lanes, rm.rpi, act, slope);
-    else
-        hipLaunchKernelGGL((norm_act_fwd_kernel<false>), grid, dim3(256), 0, st, x, ldx, mean, rstd, gamma,
-                           beta, res, ldres, y, ldy, rows, C, rm.lanes, rm.rpi, act, slope);
-    SEG_CHECK_LAUNCH();
-    return MI355SEG_OK;
-}
-
-static int norm_act_bwd_impl(const float* dy, int lddy, const float* x, int ldx,
-                             const float* mean, const float* rstd, const float* gamma, const float* beta,
-                             const float* res, int ldres,
-                             float* dx, int lddx, float* dgamma, float* dbeta, float* dres, int lddres, float* dx_colsum,
-                             long long rows, int groups, int C, int act, float slope,
-                             void* ws, size_t ws_bytes, void* stream) {
-    SEG_CHECK_ARG(dy && x && mean && rstd && dx && rows > 0 && groups > 0 && C > 0, "norm_act_bwd: bad arguments");
-    SEG_CHECK_ARG(!(dgamma && groups != 1), "norm_act_bwd: affine grads need groups == 1");
-    SEG_CHECK_ARG(!(dx_colsum && groups != 1), "norm_act_bwd: dx column sums need groups == 1");
-    SEG_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "norm_act_bwd: dgamma/dbeta must come together");
-    RedPlan p;
-    int ldmin = 4;
-    if ((lddy % 4) || (ldx % 4) || (res && (ldres % 4))) ldmin = 1;
-    SEG_CHECK_ARG(red_plan(rows, C, ldmin, &p), "norm_act_bwd: unsupported channel count C=%d", C);
-    bool v = vec_ok(C, {lddy, ldx, lddx, res ? ldres : 4, dres ? lddres : 4});
-    RowMap rm = ew_map(C, v);
-    int nrb = row_grid(rows, rm.rpi);
-    if (dx_colsum && nrb > 1024) nrb = 1024;       // bounds the per-block partials the column-sum finalise walks
-    const bool fused_sum = dx_colsum && rm.lanes == (v ? C / 4 : C) && (256 % rm.lanes) == 0;
-    Carver cv(ws);
-    float* part = cv.take<float>((size_t)groups * p.nblk * C * 2);
-    float* s1 = cv.take<float>((size_t)groups * C);
-    float* s2 = cv.take<float>((size_t)groups * C);
-    float* dxpart = fused_sum ? cv.take<float>((size_t)nrb * C * 2) : nullptr;
-    SEG_CHECK_WS(cv.used(), ws_bytes);
-    hipStream_t st = (hipStream_t)stream;
-    BwdF f{dy, lddy, x, ldx, mean, rstd, gamma, beta, res, ldres, act, slope};
-    int rc = launch_colreduce2(f, rows, groups, C, ldmin, part, &p, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(bwd_finalize_kernel, dim3(groups * C), dim3(64), 0, st, part, p.nblk, C,
-                       groups, s1, s2, dgamma, dbeta);
-    SEG_CHECK_LAUNCH();
-    dim3 grid(nrb, groups);
-    {
-        ProfScope ps(PF_NORM, 0.0, 4.0 * rows * groups * C * 3.0, st);
-        if (v)
-            hipLaunchKernelGGL((norm_act_bwd_apply_kernel<true>), grid, dim3(256), 0, st, dy, lddy, x, ldx, mean,
-                               rstd, gamma, beta, res, ldres, s1, s2, dx, lddx, dres, lddres, rows, C, rm.lanes, rm.rpi, act, slope, dxpart);
-        else
-            hipLaunchKernelGGL((norm_act_bwd_apply_kernel<false>), grid, dim3(256), 0, st, dy, lddy, x, ldx, mean,
-                               rstd, gamma, beta, res, ldres, s1, s2, dx, lddx, dres, lddres, rows, C, rm.lanes, rm.rpi, act, slope, dxpart);
-        SEG_CHECK_LAUNCH();
-    }
-    if (dx_colsum) {
-        if (fused_sum) {
-            hipLaunchKernelGGL(sums_finalize_kernel, dim3(C), dim3(64), 0, st, dxpart, nrb, C, (double*)nullptr, (double*)nullptr, dx_colsum, 0,
-                               (const float*)nullptr, 0, 0LL, 0);
-            SEG_CHECK_LAUNCH();
-        } else {
-            return channel_sums(dx, lddx, rows, C, nullptr, nullptr, dx_colsum, 0, ws, ws_bytes, st);
-        }
-    }
-    return MI355SEG_OK;
-}
-
-int mi355seg_norm_act_bwd_f32(const float* dy, int lddy, const float* x, int ldx,
-                              const float* mean, const float* rstd, const float* gamma, const float* beta,
-                              const float* res, int ldres,
-                              float* dx, int lddx, float* dgamma, float* dbeta, float* dres, int lddres,
-                              long long rows, int groups, int C, int act, float slope,
-                              void* ws, size_t ws_bytes, void* stream) {
-    return norm_act_bwd_impl(dy, lddy, x, ldx, mean, rstd, gamma, beta, res, ldres, dx, lddx, dgamma, dbeta, dres, lddres, nullptr,
-                             rows, groups, C, act, slope, ws, ws_bytes, stream);
-}
-
-int mi355seg_norm_act_bwd_colsum_f32(const float* dy, int lddy, const float* x, int ldx,
-                                     const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                     const float* res, int ldres,
-                                     float* dx, int lddx, float* dgamma, float* dbeta, float* dres, int lddres, float* dx_colsum,
-                                     long long rows, int groups, int C, int act, float slope,
-                                     void* ws, size_t ws_bytes, void* stream) {
-    return norm_act_bwd_impl(dy, lddy, x, ldx, mean, rstd, gamma, beta, res, ldres, dx, lddx, dgamma, dbeta, dres, lddres, dx_colsum,
-                             rows, groups, C, act, slope, ws, ws_bytes, stream);
-}
-
 int mi355seg_rstd_from_var_f32(const float* var, float eps, float* rstd, int C, void* stream) {
     SEG_CHECK_ARG(var && rstd && C > 0, "rstd_from_var: bad arguments");
     hipLaunchKernelGGL(rstd_from_var_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, var, eps, rstd, C);
@@ -699,48 +587,19 @@ int mi355seg_rstd_from_var_f32(const float* var, float eps, float* rstd, int C, 
     return MI355SEG_OK;
 }
 
-int mi355seg_scale_channels_f32(const float* x, int ldx, const float* scale, float* y, int ldy,
-                                long long rows, int groups, int C, void* stream) {
-    SEG_CHECK_ARG(x && scale && y && rows > 0 && groups > 0 && C > 0 && ldx >= C && ldy >= C, "scale_channels: bad arguments");
-    bool v = vec_ok(C, {ldx, ldy});
-    RowMap rm = ew_map(C, v);
-    dim3 grid(row_grid(rows, rm.rpi), groups);
-    if (v) hipLaunchKernelGGL((scale_channels_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, scale, y, ldy, rows, C, rm.lanes, rm.rpi);
-    else hipLaunchKernelGGL((scale_channels_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, scale, y, ldy, rows, C, rm.lanes, rm.rpi);
-    SEG_CHECK_LAUNCH();
-    return MI355SEG_OK;
-}
-
-int mi355seg_act_fwd_f32(const float* x, int ldx, const float* res, int ldres, float* y, int ldy,
-                         long long rows, int C, int act, float slope, void* stream) {
-    SEG_CHECK_ARG(x && y && rows > 0 && C > 0 && act >= 0 && act <= 4, "act_fwd: bad arguments");
-    bool v = vec_ok(C, {ldx, ldy, res ? ldres : 4});
-    RowMap rm = ew_map(C, v);
-    dim3 grid(row_grid(rows, rm.rpi));
-    if (v)
-        hipLaunchKernelGGL((act_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, nullptr, 0, x,
-                           ldx, res, ldres, y, ldy, rows, C, rm.lanes, rm.rpi, act, slope);
-    else
-        hipLaunchKernelGGL((act_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, nullptr, 0, x,
-                           ldx, res, ldres, y, ldy, rows, C, rm.lanes, rm.rpi, act, slope);
-    SEG_CHECK_LAUNCH();
-    return MI355SEG_OK;
-}
-
-int mi355seg_act_bwd_f32(const float* dy, int lddy, const float* x, int ldx, const float* res, int ldres,
-                         float* dx, int lddx, long long rows, int C, int act, float slope, void* stream) {
-    SEG_CHECK_ARG(dy && x && dx && rows > 0 && C > 0 && act >= 0 && act <= 4, "act_bwd: bad arguments");
-    bool v = vec_ok(C, {lddy, ldx, lddx, res ? ldres : 4});
-    RowMap rm = ew_map(C, v);
-    dim3 grid(row_grid(rows, rm.rpi));
-    if (v)
-        hipLaunchKernelGGL((act_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx,
-                           res, ldres, dx, lddx, rows, C, rm.lanes, rm.rpi, act, slope);
-    else
-        hipLaunchKernelGGL((act_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, dy, lddy, x,
-                           ldx, res, ldres, dx, lddx, rows, C, rm.lanes, rm.rpi, act, slope);
-    SEG_CHECK_LAUNCH();
-    return MI355SEG_OK;
-}
+#define TT float
+#define FN(name) mi355seg_##name##_f32
+#define NORM_IMPL norm_act_bwd_impl_f32
+#include "norm_api.inc"
+#undef TT
+#undef FN
+#undef NORM_IMPL
+#define TT bf16
+#define FN(name) mi355seg_##name##_bf16
+#define NORM_IMPL norm_act_bwd_impl_bf16
+#include "norm_api.inc"
+#undef TT
+#undef FN
+#undef NORM_IMPL
 
 }  // extern "C"

@@ -17,6 +17,38 @@ ACT_NONE, ACT_RELU, ACT_ELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 
 _WS = {}
 
+# ---- activation storage type.  fp32 by default; inside ``autocast(torch.bfloat16)`` the models' entry layout conversion
+# (to_channels_last) produces bf16 activations and every op below follows its input's dtype: what
+# ``Accelerator(mixed_precision="bf16")`` / torch.autocast does for the reference (parameters, their gradients, norm
+# statistics and the loss stay fp32; conv products are bf16 MFMAs with fp32 accumulation).
+_COMPUTE_DTYPE = [torch.float32]
+_SFX = {torch.float32: "f32", torch.bfloat16: "bf16"}
+
+
+class autocast:
+    """``with mi355seg.functional.autocast(torch.bfloat16): pred = model(x)`` -- activations in bf16 (NDHWC in HBM)."""
+
+    def __init__(self, dtype=torch.bfloat16, enabled=True):
+        if dtype not in _SFX:
+            raise Mi355SegError(f"autocast: dtype must be torch.float32 or torch.bfloat16, got {dtype}")
+        self.dtype = dtype if enabled else torch.float32
+
+    def __enter__(self):
+        _COMPUTE_DTYPE.append(self.dtype)
+        return self
+
+    def __exit__(self, *exc):
+        _COMPUTE_DTYPE.pop()
+        return False
+
+
+def compute_dtype():
+    return _COMPUTE_DTYPE[-1]
+
+
+def _sfx(t):
+    return _SFX[t.dtype]
+
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
@@ -32,18 +64,18 @@ def workspace(nbytes, device):
     return buf
 
 
-def _require_cuda(t, what):
+def _require_cuda(t, what, allow_bf16=False):
     if not t.is_cuda:
         raise Mi355SegError(f"{what}: expected a tensor on an MI355X (cuda/HIP) device, got {t.device}; "
                             "there is no CPU fallback in this package")
-    if t.dtype != torch.float32:
-        raise Mi355SegError(f"{what}: expected float32, got {t.dtype}")
+    if t.dtype != torch.float32 and not (allow_bf16 and t.dtype == torch.bfloat16):
+        raise Mi355SegError(f"{what}: expected float32{' or bfloat16' if allow_bf16 else ''}, got {t.dtype}")
 
 
-def cl_view(t, what="tensor"):
+def cl_view(t, what="tensor", allow_bf16=True):
     """Return (tensor, ld) with tensor laid out NDHWC (last stride 1, dense in N,D,H,W with
     voxel pitch ld >= C).  Copies only if the given tensor does not already satisfy that."""
-    _require_cuda(t, what)
+    _require_cuda(t, what, allow_bf16=allow_bf16)
     if t.dim() != 5:
         raise Mi355SegError(f"{what}: expected 5-D [N,D,H,W,C], got shape {tuple(t.shape)}")
     N, D, H, W, C = t.shape
@@ -62,31 +94,55 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-def to_channels_last(x):
-    """[N,C,D,H,W] -> [N,D,H,W,C] (free view when C == 1)."""
-    return _ToNDHWC.apply(x)
+def _like(g, x):
+    """An incoming gradient in the storage type of the tensor it belongs to (autograd may hand over fp32 zeros)."""
+    return g if g.dtype == x.dtype else g.to(x.dtype)
+
+
+def _conv_ws(L, x, N, D, H, W, Cin, Cout, k, stride, pad):
+    name = "mi355seg_conv3d_ws_bytes_bf16" if x.dtype == torch.bfloat16 else "mi355seg_conv3d_ws_bytes"
+    return L.query(name, N, D, H, W, Cin, Cout, k, stride, pad)
+
+
+def _w32(w, what):
+    if w.dtype != torch.float32:
+        raise Mi355SegError(f"{what}: parameters are fp32 masters, got {w.dtype}")
+    return w.contiguous()
+
+
+def to_channels_last(x, dtype=None):
+    """fp32 [N,C,D,H,W] -> [N,D,H,W,C] in ``dtype`` (default: the autocast compute dtype; a free view when C == 1 and
+    the result stays fp32).  This is where a model's activations take their storage type."""
+    return _ToNDHWC.apply(x, dtype or compute_dtype())
 
 
 def to_channels_first(x):
-    """[N,D,H,W,C] -> [N,C,D,H,W] contiguous (free view when C == 1)."""
+    """[N,D,H,W,C] (fp32 or bf16) -> fp32 [N,C,D,H,W] contiguous (free view when C == 1 and fp32): the model boundary
+    always hands fp32 NCDHW tensors to the caller (logits go to an fp32 loss, as under torch autocast)."""
     return _ToNCDHW.apply(x)
 
 
 class _ToNDHWC(Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, dtype):
         _require_cuda(x, "to_channels_last")
+        if x.dtype != torch.float32:
+            raise Mi355SegError(f"to_channels_last: the NCDHW side is fp32, got {x.dtype}")
         N, C, D, H, W = x.shape
         x = x.contiguous()
-        if C == 1:
-            return x.view(N, D, H, W, 1)
-        y = torch.empty((N, D, H, W, C), dtype=x.dtype, device=x.device)
-        lib().call("mi355seg_ncdhw_to_ndhwc_f32", _p(x), _p(y), C, N, C, D * H * W, _stream())
+        if dtype == torch.float32:
+            if C == 1:
+                return x.view(N, D, H, W, 1)
+            y = torch.empty((N, D, H, W, C), dtype=x.dtype, device=x.device)
+            lib().call("mi355seg_ncdhw_to_ndhwc_f32", _p(x), _p(y), C, N, C, D * H * W, _stream())
+            return y
+        y = torch.empty((N, D, H, W, C), dtype=torch.bfloat16, device=x.device)
+        lib().call("mi355seg_ncdhw_f32_to_ndhwc_bf16", _p(x), _p(y), C, N, C, D * H * W, _stream())
         return y
 
     @staticmethod
     def backward(ctx, g):
-        return _ToNCDHW.apply(g)
+        return _ToNCDHW.apply(g), None
 
 
 class _ToNCDHW(Function):
@@ -94,15 +150,48 @@ class _ToNCDHW(Function):
     def forward(ctx, x):
         x, ld = cl_view(x, "to_channels_first")
         N, D, H, W, C = x.shape
-        if C == 1 and ld == 1:
-            return x.view(N, 1, D, H, W)
-        y = torch.empty((N, C, D, H, W), dtype=x.dtype, device=x.device)
-        lib().call("mi355seg_ndhwc_to_ncdhw_f32", _p(x), ld, _p(y), N, C, D * H * W, _stream())
+        ctx.src_dtype = x.dtype
+        if x.dtype == torch.float32:
+            if C == 1 and ld == 1:
+                return x.view(N, 1, D, H, W)
+            y = torch.empty((N, C, D, H, W), dtype=x.dtype, device=x.device)
+            lib().call("mi355seg_ndhwc_to_ncdhw_f32", _p(x), ld, _p(y), N, C, D * H * W, _stream())
+            return y
+        y = torch.empty((N, C, D, H, W), dtype=torch.float32, device=x.device)
+        lib().call("mi355seg_ndhwc_bf16_to_ncdhw_f32", _p(x), ld, _p(y), N, C, D * H * W, _stream())
         return y
 
     @staticmethod
     def backward(ctx, g):
-        return _ToNDHWC.apply(g)
+        return _ToNDHWC.apply(g, ctx.src_dtype)
+
+
+class _Cast(Function):
+    """Storage-type change of a channel-last tensor (an autocast boundary inside a model, e.g. UNETR's fp32 token
+    tensors entering the bf16 convolutional decoder); the gradient takes the opposite cast."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        _require_cuda(x, "cast input", allow_bf16=True)
+        ctx.src_dtype = x.dtype
+        if x.dtype == dtype:
+            return x.view_as(x)
+        xc = x.contiguous()
+        C = xc.shape[-1]
+        rows = xc.numel() // C
+        y = torch.empty(xc.shape, dtype=dtype, device=x.device)
+        name = "mi355seg_cast_f32_to_bf16" if dtype == torch.bfloat16 else "mi355seg_cast_bf16_to_f32"
+        lib().call(name, _p(xc), C, _p(y), C, rows, C, _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Cast.apply(g, ctx.src_dtype), None
+
+
+def cast(x, dtype=None):
+    """x in the storage type ``dtype`` (default: the autocast compute dtype)."""
+    return _Cast.apply(x, dtype or compute_dtype())
 
 
 # ----------------------------------------------------------------------------- conv
@@ -114,13 +203,12 @@ class _Conv3d(Function):
         Cout, Cin_w, k = w.shape[0], w.shape[1], w.shape[2]
         if Cin_w != Cin or w.shape[3] != k or w.shape[4] != k:
             raise Mi355SegError(f"conv3d: weight {tuple(w.shape)} does not match input channels {Cin} / cubic kernel")
-        w = w.contiguous()
+        w = _w32(w, "conv3d weight")
         Do, Ho, Wo = [(e + 2 * pad - k) // stride + 1 for e in (D, H, W)]
         y = torch.empty((N, Do, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
         L = lib()
-        nb = L.query("mi355seg_conv3d_ws_bytes", N, D, H, W, Cin, Cout, k, stride, pad)
-        ws = workspace(nb, x.device)
-        L.call("mi355seg_conv3d_fwd_f32", _p(x), ldx, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
+        ws = workspace(_conv_ws(L, x, N, D, H, W, Cin, Cout, k, stride, pad), x.device)
+        L.call("mi355seg_conv3d_fwd_" + _sfx(x), _p(x), ldx, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
                None, None, _p(ws), ws.numel(), _stream())
         ctx.save_for_backward(x, w)
         ctx.geom = (N, D, H, W, Cin, Cout, k, stride, pad, ldx, b is not None)
@@ -130,19 +218,18 @@ class _Conv3d(Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         N, D, H, W, Cin, Cout, k, stride, pad, ldx, has_b = ctx.geom
-        dy, lddy = cl_view(dy, "conv3d grad")
+        dy, lddy = cl_view(_like(dy, x), "conv3d grad")
         L = lib()
-        nb = L.query("mi355seg_conv3d_ws_bytes", N, D, H, W, Cin, Cout, k, stride, pad)
-        ws = workspace(nb, x.device)
+        ws = workspace(_conv_ws(L, x, N, D, H, W, Cin, Cout, k, stride, pad), x.device)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((N, D, H, W, Cin), dtype=x.dtype, device=x.device)
-            L.call("mi355seg_conv3d_dgrad_f32", _p(dy), lddy, _p(w), _p(dx), Cin, N, D, H, W, Cin, Cout, k, stride, pad,
+            L.call("mi355seg_conv3d_dgrad_" + _sfx(x), _p(dy), lddy, _p(w), _p(dx), Cin, N, D, H, W, Cin, Cout, k, stride, pad,
                    _p(ws), ws.numel(), _stream())
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
             dw = torch.empty_like(w)
-            db = torch.empty(Cout, dtype=x.dtype, device=x.device) if has_b else None
-            L.call("mi355seg_conv3d_wgrad_f32", _p(dy), lddy, _p(x), ldx, _p(dw), _p(db), N, D, H, W, Cin, Cout, k, stride, pad,
+            db = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_b else None
+            L.call("mi355seg_conv3d_wgrad_" + _sfx(x), _p(dy), lddy, _p(x), ldx, _p(dw), _p(db), N, D, H, W, Cin, Cout, k, stride, pad,
                    0, _p(ws), ws.numel(), _stream())
         return dx, dw, db, None, None
 
@@ -164,7 +251,7 @@ class _ConvT3dK2S2(Function):
         y = torch.empty((N, 2 * D, 2 * H, 2 * W, Cout), dtype=x.dtype, device=x.device)
         L = lib()
         ws = workspace(L.query("mi355seg_convt3d_k2s2_ws_bytes", N, D, H, W, Cin, Cout), x.device)
-        L.call("mi355seg_convt3d_k2s2_fwd_f32", _p(x), ldx, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout,
+        L.call("mi355seg_convt3d_k2s2_fwd_" + _sfx(x), _p(x), ldx, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout,
                _p(ws), ws.numel(), _stream())
         ctx.save_for_backward(x, w)
         ctx.geom = (N, D, H, W, Cin, Cout, ldx, b is not None)
@@ -174,18 +261,18 @@ class _ConvT3dK2S2(Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         N, D, H, W, Cin, Cout, ldx, has_b = ctx.geom
-        dy, lddy = cl_view(dy, "conv_transpose3d grad")
+        dy, lddy = cl_view(_like(dy, x), "conv_transpose3d grad")
         L = lib()
         ws = workspace(L.query("mi355seg_convt3d_k2s2_ws_bytes", N, D, H, W, Cin, Cout), x.device)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((N, D, H, W, Cin), dtype=x.dtype, device=x.device)
-            L.call("mi355seg_convt3d_k2s2_dgrad_f32", _p(dy), lddy, _p(w), _p(dx), Cin, N, D, H, W, Cin, Cout,
+            L.call("mi355seg_convt3d_k2s2_dgrad_" + _sfx(x), _p(dy), lddy, _p(w), _p(dx), Cin, N, D, H, W, Cin, Cout,
                    _p(ws), ws.numel(), _stream())
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
             dw = torch.empty_like(w)
-            db = torch.empty(Cout, dtype=x.dtype, device=x.device) if has_b else None
-            L.call("mi355seg_convt3d_k2s2_wgrad_f32", _p(dy), lddy, _p(x), ldx, _p(dw), _p(db), N, D, H, W, Cin, Cout,
+            db = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_b else None
+            L.call("mi355seg_convt3d_k2s2_wgrad_" + _sfx(x), _p(dy), lddy, _p(x), ldx, _p(dw), _p(db), N, D, H, W, Cin, Cout,
                    _p(ws), ws.numel(), _stream())
         return dx, dw, db
 
@@ -203,13 +290,14 @@ class _ConvT3dK2S2Cat(Function):
         base = skip._base
         Cs = skip.shape[-1]
         ok = (base is not None and base.dim() == 5 and base.is_contiguous() and tuple(base.shape[:4]) == (N, 2 * D, 2 * H, 2 * W)
-              and base.shape[-1] == Cout + Cs and skip.data_ptr() == base.data_ptr() + 4 * Cout and skip.stride() == base.stride())
+              and base.shape[-1] == Cout + Cs and skip.data_ptr() == base.data_ptr() + base.element_size() * Cout and skip.stride() == base.stride()
+              and base.dtype == x.dtype)
         if not ok:
             raise Mi355SegError("conv_transpose3d_k2s2_cat: `skip` is not the right channel slice of a matching concat buffer")
         w = w.contiguous()
         L = lib()
         ws = workspace(L.query("mi355seg_convt3d_k2s2_ws_bytes", N, D, H, W, Cin, Cout), x.device)
-        L.call("mi355seg_convt3d_k2s2_fwd_f32", _p(x), ldx, _p(w), _p(b), _p(base), Cout + Cs, N, D, H, W, Cin, Cout,
+        L.call("mi355seg_convt3d_k2s2_fwd_" + _sfx(x), _p(x), ldx, _p(w), _p(b), _p(base), Cout + Cs, N, D, H, W, Cin, Cout,
                _p(ws), ws.numel(), _stream())
         ctx.save_for_backward(x, w)
         ctx.geom = (N, D, H, W, Cin, Cout, Cs, ldx, b is not None)
@@ -219,18 +307,18 @@ class _ConvT3dK2S2Cat(Function):
     def backward(ctx, dcat):
         x, w = ctx.saved_tensors
         N, D, H, W, Cin, Cout, Cs, ldx, has_b = ctx.geom
-        dcat, ldd = cl_view(dcat, "conv_transpose3d grad")
+        dcat, ldd = cl_view(_like(dcat, x), "conv_transpose3d grad")
         L = lib()
         ws = workspace(L.query("mi355seg_convt3d_k2s2_ws_bytes", N, D, H, W, Cin, Cout), x.device)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((N, D, H, W, Cin), dtype=x.dtype, device=x.device)
-            L.call("mi355seg_convt3d_k2s2_dgrad_f32", _p(dcat), ldd, _p(w), _p(dx), Cin, N, D, H, W, Cin, Cout,
+            L.call("mi355seg_convt3d_k2s2_dgrad_" + _sfx(x), _p(dcat), ldd, _p(w), _p(dx), Cin, N, D, H, W, Cin, Cout,
                    _p(ws), ws.numel(), _stream())
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
             dw = torch.empty_like(w)
-            db = torch.empty(Cout, dtype=x.dtype, device=x.device) if has_b else None
-            L.call("mi355seg_convt3d_k2s2_wgrad_f32", _p(dcat), ldd, _p(x), ldx, _p(dw), _p(db), N, D, H, W, Cin, Cout,
+            db = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_b else None
+            L.call("mi355seg_convt3d_k2s2_wgrad_" + _sfx(x), _p(dcat), ldd, _p(x), ldx, _p(dw), _p(db), N, D, H, W, Cin, Cout,
                    _p(ws), ws.numel(), _stream())
         return dx, dw, db, dcat[..., Cout:]
 
@@ -247,7 +335,7 @@ class _ConvT3dAdjoint(Function):
 
     @staticmethod
     def forward(ctx, x, w, b, k):
-        x, ldx = cl_view(x, "conv_transpose3d input")
+        x, ldx = cl_view(x, "conv_transpose3d input", allow_bf16=False)
         N, D, H, W, Cin = x.shape
         if w.shape[0] != Cin or tuple(w.shape[2:]) != (k, k, k):
             raise Mi355SegError(f"conv_transpose3d: weight {tuple(w.shape)} does not match input channels {Cin} / kernel {k}")
@@ -315,7 +403,7 @@ class _NormAct(Function):
             mean = torch.empty(groups * C, dtype=torch.float32, device=dev)
             rstd = torch.empty(groups * C, dtype=torch.float32, device=dev)
             upd = training and (running_mean is not None) and not instance
-            L.call("mi355seg_norm_stats_f32", _p(x), ldx, rows, groups, C, eps, _p(mean), _p(rstd),
+            L.call("mi355seg_norm_stats_" + _sfx(x), _p(x), ldx, rows, groups, C, eps, _p(mean), _p(rstd),
                    _p(running_mean) if upd else None, _p(running_var) if upd else None, momentum,
                    _p(ws), ws.numel(), _stream())
         else:
@@ -323,7 +411,7 @@ class _NormAct(Function):
             rstd = torch.empty(C, dtype=torch.float32, device=dev)
             L.call("mi355seg_rstd_from_var_f32", _p(running_var), eps, _p(rstd), C, _stream())
         y = torch.empty((N, D, H, W, C), dtype=x.dtype, device=dev)
-        L.call("mi355seg_norm_act_fwd_f32", _p(x), ldx, _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), ldres,
+        L.call("mi355seg_norm_act_fwd_" + _sfx(x), _p(x), ldx, _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), ldres,
                _p(y), C, rows, groups, C, act, slope, _stream())
         ctx.save_for_backward(x, mean, rstd, gamma, beta, res)
         ctx.cfg = (ldx, ldres, rows, groups, C, act, slope, bool(training or instance))
@@ -335,7 +423,7 @@ class _NormAct(Function):
         ldx, ldres, rows, groups, C, act, slope, batch_stats = ctx.cfg
         if not batch_stats:
             raise Mi355SegError("backward through eval-mode BatchNorm (running statistics) is not supported")
-        dy, lddy = cl_view(dy, "norm grad")
+        dy, lddy = cl_view(_like(dy, x), "norm grad")
         L = lib()
         dev = x.device
         ws = workspace(L.query("mi355seg_norm_ws_bytes", rows, groups, C), dev)
@@ -343,7 +431,7 @@ class _NormAct(Function):
         dgamma = torch.empty(C, dtype=torch.float32, device=dev) if gamma is not None else None
         dbeta = torch.empty(C, dtype=torch.float32, device=dev) if gamma is not None else None
         dres = torch.empty(x.shape, dtype=x.dtype, device=dev) if res is not None else None
-        L.call("mi355seg_norm_act_bwd_f32", _p(dy), lddy, _p(x), ldx, _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), ldres,
+        L.call("mi355seg_norm_act_bwd_" + _sfx(x), _p(dy), lddy, _p(x), ldx, _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), ldres,
                _p(dx), C, _p(dgamma), _p(dbeta), _p(dres), C, rows, groups, C, act, slope, _p(ws), ws.numel(), _stream())
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
 
@@ -377,19 +465,19 @@ class _ConvBnAct(Function):
         dev = x.device
         y = torch.empty((N, Do, Ho, Wo, Cout), dtype=x.dtype, device=dev)
         L = lib()
-        ws = workspace(max(L.query("mi355seg_conv3d_ws_bytes", N, D, H, W, Cin, Cout, k, stride, pad),
+        ws = workspace(max(_conv_ws(L, x, N, D, H, W, Cin, Cout, k, stride, pad),
                            L.query("mi355seg_norm_ws_bytes", N * Do * Ho * Wo, 1, Cout)), dev)
         rows = N * Do * Ho * Wo
         if training:
             sums = torch.empty(2 * Cout, dtype=torch.float64, device=dev)
-            L.call("mi355seg_conv3d_fwd_f32", _p(x), ldx, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
+            L.call("mi355seg_conv3d_fwd_" + _sfx(x), _p(x), ldx, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
                    sums.data_ptr(), sums.data_ptr() + 8 * Cout, _p(ws), ws.numel(), _stream())
             mean = torch.empty(Cout, dtype=torch.float32, device=dev)
             rstd = torch.empty(Cout, dtype=torch.float32, device=dev)
             L.call("mi355seg_norm_stats_from_sums_f32", sums.data_ptr(), sums.data_ptr() + 8 * Cout, rows, Cout, eps,
                    _p(mean), _p(rstd), _p(rmean), _p(rvar), momentum, _stream())
         else:
-            L.call("mi355seg_conv3d_fwd_f32", _p(x), ldx, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
+            L.call("mi355seg_conv3d_fwd_" + _sfx(x), _p(x), ldx, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
                    None, None, _p(ws), ws.numel(), _stream())
             mean = rmean
             rstd = torch.empty(Cout, dtype=torch.float32, device=dev)
@@ -401,7 +489,7 @@ class _ConvBnAct(Function):
             a = full[..., left_pad:]
         else:
             a = torch.empty_like(y)
-        L.call("mi355seg_norm_act_fwd_f32", _p(y), Cout, _p(mean), _p(rstd), _p(gamma), _p(beta), None, 0,
+        L.call("mi355seg_norm_act_fwd_" + _sfx(x), _p(y), Cout, _p(mean), _p(rstd), _p(gamma), _p(beta), None, 0,
                a.data_ptr(), left_pad + Cout, rows, 1, Cout, act, slope, _stream())
         ctx.save_for_backward(x, w, y, mean, rstd, gamma, beta)
         ctx.cfg = (N, D, H, W, Cin, Cout, k, stride, pad, ldx, b is not None, rows, act, slope, bool(training))
@@ -413,25 +501,25 @@ class _ConvBnAct(Function):
         N, D, H, W, Cin, Cout, k, stride, pad, ldx, has_b, rows, act, slope, training = ctx.cfg
         if not training:
             raise Mi355SegError("backward through eval-mode BatchNorm (running statistics) is not supported")
-        da, ldda = cl_view(da, "conv+norm grad")
+        da, ldda = cl_view(_like(da, x), "conv+norm grad")
         L = lib()
         dev = x.device
-        ws = workspace(max(L.query("mi355seg_conv3d_ws_bytes", N, D, H, W, Cin, Cout, k, stride, pad),
+        ws = workspace(max(_conv_ws(L, x, N, D, H, W, Cin, Cout, k, stride, pad),
                            L.query("mi355seg_norm_ws_bytes", rows, 1, Cout)), dev)
         dy = torch.empty_like(y)
         dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
         dbeta = torch.empty(Cout, dtype=torch.float32, device=dev)
         db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
-        L.call("mi355seg_norm_act_bwd_colsum_f32", _p(da), ldda, _p(y), Cout, _p(mean), _p(rstd), _p(gamma), _p(beta), None, 0,
+        L.call("mi355seg_norm_act_bwd_colsum_" + _sfx(x), _p(da), ldda, _p(y), Cout, _p(mean), _p(rstd), _p(gamma), _p(beta), None, 0,
                _p(dy), Cout, _p(dgamma), _p(dbeta), None, 0, _p(db), rows, 1, Cout, act, slope, _p(ws), ws.numel(), _stream())
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((N, D, H, W, Cin), dtype=x.dtype, device=dev)
-            L.call("mi355seg_conv3d_dgrad_f32", _p(dy), Cout, _p(w), _p(dx), Cin, N, D, H, W, Cin, Cout, k, stride, pad,
+            L.call("mi355seg_conv3d_dgrad_" + _sfx(x), _p(dy), Cout, _p(w), _p(dx), Cin, N, D, H, W, Cin, Cout, k, stride, pad,
                    _p(ws), ws.numel(), _stream())
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
-            L.call("mi355seg_conv3d_wgrad_f32", _p(dy), Cout, _p(x), ldx, _p(dw), None, N, D, H, W, Cin, Cout, k, stride, pad,
+            L.call("mi355seg_conv3d_wgrad_" + _sfx(x), _p(dy), Cout, _p(x), ldx, _p(dw), None, N, D, H, W, Cin, Cout, k, stride, pad,
                    0, _p(ws), ws.numel(), _stream())
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
@@ -459,7 +547,7 @@ class _Act(Function):
             ldres = 0
         y = torch.empty((N, D, H, W, C), dtype=x.dtype, device=x.device)
         rows = N * D * H * W
-        lib().call("mi355seg_act_fwd_f32", _p(x), ldx, _p(res), ldres, _p(y), C, rows, C, act, slope, _stream())
+        lib().call("mi355seg_act_fwd_" + _sfx(x), _p(x), ldx, _p(res), ldres, _p(y), C, rows, C, act, slope, _stream())
         ctx.save_for_backward(x, res)
         ctx.cfg = (ldx, ldres, rows, C, act, slope)
         return y
@@ -468,9 +556,9 @@ class _Act(Function):
     def backward(ctx, dy):
         x, res = ctx.saved_tensors
         ldx, ldres, rows, C, act, slope = ctx.cfg
-        dy, lddy = cl_view(dy, "activation grad")
+        dy, lddy = cl_view(_like(dy, x), "activation grad")
         dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
-        lib().call("mi355seg_act_bwd_f32", _p(dy), lddy, _p(x), ldx, _p(res), ldres, _p(dx), C, rows, C, act, slope, _stream())
+        lib().call("mi355seg_act_bwd_" + _sfx(x), _p(dy), lddy, _p(x), ldx, _p(res), ldres, _p(dx), C, rows, C, act, slope, _stream())
         return dx, (dx if res is not None else None), None, None
 
 
@@ -488,7 +576,7 @@ class _ScaleChannels(Function):
         if scale.numel() != N * C:
             raise Mi355SegError(f"scale_channels: scale must hold N*C = {N * C} values, got {scale.numel()}")
         y = torch.empty((N, D, H, W, C), dtype=x.dtype, device=x.device)
-        lib().call("mi355seg_scale_channels_f32", _p(x), ldx, _p(scale), _p(y), C, D * H * W, N, C, _stream())
+        lib().call("mi355seg_scale_channels_" + _sfx(x), _p(x), ldx, _p(scale), _p(y), C, D * H * W, N, C, _stream())
         ctx.save_for_backward(scale)
         return y
 
@@ -498,7 +586,7 @@ class _ScaleChannels(Function):
         dy, lddy = cl_view(dy, "dropout grad")
         N, D, H, W, C = dy.shape
         dx = torch.empty((N, D, H, W, C), dtype=dy.dtype, device=dy.device)
-        lib().call("mi355seg_scale_channels_f32", _p(dy), lddy, _p(scale), _p(dx), C, D * H * W, N, C, _stream())
+        lib().call("mi355seg_scale_channels_" + _sfx(dy), _p(dy), lddy, _p(scale), _p(dx), C, D * H * W, N, C, _stream())
         return dx, None
 
 
@@ -515,7 +603,7 @@ class _MaxPool2(Function):
         N, D, H, W, C = x.shape
         y = torch.empty((N, D // 2, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
         idx = torch.empty((N, D // 2, H // 2, W // 2, C), dtype=torch.uint8, device=x.device)
-        lib().call("mi355seg_maxpool2_fwd_f32", _p(x), ldx, _p(y), C, _p(idx), N, D, H, W, C, _stream())
+        lib().call("mi355seg_maxpool2_fwd_" + _sfx(x), _p(x), ldx, _p(y), C, _p(idx), N, D, H, W, C, _stream())
         ctx.save_for_backward(idx)
         ctx.geom = (N, D, H, W, C)
         return y
@@ -526,7 +614,7 @@ class _MaxPool2(Function):
         N, D, H, W, C = ctx.geom
         dy, lddy = cl_view(dy, "max_pool3d grad")
         dx = torch.empty((N, D, H, W, C), dtype=dy.dtype, device=dy.device)
-        lib().call("mi355seg_maxpool2_bwd_f32", _p(dy), lddy, _p(idx), _p(dx), C, N, D, H, W, C, _stream())
+        lib().call("mi355seg_maxpool2_bwd_" + _sfx(dy), _p(dy), lddy, _p(idx), _p(dx), C, N, D, H, W, C, _stream())
         return dx
 
 
@@ -540,7 +628,7 @@ class _PoolAndSkip(Function):
         N, D, H, W, C = xv.shape
         y = torch.empty((N, D // 2, H // 2, W // 2, C), dtype=xv.dtype, device=xv.device)
         idx = torch.empty((N, D // 2, H // 2, W // 2, C), dtype=torch.uint8, device=xv.device)
-        lib().call("mi355seg_maxpool2_fwd_f32", _p(xv), ldx, _p(y), C, _p(idx), N, D, H, W, C, _stream())
+        lib().call("mi355seg_maxpool2_fwd_" + _sfx(xv), _p(xv), ldx, _p(y), C, _p(idx), N, D, H, W, C, _stream())
         ctx.save_for_backward(idx)
         ctx.geom = (N, D, H, W, C)
         return y, x.view_as(x)
@@ -552,7 +640,7 @@ class _PoolAndSkip(Function):
         dy, lddy = cl_view(dy, "max_pool3d grad")
         ds, lds = cl_view(dskip, "skip grad")
         dx = torch.empty((N, D, H, W, C), dtype=dy.dtype, device=dy.device)
-        lib().call("mi355seg_maxpool2_bwd_add_f32", _p(dy), lddy, _p(idx), _p(ds), lds, _p(dx), C, N, D, H, W, C, _stream())
+        lib().call("mi355seg_maxpool2_bwd_add_" + _sfx(dy), _p(dy), lddy, _p(idx), _p(ds), lds, _p(dx), C, N, D, H, W, C, _stream())
         return dx
 
 
@@ -571,7 +659,7 @@ class _Upsample2(Function):
         x, ldx = cl_view(x, "upsample input")
         N, D, H, W, C = x.shape
         y = torch.empty((N, 2 * D, 2 * H, 2 * W, C), dtype=x.dtype, device=x.device)
-        lib().call("mi355seg_upsample2_fwd_f32", _p(x), ldx, _p(y), C, N, D, H, W, C, _stream())
+        lib().call("mi355seg_upsample2_fwd_" + _sfx(x), _p(x), ldx, _p(y), C, N, D, H, W, C, _stream())
         ctx.geom = (N, D, H, W, C)
         return y
 
@@ -580,7 +668,7 @@ class _Upsample2(Function):
         N, D, H, W, C = ctx.geom
         dy, lddy = cl_view(dy, "upsample grad")
         dx = torch.empty((N, D, H, W, C), dtype=dy.dtype, device=dy.device)
-        lib().call("mi355seg_upsample2_bwd_f32", _p(dy), lddy, _p(dx), C, N, D, H, W, C, _stream())
+        lib().call("mi355seg_upsample2_bwd_" + _sfx(dy), _p(dy), lddy, _p(dx), C, N, D, H, W, C, _stream())
         return dx
 
 
@@ -800,8 +888,8 @@ class _Gate(Function):
 
     @staticmethod
     def forward(ctx, enc, t):
-        enc, lde = cl_view(enc, "gate features")
-        t, ldt = cl_view(t, "gate map")
+        enc, lde = cl_view(enc, "gate features", allow_bf16=False)
+        t, ldt = cl_view(t, "gate map", allow_bf16=False)
         N, D, H, W, C = enc.shape
         if tuple(t.shape) != (N, D, H, W, 1):
             raise Mi355SegError(f"gate: map {tuple(t.shape)} must be one channel over the voxels of {tuple(enc.shape)}")
@@ -832,8 +920,8 @@ class _SFPool(Function):
 
     @staticmethod
     def forward(ctx, x1, x2):
-        x1, ld1 = cl_view(x1, "sf_pool input")
-        x2, ld2 = cl_view(x2, "sf_pool input")
+        x1, ld1 = cl_view(x1, "sf_pool input", allow_bf16=False)
+        x2, ld2 = cl_view(x2, "sf_pool input", allow_bf16=False)
         N, D, H, W, C = x1.shape
         if x2.shape != x1.shape:
             raise Mi355SegError(f"sf_pool: shapes differ: {tuple(x1.shape)} vs {tuple(x2.shape)}")
@@ -860,8 +948,8 @@ class _SFMix(Function):
 
     @staticmethod
     def forward(ctx, x1, x2, a, b):
-        x1, ld1 = cl_view(x1, "sf_mix input")
-        x2, ld2 = cl_view(x2, "sf_mix input")
+        x1, ld1 = cl_view(x1, "sf_mix input", allow_bf16=False)
+        x2, ld2 = cl_view(x2, "sf_mix input", allow_bf16=False)
         N, D, H, W, C = x1.shape
         a, b = a.contiguous(), b.contiguous()
         if x2.shape != x1.shape or a.numel() != N * C or b.numel() != N * C:
@@ -941,8 +1029,10 @@ class _CatChannels(Function):
         out = torch.empty((N, D, H, W, Ca + Cb), dtype=a.dtype, device=a.device)
         rows = N * D * H * W
         L = lib()
-        L.call("mi355seg_copy_rows_f32", _p(a), lda, _p(out), Ca + Cb, rows, Ca, _stream())
-        L.call("mi355seg_copy_rows_f32", _p(b), ldb, out.data_ptr() + 4 * Ca, Ca + Cb, rows, Cb, _stream())
+        if a.dtype != b.dtype:
+            raise Mi355SegError(f"cat_channels: storage types differ: {a.dtype} vs {b.dtype}")
+        L.call("mi355seg_copy_rows_" + _sfx(a), _p(a), lda, _p(out), Ca + Cb, rows, Ca, _stream())
+        L.call("mi355seg_copy_rows_" + _sfx(a), _p(b), ldb, out.data_ptr() + out.element_size() * Ca, Ca + Cb, rows, Cb, _stream())
         ctx.ca = Ca
         return out
 
@@ -963,7 +1053,7 @@ class _RepeatChannels(Function):
         x, ldx = cl_view(x, "repeat_channels input")
         N, D, H, W, C = x.shape
         y = torch.empty((N, D, H, W, C * rep), dtype=x.dtype, device=x.device)
-        lib().call("mi355seg_repeat_channels_f32", _p(x), ldx, _p(y), C * rep, N * D * H * W, C, rep, _stream())
+        lib().call("mi355seg_repeat_channels_" + _sfx(x), _p(x), ldx, _p(y), C * rep, N * D * H * W, C, rep, _stream())
         ctx.cfg = (C, rep)
         return y
 
@@ -973,7 +1063,7 @@ class _RepeatChannels(Function):
         dy, lddy = cl_view(dy, "repeat_channels grad")
         N, D, H, W, _ = dy.shape
         dx = torch.empty((N, D, H, W, C), dtype=dy.dtype, device=dy.device)
-        lib().call("mi355seg_repeat_channels_bwd_f32", _p(dy), lddy, _p(dx), C, N * D * H * W, C, rep, _stream())
+        lib().call("mi355seg_repeat_channels_bwd_" + _sfx(dy), _p(dy), lddy, _p(dx), C, N * D * H * W, C, rep, _stream())
         return dx, None
 
 

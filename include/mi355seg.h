@@ -29,6 +29,14 @@
 extern "C" {
 #endif
 
+/* 16-bit brain-float storage element of the *_bf16 entry points (same bits as torch.bfloat16).  The HIP compiler sees its
+ * native __bf16, a plain C / C++ host compiler an opaque 16-bit integer: one ABI, one storage format. */
+#if defined(__HIP__) || defined(__HIPCC__)
+typedef __bf16 mi355seg_bf16;
+#else
+typedef uint16_t mi355seg_bf16;
+#endif
+
 #define MI355SEG_OK 0
 #define MI355SEG_EINVAL (-1)   /* bad shape / unsupported argument combination */
 #define MI355SEG_EWORKSPACE (-2) /* workspace too small */
@@ -309,6 +317,44 @@ int mi355seg_broadcast_channels_f32(const float* v, float alpha, float* y, int l
 int mi355seg_add_bias_f32(float* y, int ldy, const float* bias, long long rows, int C, void* stream);
 /* out[i] = a[i] * b[i] (attention-probability dropout mask, unetr.py:112; out may alias a). */
 int mi355seg_mul_f32(const float* a, const float* b, float* out, long long n, void* stream);
+
+
+/* ------------------------------------------------------------------ bf16 tensors (BASELINE cfg 3-5: V-Net / Residual U-Net / UNETR in bf16)
+ * What torch autocast(bfloat16) does for the reference's modules (vnet3d.py:21-121, residual_unet3d.py:82-107,
+ * unetr.py:8-51): activations and activation gradients are bf16 NDHWC tensors in HBM, parameters, parameter gradients,
+ * norm statistics and the loss stay fp32, every convolution product is a bf16 MFMA with fp32 accumulation, every
+ * elementwise / norm / pool kernel loads bf16, computes in fp32 registers and rounds once (RNE) on the store.
+ * Each mi355seg_<op>_bf16 below has the contract of mi355seg_<op>_f32 above with the tensor pointers retyped; pitches
+ * (ld*) count ELEMENTS.  Conv3d shapes without a native bf16 kernel run through the fp32 entry point on fp32 copies
+ * made in the workspace (mi355seg_conv3d_ws_bytes_bf16 sizes for that). */
+int mi355seg_norm_stats_bf16(const mi355seg_bf16* x, int ldx, long long rows, int groups, int C, float eps, float* mean, float* rstd, float* running_mean, float* running_var, float momentum, void* ws, size_t ws_bytes, void* stream);
+int mi355seg_norm_act_fwd_bf16(const mi355seg_bf16* x, int ldx, const float* mean, const float* rstd, const float* gamma, const float* beta, const mi355seg_bf16* res, int ldres, mi355seg_bf16* y, int ldy, long long rows, int groups, int C, int act, float slope, void* stream);
+int mi355seg_norm_act_bwd_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, const float* mean, const float* rstd, const float* gamma, const float* beta, const mi355seg_bf16* res, int ldres, mi355seg_bf16* dx, int lddx, float* dgamma, float* dbeta, mi355seg_bf16* dres, int lddres, long long rows, int groups, int C, int act, float slope, void* ws, size_t ws_bytes, void* stream);
+int mi355seg_norm_act_bwd_colsum_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, const float* mean, const float* rstd, const float* gamma, const float* beta, const mi355seg_bf16* res, int ldres, mi355seg_bf16* dx, int lddx, float* dgamma, float* dbeta, mi355seg_bf16* dres, int lddres, float* dx_colsum, long long rows, int groups, int C, int act, float slope, void* ws, size_t ws_bytes, void* stream);
+int mi355seg_scale_channels_bf16(const mi355seg_bf16* x, int ldx, const float* scale, mi355seg_bf16* y, int ldy, long long rows, int groups, int C, void* stream);
+int mi355seg_act_fwd_bf16(const mi355seg_bf16* x, int ldx, const mi355seg_bf16* res, int ldres, mi355seg_bf16* y, int ldy, long long rows, int C, int act, float slope, void* stream);
+int mi355seg_act_bwd_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, const mi355seg_bf16* res, int ldres, mi355seg_bf16* dx, int lddx, long long rows, int C, int act, float slope, void* stream);
+int mi355seg_maxpool2_fwd_bf16(const mi355seg_bf16* x, int ldx, mi355seg_bf16* y, int ldy, uint8_t* idx, int N, int D, int H, int W, int C, void* stream);
+int mi355seg_maxpool2_bwd_bf16(const mi355seg_bf16* dy, int lddy, const uint8_t* idx, mi355seg_bf16* dx, int lddx, int N, int D, int H, int W, int C, void* stream);
+int mi355seg_maxpool2_bwd_add_bf16(const mi355seg_bf16* dy, int lddy, const uint8_t* idx, const mi355seg_bf16* add, int ldadd, mi355seg_bf16* dx, int lddx, int N, int D, int H, int W, int C, void* stream);
+int mi355seg_upsample2_fwd_bf16(const mi355seg_bf16* x, int ldx, mi355seg_bf16* y, int ldy, int N, int D, int H, int W, int C, void* stream);
+int mi355seg_upsample2_bwd_bf16(const mi355seg_bf16* dy, int lddy, mi355seg_bf16* dx, int lddx, int N, int D, int H, int W, int C, void* stream);
+int mi355seg_convt3d_k2s2_fwd_bf16(const mi355seg_bf16* x, int ldx, const float* w, const float* bias, mi355seg_bf16* y, int ldy, int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+int mi355seg_convt3d_k2s2_dgrad_bf16(const mi355seg_bf16* dy, int lddy, const float* w, mi355seg_bf16* dx, int lddx, int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+int mi355seg_convt3d_k2s2_wgrad_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, float* dw, float* db, int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+int mi355seg_ncdhw_f32_to_ndhwc_bf16(const float* src, mi355seg_bf16* dst, int lddst, long long N, int C, long long S, void* stream);
+int mi355seg_ndhwc_bf16_to_ncdhw_f32(const mi355seg_bf16* src, int ldsrc, float* dst, long long N, int C, long long S, void* stream);
+int mi355seg_copy_rows_bf16(const mi355seg_bf16* src, int ldsrc, mi355seg_bf16* dst, int lddst, long long rows, int C, void* stream);
+int mi355seg_add_rows_bf16(const mi355seg_bf16* src, int ldsrc, mi355seg_bf16* dst, int lddst, long long rows, int C, void* stream);
+int mi355seg_repeat_channels_bf16(const mi355seg_bf16* x, int ldx, mi355seg_bf16* y, int ldy, long long rows, int C, int rep, void* stream);
+int mi355seg_repeat_channels_bwd_bf16(const mi355seg_bf16* dy, int lddy, mi355seg_bf16* dx, int lddx, long long rows, int C, int rep, void* stream);
+int mi355seg_add_bias_bf16(mi355seg_bf16* y, int ldy, const float* bias, long long rows, int C, void* stream);
+size_t mi355seg_conv3d_ws_bytes_bf16(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad);
+int mi355seg_conv3d_fwd_bf16(const mi355seg_bf16* x, int ldx, const float* w, const float* bias, mi355seg_bf16* y, int ldy, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, double* stats_sum, double* stats_sq, void* ws, size_t ws_bytes, void* stream);
+int mi355seg_conv3d_dgrad_bf16(const mi355seg_bf16* dy, int lddy, const float* w, mi355seg_bf16* dx, int lddx, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
+int mi355seg_conv3d_wgrad_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, float* dw, float* db, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, void* stream);
+int mi355seg_cast_f32_to_bf16(const float* src, int ldsrc, mi355seg_bf16* dst, int lddst, long long rows, int C, void* stream);
+int mi355seg_cast_bf16_to_f32(const mi355seg_bf16* src, int ldsrc, float* dst, int lddst, long long rows, int C, void* stream);
 
 #ifdef __cplusplus
 }
