@@ -52,6 +52,9 @@ static int native_dgrad(int N, int D, int H, int W, int Cin, int Cout, int k, in
 }
 static int native_wgrad(int N, int D, int H, int W, int Cin, int Cout, int k, int s, int p, int ldx, int lddy) {
     if (wgrad_lowp_supported(MATH_B16, N, D, H, W, Cin, Cout, k, s, p, ldx, lddy)) return NB_LOWP;
+    // V-Net's two-channel k5 head and one-channel k5 stem: the fp32 z-marching kernels (conv_headk.hip) behind the cast
+    // fall-back are 5-8x faster than the generic small-channel wgrads below
+    if (headk_wgrad_supported(Cin, Cout, k, s, p, Cin, Cout) || stemk_supported(Cin, Cout, k, s, p, Cin, Cout)) return NB_NONE;
     if (k == 1 && s == 1 && p == 0 && pw_wgrad_supported((long long)N * D * H * W, Cin, Cout, 1, ldx, lddy)) return NB_PW;
     if (stem_supported(Cin, Cout, k, s, p, lddy)) return NB_STEM;
     if (head_supported(Cin, Cout, k, s, p, ldx)) return NB_HEAD;

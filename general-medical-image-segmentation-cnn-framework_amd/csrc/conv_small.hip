@@ -516,7 +516,7 @@ int smallcin_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N,
     dim3 grid(nblk, Cin, (g.T + TPG - 1) / TPG);
     size_t lds = (size_t)4 * TPG * Cout * 4;
     {
-        ProfScope ps(PF_DIRECT, 2.0 * nvox * g.T * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
+        ProfScope ps(PF_DIRECT, 2.0 * nvox * g.T * Cin * Cout, (double)sizeof(T) * nvox * (Cin + Cout), st);
         if (vw == 4) hipLaunchKernelGGL((smallcin_wgrad_kernel<T, 25, 4>), grid, dim3(256), lds, st, x, dy, part, g);
         else hipLaunchKernelGGL((smallcin_wgrad_kernel<T, 25, 1>), grid, dim3(256), lds, st, x, dy, part, g);
         SEG_CHECK_LAUNCH();
@@ -537,7 +537,7 @@ int smallcout_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N
     SEG_CHECK_WS((size_t)nblk * g.T * Cin * Cout * sizeof(float), ws_bytes);
     float* part = (float*)ws;
     {
-        ProfScope ps(PF_DIRECT, 2.0 * nvox * g.T * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
+        ProfScope ps(PF_DIRECT, 2.0 * nvox * g.T * Cin * Cout, (double)sizeof(T) * nvox * (Cin + Cout), st);
         if (Cout == 2) {
             constexpr int TPG = 25;
             dim3 grid(nblk, (g.T + TPG - 1) / TPG);
@@ -585,7 +585,7 @@ int stem_fwd(const T* x, int ldx, const float* w, const float* bias, T* y, int l
         const int ntiles = (int)(nvox / ((long long)S1_TZ * S1_TY * (256 / (Cout / 4))));   // tile = 2 x 4 x TX voxels
         int nb = ntiles < 1024 ? ntiles : 1024;
         {
-            ProfScope ps(PF_DIRECT, 2.0 * nvox * 27.0 * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
+            ProfScope ps(PF_DIRECT, 2.0 * nvox * 27.0 * Cin * Cout, (double)sizeof(T) * nvox * (Cin + Cout), st);
             hipLaunchKernelGGL(stem1_fwd_kernel<T>, dim3(nb), dim3(256), stem1_lds(Cout), st, x, w, bias, y, spart, g, ntiles);
             SEG_CHECK_LAUNCH();
         }
@@ -593,7 +593,7 @@ int stem_fwd(const T* x, int ldx, const float* w, const float* bias, T* y, int l
         return MI355SEG_OK;
     }
     {
-        ProfScope ps(PF_DIRECT, 2.0 * nvox * 27.0 * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
+        ProfScope ps(PF_DIRECT, 2.0 * nvox * 27.0 * Cin * Cout, (double)sizeof(T) * nvox * (Cin + Cout), st);
         if (Cin == 1) hipLaunchKernelGGL((stem_fwd_kernel<T, 1>), dim3(nblk), dim3(256), lds, st, x, w, bias, y, spart, g);
         else if (Cin == 2) hipLaunchKernelGGL((stem_fwd_kernel<T, 2>), dim3(nblk), dim3(256), lds, st, x, w, bias, y, spart, g);
         else hipLaunchKernelGGL((stem_fwd_kernel<T, 4>), dim3(nblk), dim3(256), lds, st, x, w, bias, y, spart, g);
@@ -618,7 +618,7 @@ int stem_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N, int
         const int ntiles = (int)(nvox / ((long long)S1_TZ * S1_TY * (256 / (Cout / 4))));   // tile = 2 x 4 x TX voxels
         int nb = ntiles < 512 ? ntiles : 512;
         {
-            ProfScope ps(PF_DIRECT, 2.0 * nvox * 27.0 * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
+            ProfScope ps(PF_DIRECT, 2.0 * nvox * 27.0 * Cin * Cout, (double)sizeof(T) * nvox * (Cin + Cout), st);
             hipLaunchKernelGGL(stem1_wgrad_kernel<T>, dim3(nb), dim3(256), stem1_lds(Cout), st, x, dy, part, g, lddy, ntiles);
             SEG_CHECK_LAUNCH();
         }
@@ -627,7 +627,7 @@ int stem_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N, int
         return MI355SEG_OK;
     }
     {
-        ProfScope ps(PF_DIRECT, 2.0 * nvox * 27.0 * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
+        ProfScope ps(PF_DIRECT, 2.0 * nvox * 27.0 * Cin * Cout, (double)sizeof(T) * nvox * (Cin + Cout), st);
         hipLaunchKernelGGL((stem_wgrad_kernel<T, 0>), dim3(nblk, Cin), dim3(256), lds, st, x, dy, part, g, lddy);
         SEG_CHECK_LAUNCH();
     }
@@ -642,7 +642,7 @@ int head_fwd(const T* x, int ldx, const float* w, const float* bias, T* y, int l
     SmallGeom g{N, D, H, W, Cin, Cout, ldx, ldy};
     const long long nvox = (long long)N * D * H * W;
     const int nblk = small_grid(nvox, 256 / (Cin / 4)) * 2;
-    ProfScope ps(PF_DIRECT, 2.0 * nvox * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
+    ProfScope ps(PF_DIRECT, 2.0 * nvox * Cin * Cout, (double)sizeof(T) * nvox * (Cin + Cout), st);
     if (Cout == 2) hipLaunchKernelGGL((head_fwd_kernel<T, 2>), dim3(nblk), dim3(256), 0, st, x, w, bias, y, g);
     else hipLaunchKernelGGL((head_fwd_kernel<T, 4>), dim3(nblk), dim3(256), 0, st, x, w, bias, y, g);
     SEG_CHECK_LAUNCH();
@@ -655,7 +655,7 @@ int head_dgrad(const T* dy, int lddy, const float* w, T* dx, int lddx, int N, in
     SmallGeom g{N, D, H, W, Cin, Cout, lddx, 0};
     const long long nvox = (long long)N * D * H * W;
     const int nblk = small_grid(nvox, 256 / (Cin / 4)) * 2;
-    ProfScope ps(PF_DIRECT, 2.0 * nvox * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
+    ProfScope ps(PF_DIRECT, 2.0 * nvox * Cin * Cout, (double)sizeof(T) * nvox * (Cin + Cout), st);
     if (Cout == 2) hipLaunchKernelGGL((head_dgrad_kernel<T, 2>), dim3(nblk), dim3(256), 0, st, dy, lddy, w, dx, g);
     else hipLaunchKernelGGL((head_dgrad_kernel<T, 4>), dim3(nblk), dim3(256), 0, st, dy, lddy, w, dx, g);
     SEG_CHECK_LAUNCH();
@@ -672,7 +672,7 @@ int head_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N, int
     SEG_CHECK_WS((size_t)nblk * Cin * Cout * sizeof(float), ws_bytes);
     float* part = (float*)ws;
     {
-        ProfScope ps(PF_DIRECT, 2.0 * nvox * Cin * Cout, 4.0 * nvox * (Cin + Cout), st);
+        ProfScope ps(PF_DIRECT, 2.0 * nvox * Cin * Cout, (double)sizeof(T) * nvox * (Cin + Cout), st);
         if (Cout == 2) hipLaunchKernelGGL((head_wgrad_kernel<T, 2>), dim3(nblk), dim3(256), 0, st, x, dy, lddy, part, g);
         else hipLaunchKernelGGL((head_wgrad_kernel<T, 4>), dim3(nblk), dim3(256), 0, st, x, dy, lddy, part, g);
         SEG_CHECK_LAUNCH();

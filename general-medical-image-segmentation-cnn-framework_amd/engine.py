@@ -15,8 +15,26 @@ def two_channel_gt(gt):
     return F.two_channel_gt(gt)
 
 
-def train_step(model, optimizer, x, gt, criterion=None, sync_metric=True, grad_hook=None):
-    """One iteration.  ``gt`` is the single-channel label volume [N,1,D,H,W].
+def mixed_precision_dtype(config=None):
+    """The activation storage type of a run: ``Accelerator()`` (train.py:167) takes its mixed-precision mode from
+    ``accelerate config`` / the ACCELERATE_MIXED_PRECISION environment variable ("no" | "bf16"); the same variable, or
+    ``config.mixed_precision`` on the command line, selects it here.  "bf16" = bf16 activations in HBM + bf16 MFMA
+    convolutions (fp32 parameters, gradients, statistics and loss); fp16 is not offered (no loss scaler on this path)."""
+    import os
+    mode = None
+    if config is not None:
+        mode = config.get("mixed_precision") if hasattr(config, "get") else getattr(config, "mixed_precision", None)
+    mode = str(mode if mode is not None else os.environ.get("ACCELERATE_MIXED_PRECISION", "no")).lower()
+    if mode in ("no", "none", "false", "fp32", "f32", ""):
+        return torch.float32
+    if mode in ("bf16", "bfloat16"):
+        return torch.bfloat16
+    raise ValueError(f"mixed_precision must be 'no' or 'bf16', got {mode!r}")
+
+
+def train_step(model, optimizer, x, gt, criterion=None, sync_metric=True, grad_hook=None, dtype=None):
+    """One iteration.  ``gt`` is the single-channel label volume [N,1,D,H,W].  ``dtype`` = torch.bfloat16 runs the
+    forward under mi355seg.autocast (bf16 activations; the loss and everything after it stay fp32).
     ``grad_hook`` (if given) runs between backward and optimizer.step -- the data-parallel
     gradient all-reduce plugs in there.  Returns a dict with pred, mask, loss and, when
     ``sync_metric``, python floats jaccard/dice (one tiny D2H copy); otherwise the raw
@@ -24,12 +42,13 @@ def train_step(model, optimizer, x, gt, criterion=None, sync_metric=True, grad_h
     optimizer.zero_grad(set_to_none=True)
     gt2 = two_channel_gt(gt)
     x = x.to(torch.float32)
-    if getattr(model, "takes_frequency_bands", False):      # the IS network, train.py:198-201: second output discarded
-        from .models.three_d.IS import frequency_bands
-        low_x, high_x = frequency_bands(x)
-        pred, _ = model(x, low_x, high_x)
-    else:
-        pred = model(x)
+    with F.autocast(dtype or F.compute_dtype()):
+        if getattr(model, "takes_frequency_bands", False):      # the IS network, train.py:198-201: second output discarded
+            from .models.three_d.IS import frequency_bands
+            low_x, high_x = frequency_bands(x)
+            pred, _ = model(x, low_x, high_x)
+        else:
+            pred = model(x)
     if criterion is None:
         # nn.BCEWithLogitsLoss + pred.argmax + gt.argmax + the Dice counters in one pass over the logits
         loss, mask, counts = F.bce_argmax_dice(pred, gt2)

@@ -16,7 +16,7 @@ from torch.optim.lr_scheduler import StepLR
 from . import distributed as D
 from .config import compose, parse_patch_size
 from .data import make_loader
-from .engine import train_step, weights_init_normal
+from .engine import mixed_precision_dtype, train_step, weights_init_normal
 from .registry import build_model
 
 
@@ -66,6 +66,9 @@ def train(config, model, logger):
     # accelerator.prepare (train.py:167-169): rank 0's parameters / buffers everywhere (after the optional checkpoint
     # load, so a resumed rank 0 wins), flat buffers for the per-step broadcast, bucketed gradient reducer
     reducer = D.setup_replica(model)
+    act_dtype = mixed_precision_dtype(config)                                   # Accelerator(mixed_precision=...) of train.py:167
+    if act_dtype != torch.float32:
+        logger.info(f"mixed precision: activations in {act_dtype} (fp32 parameters, gradients, statistics, loss)")
     epochs = config.epochs - elapsed_epochs
     iteration = elapsed_epochs * len(loader)
     loss_meter, dice_meter = AverageMeter(), AverageMeter()
@@ -76,7 +79,7 @@ def train(config, model, logger):
             x, gt = batch["source"]["data"], batch["gt"]["data"]
             if world > 1:
                 D.broadcast_buffers(model)
-            out = train_step(model, optimizer, x, gt, grad_hook=reducer)        # train.py:187-221
+            out = train_step(model, optimizer, x, gt, grad_hook=reducer, dtype=act_dtype)        # train.py:187-221
             iteration += 1
             loss_meter.update(out["loss"].item(), x.size(0))
             dice_meter.update(out["dice"], x.size(0))

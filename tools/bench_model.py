@@ -1,50 +1,127 @@
 #!/usr/bin/env python3
-"""Time the train step (train.py:187-221) of any in-scope network on synthetic patches.
-usage: bench_model.py <unet|vnet|res_unet|unetr> N C D H W [steps] [classes]"""
-import os, sys, time
+"""Time the train step (train.py:187-221: forward, BCE-with-logits, backward, Adam) of any in-scope network on synthetic
+patches and price every kernel family against the roofline that bounds it.
+
+usage: bench_model.py <unet|vnet|res_unet|unetr> N C D H W [--steps K] [--classes M] [--dtype f32|bf16] [--conv-math fp32|bf16x6]
+                      [--json out.json]
+
+BASELINE.json configurations:   cfg 3  vnet 2 1 128 128 128 --dtype bf16
+                                cfg 4  res_unet 1 4 160 192 160 --classes 4 --dtype bf16
+                                cfg 5  unetr 1 1 96 96 96 --dtype bf16
+Per family (in-library HIP events on the launch stream): launches, ms, algorithmic TFLOP/s against the matrix peak of the
+arithmetic in use (bf16 2500, bf16x6 416.7, fp32 157.3 TFLOP/s) and algorithmic GB/s against HBM (8 TB/s) -- the MFMA
+families are compute-priced, the norm / pool / stem-head families are bandwidth-priced."""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-import mi355seg
-from mi355seg.engine import train_step, weights_init_normal
-from mi355seg import functional as F
+import torch  # noqa: E402
+import mi355seg  # noqa: E402
+from mi355seg import functional as F  # noqa: E402
+from mi355seg.engine import weights_init_normal  # noqa: E402
 
-name = sys.argv[1]
-N, C, D, H, W = [int(v) for v in sys.argv[2:7]]
-steps = int(sys.argv[7]) if len(sys.argv) > 7 else 3
-classes = int(sys.argv[8]) if len(sys.argv) > 8 else 2
-torch.manual_seed(0)
-if name == "unet":
-    from mi355seg.models.three_d.unet3d import UNet3D
-    m = UNet3D(C, classes, 32)
-elif name == "vnet":
-    from mi355seg.models.three_d.vnet3d import VNet
-    m = VNet(in_channels=C, classes=classes)
-elif name == "res_unet":
-    from mi355seg.models.three_d.residual_unet3d import UNet
-    m = UNet(C, classes, 32)
-else:
+PEAK = {"bf16": 2500.0, "bf16x6": 2500.0 / 6.0, "fp32": 157.3}
+HBM_GBS = 8000.0
+FAMILIES = ["conv_igemm_mfma", "conv_wgrad_mfma", "conv_generic", "convT_k2s2", "norm_act_stats", "pool_upsample", "loss_metric", "conv_direct_stem_head"]
+BOUND = {"conv_igemm_mfma": "mfma", "conv_wgrad_mfma": "mfma", "conv_generic": "valu", "convT_k2s2": "hbm", "norm_act_stats": "hbm",
+         "pool_upsample": "hbm", "loss_metric": "hbm", "conv_direct_stem_head": "hbm"}
+
+
+def build(name, C, classes, D, H, W):
+    if name == "unet":
+        from mi355seg.models.three_d.unet3d import UNet3D
+        return UNet3D(C, classes, 32)
+    if name == "vnet":
+        from mi355seg.models.three_d.vnet3d import VNet
+        return VNet(in_channels=C, classes=classes)
+    if name == "res_unet":
+        from mi355seg.models.three_d.residual_unet3d import UNet
+        return UNet(C, classes, 32)
     from mi355seg.models.three_d.unetr import UNETR
-    m = UNETR(img_shape=(D, H, W), input_dim=C, output_dim=classes)
-m.apply(weights_init_normal("kaiming"))
-m = m.cuda().train()
-opt = torch.optim.Adam(m.parameters(), lr=1e-3)
-x = torch.randn(N, C, D, H, W, device="cuda")
-lab = torch.randint(0, classes, (N, 1, D, H, W), device="cuda")
-tgt = torch.cat([(lab == i).float() for i in range(classes)], dim=1)
+    return UNETR(img_shape=(D, H, W), input_dim=C, output_dim=classes)
 
-def step():
-    opt.zero_grad(set_to_none=True)
-    pred = m(x)
-    loss = F.bce_with_logits(pred, tgt)
-    loss.backward()
-    opt.step()
-    return loss
 
-step(); torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(steps):
-    l = step()
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / steps
-print(f"{name} x=[{N},{C},{D},{H},{W}] classes={classes}: {dt * 1e3:.1f} ms/step, {N * D * H * W / dt / 1e6:.1f} Mvoxel/s, loss {l.item():.4f}, "
-      f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("name", choices=["unet", "vnet", "res_unet", "unetr"])
+    ap.add_argument("shape", type=int, nargs=5, metavar=("N", "C", "D", "H", "W"))
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--classes", type=int, default=2)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--conv-math", default=None, choices=["fp32", "bf16x6"])
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--no-prof", action="store_true")
+    a = ap.parse_args()
+    N, C, D, H, W = a.shape
+    L = mi355seg.lib()
+    if a.conv_math:
+        mi355seg.set_conv_math(a.conv_math)
+    math = "bf16" if a.dtype == "bf16" else mi355seg.get_conv_math()
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)
+    m = build(a.name, C, a.classes, D, H, W)
+    m.apply(weights_init_normal("kaiming"))
+    m = m.cuda().train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    x = torch.randn(N, C, D, H, W, device="cuda")
+    lab = torch.randint(0, a.classes, (N, 1, D, H, W), device="cuda")
+    tgt = torch.cat([(lab == i).float() for i in range(a.classes)], dim=1)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with mi355seg.autocast(dtype):
+            pred = m(x)
+        loss = F.bce_with_logits(pred, tgt)
+        loss.backward()
+        opt.step()
+        return loss
+
+    step()
+    step()
+    torch.cuda.synchronize()
+    if not a.no_prof:
+        L.call("mi355seg_prof_reset")
+        L.call("mi355seg_prof_enable", 1)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    L.call("mi355seg_prof_enable", 0)
+    res = {"model": a.name, "x": [N, C, D, H, W], "classes": a.classes, "dtype": a.dtype, "conv_math": math, "steps": a.steps,
+           "ms_per_step": dt * 1e3, "voxels_per_s": N * D * H * W / dt, "loss": float(loss.item()),
+           "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30, "families": {}}
+    if not a.no_prof:
+        buf = (ctypes.c_double * 32)()
+        L.call("mi355seg_prof_read", buf, 32)
+        covered = 0.0
+        for f, nm in enumerate(FAMILIES):
+            n, tms, fl, by = buf[4 * f], buf[4 * f + 1], buf[4 * f + 2], buf[4 * f + 3]
+            if n <= 0:
+                continue
+            tf, gb = fl / (tms * 1e-3) / 1e12, by / (tms * 1e-3) / 1e9
+            covered += tms / a.steps
+            ent = {"launches_per_step": n / a.steps, "ms_per_step": tms / a.steps, "algorithmic_tflops": tf, "algorithmic_gbs": gb, "bound": BOUND[nm]}
+            if BOUND[nm] == "mfma":
+                ent["roofline"] = {"peak_tflops": PEAK[math], "frac": tf / PEAK[math], "hbm_frac": gb / HBM_GBS}
+            elif BOUND[nm] == "hbm":
+                ent["roofline"] = {"peak_gbs": HBM_GBS, "frac": gb / HBM_GBS}
+            res["families"][nm] = ent
+        res["ms_in_profiled_families"] = covered
+    print(f"{a.name} x=[{N},{C},{D},{H},{W}] classes={a.classes} {a.dtype} (conv math {math}): {dt * 1e3:.1f} ms/step, "
+          f"{N * D * H * W / dt / 1e6:.1f} Mvoxel/s, loss {loss.item():.4f}, peak mem {res['peak_mem_gib']:.1f} GiB")
+    for nm, e in res["families"].items():
+        r = e.get("roofline", {})
+        print(f"  {nm:24s} {e['launches_per_step']:6.1f} launches {e['ms_per_step']:8.3f} ms  {e['algorithmic_tflops']:8.1f} TFLOP/s  {e['algorithmic_gbs']:8.1f} GB/s  "
+              f"[{e['bound']}-bound: {r.get('frac', float('nan')):.3f} of peak]")
+    if a.json:
+        json.dump(res, open(a.json, "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
