@@ -165,7 +165,7 @@ int mi355seg_conv3d_wgrad_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg
     }
     const bool al16 = ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, al8 = ((uintptr_t)x % 8) == 0 && ((uintptr_t)dy % 8) == 0;
     const int nb = native_wgrad(N, D, H, W, Cin, Cout, k, stride, pad, ldx, lddy);
-    if (nb == NB_LOWP && al16) return conv_wgrad_lowp(MATH_B16, dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, accumulate, ws, ws_bytes, st);
+    if (nb == NB_LOWP && al16) return conv_wgrad_lowp(MATH_B16, dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, stride, accumulate, ws, ws_bytes, st);
     if (nb == NB_PW && al8) {
         float* part; int nstrips;
         int rc = pw_wgrad_mfma(dy, lddy, x, ldx, N, D, H, W, Cin, Cout, 1, &part, &nstrips, ws, ws_bytes, st);

@@ -416,6 +416,7 @@ size_t mi355seg_conv3d_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, i
     if ((smallcin_wgrad_supported(Cin, Cout, k) || smallcout_wgrad_supported(Cin, Cout, k, 4)) && small_wgrad_ws_bytes(Cin, Cout, k) > d)
         d = small_wgrad_ws_bytes(Cin, Cout, k);
     size_t e = conv_gather_ws_bytes(N, D, H, W, Cin, Cout, k, stride, pad);
+    if (wgrad_lowp_ws_bytes_geom(N, D, H, W, Cin, Cout, k, stride, pad) > e) e = wgrad_lowp_ws_bytes_geom(N, D, H, W, Cin, Cout, k, stride, pad);
     if (b > a) a = b;
     if (d > a) a = d;
     if (e > a) a = e;
@@ -517,7 +518,7 @@ int mi355seg_conv3d_wgrad_f32(const float* dy, int lddy, const float* x, int ldx
     }
     if (f32_conv_policy() == MATH_X3 && wgrad_lowp_supported(MATH_X3, N, D, H, W, Cin, Cout, k, stride, pad, ldx, lddy) &&
         ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0)
-        return conv_wgrad_lowp(MATH_X3, dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, accumulate, ws, ws_bytes, st);
+        return conv_wgrad_lowp(MATH_X3, dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, stride, accumulate, ws, ws_bytes, st);
     if (wgrad_mfma_supported(N, D, H, W, Cin, Cout, k, stride, pad, ldx, lddy) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0)
         return conv_wgrad_mfma(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, accumulate, ws, ws_bytes, st);
     if (k == 1 && stride == 1 && pad == 0 && pw_wgrad_supported((long long)N * D * H * W, Cin, Cout, 1, ldx, lddy)) {

@@ -13,8 +13,8 @@ namespace seg {
 bool igemm_lowp_has(int math, int KS, int CK, int BX, int MB) {
     if (math == MATH_X3) return KS == 3 && CK == 16 && (BX == 16 || BX == 8) && (MB == 1 || MB == 2);
     if (math == MATH_B16) {
-        if (KS == 3) return CK == 16 && (MB == 1 || MB == 2);
-        if (KS == 5) return CK == 16 && MB == 1;
+        if (KS == 3) return CK == 16 && (MB == 1 || MB == 2 || ((MB == 3 || MB == 4) && BX == 32));
+        if (KS == 5) return CK == 16 && (MB == 1 || (MB == 2 && BX != 32));
         if (KS == 1) return (CK == 16 || CK == 64) && (MB == 1 || MB == 2);
     }
     return false;
@@ -37,7 +37,14 @@ void dispatch_igemm_lowp(int math, const IgemmPlan& p, const IgemmArgs& a, int n
     if (math == MATH_X3) {
         dispatch_ck<MATH_X3, 3, 16, true, false>(p, a, nwg, st);
     } else {
-        if (p.KS == 3) dispatch_ck<MATH_B16, 3, 16, true, true>(p, a, nwg, st);
+        if (p.KS == 3 && p.WN == 2) launch_igemm<MATH_B16, 3, 32, 6, 1, 16, 2>(a, nwg, st);
+        else if (p.KS == 3 && p.MB == 4 && p.NBW == 1) launch_igemm<MATH_B16, 3, 32, 4, 1, 16>(a, nwg, st);
+        else if (p.KS == 3 && p.MB == 3 && p.NBW == 2) launch_igemm<MATH_B16, 3, 32, 3, 2, 16>(a, nwg, st);
+        else if (p.KS == 3) dispatch_ck<MATH_B16, 3, 16, true, true>(p, a, nwg, st);
+        else if (p.KS == 5 && p.MB == 2) {
+            if (p.BX == 16) { if (p.NBW == 2) launch_igemm<MATH_B16, 5, 16, 2, 2, 16>(a, nwg, st); else launch_igemm<MATH_B16, 5, 16, 2, 1, 16>(a, nwg, st); }
+            else { if (p.NBW == 2) launch_igemm<MATH_B16, 5, 8, 2, 2, 16>(a, nwg, st); else launch_igemm<MATH_B16, 5, 8, 2, 1, 16>(a, nwg, st); }
+        }
         else if (p.KS == 5) dispatch_ck<MATH_B16, 5, 16, false, true>(p, a, nwg, st);
         else if (p.CK == 64) dispatch_ck<MATH_B16, 1, 64, true, true>(p, a, nwg, st);
         else dispatch_ck<MATH_B16, 1, 16, true, true>(p, a, nwg, st);

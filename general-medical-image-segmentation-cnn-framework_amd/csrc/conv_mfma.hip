@@ -172,6 +172,9 @@ static bool igemm_plan(int math, int KS, int N, int D, int H, int W, int Kc, int
     int BX = 0; long long best = -1;
     for (int bx : {32, 16, 8}) {
         if (math == MATH_X3 && bx == 32) continue;
+        // bf16 k5: the 5^3 halo of a two-block tile fits twice per CU only for the 16- and 8-wide tiles (61 / 55 KB vs 83 KB),
+        // and two M-blocks per wave halve both the halo overfetch (11x -> 5x) and the weight-fragment loads per MFMA
+        if (math == MATH_B16 && KS == 5 && bx == 32 && W % 16 == 0) continue;
         long long padded = (long long)((W + bx - 1) / bx) * bx;
         if (best < 0 || padded < best) { best = padded; BX = bx; }
     }
@@ -193,18 +196,32 @@ static bool igemm_plan(int math, int KS, int N, int D, int H, int W, int Kc, int
 #else
     constexpr const char* force = nullptr;
 #endif
-    int tz3;
-    const long long m3 = tiles(3, &tz3);
-    if (KS == 5) MB = 1;                                             // the 5^3 halo of a 2-block tile does not fit twice per CU
+    int tz3, tz4;
+    const long long m3 = tiles(3, &tz3), m4 = tiles(4, &tz4);
+    if (KS == 5 && !(math == MATH_B16 && BX != 32 && m2 * nN >= 512 && waste(tz2) <= waste(tz1) * 1.2)) MB = 1;   // the 5^3 halo of a 2-block tile does not fit twice per CU
+    else if (KS == 5) MB = 2;
     else if (force && force[0] == '1') MB = 1;
     // one 32-channel N-block per tile (Cout = 32 at full resolution): a 384-voxel tile still fits twice per CU (2 x 81.6 KB),
     // cuts the halo overfetch from 3.2x to 2.7x and spreads the per-tile prologue / epilogue over 1.5x the MFMAs (+3 %)
     else if (math == MATH_F32 && !(force && force[0] == '2') && KS == 3 && BX == 32 && NBW == 1 && m3 * nN >= 2048 && waste(tz3) <= 1.05) MB = 3;
+    // bf16 k3: four M-blocks per wave (512-voxel tiles, 59 KB of LDS, still two workgroups per CU): every weight fragment a
+    // wave loads feeds twice the MFMAs -- at one MFMA per k-step the four waves' re-loads of the same fragments otherwise
+    // saturate the L1 path -- and the halo overfetch drops from 3.2x to 2.4x
+    else if (math == MATH_B16 && !(force && force[0] == '2') && KS == 3 && BX == 32 && NBW == 1 && m4 * nN >= 1024 && waste(tz4) <= 1.05) MB = 4;
+    else if (math == MATH_B16 && !(force && force[0] == '2') && KS == 3 && BX == 32 && NBW == 2 && m3 * nN >= 1024 && waste(tz3) <= 1.05) MB = 3;
     else if (m2 * nN >= 512 && waste(tz2) <= waste(tz1) * 1.2) MB = 2;
     else MB = 1;
-    p->KS = KS; p->CK = CK; p->BX = BX; p->MB = MB; p->NBW = NBW; p->TZ = MB == 3 ? tz3 : (MB == 2 ? tz2 : tz1);
+    p->KS = KS; p->CK = CK; p->BX = BX; p->MB = MB; p->NBW = NBW; p->WN = 1; p->NT = 32 * NBW;
+    p->TZ = MB == 4 ? tz4 : (MB == 3 ? tz3 : (MB == 2 ? tz2 : tz1));
+    int nNp = nN;
+    // bf16 k3, 64-channel tiles at full width: 2 (M) x 2 (N) wave grid, six M-blocks per wave (384-voxel tiles like MB = 3;
+    // eight blocks = 128 accumulator registers spill)
+    if (math == MATH_B16 && KS == 3 && BX == 32 && NBW == 2 && !flat && ntaps_out == 1 && m3 * nN >= 1024 && waste(tz3) <= 1.05) {
+        p->WN = 2; p->NBW = 1; p->MB = 6; p->TZ = tz3; p->NT = 64;
+    }
     p->ntx = (W + BX - 1) / BX; p->nty = (H + 3) / 4; p->ntz = (D + p->TZ - 1) / p->TZ;
-    p->nM = N * p->ntz * p->nty * p->ntx; p->nN = nN;
+    p->nM = N * p->ntz * p->nty * p->ntx; p->nN = nNp;
+    if (p->WN == 2) return true;
     if (math != MATH_F32 && !igemm_lowp_has(math, KS, CK, BX, MB)) return false;
     return true;
 }
@@ -309,7 +326,7 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
     float* slabs = ksplit > 1 ? cv.take<float>((size_t)ksplit * nvox * Cout) : nullptr;
     size_t tail = cv.used();
     SEG_CHECK_WS(tail + ((ssum && ksplit > 1) ? colsum_ws_bytes(Cout) : 0), ws_bytes);
-    launch_pack(math, w, wq, Cin, Cout, T, 32 * p.NBW, dgrad ? 1 : 0, 0, p.CK, T, TapList{}, st);
+    launch_pack(math, w, wq, Cin, Cout, T, p.NT, dgrad ? 1 : 0, 0, p.CK, T, TapList{}, st);
     SEG_CHECK_LAUNCH();
     IgemmArgs a{x, wq, ksplit > 1 ? nullptr : bias, ksplit > 1 ? (void*)slabs : y, spart, ldx, ksplit > 1 ? Cout : ldy, N, D, H, W, Cout,
                 p.ntx, p.nty, p.ntz, p.nN, nchunks, nchunks, p.nN, 1, 1, p.nM, ksplit, nchunks / ksplit, nvox * Cout, dbg_flags()};
@@ -354,7 +371,7 @@ int convt_fwd_mfma(int math, const void* x, int ldx, const float* w, const float
     Carver cv(ws);
     void* wq = cv.take<char>(wq_bytes(math, (size_t)8 * Cin * Cout));
     SEG_CHECK_WS(cv.used(), ws_bytes);
-    launch_pack(math, w, wq, Cin, 8 * Cout, 1, 32 * p.NBW, 2, Cout, p.CK, 8, TapList{}, st);
+    launch_pack(math, w, wq, Cin, 8 * Cout, 1, p.NT, 2, Cout, p.CK, 8, TapList{}, st);
     SEG_CHECK_LAUNCH();
     IgemmArgs a{x, wq, bias, y, nullptr, ldx, ldy, N, D, H, W, Cout, p.ntx, p.nty, p.ntz, p.nN, Cin / p.CK, Cin / p.CK,
                 p.flat ? p.nN : p.nN / 8, 1, 2, p.nM, 1, Cin / p.CK, 0, 0};
@@ -374,7 +391,7 @@ int convt_dgrad_mfma(int math, const void* dy, int lddy, const float* w, void* d
     Carver cv(ws);
     void* wq = cv.take<char>(wq_bytes(math, (size_t)8 * Cin * Cout));
     SEG_CHECK_WS(cv.used(), ws_bytes);
-    launch_pack(math, w, wq, 8 * Cout, Cin, 1, 32 * p.NBW, 3, Cout, p.CK, 8, TapList{}, st);
+    launch_pack(math, w, wq, 8 * Cout, Cin, 1, p.NT, 3, Cout, p.CK, 8, TapList{}, st);
     SEG_CHECK_LAUNCH();
     IgemmArgs a{dy, wq, nullptr, dx, nullptr, lddy, lddx, N, D, H, W, Cin, p.ntx, p.nty, p.ntz, p.nN, 8 * Cout / p.CK, Cout / p.CK, p.nN, 2, 1,
                 p.nM, 1, 8 * Cout / p.CK, 0, 0};
@@ -432,7 +449,7 @@ int conv_gather_fwd_mfma(int math, const void* x, int ldx, const float* w, const
     void* wq = cv.take<char>(wq_bytes(math, (size_t)T * Cin * Cout));
     float* spart = ssum ? cv.take<float>((size_t)p.nM * Cout * 3) : nullptr;
     SEG_CHECK_WS(cv.used(), ws_bytes);
-    launch_pack(math, w, wq, T * Cin, Cout, 1, 32 * p.NBW, 5, Cin, p.CK, T, TapList{}, st);
+    launch_pack(math, w, wq, T * Cin, Cout, 1, p.NT, 5, Cin, p.CK, T, TapList{}, st);
     SEG_CHECK_LAUNCH();
     IgemmArgs a{x, wq, bias, y, spart, ldx, ldy, N, Do, Ho, Wo, Cout, p.ntx, p.nty, p.ntz, p.nN, nchunks, cpt, p.nN, stride, 1,
                 p.nM, 1, nchunks, 0, 0};
@@ -491,7 +508,7 @@ int conv_gather_dgrad_mfma(int math, const void* dy, int lddy, const float* w, v
                     tl.t[slot] = (unsigned char)((lz[iz] * k + ly[iy]) * k + lx[ix]);
                     a.toff[slot][0] = (signed char)dz[iz]; a.toff[slot][1] = (signed char)dyo[iy]; a.toff[slot][2] = (signed char)dxo[ix];
                 }
-        launch_pack(math, w, wq, nt * Cout, Cin, 1, 32 * p.NBW, 6, Cout, p.CK, T, tl, st);
+        launch_pack(math, w, wq, nt * Cout, Cin, 1, p.NT, 6, Cout, p.CK, T, tl, st);
         SEG_CHECK_LAUNCH();
         dispatch_igemm(math, p, a, p.nM * p.nN, st);
         SEG_CHECK_LAUNCH();

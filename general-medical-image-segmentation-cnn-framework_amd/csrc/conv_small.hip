@@ -121,6 +121,66 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const T* __restrict__ x
     }
 }
 
+// ---------------------------------------------------------------- Cin == 4 stem wgrad (Residual U-Net conv3d_c1_1, residual_unet3d.py:22)
+// grid = (blocks, 3 dz planes).  thread = (voxel, cout quad) keeps 9 taps x 4 input channels x 4 output channels of
+// accumulators and fetches the four input channels of a tap with ONE 4-element load (the generic kernel above issues one
+// scalar load per (tap, channel) and re-reads dy once per input channel): 27 vector loads per voxel instead of 108 scalar ones.
+template <typename T>
+__global__ __launch_bounds__(256) void stem4_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+        float* __restrict__ part, SmallGeom g, int lddy) {
+    extern __shared__ __attribute__((aligned(16))) float sred[];     // [4 waves][9 taps][4 ci][LPV][4]
+    const int Cout = g.Cout, LPV = Cout / 4, VPB = 256 / LPV;
+    const int cq = threadIdx.x % LPV, vl = threadIdx.x / LPV;
+    const int dz = (int)blockIdx.y - 1;
+    const long long nvox = (long long)g.N * g.D * g.H * g.W;
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) acc[t][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long long v = (long long)blockIdx.x * VPB + vl; v < nvox; v += (long long)gridDim.x * VPB) {
+        int xw = (int)(v % g.W); long long r = v / g.W;
+        int yh = (int)(r % g.H); r /= g.H;
+        int zd = (int)(r % g.D); int n = (int)(r / g.D);
+        const int iz = zd + dz;
+        if ((unsigned)iz >= (unsigned)g.D) continue;
+        const f32x4 d = ld4(dy + v * lddy + cq * 4);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = yh + t / 3 - 1, ix = xw + t % 3 - 1;
+            f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+                xv = ld4(x + ((((long long)n * g.D + iz) * g.H + iy) * g.W + ix) * g.ldx);
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) acc[t][ci] += xv[ci] * d;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s = acc[t][ci][j];
+                for (int o = 32; o >= LPV; o >>= 1) s += __shfl_xor(s, o, 64);
+                acc[t][ci][j] = s;
+            }
+    if (lane < LPV) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) st4(sred + (((wave * 9 + t) * 4 + ci) * LPV + lane) * 4, acc[t][ci]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * 4 * Cout; i += 256) {
+        const int co = i % Cout, ci = (i / Cout) % 4, t = i / (4 * Cout);
+        float s = 0.f;
+        for (int w = 0; w < 4; ++w) s += sred[(((w * 9 + t) * 4 + ci) * LPV + co / 4) * 4 + co % 4];
+        part[(((long long)blockIdx.x * 27 + (dz + 1) * 9 + t) * 4 + ci) * Cout + co] = s;
+    }
+}
+
 // ---------------------------------------------------------------- Cin == 1 stem, LDS-tiled
 // The 1-channel NDHWC input is a plain 3-D volume: a (2+2) x (4+2) x (TX+2) halo tile sits in LDS,
 // every tap is a fixed LDS offset (no per-tap bounds / address arithmetic), and the 27 x 4 weights of
@@ -626,7 +686,11 @@ int stem_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N, int
         SEG_CHECK_LAUNCH();
         return MI355SEG_OK;
     }
-    {
+    if (Cin == 4 && ldx % 4 == 0 && ((uintptr_t)x % (4 * sizeof(T))) == 0 && (size_t)4 * 9 * 4 * Cout * 4 <= 64 * 1024) {
+        ProfScope ps(PF_DIRECT, 2.0 * nvox * 27.0 * Cin * Cout, (double)sizeof(T) * nvox * (Cin + Cout), st);
+        hipLaunchKernelGGL((stem4_wgrad_kernel<T>), dim3(nblk, 3), dim3(256), (size_t)4 * 9 * 4 * Cout * 4, st, x, dy, part, g, lddy);
+        SEG_CHECK_LAUNCH();
+    } else {
         ProfScope ps(PF_DIRECT, 2.0 * nvox * 27.0 * Cin * Cout, (double)sizeof(T) * nvox * (Cin + Cout), st);
         hipLaunchKernelGGL((stem_wgrad_kernel<T, 0>), dim3(nblk, Cin), dim3(256), lds, st, x, dy, part, g, lddy);
         SEG_CHECK_LAUNCH();

@@ -37,16 +37,20 @@ constexpr int LW_WAVES = 8;
 constexpr int LW_THREADS = LW_WAVES * 64;
 constexpr int LW_TPW = 4;                    // tap-tiles per wave (27 or 25 taps over 8 waves; the last waves own one fewer)
 
-template <int BX, int KS, int NP>
+// S = stride of the convolution (1, or 2 for the k3 s2 p1 down-convolutions of the Residual U-Net, residual_unet3d.py:30-60):
+// the tile is cut in OUTPUT space, its input halo spans (B - 1) * S + KS voxels per axis, and since every lane of a
+// transposing read supplies its own row address the S-strided voxels of a k-step need no gather pass.
+template <int BX, int KS, int NP, int S = 1>
 struct LTile {
     static constexpr int HALO = KS / 2;
     static constexpr int NTAPS = KS == 3 ? 27 : KS * KS;          // taps per workgroup (k5: one dz plane)
     static constexpr int PLANES = KS == 3 ? 1 : KS;
-    static constexpr int VOX = NP == 3 ? 128 : 256;               // output voxels per tile (three planes per operand: half the tile)
+    static constexpr int VOX = (NP == 3 || S == 2) ? 128 : 256;   // output voxels per tile (three planes per operand / strided halo: half the tile)
     static constexpr int TY = BX == 8 ? 8 : 4;
     static constexpr int LINES = VOX / BX;
     static constexpr int TZ = LINES / TY;
-    static constexpr int HX = BX + 2 * HALO, HY = TY + 2 * HALO, HZ = KS == 3 ? TZ + 2 : TZ;
+    static constexpr int HX = (BX - 1) * S + KS, HY = (TY - 1) * S + KS, HZ = KS == 3 ? (TZ - 1) * S + 3 : TZ;
+    static_assert(S == 1 || KS == 3, "strided tiles are built for k3");
     static constexpr int NVOX = HX * HY * HZ;
     static constexpr int ROW = 64 * NP;                           // bytes per voxel row: NP planes of 32 bf16 channels
     static constexpr int KSTEPS = VOX / 16;
@@ -58,7 +62,8 @@ struct LTile {
 
 struct LWgradArgs {
     const void* x; const void* dy; float* part;
-    int ldx, lddy, N, D, H, W, Cin, Cout;
+    int ldx, lddy, N, D, H, W, Cin, Cout;      // D, H, W: input (x) extents
+    int Do, Ho, Wo;                            // output (dy) extents
     int ntx, nty, ntz, ntiles, nstrips, npairs, ncob, ntaps_total;
 };
 
@@ -70,9 +75,9 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* lds, int off0, 
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <int BX, int KS, int NP, typename IN_T>
+template <int BX, int KS, int NP, typename IN_T, int S = 1>
 __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradArgs a) {
-    using T = LTile<BX, KS, NP>;
+    using T = LTile<BX, KS, NP, S>;
     constexpr int EPP = std::is_same<IN_T, float>::value ? 4 : 8;            // elements per staged 16-byte piece
     constexpr int PPV = 32 / EPP;                                             // pieces per voxel (32 channels)
     constexpr int XPIECES = T::NVOX * PPV, DPIECES = T::VOX * PPV;
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
     // 16-channel half; group (h, cg) covers k = 8h .. 8h+7 (two reads of 4) and channels 16cg .. 16cg+15
     const int li = lane & 15, q = li >> 2, p = li & 3, cg = (lane >> 4) & 1;
     const int chan_off = (16 * cg + 4 * p) * 2;
-    const int kq_x = (BX >= 16 ? 8 * h + q : h * T::HX + q);    // BX = 8: the two halves of a k-step are two x-lines
+    const int kq_x = (BX >= 16 ? (8 * h + q) * S : h * S * T::HX + q * S);    // BX = 8: the two halves of a k-step are two x-lines
     const int lane_x = kq_x * T::ROW + chan_off;
     const int lane_d = (8 * h + q) * T::ROW + chan_off;
 
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
             const int vox = pc / PPV, part = pc % PPV;
             const int hz = vox / (T::HY * T::HX), rem = vox % (T::HY * T::HX);
             const int hy = rem / T::HX, hx = rem % T::HX;
-            const int gz = z0 + hz + (KS == 3 ? -1 : plane - T::HALO), gy = y0 - T::HALO + hy, gx = x0 - T::HALO + hx;
+            const int gz = z0 * S + hz + (KS == 3 ? -1 : plane - T::HALO), gy = y0 * S - T::HALO + hy, gx = x0 * S - T::HALO + hx;
             const bool ok = (pc < XPIECES) && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
             stage_t v = {};
             if (ok) v = *reinterpret_cast<const stage_t*>(xin + ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.ldx + ci0 + part * EPP);
@@ -149,8 +154,8 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
             const int line = vox / BX, xx = vox % BX;
             const int gz = z0 + line / T::TY, gy = y0 + line % T::TY, gx = x0 + xx;
             stage_t dv = {};                          // partial tiles: voxels outside the volume contribute nothing
-            if (gz < a.D && gy < a.H && gx < a.W)
-                dv = *reinterpret_cast<const stage_t*>(din + ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.lddy + co0 + part * EPP);
+            if (gz < a.Do && gy < a.Ho && gx < a.Wo)
+                dv = *reinterpret_cast<const stage_t*>(din + ((((long long)n * a.Do + gz) * a.Ho + gy) * a.Wo + gx) * a.lddy + co0 + part * EPP);
             sd[it] = dv;
         }
     };
@@ -188,10 +193,10 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
     auto xoff = [](int ks, int t) {
         if constexpr (BX >= 16) {
             const int line = ks / (BX / 16), xp = ks % (BX / 16);
-            return ((((line / T::TY) * T::HY + (line % T::TY)) * T::HX) + xp * 16 + 4 * t) * T::ROW;
+            return ((((line / T::TY) * S * T::HY + (line % T::TY) * S) * T::HX) + (xp * 16 + 4 * t) * S) * T::ROW;
         } else {
             const int line = 2 * ks;
-            return ((((line / T::TY) * T::HY + (line % T::TY)) * T::HX) + 4 * t) * T::ROW;
+            return ((((line / T::TY) * S * T::HY + (line % T::TY) * S) * T::HX) + 4 * t * S) * T::ROW;
         }
     };
     auto doff = [](int ks, int t) { return (ks * 16 + 4 * t) * T::ROW; };
@@ -254,9 +259,11 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
 
 struct LWgradPlan { int KS, BX, ntx, nty, ntz, ntiles, nstrips, npairs, taps, planes; };
 
-static bool lwgrad_plan(int math, int KS, int N, int D, int H, int W, int Cin, int Cout, LWgradPlan* p) {
+// D, H, W: OUTPUT extents (the space the tiles are cut in)
+static bool lwgrad_plan(int math, int KS, int stride, int N, int D, int H, int W, int Cin, int Cout, LWgradPlan* p) {
     if ((KS != 3 && KS != 5) || Cin % 32 || Cout % 32 || W < 4) return false;
-    const int vox = math == MATH_X3 ? 128 : 256;
+    if (stride != 1 && !(stride == 2 && KS == 3 && math == MATH_B16)) return false;
+    const int vox = (math == MATH_X3 || stride == 2) ? 128 : 256;
     int BX = 0; long long best = -1;
     for (int bx : {32, 16, 8}) {
         if (math == MATH_X3 && bx == 32) continue;          // 128-voxel tiles: the 16-wide tile has the smaller halo
@@ -279,33 +286,48 @@ static bool lwgrad_plan(int math, int KS, int N, int D, int H, int W, int Cin, i
     return true;
 }
 
+static int lw_out(int n, int k, int s, int p) { return (n + 2 * p - k) / s + 1; }
+
 bool wgrad_lowp_supported(int math, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int lddy) {
     const int al = math == MATH_B16 ? 8 : 4;
-    if (!((k == 3 && pad == 1) || (k == 5 && pad == 2)) || stride != 1 || (ldx % al) || (lddy % al)) return false;
+    if (!((k == 3 && pad == 1) || (k == 5 && pad == 2)) || (ldx % al) || (lddy % al)) return false;
     LWgradPlan p;
-    return lwgrad_plan(math, k, N, D, H, W, Cin, Cout, &p);
+    return lwgrad_plan(math, k, stride, N, lw_out(D, k, stride, pad), lw_out(H, k, stride, pad), lw_out(W, k, stride, pad), Cin, Cout, &p);
 }
 
-size_t wgrad_lowp_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k) {
+// any supported geometry (D, H, W = input extents)
+size_t wgrad_lowp_ws_bytes_geom(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
+    if (!((k == 3 && pad == 1) || (k == 5 && pad == 2)) || D + 2 * pad < k || H + 2 * pad < k || W + 2 * pad < k) return 0;
     size_t best = 0;
     for (int math : {MATH_X3, MATH_B16}) {
         LWgradPlan p;
-        if (!lwgrad_plan(math, k, N, D, H, W, Cin, Cout, &p)) continue;
+        if (!lwgrad_plan(math, k, stride, N, lw_out(D, k, stride, pad), lw_out(H, k, stride, pad), lw_out(W, k, stride, pad), Cin, Cout, &p)) continue;
         const size_t need = align_up((size_t)p.nstrips * p.taps * Cin * Cout * sizeof(float), 256) + 1024;
         if (need > best) best = need;
     }
     return best;
 }
 
-template <int BX, int KS, int NP, typename IN_T>
+size_t wgrad_lowp_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k) {
+    size_t best = 0;
+    for (int math : {MATH_X3, MATH_B16}) {
+        LWgradPlan p;
+        if (!lwgrad_plan(math, k, 1, N, D, H, W, Cin, Cout, &p)) continue;
+        const size_t need = align_up((size_t)p.nstrips * p.taps * Cin * Cout * sizeof(float), 256) + 1024;
+        if (need > best) best = need;
+    }
+    return best;
+}
+
+template <int BX, int KS, int NP, typename IN_T, int S = 1>
 static void launch_lwgrad(const LWgradArgs& a, int nwg, hipStream_t st) {
-    using T = LTile<BX, KS, NP>;
+    using T = LTile<BX, KS, NP, S>;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_lowp_kernel<BX, KS, NP, IN_T>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_lowp_kernel<BX, KS, NP, IN_T, S>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_wgrad_lowp_kernel<BX, KS, NP, IN_T>), dim3(nwg), dim3(LW_THREADS), T::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv_wgrad_lowp_kernel<BX, KS, NP, IN_T, S>), dim3(nwg), dim3(LW_THREADS), T::LDS_BYTES, st, a);
 }
 
 template <int KS>
@@ -321,19 +343,25 @@ static void dispatch_lwgrad(int math, const LWgradPlan& p, const LWgradArgs& a, 
 }
 
 int conv_wgrad_lowp(int math, const void* dy, int lddy, const void* x, int ldx, float* dw, int N, int D, int H, int W, int Cin,
-                    int Cout, int k, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+                    int Cout, int k, int stride, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
     LWgradPlan p;
-    SEG_CHECK_ARG(lwgrad_plan(math, k, N, D, H, W, Cin, Cout, &p), "conv_wgrad_lowp: unsupported shape");
+    const int pad = k / 2, Do = lw_out(D, k, stride, pad), Ho = lw_out(H, k, stride, pad), Wo = lw_out(W, k, stride, pad);
+    SEG_CHECK_ARG(lwgrad_plan(math, k, stride, N, Do, Ho, Wo, Cin, Cout, &p), "conv_wgrad_lowp: unsupported shape");
     SEG_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, "conv_wgrad_lowp: pointers must be 16-byte aligned");
     Carver cv(ws);
     float* part = cv.take<float>((size_t)p.nstrips * p.taps * Cin * Cout);
     SEG_CHECK_WS(cv.used(), ws_bytes);
-    LWgradArgs a{x, dy, part, ldx, lddy, N, D, H, W, Cin, Cout, p.ntx, p.nty, p.ntz, p.ntiles, p.nstrips, p.npairs, Cout / 32, p.taps};
+    LWgradArgs a{x, dy, part, ldx, lddy, N, D, H, W, Cin, Cout, Do, Ho, Wo, p.ntx, p.nty, p.ntz, p.ntiles, p.nstrips, p.npairs, Cout / 32, p.taps};
     const int nwg = p.nstrips * p.npairs * p.planes;
-    const double vox = (double)N * D * H * W;
+    const double vox = (double)N * Do * Ho * Wo;
     {
         ProfScope ps(PF_WGRAD, 2.0 * vox * p.taps * Cin * Cout, (math == MATH_B16 ? 2.0 : 4.0) * vox * (Cin + Cout) + 4.0 * p.taps * Cin * Cout, st);
-        if (k == 3) dispatch_lwgrad<3>(math, p, a, nwg, st);
+        if (k == 3 && stride == 2) {
+            if (p.BX == 32) launch_lwgrad<32, 3, 1, bf16, 2>(a, nwg, st);
+            else if (p.BX == 16) launch_lwgrad<16, 3, 1, bf16, 2>(a, nwg, st);
+            else launch_lwgrad<8, 3, 1, bf16, 2>(a, nwg, st);
+        }
+        else if (k == 3) dispatch_lwgrad<3>(math, p, a, nwg, st);
         else dispatch_lwgrad<5>(math, p, a, nwg, st);
         SEG_CHECK_LAUNCH();
     }

@@ -44,14 +44,14 @@ template <> struct MathTraits<MATH_B16> { using in_t = bf16; using out_t = bf16;
 // CK = input channels per LDS chunk: 16 for k3 (two workgroups per CU), 8 for fp32 k5 (the 5^3 halo is 4x larger), 64 for
 // k1 / ConvTranspose where there is no halo and few MFMAs per chunk otherwise.
 // PITCH (in LDS elements) = NP planes of CK channels + 16 bytes of padding -> an odd number of 16-byte slots per voxel.
-template <int MATH, int KS, int BX, int MB, int CK>
+template <int MATH, int KS, int BX, int MB, int CK, int WN = 1>
 struct Tile {
     using MT = MathTraits<MATH>;
     static constexpr int PITCH = MT::NP * CK + 16 / MT::LDS_ELEM;
     static constexpr int HALO = KS / 2;
     static constexpr int NTAP = KS * KS * KS;
     static constexpr int LPB = 32 / BX;           // x-lines per 32-voxel M-block
-    static constexpr int LINES = 4 * MB * LPB;    // x-lines per workgroup tile
+    static constexpr int LINES = (4 / WN) * MB * LPB;    // x-lines per workgroup tile (WN waves share an M-block row, each on its own N-blocks)
     static constexpr int TY = 4;
     static constexpr int TZ = LINES / TY;
     static constexpr int HX = BX + 2 * HALO, HY = TY + 2 * HALO, HZ = TZ + 2 * HALO;
@@ -91,7 +91,7 @@ struct IgemmArgs {
 };
 
 struct TapList { unsigned char t[64]; };
-struct IgemmPlan { int KS, CK, BX, MB, NBW, TZ, nM, nN, ntx, nty, ntz, flat; };
+struct IgemmPlan { int KS, CK, BX, MB, NBW, TZ, nM, nN, ntx, nty, ntz, flat, WN, NT; };     // NT = 32 * NBW * WN: tile width in channels
 
 // ---------------------------------------------------------------- the kernel
 // One virtual tile = (M-tile, N-tile, K-split) per workgroup; up to two workgroups share a CU and the
@@ -99,21 +99,28 @@ struct IgemmPlan { int KS, CK, BX, MB, NBW, TZ, nM, nN, ntx, nty, ntz, flat; };
 // variant was measured 8-10 % slower on the large layers: co-resident workgroups fall into lockstep).
 // With ksplit > 1 (few-tile deep layers) every split writes raw fp32 partial sums to its own slab and a
 // tiny second kernel adds them in fixed order.
-template <int MATH, int KS, int BX, int MB, int NBW, int CK>
+// Wave grid: WN = 1 -- every wave owns MB M-blocks and all NBW N-blocks of the tile; WN = 2 -- the four waves form a
+// 2 (M) x 2 (N) grid, a wave owns MB M-blocks and its own NBW N-blocks (tile = 64*MB voxels x 64*NBW channels): each weight
+// fragment a wave loads then feeds MB MFMAs and is loaded by two waves instead of four -- the layout of the bf16 tiles,
+// whose single MFMA per k-step would otherwise leave the L1 path saturated by the four waves' re-loads of the same weights.
+template <int MATH, int KS, int BX, int MB, int NBW, int CK, int WN = 1>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
-    using T = Tile<MATH, KS, BX, MB, CK>;
+    using T = Tile<MATH, KS, BX, MB, CK, WN>;
     using MT = MathTraits<MATH>;
     using in_t = typename MT::in_t;
     using out_t = typename MT::out_t;
     constexpr int PITCH = T::PITCH;
     constexpr int PPV = T::PPV;
-    constexpr int NT = 32 * NBW;
+    constexpr int NT = 32 * NBW * WN;                         // output channels of the tile
+    constexpr int WM = 4 / WN;                                // waves along M
     constexpr int NTAP = T::NTAP;
     constexpr int NP = MT::NP;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, i = lane & 31;
+    const int wave_m = wave / WN, wave_n = wave % WN;          // position in the wave grid
+    const int nbase = wave_n * NBW;                           // first N-block of this wave
 
     // XCD-aware block -> tile map: blocks dealt round-robin to the 8 XCDs get contiguous tile ranges,
     // so halo-sharing neighbours and the N-tiles / K-splits of one M-tile share an L2 (bijective).
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
     int abase[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-        const int m = wave * MB + mb;
+        const int m = wave_m * MB + mb;
         const int line = m * T::LPB + i / BX, xx = i % BX;
         abase[mb] = (((line / T::TY) * T::HY + (line % T::TY)) * T::HX + xx) * PITCH + (16 / MT::LDS_ELEM) * h;
     }
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
 #pragma unroll
             for (int d = 0; d < PFD; ++d)
 #pragma unroll
-                for (int nb = 0; nb < NBW; ++nb) bq[d][nb] = *reinterpret_cast<const f32x4*>(wp + d * STEP_FLOATS + nb * 128);
+                for (int nb = 0; nb < NBW; ++nb) bq[d][nb] = *reinterpret_cast<const f32x4*>(wp + d * STEP_FLOATS + (nbase + nb) * 128);
             if (!SEG_DBG(a, 1) || chunk == c0) {
                 __syncthreads();                 // every wave is done reading the previous chunk
                 write_stage();
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
                     if (step + PFD < NSTEP && !SEG_DBG(a, 2)) {
 #pragma unroll
                         for (int nb = 0; nb < NBW; ++nb)
-                            bq[fill][nb] = *reinterpret_cast<const f32x4*>(wp + (step + PFD) * STEP_FLOATS + nb * 128);
+                            bq[fill][nb] = *reinterpret_cast<const f32x4*>(wp + (step + PFD) * STEP_FLOATS + (nbase + nb) * 128);
                     }
                     f32x4 av[MB];
 #pragma unroll
@@ -272,14 +279,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
         const bf16* wlane = reinterpret_cast<const bf16*>(a.wq) + (long long)ntile * a.nchunks * CHUNK + (h * NT + i) * 8;
         for (int chunk = c0; chunk < c1; ++chunk) {
             const bf16* wp = wlane + (long long)chunk * CHUNK;
-            constexpr int PFD = NSTEP > 4 ? (NP == 3 ? 2 : 4) : 1;
+            constexpr int PFD = NSTEP > 4 ? ((NP == 3 || MB >= 4) ? 2 : 4) : 1;      // ring depth; the deep-tile variants are register-bound
             bf16x8_t bq[PFD + 1][NBW][NP];
 #pragma unroll
             for (int d = 0; d < PFD; ++d)
 #pragma unroll
                 for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) bq[d][nb][pl] = *reinterpret_cast<const bf16x8_t*>(wp + d * STEP + pl * PLANE + nb * 256);
+                    for (int pl = 0; pl < NP; ++pl) bq[d][nb][pl] = *reinterpret_cast<const bf16x8_t*>(wp + d * STEP + pl * PLANE + (nbase + nb) * 256);
             __syncthreads();                 // every wave is done reading the previous chunk
             write_stage();
             __syncthreads();
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
                         for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
                             for (int pl = 0; pl < NP; ++pl)
-                                bq[fill][nb][pl] = *reinterpret_cast<const bf16x8_t*>(wp + (step + PFD) * STEP + pl * PLANE + nb * 256);
+                                bq[fill][nb][pl] = *reinterpret_cast<const bf16x8_t*>(wp + (step + PFD) * STEP + pl * PLANE + (nbase + nb) * 256);
                     }
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb) {
@@ -332,14 +339,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
     float ssum[NBW];
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
-        int col = n0 + nb * 32 + i, child = tapn;
-        if (a.flatn) { const int nf = ntile * NT + nb * 32 + i; child = nf / a.Cout; col = nf - child * a.Cout; }   // per-lane child
+        int col = n0 + (nbase + nb) * 32 + i, child = tapn;
+        if (a.flatn) { const int nf = ntile * NT + (nbase + nb) * 32 + i; child = nf / a.Cout; col = nf - child * a.Cout; }   // per-lane child
         const int oz = ((child >> 2) & 1) + a.cz, oy = ((child >> 1) & 1) + a.cy, ox = (child & 1) + a.cx;
         const float bv = a.bias ? a.bias[col] : 0.f;
         float s1 = 0.f;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-            const int m = wave * MB + mb;
+            const int m = wave_m * MB + mb;
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int r = (v & 3) + 8 * (v >> 2) + 4 * h;      // row of the 32x32 tile held in register v
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
             float s1 = ssum[nb] + __shfl_xor(ssum[nb], 32, 64);
-            if (h == 0) lds[wave * NT + nb * 32 + i] = s1;
+            if (h == 0) lds[wave_m * NT + (nbase + nb) * 32 + i] = s1;
         }
         {   // valid rows of this tile (same for every channel)
             const int vz = min(T::TZ, a.D - z0), vy = min(T::TY, a.H - y0), vx = min(BX, a.W - x0);
@@ -389,17 +396,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
         float tmean[NBW];
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
-            const int c = nb * 32 + i;
-            tmean[nb] = (lds[c] + lds[NT + c] + lds[2 * NT + c] + lds[3 * NT + c]) / cnt;
+            const int c = (nbase + nb) * 32 + i;
+            float ts = 0.f;
+#pragma unroll
+            for (int wm = 0; wm < WM; ++wm) ts += lds[wm * NT + c];
+            tmean[nb] = ts / cnt;
         }
         __syncthreads();
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
-            const float bv = a.bias ? a.bias[n0 + nb * 32 + i] : 0.f;
+            const float bv = a.bias ? a.bias[n0 + (nbase + nb) * 32 + i] : 0.f;
             float m2 = 0.f;
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-                const int m = wave * MB + mb;
+                const int m = wave_m * MB + mb;
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const int r = (v & 3) + 8 * (v >> 2) + 4 * h;
@@ -410,28 +420,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
                 }
             }
             m2 += __shfl_xor(m2, 32, 64);
-            if (h == 0) lds[4 * NT + wave * NT + nb * 32 + i] = m2;
+            if (h == 0) lds[WM * NT + wave_m * NT + (nbase + nb) * 32 + i] = m2;
         }
         __syncthreads();
         if (tid < NT) {
-            const float s1 = lds[tid] + lds[NT + tid] + lds[2 * NT + tid] + lds[3 * NT + tid];
-            const float m2 = lds[4 * NT + tid] + lds[5 * NT + tid] + lds[6 * NT + tid] + lds[7 * NT + tid];
+            float s1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int wm = 0; wm < WM; ++wm) { s1 += lds[wm * NT + tid]; m2 += lds[(WM + wm) * NT + tid]; }
             float* dst = a.spart + ((long long)mtile * a.Cout + n0 + tid) * 3;
             dst[0] = s1; dst[1] = m2; dst[2] = cnt;
         }
     }
 }
 
-template <int MATH, int KS, int BX, int MB, int NBW, int CK>
+template <int MATH, int KS, int BX, int MB, int NBW, int CK, int WN = 1>
 static void launch_igemm(const IgemmArgs& a, int nwg, hipStream_t st) {
-    using T = Tile<MATH, KS, BX, MB, CK>;
+    using T = Tile<MATH, KS, BX, MB, CK, WN>;
     constexpr int LDSB = T::LDS_BYTES < 8 * 64 * 4 ? 8 * 64 * 4 : T::LDS_BYTES;      // the statistics epilogue needs 8 x NT floats
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<MATH, KS, BX, MB, NBW, CK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<MATH, KS, BX, MB, NBW, CK, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<MATH, KS, BX, MB, NBW, CK>), dim3(nwg), dim3(256), LDSB, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<MATH, KS, BX, MB, NBW, CK, WN>), dim3(nwg), dim3(256), LDSB, st, a);
 }
 
 // conv_igemm_lowp.hip: the MATH_X3 / MATH_B16 instantiations (their own translation unit: they compile in parallel)

@@ -88,8 +88,9 @@ template <typename IN_T> int pw_wgrad_mfma(const IN_T* dy, int lddy, const IN_T*
 // conv_wgrad_lowp.hip -- k3 / k5 wgrad on the bf16 matrix cores (MATH_X3: fp32 tensors, bf16x6 split; MATH_B16: bf16 tensors)
 bool wgrad_lowp_supported(int math, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int lddy);
 size_t wgrad_lowp_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k);
+size_t wgrad_lowp_ws_bytes_geom(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad);
 int conv_wgrad_lowp(int math, const void* dy, int lddy, const void* x, int ldx, float* dw, int N, int D, int H, int W, int Cin,
-                    int Cout, int k, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+                    int Cout, int k, int stride, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 size_t wgrad_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k);
 bool wgrad_mfma_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int lddy);
 int conv_wgrad_mfma(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin,

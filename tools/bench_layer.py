@@ -1,27 +1,37 @@
 #!/usr/bin/env python3
 """Time one Conv3d layer (fwd / dgrad / wgrad) through the C-ABI with HIP events.
-usage: bench_layer.py N D H W Cin Cout [k] [reps]"""
+usage: bench_layer.py N D H W Cin Cout [k] [reps] [stride] [pad] [--dtype f32|bf16] [--conv-math fp32|bf16x6]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import mi355seg
 F = mi355seg.functional
 L = mi355seg.lib()
-N, D, H, W, Cin, Cout = [int(v) for v in sys.argv[1:7]]
-k = int(sys.argv[7]) if len(sys.argv) > 7 else 3
-reps = int(sys.argv[8]) if len(sys.argv) > 8 else 10
-stride = int(sys.argv[9]) if len(sys.argv) > 9 else 1
-pad = (k // 2) if len(sys.argv) <= 10 else int(sys.argv[10])
-x = torch.randn(N, D, H, W, Cin, device="cuda")
+argv = sys.argv[1:]
+dtype, math = "f32", None
+if "--dtype" in argv:
+    i = argv.index("--dtype"); dtype = argv[i + 1]; del argv[i:i + 2]
+if "--conv-math" in argv:
+    i = argv.index("--conv-math"); math = argv[i + 1]; del argv[i:i + 2]
+if math:
+    mi355seg.set_conv_math(math)
+N, D, H, W, Cin, Cout = [int(v) for v in argv[:6]]
+k = int(argv[6]) if len(argv) > 6 else 3
+reps = int(argv[7]) if len(argv) > 7 else 10
+stride = int(argv[8]) if len(argv) > 8 else 1
+pad = (k // 2) if len(argv) <= 9 else int(argv[9])
+td = torch.bfloat16 if dtype == "bf16" else torch.float32
+x = torch.randn(N, D, H, W, Cin, device="cuda").to(td)
 w = torch.randn(Cout, Cin, k, k, k, device="cuda") * 0.05
 b = torch.randn(Cout, device="cuda")
 Do, Ho, Wo = [(e + 2 * pad - k) // stride + 1 for e in (D, H, W)]
-y = torch.empty(N, Do, Ho, Wo, Cout, device="cuda")
+y = torch.randn(N, Do, Ho, Wo, Cout, device="cuda").to(td)
 dx = torch.empty_like(x)
 dw = torch.empty_like(w)
-ws = F.workspace(L.query("mi355seg_conv3d_ws_bytes", N, D, H, W, Cin, Cout, k, stride, pad), x.device)
+ws = F.workspace(L.query("mi355seg_conv3d_ws_bytes_bf16" if dtype == "bf16" else "mi355seg_conv3d_ws_bytes", N, D, H, W, Cin, Cout, k, stride, pad), x.device)
 st = torch.cuda.current_stream().cuda_stream
 flops = 2.0 * N * Do * Ho * Wo * k ** 3 * Cin * Cout
+sfx = "_" + dtype
 def run(name, fn):
     for _ in range(2): fn()
     torch.cuda.synchronize()
@@ -30,7 +40,7 @@ def run(name, fn):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    print(f"{name:6s} {ms:8.3f} ms  {flops / ms / 1e9:7.1f} TFLOP/s")
-run("fwd", lambda: L.call("mi355seg_conv3d_fwd_f32", x.data_ptr(), Cin, w.data_ptr(), b.data_ptr(), y.data_ptr(), Cout, N, D, H, W, Cin, Cout, k, stride, pad, None, None, ws.data_ptr(), ws.numel(), st))
-run("dgrad", lambda: L.call("mi355seg_conv3d_dgrad_f32", y.data_ptr(), Cout, w.data_ptr(), dx.data_ptr(), Cin, N, D, H, W, Cin, Cout, k, stride, pad, ws.data_ptr(), ws.numel(), st))
-run("wgrad", lambda: L.call("mi355seg_conv3d_wgrad_f32", y.data_ptr(), Cout, x.data_ptr(), Cin, dw.data_ptr(), None, N, D, H, W, Cin, Cout, k, stride, pad, 0, ws.data_ptr(), ws.numel(), st))
+    print(f"{name:6s} {ms:8.3f} ms  {flops / ms / 1e9:7.1f} TFLOP/s   [{dtype}, conv math {mi355seg.get_conv_math() if dtype == 'f32' else 'bf16'}] N={N} {D}x{H}x{W} {Cin}->{Cout} k{k} s{stride}")
+run("fwd", lambda: L.call("mi355seg_conv3d_fwd" + sfx, x.data_ptr(), Cin, w.data_ptr(), b.data_ptr(), y.data_ptr(), Cout, N, D, H, W, Cin, Cout, k, stride, pad, None, None, ws.data_ptr(), ws.numel(), st))
+run("dgrad", lambda: L.call("mi355seg_conv3d_dgrad" + sfx, y.data_ptr(), Cout, w.data_ptr(), dx.data_ptr(), Cin, N, D, H, W, Cin, Cout, k, stride, pad, ws.data_ptr(), ws.numel(), st))
+run("wgrad", lambda: L.call("mi355seg_conv3d_wgrad" + sfx, y.data_ptr(), Cout, x.data_ptr(), Cin, dw.data_ptr(), None, N, D, H, W, Cin, Cout, k, stride, pad, 0, ws.data_ptr(), ws.numel(), st))
