@@ -3,6 +3,7 @@ forward/backward, losses and Dice metric as hand-written gfx950 kernels behind a
 (include/mi355seg.h), exposed with the reference framework's own module interface."""
 from . import functional
 from .functional import autocast
+from . import custom_ops          # registers torch.ops.mi355seg.* (dispatcher view of the same C-ABI entry points)
 from ._lib import LIB_PATH, Mi355SegError, lib
 
 _MATH = {"fp32": 0, "bf16x6": 2}
