@@ -59,7 +59,17 @@ struct Tile {
     static constexpr int PPV = CK / MT::EPP;                  // staged pieces (one global load each) per voxel
     static constexpr int NPIECE = NVOX * PPV;
     static constexpr int NITER = (NPIECE + 255) / 256;
-    static constexpr int LDS_BYTES = NVOX * PITCH * MT::LDS_ELEM;
+    // x-row stride in LDS elements.  A 32-wide M-block reads ONE x-row per ds_read_b128 (32 lanes = 32 consecutive voxels)
+    // and the odd voxel pitch alone keeps it conflict-free; the 16- / 8-wide tiles read 2 / 4 rows per instruction, and
+    // the lanes of different rows share 16-byte slots unless the next row continues the slot sequence of the previous
+    // one, i.e. row stride == BX * voxel pitch (mod 16 slots): the rows of those tiles are padded up to that (at most 15
+    // slots per row; r1 PMC: 0.50 / 0.65 conflict cycles per active LDS cycle on the unpadded BX = 16 / 8 tiles, none by
+    // construction now -- tools/lds_conflicts.py enumerates the lane groups).
+    static constexpr int SLOT = 16 / MT::LDS_ELEM;              // elements per 16-byte slot
+    static constexpr int ROW_RAW = HX * PITCH;
+    static constexpr int ROW_SLOTS = ROW_RAW / SLOT + ((BX < 32 && HALO > 0) ? ((BX * (PITCH / SLOT) - ROW_RAW / SLOT) % 16 + 16) % 16 : 0);
+    static constexpr int ROW = ROW_SLOTS * SLOT;
+    static constexpr int LDS_BYTES = HY * HZ * ROW * MT::LDS_ELEM;
     static_assert(LINES % TY == 0, "tile lines must fill whole y-rows");
     static_assert(CK % MT::KGRAN == 0, "chunk must hold whole MFMA k-steps");
     static_assert(((PITCH * MT::LDS_ELEM / 16) & 1) == 1, "voxel pitch must be an odd number of 16-byte slots");
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
     for (int mb = 0; mb < MB; ++mb) {
         const int m = wave_m * MB + mb;
         const int line = m * T::LPB + i / BX, xx = i % BX;
-        abase[mb] = (((line / T::TY) * T::HY + (line % T::TY)) * T::HX + xx) * PITCH + (16 / MT::LDS_ELEM) * h;
+        abase[mb] = ((line / T::TY) * T::HY + (line % T::TY)) * T::ROW + xx * PITCH + (16 / MT::LDS_ELEM) * h;
     }
 
     const int c0 = ks * a.cps, c1 = c0 + a.cps;             // this split's chunk range
@@ -195,23 +205,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
             stage[it] = v;
         }
     };
+    auto vox_off = [](int vox) { return (vox / T::HX) * T::ROW + (vox % T::HX) * PITCH; };     // halo voxel -> LDS element offset
     auto write_stage = [&]() {
 #pragma unroll
         for (int it = 0; it < T::NITER; ++it) {
             const int p = it * 256 + tid;
             if (p < T::NPIECE) {
                 if constexpr (MATH == MATH_F32) {
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(lds_raw) + (p / PPV) * PITCH + (p % PPV) * 4) = stage[it];
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(lds_raw) + vox_off(p / PPV) + (p % PPV) * 4) = stage[it];
                 } else if constexpr (MATH == MATH_X3) {          // split once per staged value: planes h | m | l of the voxel
                     bf16x4_t qh, qm, ql;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { bf16 bh, bm, bl; split3(stage[it][e], bh, bm, bl); qh[e] = bh; qm[e] = bm; ql[e] = bl; }
-                    bf16* dst = reinterpret_cast<bf16*>(lds_raw) + (p / PPV) * PITCH + (p % PPV) * 4;
+                    bf16* dst = reinterpret_cast<bf16*>(lds_raw) + vox_off(p / PPV) + (p % PPV) * 4;
                     *reinterpret_cast<bf16x4_t*>(dst) = qh;
                     *reinterpret_cast<bf16x4_t*>(dst + CK) = qm;
                     *reinterpret_cast<bf16x4_t*>(dst + 2 * CK) = ql;
                 } else {
-                    *reinterpret_cast<bf16x8_t*>(reinterpret_cast<bf16*>(lds_raw) + (p / PPV) * PITCH + (p % PPV) * 8) = stage[it];
+                    *reinterpret_cast<bf16x8_t*>(reinterpret_cast<bf16*>(lds_raw) + vox_off(p / PPV) + (p % PPV) * 8) = stage[it];
                 }
             }
         }
@@ -244,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
 #pragma unroll
             for (int tap = 0; tap < NTAP; ++tap) {
                 const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
-                const int tapoff = ((dz * T::HY + dy) * T::HX + dx) * PITCH;
+                const int tapoff = (dz * T::HY + dy) * T::ROW + dx * PITCH;
 #pragma unroll
                 for (int kk = 0; kk < CK / 8; ++kk) {
                     const int step = tap * (CK / 8) + kk;
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
 #pragma unroll
             for (int tap = 0; tap < NTAP; ++tap) {
                 const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
-                const int tapoff = ((dz * T::HY + dy) * T::HX + dx) * PITCH;
+                const int tapoff = (dz * T::HY + dy) * T::ROW + dx * PITCH;
 #pragma unroll
                 for (int kk = 0; kk < KSTEPS; ++kk) {
                     const int step = tap * KSTEPS + kk;
