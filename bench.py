@@ -137,25 +137,24 @@ def pmc_traffic():
     stamp = rec.get("git_head")
     if not stamp:
         return None, "profiles/pmc_traffic.json carries no git stamp"
+    # (1) the kernel sources must hash to what was profiled -- holds with or without a .git directory (the GPU box gets a
+    #     snapshot without one); (2) where git is available the stamp must also be an ancestor of HEAD
+    import hashlib
+    h = hashlib.sha256()
+    for f in rec.get("kernel_sources", []):
+        try:
+            h.update(open(os.path.join(ROOT, f), "rb").read())
+        except Exception:
+            return None, f"stamped kernel source {f} is missing"
+    if h.hexdigest()[:16] != rec.get("kernel_sources_sha16"):
+        return None, f"kernel sources changed since the PMC passes were taken at {stamp[:10]} (stale)"
     try:
         rc = subprocess.run(["git", "-C", ROOT, "merge-base", "--is-ancestor", stamp, "HEAD"], capture_output=True, timeout=20).returncode
     except Exception:
         rc = None
-    if rc is None or rc > 1:
-        # not a git checkout (the GPU box gets a snapshot without .git): trust the stamped kernel source hash instead
-        import hashlib
-        h = hashlib.sha256()
-        for f in rec.get("kernel_sources", []):
-            try:
-                h.update(open(os.path.join(ROOT, f), "rb").read())
-            except Exception:
-                return None, f"stamped kernel source {f} is missing"
-        if h.hexdigest()[:16] != rec.get("kernel_sources_sha16"):
-            return None, "kernel sources changed since the PMC passes were taken (stale stamp)"
-        return rec, "offline rocprofv3 --pmc (kernel sources match the stamp)"
     if rc == 1:
         return None, f"PMC stamp {stamp[:10]} is not an ancestor of HEAD"
-    return rec, f"offline rocprofv3 --pmc at {stamp[:10]}"
+    return rec, f"offline rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes at {stamp[:10]} (kernel sources unchanged since)"
 
 
 def main():
