@@ -36,25 +36,31 @@ static void cast_rows(const TS* src, int lds, TD* dst, int ldd, long long rows, 
 static int oext(int n, int k, int s, int p) { return (n + 2 * p - k) / s + 1; }
 
 // which native bf16 kernel serves a shape (0 = none: fp32 fallback)
-enum { NB_NONE = 0, NB_IGEMM, NB_GATHER, NB_STEM, NB_HEAD, NB_LOWP, NB_PW, NB_SMALLCIN, NB_SMALLCOUT, NB_GW };
+enum { NB_NONE = 0, NB_IGEMM, NB_GATHER, NB_STEM, NB_HEAD, NB_LOWP, NB_PW, NB_SMALLCIN, NB_SMALLCOUT, NB_GW, NB_TINY, NB_CONVT };
 static int native_fwd(int N, int D, int H, int W, int Cin, int Cout, int k, int s, int p, int ldx, int ldy) {
     if (conv_mfma_supported(MATH_B16, N, D, H, W, Cin, Cout, k, s, p, ldx, ldy)) return NB_IGEMM;
     if (conv_gather_fwd_supported(MATH_B16, N, D, H, W, Cin, Cout, k, s, p, ldx, ldy)) return NB_GATHER;
     if (stem_supported(Cin, Cout, k, s, p, ldy)) return NB_STEM;
     if (head_supported(Cin, Cout, k, s, p, ldx)) return NB_HEAD;
+    if (tinypw_supported(Cin, Cout, k, s, p)) return NB_TINY;
     return NB_NONE;
 }
 static int native_dgrad(int N, int D, int H, int W, int Cin, int Cout, int k, int s, int p, int lddy, int lddx) {
     if (conv_mfma_supported(MATH_B16, N, D, H, W, Cout, Cin, k, s, p, lddy, lddx)) return NB_IGEMM;
     if (conv_gather_dgrad_supported(MATH_B16, N, D, H, W, Cin, Cout, k, s, p, lddy, lddx)) return NB_GATHER;
     if (head_supported(Cin, Cout, k, s, p, lddx)) return NB_HEAD;
+    if (tinypw_supported(Cin, Cout, k, s, p)) return NB_TINY;
+    // k2 s2 p0: the input gradient is the forward of ConvTranspose3d k2 s2 with the same weight tensor (conv_generic.hip)
+    if (k == 2 && s == 2 && p == 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0 && convt_mfma_supported(MATH_B16, N, D / 2, H / 2, W / 2, Cout, Cin, lddy, lddx))
+        return NB_CONVT;
     return NB_NONE;
 }
 static int native_wgrad(int N, int D, int H, int W, int Cin, int Cout, int k, int s, int p, int ldx, int lddy) {
     if (wgrad_lowp_supported(MATH_B16, N, D, H, W, Cin, Cout, k, s, p, ldx, lddy)) return NB_LOWP;
-    // V-Net's two-channel k5 head and one-channel k5 stem: the fp32 z-marching kernels (conv_headk.hip) behind the cast
-    // fall-back are 5-8x faster than the generic small-channel wgrads below
-    if (headk_wgrad_supported(Cin, Cout, k, s, p, Cin, Cout) || stemk_supported(Cin, Cout, k, s, p, Cin, Cout)) return NB_NONE;
+    // V-Net's two-channel k5 head: the fp32 z-marching kernel (conv_headk.hip) behind the cast fall-back is 8x faster than the
+    // generic small-channel wgrad below (the one-channel k5 stem has its own LDS-tiled kernel inside smallcin_wgrad)
+    if (headk_wgrad_supported(Cin, Cout, k, s, p, Cin, Cout)) return NB_NONE;
+    if (tinypw_supported(Cin, Cout, k, s, p)) return NB_TINY;
     if (k == 1 && s == 1 && p == 0 && pw_wgrad_supported((long long)N * D * H * W, Cin, Cout, 1, ldx, lddy)) return NB_PW;
     if (stem_supported(Cin, Cout, k, s, p, lddy)) return NB_STEM;
     if (head_supported(Cin, Cout, k, s, p, ldx)) return NB_HEAD;
@@ -104,6 +110,11 @@ int mi355seg_conv3d_fwd_bf16(const mi355seg_bf16* x, int ldx, const float* w, co
         if (rc || !stats_sum) return rc;
         return channel_sums(y, ldy, vout, Cout, stats_sum, stats_sq, nullptr, 0, ws, ws_bytes, st);
     }
+    if (nb == NB_TINY) {
+        int rc = tinypw_fwd(x, ldx, w, bias, y, ldy, vout, Cin, Cout, st);
+        if (rc || !stats_sum) return rc;
+        return channel_sums(y, ldy, vout, Cout, stats_sum, stats_sq, nullptr, 0, ws, ws_bytes, st);
+    }
     // fp32 fallback
     Carver cv(ws);
     float* xf = cv.take<float>((size_t)N * D * H * W * Cin);
@@ -136,6 +147,8 @@ int mi355seg_conv3d_dgrad_bf16(const mi355seg_bf16* dy, int lddy, const float* w
         return conv_gather_dgrad_mfma(MATH_B16, dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, k, stride, pad, ws, ws_bytes, st);
     if (nb == NB_HEAD && ((uintptr_t)dx % 8) == 0)
         return head_dgrad(dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, st);
+    if (nb == NB_TINY) return tinypw_dgrad(dy, lddy, w, dx, lddx, vin, Cin, Cout, st);
+    if (nb == NB_CONVT && al) return convt_fwd_mfma(MATH_B16, dy, lddy, w, nullptr, dx, lddx, N, D / 2, H / 2, W / 2, Cout, Cin, ws, ws_bytes, st);
     Carver cv(ws);
     float* dxf = cv.take<float>((size_t)vin * Cin);
     float* dyf = cv.take<float>((size_t)vout * Cout);
@@ -174,6 +187,7 @@ int mi355seg_conv3d_wgrad_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg
         SEG_CHECK_LAUNCH();
         return MI355SEG_OK;
     }
+    if (nb == NB_TINY) return tinypw_wgrad(dy, lddy, x, ldx, dw, vin, Cin, Cout, accumulate, ws, ws_bytes, st);
     if (nb == NB_STEM && al8) return stem_wgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, st);
     if (nb == NB_HEAD && al8) return head_wgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, st);
     if (nb == NB_SMALLCIN && al8) return smallcin_wgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, stride, pad, accumulate, ws, ws_bytes, st);

@@ -465,6 +465,11 @@ int mi355seg_conv3d_fwd_f32(const float* x, int ldx, const float* w, const float
     }
     if (stem_supported(Cin, Cout, k, stride, pad, ldy))
         return stem_fwd(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, stats_sum, stats_sq, ws, ws_bytes, st);
+    if (tinypw_supported(Cin, Cout, k, stride, pad)) {
+        rc = tinypw_fwd(x, ldx, w, bias, y, ldy, (long long)N * D * H * W, Cin, Cout, st);
+        if (rc || !stats_sum) return rc;
+        return channel_sums(y, ldy, (long long)N * D * H * W, Cout, stats_sum, stats_sq, nullptr, 0, ws, ws_bytes, st);
+    }
     if (head_supported(Cin, Cout, k, stride, pad, ldx)) {
         rc = head_fwd(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, st);
         if (rc || !stats_sum) return rc;
@@ -493,6 +498,13 @@ int mi355seg_conv3d_dgrad_f32(const float* dy, int lddy, const float* w, float* 
         return headk_conv(true, dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cin, k, ws, ws_bytes, st);
     if (head_supported(Cin, Cout, k, stride, pad, lddx))
         return head_dgrad(dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, st);
+    if (tinypw_supported(Cin, Cout, k, stride, pad)) return tinypw_dgrad(dy, lddy, w, dx, lddx, (long long)N * D * H * W, Cin, Cout, st);
+    // k2 s2 p0 (V-Net's down-convolutions, vnet3d.py:66): the windows do not overlap, so the input gradient IS the forward of
+    // ConvTranspose3d k2 s2 with the same weight tensor read as (Cin_T = Cout, Cout_T = Cin, 2, 2, 2) -- also for Cin = 16,
+    // which the 32-column tiles of the gather dgrad cannot cut (the transposed conv tiles the flat (child, channel) axis)
+    if (k == 2 && stride == 2 && pad == 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0 && ((uintptr_t)dy % 16) == 0 &&
+        convt_mfma_supported(MATH_F32, N, D / 2, H / 2, W / 2, Cout, Cin, lddy, lddx))
+        return convt_fwd_mfma(MATH_F32, dy, lddy, w, nullptr, dx, lddx, N, D / 2, H / 2, W / 2, Cout, Cin, ws, ws_bytes, st);
     return conv_dgrad_generic(dy, lddy, w, dx, lddx, g, ws, ws_bytes, st);
 }
 
@@ -529,6 +541,8 @@ int mi355seg_conv3d_wgrad_f32(const float* dy, int lddy, const float* x, int ldx
         SEG_CHECK_LAUNCH();
         return MI355SEG_OK;
     }
+    if (tinypw_supported(Cin, Cout, k, stride, pad))
+        return tinypw_wgrad(dy, lddy, x, ldx, dw, (long long)N * D * H * W, Cin, Cout, accumulate, ws, ws_bytes, st);
     if (stem_supported(Cin, Cout, k, stride, pad, lddy))
         return stem_wgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, st);
     if (head_supported(Cin, Cout, k, stride, pad, ldx))

@@ -162,7 +162,9 @@ static int pick_ck(int math, int KS, int Kc) {
 // Kc = GEMM K channels per input tap (multiple of CK), Nc = GEMM N per output tap (multiple of 32)
 static bool igemm_plan(int math, int KS, int N, int D, int H, int W, int Kc, int Nc, int ntaps_out, IgemmPlan* p) {
     if (KS != 1 && KS != 3 && KS != 5) return false;
-    if (math == MATH_X3 && KS != 3) return false;                      // the split-precision policy is built for the k3 layers
+    // the split-precision igemm serves the k3 layers.  (k5 was measured: three planes of the 5^3 halo are 86-110 KB, one workgroup
+    // per CU; 150 TFLOP/s on 32->32 @128^3 against 120 for the fp32 MFMA, but slower on the deep layers: V-Net fp32 step 79.6 -> 96.9 ms)
+    if (math == MATH_X3 && KS != 3) return false;
     const int CK = pick_ck(math, KS, Kc);
     // ConvT with a narrow Cout: tile the flat (child, cout) axis instead of each child's channels
     const bool flat = ntaps_out > 1 && (Nc % 32) != 0 && ((long long)Nc * ntaps_out) % 32 == 0;

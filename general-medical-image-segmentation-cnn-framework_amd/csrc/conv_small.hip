@@ -319,6 +319,130 @@ __global__ __launch_bounds__(256) void stem1_wgrad_kernel(const T* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------- Cin == 1, k5 p2 stem wgrad (V-Net InputTransition, vnet3d.py:47)
+// grid = (blocks, 5 dz planes).  As stem1_wgrad_kernel, with the 25 (dy, dx) taps of one dz plane per block: the LDS tile is
+// the z-shifted slab S1_TZ x (S1_TY+4) x (TX+4) of the one-channel input.  part[blk][tap][0][co], tap = dz*25 + dy*5 + dx.
+template <typename T>
+__global__ __launch_bounds__(256) void stem1k5_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+        float* __restrict__ part, SmallGeom g, int lddy, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Cout = g.Cout, LPV = Cout / 4, TX = 256 / LPV, HX = TX + 4, HY = S1_TY + 4;
+    const int cq = threadIdx.x % LPV, xs = threadIdx.x / LPV;
+    const int dzp = blockIdx.y;
+    f32x4 acc[25];
+#pragma unroll
+    for (int t = 0; t < 25; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ntx = g.W / TX, nty = g.H / S1_TY, ntz = g.D / S1_TZ;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int mt = tile;
+        const int txi = mt % ntx; mt /= ntx;
+        const int tyi = mt % nty; mt /= nty;
+        const int tzi = mt % ntz; const int n = mt / ntz;
+        const int x0 = txi * TX, y0 = tyi * S1_TY, z0 = tzi * S1_TZ;
+        f32x4 dreg[S1_TZ * S1_TY];
+#pragma unroll
+        for (int line = 0; line < S1_TZ * S1_TY; ++line) {
+            const int lz = line / S1_TY, ly = line % S1_TY;
+            const long long v = (((long long)n * g.D + z0 + lz) * g.H + y0 + ly) * g.W + x0 + xs;
+            dreg[line] = ld4(dy + v * lddy + cq * 4);
+        }
+        __syncthreads();
+        for (int p = threadIdx.x; p < HX * HY * S1_TZ; p += 256) {
+            const int hx = p % HX, r = p / HX, hy = r % HY, hz = r / HY;
+            const int gz = z0 + hz + dzp - 2, gy = y0 - 2 + hy, gx = x0 - 2 + hx;
+            float v = 0.f;
+            if ((unsigned)gz < (unsigned)g.D && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W)
+                v = ld1(x + ((((long long)n * g.D + gz) * g.H + gy) * g.W + gx) * g.ldx);
+            sm[p] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int line = 0; line < S1_TZ * S1_TY; ++line) {
+            const int lz = line / S1_TY, ly = line % S1_TY;
+            const float* tp = sm + (lz * HY + ly) * HX + xs;
+            const f32x4 d = dreg[line];
+#pragma unroll
+            for (int t = 0; t < 25; ++t) acc[t] += tp[(t / 5) * HX + t % 5] * d;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < 25; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = acc[t][j];
+            for (int o = 32; o >= LPV; o >>= 1) s += __shfl_xor(s, o, 64);
+            acc[t][j] = s;
+        }
+    __syncthreads();
+    if (lane < LPV) {
+#pragma unroll
+        for (int t = 0; t < 25; ++t) st4(sm + ((wave * 25 + t) * LPV + lane) * 4, acc[t]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 25 * Cout; i += 256) {
+        const int t = i / Cout, co = i % Cout;
+        float s = 0.f;
+        for (int w = 0; w < 4; ++w) s += sm[((w * 25 + t) * LPV + co / 4) * 4 + co % 4];
+        part[((long long)blockIdx.x * 125 + dzp * 25 + t) * Cout + co] = s;
+    }
+}
+
+// ---------------------------------------------------------------- tiny pointwise convolutions (k1, Cin <= 4, Cout <= 4)
+// V-Net's classes -> classes output convolution (vnet3d.py:113, 2 -> 2): thread = voxel, weights in registers.
+struct TinyPw { int Cin, Cout, ldx, ldy; long long nvox; };
+template <typename T>
+__global__ __launch_bounds__(256) void tinypw_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         T* __restrict__ y, TinyPw g) {
+    float wr[4][4], br[4];
+    for (int co = 0; co < 4; ++co) {
+        br[co] = (bias && co < g.Cout) ? bias[co] : 0.f;
+        for (int ci = 0; ci < 4; ++ci) wr[co][ci] = (co < g.Cout && ci < g.Cin) ? w[co * g.Cin + ci] : 0.f;
+    }
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < g.nvox; v += (long long)gridDim.x * 256) {
+        float xv[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int ci = 0; ci < g.Cin; ++ci) xv[ci] = ld1(x + v * g.ldx + ci);
+        for (int co = 0; co < g.Cout; ++co)
+            st1(y + v * g.ldy + co, br[co] + xv[0] * wr[co][0] + xv[1] * wr[co][1] + xv[2] * wr[co][2] + xv[3] * wr[co][3]);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void tinypw_dgrad_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx, TinyPw g) {
+    float wr[4][4];
+    for (int co = 0; co < 4; ++co)
+        for (int ci = 0; ci < 4; ++ci) wr[co][ci] = (co < g.Cout && ci < g.Cin) ? w[co * g.Cin + ci] : 0.f;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < g.nvox; v += (long long)gridDim.x * 256) {
+        float d[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int co = 0; co < g.Cout; ++co) d[co] = ld1(dy + v * g.ldy + co);
+        for (int ci = 0; ci < g.Cin; ++ci)
+            st1(dx + v * g.ldx + ci, d[0] * wr[0][ci] + d[1] * wr[1][ci] + d[2] * wr[2][ci] + d[3] * wr[3][ci]);
+    }
+}
+// part[blk][0][ci][co]: per-block sums in fixed order (wave shuffle, then the four waves through LDS)
+template <typename T>
+__global__ __launch_bounds__(256) void tinypw_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part, TinyPw g) {
+    __shared__ float sh[4][16];
+    float acc[16];
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < g.nvox; v += (long long)gridDim.x * 256) {
+        float xv[4] = {0.f, 0.f, 0.f, 0.f}, d[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int ci = 0; ci < g.Cin; ++ci) xv[ci] = ld1(x + v * g.ldx + ci);
+        for (int co = 0; co < g.Cout; ++co) d[co] = ld1(dy + v * g.ldy + co);
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+            for (int co = 0; co < 4; ++co) acc[ci * 4 + co] += xv[ci] * d[co];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const float s = wave_sum(acc[i]); if (lane == 0) sh[wave][i] = s; }
+    __syncthreads();
+    if (threadIdx.x < g.Cin * g.Cout) {
+        const int ci = threadIdx.x / g.Cout, co = threadIdx.x % g.Cout;
+        part[((long long)blockIdx.x * g.Cin + ci) * g.Cout + co] = sh[0][ci * 4 + co] + sh[1][ci * 4 + co] + sh[2][ci * 4 + co] + sh[3][ci * 4 + co];
+    }
+}
+
 static bool stem1_tiled_ok(const SmallGeom& g) {
     if (g.Cin != 1) return false;
     const int TX = 256 / (g.Cout / 4);
@@ -567,6 +691,27 @@ int smallcin_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N,
     SmallConv g{N, D, H, W, (D + 2 * pad - k) / stride + 1, (H + 2 * pad - k) / stride + 1, (W + 2 * pad - k) / stride + 1,
                 Cin, Cout, k, stride, pad, k * k * k, ldx, lddy};
     const long long nvox = (long long)N * g.Do * g.Ho * g.Wo;
+    if (Cin == 1 && k == 5 && stride == 1 && pad == 2 && Cout % 4 == 0 && Cout <= 64 && (256 % (Cout / 4)) == 0 && lddy % 4 == 0 &&
+        ((uintptr_t)dy % (4 * sizeof(T))) == 0) {
+        SmallGeom sg{N, D, H, W, 1, Cout, ldx, 0};
+        const int TX = 256 / (Cout / 4);
+        if (W % TX == 0 && H % S1_TY == 0 && D % S1_TZ == 0) {      // LDS-tiled k5 stem wgrad: one block per (tile strip, dz plane)
+            const int ntiles = (int)(nvox / ((long long)S1_TZ * S1_TY * TX));
+            int nb = ntiles < 128 ? ntiles : 128;
+            SEG_CHECK_WS((size_t)nb * 125 * Cout * sizeof(float), ws_bytes);
+            float* part5 = (float*)ws;
+            size_t lds5 = (size_t)(TX + 4) * (S1_TY + 4) * S1_TZ * 4, red5 = (size_t)4 * 25 * Cout * 4;
+            if (red5 > lds5) lds5 = red5;
+            {
+                ProfScope ps(PF_DIRECT, 2.0 * nvox * 125.0 * Cout, (double)sizeof(T) * nvox * (1 + Cout), st);
+                hipLaunchKernelGGL((stem1k5_wgrad_kernel<T>), dim3(nb, 5), dim3(256), lds5, st, x, dy, part5, sg, lddy, ntiles);
+                SEG_CHECK_LAUNCH();
+            }
+            wgrad_reduce(part5, dw, nb, 125, 1, Cout, accumulate, st);
+            SEG_CHECK_LAUNCH();
+            return MI355SEG_OK;
+        }
+    }
     const int vw = (Cout % 4 == 0) ? 4 : 1, lpv = Cout / vw;
     int nblk = small_grid(nvox, 256 / lpv);
     if (nblk > 512) nblk = 512;
@@ -746,6 +891,41 @@ int head_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N, int
     return MI355SEG_OK;
 }
 
+bool tinypw_supported(int Cin, int Cout, int k, int stride, int pad) { return k == 1 && stride == 1 && pad == 0 && Cin <= 4 && Cout <= 4; }
+template <typename T>
+int tinypw_fwd(const T* x, int ldx, const float* w, const float* bias, T* y, int ldy, long long nvox, int Cin, int Cout, hipStream_t st) {
+    TinyPw g{Cin, Cout, ldx, ldy, nvox};
+    ProfScope ps(PF_DIRECT, 2.0 * nvox * Cin * Cout, (double)sizeof(T) * nvox * (Cin + Cout), st);
+    hipLaunchKernelGGL((tinypw_fwd_kernel<T>), dim3(small_grid(nvox, 256) * 4), dim3(256), 0, st, x, w, bias, y, g);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+template <typename T>
+int tinypw_dgrad(const T* dy, int lddy, const float* w, T* dx, int lddx, long long nvox, int Cin, int Cout, hipStream_t st) {
+    TinyPw g{Cin, Cout, lddx, lddy, nvox};
+    ProfScope ps(PF_DIRECT, 2.0 * nvox * Cin * Cout, (double)sizeof(T) * nvox * (Cin + Cout), st);
+    hipLaunchKernelGGL((tinypw_dgrad_kernel<T>), dim3(small_grid(nvox, 256) * 4), dim3(256), 0, st, dy, w, dx, g);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+template <typename T>
+int tinypw_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, long long nvox, int Cin, int Cout, int accumulate, void* ws, size_t ws_bytes,
+                 hipStream_t st) {
+    TinyPw g{Cin, Cout, ldx, lddy, nvox};
+    int nblk = small_grid(nvox, 256);
+    if (nblk > 512) nblk = 512;
+    SEG_CHECK_WS((size_t)nblk * Cin * Cout * sizeof(float), ws_bytes);
+    float* part = (float*)ws;
+    {
+        ProfScope ps(PF_DIRECT, 2.0 * nvox * Cin * Cout, (double)sizeof(T) * nvox * (Cin + Cout), st);
+        hipLaunchKernelGGL((tinypw_wgrad_kernel<T>), dim3(nblk), dim3(256), 0, st, x, dy, part, g);
+        SEG_CHECK_LAUNCH();
+    }
+    wgrad_reduce(part, dw, nblk, 1, Cin, Cout, accumulate, st);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
 // explicit instantiations for the two storage types (declared as templates in internal.h)
 #define SEG_INST(T) \
     template int smallcin_wgrad<T>(const T*, int, const T*, int, float*, int, int, int, int, int, int, int, int, int, int, void*, size_t, hipStream_t); \
@@ -754,7 +934,10 @@ int head_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N, int
     template int stem_wgrad<T>(const T*, int, const T*, int, float*, int, int, int, int, int, int, int, void*, size_t, hipStream_t); \
     template int head_fwd<T>(const T*, int, const float*, const float*, T*, int, int, int, int, int, int, int, hipStream_t); \
     template int head_dgrad<T>(const T*, int, const float*, T*, int, int, int, int, int, int, int, hipStream_t); \
-    template int head_wgrad<T>(const T*, int, const T*, int, float*, int, int, int, int, int, int, int, void*, size_t, hipStream_t);
+    template int head_wgrad<T>(const T*, int, const T*, int, float*, int, int, int, int, int, int, int, void*, size_t, hipStream_t); \
+    template int tinypw_fwd<T>(const T*, int, const float*, const float*, T*, int, long long, int, int, hipStream_t); \
+    template int tinypw_dgrad<T>(const T*, int, const float*, T*, int, long long, int, int, hipStream_t); \
+    template int tinypw_wgrad<T>(const T*, int, const T*, int, float*, long long, int, int, int, void*, size_t, hipStream_t);
 SEG_INST(float)
 SEG_INST(bf16)
 #undef SEG_INST

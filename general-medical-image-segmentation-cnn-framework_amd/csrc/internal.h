@@ -25,6 +25,11 @@ template <typename T> int head_fwd(const T* x, int ldx, const float* w, const fl
              int Cout, hipStream_t st);
 template <typename T> int head_dgrad(const T* dy, int lddy, const float* w, T* dx, int lddx, int N, int D, int H, int W, int Cin, int Cout,
                hipStream_t st);
+bool tinypw_supported(int Cin, int Cout, int k, int stride, int pad);      // k1 with at most 4 channels on either side
+template <typename T> int tinypw_fwd(const T* x, int ldx, const float* w, const float* bias, T* y, int ldy, long long nvox, int Cin, int Cout, hipStream_t st);
+template <typename T> int tinypw_dgrad(const T* dy, int lddy, const float* w, T* dx, int lddx, long long nvox, int Cin, int Cout, hipStream_t st);
+template <typename T> int tinypw_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, long long nvox, int Cin, int Cout, int accumulate, void* ws,
+                                       size_t ws_bytes, hipStream_t st);
 bool smallcin_wgrad_supported(int Cin, int Cout, int k);
 bool smallcout_wgrad_supported(int Cin, int Cout, int k, int ldx);
 size_t small_wgrad_ws_bytes(int Cin, int Cout, int k);
