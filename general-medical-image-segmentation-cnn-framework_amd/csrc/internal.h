@@ -15,6 +15,13 @@ int finalize_channel_partials(const float* part, int nblk, int C, double* sum, d
 
 // conv_small.hip -- direct kernels for Cin<=4 stems and Cout<=4 pointwise heads
 bool stem_supported(int Cin, int Cout, int k, int stride, int pad, int ldy);
+// conv_stem4_lowp.hip: Conv3d(4 -> 32 | 64, k3 p1) on bf16 tensors through the matrix cores ((tap, channel) is the GEMM axis)
+bool stem4_lowp_supported(int Cin, int Cout, int k, int stride, int pad, int ldx, int ldy);
+size_t stem4_lowp_ws_bytes(int Cout);
+int stem4_fwd_lowp(const bf16* x, const float* w, const float* bias, bf16* y, int ldy, int N, int D, int H, int W, int Cout,
+                   void* ws, size_t ws_bytes, hipStream_t st);
+int stem4_wgrad_lowp(const bf16* dy, int lddy, const bf16* x, float* dw, int N, int D, int H, int W, int Cout, int accumulate,
+                     void* ws, size_t ws_bytes, hipStream_t st);
 bool head_supported(int Cin, int Cout, int k, int stride, int pad, int ldx);
 size_t small_ws_bytes(int Cin, int Cout, int k);
 template <typename T> int stem_fwd(const T* x, int ldx, const float* w, const float* bias, T* y, int ldy, int N, int D, int H, int W, int Cin,
