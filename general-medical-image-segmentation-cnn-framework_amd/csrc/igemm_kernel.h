@@ -288,6 +288,70 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
         constexpr int CHUNK = NSTEP * STEP;
         const bf16* lds = reinterpret_cast<const bf16*>(lds_raw);
         const bf16* wlane = reinterpret_cast<const bf16*>(a.wq) + (long long)ntile * a.nchunks * CHUNK + (h * NT + i) * 8;
+        if constexpr (NP == 3 && NSTEP > 4) {
+            // bf16x6: 6 * NBW MFMAs per (k-step, M-block) leave room to software-pipeline by hand -- the weights of step s+1
+            // and the voxels of the next M-block are requested while the MFMAs of the current one issue, and the scheduling
+            // groups pin that interleave (left alone the compiler sinks the loads next to their first use to save registers,
+            // which exposed an LDS or L2 latency every few MFMAs: 0.60 MFMA-busy before).
+            for (int chunk = c0; chunk < c1; ++chunk) {
+                const bf16* wp = wlane + (long long)chunk * CHUNK;
+                bf16x8_t bq[2][NBW][3], av[2][3];
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) bq[0][nb][pl] = *reinterpret_cast<const bf16x8_t*>(wp + pl * PLANE + (nbase + nb) * 256);
+                __syncthreads();
+                write_stage();
+                __syncthreads();
+                if (chunk + 1 < c1) load_stage(chunk + 1);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) av[0][pl] = *reinterpret_cast<const bf16x8_t*>(lds + abase[0] + pl * CK);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int step = 0; step < NSTEP; ++step) {
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const int q = step * MB + mb, cur = q & 1, nxt = cur ^ 1;
+                        if (mb == 0 && step + 1 < NSTEP) {
+#pragma unroll
+                            for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                                for (int pl = 0; pl < 3; ++pl)
+                                    bq[(step + 1) & 1][nb][pl] = *reinterpret_cast<const bf16x8_t*>(wp + (step + 1) * STEP + pl * PLANE + (nbase + nb) * 256);
+                        }
+                        if (q + 1 < NSTEP * MB) {
+                            const int ns = (q + 1) / MB, nm = (q + 1) % MB, tap = ns / KSTEPS, kk = ns % KSTEPS;
+                            const int tapoff = ((tap / (KS * KS)) * T::HY + (tap / KS) % KS) * T::ROW + (tap % KS) * PITCH;
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl) av[nxt][pl] = *reinterpret_cast<const bf16x8_t*>(lds + abase[nm] + tapoff + pl * CK + kk * 16);
+                        }
+                        // planes 0 / 1 / 2 = h / m / l; the small cross terms go in first; N-blocks alternate so that no MFMA
+                        // waits on the accumulator of the one before it
+                        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                        for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                            for (int nb = 0; nb < NBW; ++nb)
+                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cur][PA[pr]], bq[step & 1][nb][PB[pr]], acc[mb][nb], 0, 0, 0);
+                        // interleave: the next block's voxels (DS, needed first) behind the first MFMAs, then the next step's weights
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) {
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        }
+                        if (mb == 0) {
+#pragma unroll
+                            for (int g = 0; g < 3 * NBW; ++g) {
+                                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);      // one scheduling region per (k-step, M-block)
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
         for (int chunk = c0; chunk < c1; ++chunk) {
             const bf16* wp = wlane + (long long)chunk * CHUNK;
             constexpr int PFD = NSTEP > 4 ? ((NP == 3 || MB >= 4) ? 2 : 4) : 1;      // ring depth; the deep-tile variants are register-bound
