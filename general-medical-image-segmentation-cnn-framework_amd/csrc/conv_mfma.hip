@@ -213,15 +213,24 @@ static bool igemm_plan(int math, int KS, int N, int D, int H, int W, int Kc, int
     else if (math == MATH_B16 && !(force && force[0] == '2') && KS == 3 && BX == 32 && NBW == 2 && m3 * nN >= 1024 && waste(tz3) <= 1.05) MB = 3;
     else if (m2 * nN >= 512 && waste(tz2) <= waste(tz1) * 1.2) MB = 2;
     else MB = 1;
-    p->KS = KS; p->CK = CK; p->BX = BX; p->MB = MB; p->NBW = NBW; p->WN = 1; p->NT = 32 * NBW;
+    p->KS = KS; p->CK = CK; p->BX = BX; p->MB = MB; p->NBW = NBW; p->WN = 1; p->NT = 32 * NBW; p->TY = 4;
     p->TZ = MB == 4 ? tz4 : (MB == 3 ? tz3 : (MB == 2 ? tz2 : tz1));
     int nNp = nN;
-    // bf16 k3, 64-channel tiles at full width: 2 (M) x 2 (N) wave grid, six M-blocks per wave (384-voxel tiles like MB = 3;
-    // eight blocks = 128 accumulator registers spill)
-    if (math == MATH_B16 && KS == 3 && BX == 32 && NBW == 2 && !flat && ntaps_out == 1 && m3 * nN >= 1024 && waste(tz3) <= 1.05) {
-        p->WN = 2; p->NBW = 1; p->MB = 6; p->TZ = tz3; p->NT = 64;
+    // bf16 k3 at full width, three or more M-blocks per wave: sliding-window tiles, TY = MB lines of one z-slab per wave
+    // (Tile::SLIDE), 4 / WN slabs per tile
+    auto slide_waste = [&](int ty, int tz) { return (double)(((H + ty - 1) / ty) * ty) * (((D + tz - 1) / tz) * tz) / ((double)H * D); };
+    // 64-channel tiles: 2 (M) x 2 (N) wave grid, six M-blocks per wave (32 x 6 x 2 voxels; eight blocks = 128 accumulator
+    // registers spill)
+    if (math == MATH_B16 && KS == 3 && BX == 32 && NBW == 2 && !flat && ntaps_out == 1 && m3 * nN >= 1024 && slide_waste(6, 2) <= 1.05) {
+        p->WN = 2; p->NBW = 1; p->MB = 6; p->NT = 64;
     }
-    p->ntx = (W + BX - 1) / BX; p->nty = (H + 3) / 4; p->ntz = (D + p->TZ - 1) / p->TZ;
+    if (math == MATH_B16 && KS == 3 && BX == 32 && p->MB >= 3) {
+        p->TY = p->MB; p->TZ = 4 / p->WN;
+        if (slide_waste(p->TY, p->TZ) > 1.10) {                      // ragged extents: back to two blocks per wave
+            p->MB = 2; p->WN = 1; p->NBW = NBW; p->NT = 32 * NBW; p->TY = 4; p->TZ = tz2;
+        }
+    }
+    p->ntx = (W + BX - 1) / BX; p->nty = (H + p->TY - 1) / p->TY; p->ntz = (D + p->TZ - 1) / p->TZ;
     p->nM = N * p->ntz * p->nty * p->ntx; p->nN = nNp;
     if (p->WN == 2) return true;
     if (math != MATH_F32 && !igemm_lowp_has(math, KS, CK, BX, MB)) return false;
@@ -278,6 +287,7 @@ static int tile_block(int nt) { return nt % 4 == 0 ? 4 : (nt % 2 == 0 ? 2 : 1); 
 
 static void dispatch_igemm(int math, const IgemmPlan& p, const IgemmArgs& a_in, int nwg, hipStream_t st) {
     IgemmArgs a = a_in;
+    a.total = nwg;
 #ifdef MI355SEG_TUNE
     static const char* flat_walk = getenv("MI355SEG_IGEMM_LINEAR_WALK");      // A/B knob: 1 = plain x, y, z tile order
 #else

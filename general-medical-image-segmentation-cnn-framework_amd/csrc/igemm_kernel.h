@@ -52,7 +52,15 @@ struct Tile {
     static constexpr int NTAP = KS * KS * KS;
     static constexpr int LPB = 32 / BX;           // x-lines per 32-voxel M-block
     static constexpr int LINES = (4 / WN) * MB * LPB;    // x-lines per workgroup tile (WN waves share an M-block row, each on its own N-blocks)
-    static constexpr int TY = 4;
+    // bf16 k3 tiles of three or more full-width M-blocks per wave: the wave's blocks are the consecutive y-lines of ONE z-slab
+    // (TY = MB), so that the halo line (z + dz, y') it reads once from LDS feeds every (block, dy) pair with block + dy == y'
+    // -- MB + 2 fragment reads per (dz, dx) instead of 3 * MB (see the SLIDE main loop)
+    static constexpr bool SLIDE = MATH == MATH_B16 && KS == 3 && BX == 32 && MB >= 3;
+    // persistent tile walk with the next tile's first halo chunk prefetched behind the last MFMAs of the current one: measured
+    // SLOWER on every bf16 layer (32->32 @160x192x160 619 -> 589 TFLOP/s, 64->64 886 -> 779): vmcnt retires in order, so the
+    // weight fragments requested after the prefetch wait for it either way, and the tile loop's scalar state spills.  Kept off.
+    static constexpr bool PERSIST = false;
+    static constexpr int TY = SLIDE ? MB : 4;
     static constexpr int TZ = LINES / TY;
     static constexpr int HX = BX + 2 * HALO, HY = TY + 2 * HALO, HZ = TZ + 2 * HALO;
     static constexpr int NVOX = HX * HY * HZ;
@@ -97,11 +105,12 @@ struct IgemmArgs {
     int cz, cy, cx;     // fixed child offset of a strided-dgrad phase launch
     int flatn;          // != 0: N-tiles cut the flat (child tap, cout) axis, so one 32-column block may span two children
     int by, bz;         // (y, z) tile-block shape of the M-tile walk (divisors of nty, ntz)
+    int total;          // virtual tiles = nM * nN * ksplit (the persistent variants walk them with a smaller grid); set by dispatch
     signed char toff[64][4];   // per K-tap input offset (z, y, x); all zero for the stride-1 halo modes
 };
 
 struct TapList { unsigned char t[64]; };
-struct IgemmPlan { int KS, CK, BX, MB, NBW, TZ, nM, nN, ntx, nty, ntz, flat, WN, NT; };     // NT = 32 * NBW * WN: tile width in channels
+struct IgemmPlan { int KS, CK, BX, MB, NBW, TZ, nM, nN, ntx, nty, ntz, flat, WN, NT, TY; };     // NT = 32 * NBW * WN: tile width in channels
 
 // ---------------------------------------------------------------- the kernel
 // One virtual tile = (M-tile, N-tile, K-split) per workgroup; up to two workgroups share a CU and the
@@ -134,41 +143,50 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
 
     // XCD-aware block -> tile map: blocks dealt round-robin to the 8 XCDs get contiguous tile ranges,
     // so halo-sharing neighbours and the N-tiles / K-splits of one M-tile share an L2 (bijective).
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int ks = t % a.ksplit; t /= a.ksplit;
-    const int ntile = t % a.nN;
-    const int mtile = t / a.nN;
     // M-tiles are walked in (y, z) blocks of by x bz tiles (x fastest inside a block) so that the ~64 tiles an XCD works
     // on at any moment form a compact brick whose shared halo planes stay in that XCD's L2 (by divides nty; the last
     // z-row of bricks may be shorter than bz)
-    int mt = mtile;
-    const int per_n = a.ntx * a.nty * a.ntz;
-    const int n = mt / per_n; mt -= n * per_n;
-    const int zfull = a.ntz / a.bz;                           // full z-rows of bricks; a ragged last row holds the remaining slabs
-    const int rowtiles = a.ntx * a.nty * a.bz;                // tiles per full z-row
-    int zrow = mt / rowtiles, bzz = a.bz;
-    if (zrow >= zfull) { zrow = zfull; bzz = a.ntz - zfull * a.bz; }
-    mt -= zrow * rowtiles;
-    const int blk = a.ntx * a.by * bzz;
-    const int b = mt / blk; mt -= b * blk;
-    const int txi = mt % a.ntx; mt /= a.ntx;
-    const int tyi = b * a.by + mt % a.by;
-    const int tzi = zrow * a.bz + mt / a.by;
-    const int x0 = txi * BX, y0 = tyi * T::TY, z0 = tzi * T::TZ;
-    const int tapn = ntile / a.nNpt;                          // output child (ConvT fwd), else 0
-    const int n0 = (ntile % a.nNpt) * NT;
-    const int Di = a.Di, Hi = a.Hi, Wi = a.Wi;
+    struct TC { int ks, ntile, mtile, n, x0, y0, z0; };
+    auto decode = [&](int t) {
+        TC c;
+        c.ks = t % a.ksplit; t /= a.ksplit;
+        c.ntile = t % a.nN;
+        c.mtile = t / a.nN;
+        int mt = c.mtile;
+        const int per_n = a.ntx * a.nty * a.ntz;
+        c.n = mt / per_n; mt -= c.n * per_n;
+        const int zfull = a.ntz / a.bz;                       // full z-rows of bricks; a ragged last row holds the remaining slabs
+        const int rowtiles = a.ntx * a.nty * a.bz;            // tiles per full z-row
+        int zrow = mt / rowtiles, bzz = a.bz;
+        if (zrow >= zfull) { zrow = zfull; bzz = a.ntz - zfull * a.bz; }
+        mt -= zrow * rowtiles;
+        const int blk = a.ntx * a.by * bzz;
+        const int b = mt / blk; mt -= b * blk;
+        const int txi = mt % a.ntx; mt /= a.ntx;
+        const int tyi = b * a.by + mt % a.by;
+        const int tzi = zrow * a.bz + mt / a.by;
+        c.x0 = txi * BX; c.y0 = tyi * T::TY; c.z0 = tzi * T::TZ;
+        return c;
+    };
+    // PERSIST (the bf16 tiles): the grid is at most two workgroups per CU and a workgroup walks every S-th tile of its XCD's
+    // range, requesting the first halo chunk of its next tile behind the MFMAs of the current tile's last chunk -- a thin
+    // layer (Cin = 32: two chunks, 3.5 us of MFMAs per tile) otherwise spends most of a tile's life waiting for the first
+    // loads of a freshly launched workgroup.  Not PERSIST: one tile per workgroup, grid = tiles.
+    constexpr bool PERSIST = T::PERSIST;
+    const int total = PERSIST ? a.total : (int)gridDim.x, bid = blockIdx.x;
+    const int q8 = total >> 3, r8 = total & 7, xcd = bid & 7;
+    const int xstart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, xcnt = q8 + (xcd < r8 ? 1 : 0);
+    const int xslots = ((int)gridDim.x + 7) >> 3;             // workgroups per XCD
+    int local = bid >> 3;
+    if (local >= xcnt) return;
+    TC tc = decode(xstart + local), tn = tc;
+    // the k3 / k5 kernels only ever run the plain stride-1 convolution (the gather / scatter / ConvT generalisations are k1
+    // plans): their multipliers, tap offsets and child logic fold away at compile time
+    constexpr bool PLAIN = KS != 1;
+    const int in_mul = PLAIN ? 1 : a.in_mul, out_mul = PLAIN ? 1 : a.out_mul;
+    const int Di = PLAIN ? a.D : a.Di, Hi = PLAIN ? a.H : a.Hi, Wi = PLAIN ? a.W : a.Wi;
+    const int Do = PLAIN ? a.D : a.Do, Ho = PLAIN ? a.H : a.Ho, Wo = PLAIN ? a.W : a.Wo;
     const in_t* __restrict__ xin = reinterpret_cast<const in_t*>(a.x);
-
-    f32x16 acc[MB][NBW];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < NBW; ++nb)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[mb][nb][v] = 0.f;
 
     // per-lane LDS base (LDS elements) of the A fragment for each M-block: lane (i, h) reads voxel i of the block and the
     // h-th half of a k-step's channels (4 floats / 8 bf16 = 16 bytes)
@@ -180,26 +198,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
         abase[mb] = ((line / T::TY) * T::HY + (line % T::TY)) * T::ROW + xx * PITCH + (16 / MT::LDS_ELEM) * h;
     }
 
-    const int c0 = ks * a.cps, c1 = c0 + a.cps;             // this split's chunk range
 
     // ---- halo staging: global -> registers (issue early) -> LDS (write late)
     using stage_t = typename std::conditional<MATH == MATH_B16, bf16x8_t, f32x4>::type;
     stage_t stage[T::NITER];
-    auto load_stage = [&](int chunk) {
+    auto load_stage = [&](const TC& c, int chunk) {
 #pragma unroll
         for (int it = 0; it < T::NITER; ++it) {
             const int p = it * 256 + tid;
             const int vox = p / PPV, part = p % PPV;
             const int hz = vox / (T::HY * T::HX), rem = vox % (T::HY * T::HX);
             const int hy = rem / T::HX, hx = rem % T::HX;
-            const int tapk = chunk / a.cpt, cch = chunk - tapk * a.cpt;     // input child (ConvT dgrad), else 0
-            const int gz = (z0 - T::HALO + hz) * a.in_mul + a.toff[tapk][0];
-            const int gy = (y0 - T::HALO + hy) * a.in_mul + a.toff[tapk][1];
-            const int gx = (x0 - T::HALO + hx) * a.in_mul + a.toff[tapk][2];
+            const int tapk = PLAIN ? 0 : chunk / a.cpt, cch = PLAIN ? chunk : chunk - tapk * a.cpt;     // input child (ConvT dgrad), else 0
+            const int gz = (c.z0 - T::HALO + hz) * in_mul + (PLAIN ? 0 : a.toff[tapk][0]);
+            const int gy = (c.y0 - T::HALO + hy) * in_mul + (PLAIN ? 0 : a.toff[tapk][1]);
+            const int gx = (c.x0 - T::HALO + hx) * in_mul + (PLAIN ? 0 : a.toff[tapk][2]);
             const bool ok = (p < T::NPIECE) && (unsigned)gz < (unsigned)Di && (unsigned)gy < (unsigned)Hi && (unsigned)gx < (unsigned)Wi;
             stage_t v = {};
             if (ok) {
-                const long long off = ((((long long)n * Di + gz) * Hi + gy) * Wi + gx) * a.ldx + cch * CK + part * MT::EPP;
+                const long long off = ((((long long)c.n * Di + gz) * Hi + gy) * Wi + gx) * a.ldx + cch * CK + part * MT::EPP;
                 v = *reinterpret_cast<const stage_t*>(xin + off);
             }
             stage[it] = v;
@@ -228,7 +245,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
         }
     };
 
-    load_stage(c0);
+    load_stage(tc, tc.ks * a.cps);
+    for (;;) {
+    const int ks = tc.ks, ntile = tc.ntile, mtile = tc.mtile, n = tc.n, x0 = tc.x0, y0 = tc.y0, z0 = tc.z0;
+    const int tapn = PLAIN ? 0 : ntile / a.nNpt;              // output child (ConvT fwd), else 0
+    const int n0 = (PLAIN ? ntile : ntile % a.nNpt) * NT;
+    const int c0 = ks * a.cps, c1 = c0 + a.cps;             // this split's chunk range
+    bool has_next = false;
+    if constexpr (PERSIST) {
+        local += xslots;
+        has_next = local < xcnt;
+        if (has_next) tn = decode(xstart + local);
+    }
+    // the chunk after `chunk`: the next one of this tile, else the first one of this workgroup's next tile
+    auto prefetch = [&](int chunk) {
+        if (chunk + 1 < c1) load_stage(tc, chunk + 1);
+        else if (PERSIST && has_next) load_stage(tn, tn.ks * a.cps);
+    };
+    f32x16 acc[MB][NBW];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[mb][nb][v] = 0.f;
     if constexpr (MATH == MATH_F32) {
         constexpr int STEP_FLOATS = 2 * NT * 4;                 // packed weights consumed per (tap, kk) step
         constexpr int CHUNK_FLOATS = NTAP * (CK / 8) * STEP_FLOATS;
@@ -251,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
                 write_stage();
                 __syncthreads();
             }
-            if (chunk + 1 < c1 && !SEG_DBG(a, 1)) load_stage(chunk + 1);
+            if (!SEG_DBG(a, 1)) prefetch(chunk);
 #pragma unroll
             for (int tap = 0; tap < NTAP; ++tap) {
                 const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
@@ -288,7 +328,69 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
         constexpr int CHUNK = NSTEP * STEP;
         const bf16* lds = reinterpret_cast<const bf16*>(lds_raw);
         const bf16* wlane = reinterpret_cast<const bf16*>(a.wq) + (long long)ntile * a.nchunks * CHUNK + (h * NT + i) * 8;
-        if constexpr (NP == 3 && NSTEP > 4) {
+        if constexpr (T::SLIDE) {
+            // bf16 k3, sliding window along y.  At one MFMA per (voxel fragment, weight fragment) pair the plain loop reads a
+            // 1 KB fragment from LDS per MFMA -- exactly the LDS bandwidth of a CU at full MFMA rate, so LDS, not the matrix
+            // core, set the pace (0.42 MFMA-busy).  Here the wave walks the MB + 2 halo lines of its z-slab once per (dz, dx):
+            // line y' feeds the blocks y' - dy, dy = 0..2, against the three weight fragments of that (dz, dx) column.
+            constexpr int NG = 9 * KSTEPS;                          // (dz, dx, k-step) groups
+            constexpr int NL = MB + 2;                              // halo lines per group
+            constexpr int NB3 = 3 * NBW;                            // weight fragments per group
+            constexpr int BPL = (NB3 + NL - 1) / NL;                // ... requested per line block
+            constexpr int AD = 3;                                   // fragment reads in flight
+            constexpr int BD = MB * NBW >= 6 ? 1 : 2;               // weight groups in flight (register-bound on the deep tiles)
+            const int aslab = (wave_m * T::HY) * T::ROW + i * PITCH + 8 * h;
+            auto a_off = [&](int q) {
+                const int g = q / NL, hy = q % NL, gk = g / KSTEPS, kk = g % KSTEPS;
+                return aslab + ((gk / 3) * T::HY + hy) * T::ROW + (gk % 3) * PITCH + kk * 16;
+            };
+            auto b_ptr = [&](const bf16* wp, int g, int f) {        // fragment f = (dy, nb) of group g = (dz, dx, kk)
+                const int gk = g / KSTEPS, kk = g % KSTEPS, dy = f / NBW, nb = f % NBW;
+                const int tap = (gk / 3) * 9 + dy * 3 + gk % 3;
+                return wp + (tap * KSTEPS + kk) * STEP + (nbase + nb) * 256;
+            };
+            for (int chunk = c0; chunk < c1; ++chunk) {
+                const bf16* wp = wlane + (long long)chunk * CHUNK;
+                bf16x8_t bq[BD + 1][NB3], av[AD + 1];
+#pragma unroll
+                for (int d = 0; d < BD; ++d)
+#pragma unroll
+                    for (int f = 0; f < NB3; ++f) bq[d][f] = *reinterpret_cast<const bf16x8_t*>(b_ptr(wp, d, f));
+                __syncthreads();
+                write_stage();
+                __syncthreads();
+                prefetch(chunk);
+#pragma unroll
+                for (int q = 0; q < AD; ++q) av[q] = *reinterpret_cast<const bf16x8_t*>(lds + a_off(q));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                    for (int hy = 0; hy < NL; ++hy) {
+                        const int q = g * NL + hy;
+                        if (q + AD < NG * NL) av[(q + AD) % (AD + 1)] = *reinterpret_cast<const bf16x8_t*>(lds + a_off(q + AD));
+                        if (g + BD < NG) {
+#pragma unroll
+                            for (int f = hy * BPL; f < (hy + 1) * BPL && f < NB3; ++f)
+                                bq[(g + BD) % (BD + 1)][f] = *reinterpret_cast<const bf16x8_t*>(b_ptr(wp, g + BD, f));
+                        }
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy) {
+                            const int mb = hy - dy;
+                            if (mb >= 0 && mb < MB) {
+#pragma unroll
+                                for (int nb = 0; nb < NBW; ++nb)
+                                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q % (AD + 1)], bq[g % (BD + 1)][dy * NBW + nb], acc[mb][nb], 0, 0, 0);
+                            }
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, BPL, 0);
+                        __builtin_amdgcn_sched_barrier(0);          // one scheduling region per halo line
+                    }
+                }
+            }
+        } else if constexpr (NP == 3 && NSTEP > 4) {
             // bf16x6: 6 * NBW MFMAs per (k-step, M-block) leave room to software-pipeline by hand -- the weights of step s+1
             // and the voxels of the next M-block are requested while the MFMAs of the current one issue, and the scheduling
             // groups pin that interleave (left alone the compiler sinks the loads next to their first use to save registers,
@@ -303,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
                 __syncthreads();
                 write_stage();
                 __syncthreads();
-                if (chunk + 1 < c1) load_stage(chunk + 1);
+                prefetch(chunk);
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) av[0][pl] = *reinterpret_cast<const bf16x8_t*>(lds + abase[0] + pl * CK);
                 __builtin_amdgcn_sched_barrier(0);
@@ -365,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
             __syncthreads();                 // every wave is done reading the previous chunk
             write_stage();
             __syncthreads();
-            if (chunk + 1 < c1) load_stage(chunk + 1);
+            prefetch(chunk);
 #pragma unroll
             for (int tap = 0; tap < NTAP; ++tap) {
                 const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
@@ -415,8 +517,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
         int col = n0 + (nbase + nb) * 32 + i, child = tapn;
-        if (a.flatn) { const int nf = ntile * NT + (nbase + nb) * 32 + i; child = nf / a.Cout; col = nf - child * a.Cout; }   // per-lane child
-        const int oz = ((child >> 2) & 1) + a.cz, oy = ((child >> 1) & 1) + a.cy, ox = (child & 1) + a.cx;
+        if (!PLAIN && a.flatn) { const int nf = ntile * NT + (nbase + nb) * 32 + i; child = nf / a.Cout; col = nf - child * a.Cout; }   // per-lane child
+        const int oz = PLAIN ? 0 : ((child >> 2) & 1) + a.cz, oy = PLAIN ? 0 : ((child >> 1) & 1) + a.cy, ox = PLAIN ? 0 : (child & 1) + a.cx;
         const float bv = a.bias ? a.bias[col] : 0.f;
         float s1 = 0.f;
 #pragma unroll
@@ -426,20 +528,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
             for (int v = 0; v < 16; ++v) {
                 const int r = (v & 3) + 8 * (v >> 2) + 4 * h;      // row of the 32x32 tile held in register v
                 const int line = m * T::LPB + r / BX, xx = r % BX;
-                const int gz = (z0 + line / T::TY) * a.out_mul + oz;
-                const int gy = (y0 + line % T::TY) * a.out_mul + oy;
-                const int gx = (x0 + xx) * a.out_mul + ox;
+                const int gz = (z0 + line / T::TY) * out_mul + oz;
+                const int gy = (y0 + line % T::TY) * out_mul + oy;
+                const int gx = (x0 + xx) * out_mul + ox;
                 const float val = acc[mb][nb][v] + bv;
                 // partial tiles (extents that are not tile multiples): rows outside the volume are dropped
                 const bool inside = (z0 + line / T::TY) < a.D && (y0 + line % T::TY) < a.H && (x0 + xx) < a.W &&
-                                    gz < a.Do && gy < a.Ho && gx < a.Wo;
+                                    gz < Do && gy < Ho && gx < Wo;
 #ifdef MI355SEG_TUNE
                 if (inside && (!(a.dbg & 4) || val == 12345.678f))
 #else
                 if (inside)
 #endif
                 {
-                    const long long off = ((((long long)n * a.Do + gz) * a.Ho + gy) * a.Wo + gx) * a.ldy + col;
+                    const long long off = ((((long long)n * Do + gz) * Ho + gy) * Wo + gx) * a.ldy + col;
                     if constexpr (MATH == MATH_B16) {
                         if (slab) yslab[off] = val; else yout[off] = (out_t)val;
                     } else {
@@ -506,6 +608,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
             dst[0] = s1; dst[1] = m2; dst[2] = cnt;
         }
     }
+    if (!has_next) break;
+    tc = tn;
+    }
 }
 
 template <int MATH, int KS, int BX, int MB, int NBW, int CK, int WN = 1>
@@ -517,7 +622,8 @@ static void launch_igemm(const IgemmArgs& a, int nwg, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<MATH, KS, BX, MB, NBW, CK, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<MATH, KS, BX, MB, NBW, CK, WN>), dim3(nwg), dim3(256), LDSB, st, a);
+    const int grid = (T::PERSIST && nwg > 512) ? 512 : nwg;   // persistent variants: two workgroups per CU walk the tiles
+    hipLaunchKernelGGL((conv_igemm_kernel<MATH, KS, BX, MB, NBW, CK, WN>), dim3(grid), dim3(256), LDSB, st, a);
 }
 
 // conv_igemm_lowp.hip: the MATH_X3 / MATH_B16 instantiations (their own translation unit: they compile in parallel)
