@@ -76,6 +76,53 @@ __global__ __launch_bounds__(256) void nsc_to_ncs_kernel(const TS* __restrict__ 
     }
 }
 
+// Narrow channel counts (the 2 / 4-class logits, 4-modality inputs): a 32 x 32 transpose tile would be 1/16 full.  One thread
+// moves four consecutive voxels of all C channels -- 4C contiguous elements on the channel-last side, one 4-voxel vector per
+// channel plane on the channel-first side.  Needs S % 4 == 0, a dense channel-last side (ld == C) and 16-byte bases.
+template <typename TS, typename TD, int C, bool TO_NCS>
+__global__ __launch_bounds__(256) void narrow_layout_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long long S, long long groups) {
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < groups; g += (long long)gridDim.x * 256) {
+        const long long v0 = g * 4, n = v0 / S, s = v0 - n * S;
+        float v[4][C];
+        if constexpr (TO_NCS) {
+            const TS* sp = src + v0 * C;
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                const f32x4_t q = ld4(sp + 4 * k);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[(4 * k + j) / C][(4 * k + j) % C] = q[j];
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) st4(dst + (n * C + c) * S + s, f32x4_t{v[0][c], v[1][c], v[2][c], v[3][c]});
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const f32x4_t q = ld4(src + (n * C + c) * S + s);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j][c] = q[j];
+            }
+            TD* dp = dst + v0 * C;
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                f32x4_t q;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q[j] = v[(4 * k + j) / C][(4 * k + j) % C];
+                st4(dp + 4 * k, q);
+            }
+        }
+    }
+}
+template <typename TS, typename TD, bool TO_NCS>
+static bool narrow_layout(const TS* src, TD* dst, int ld, long long N, int C, long long S, hipStream_t st) {
+    if (C < 2 || C > 4 || ld != C || (S % 4) || (((uintptr_t)src | (uintptr_t)dst) % 16)) return false;
+    const long long groups = N * S / 4;
+    const int grid = (int)((groups + 255) / 256 < 8192 ? (groups + 255) / 256 : 8192);
+    if (C == 2) hipLaunchKernelGGL((narrow_layout_kernel<TS, TD, 2, TO_NCS>), dim3(grid), dim3(256), 0, st, src, dst, S, groups);
+    else if (C == 3) hipLaunchKernelGGL((narrow_layout_kernel<TS, TD, 3, TO_NCS>), dim3(grid), dim3(256), 0, st, src, dst, S, groups);
+    else hipLaunchKernelGGL((narrow_layout_kernel<TS, TD, 4, TO_NCS>), dim3(grid), dim3(256), 0, st, src, dst, S, groups);
+    return true;
+}
+
 template <typename T, bool ADD>
 __global__ __launch_bounds__(256) void rows_kernel(const T* __restrict__ src, int lds, T* __restrict__ dst, int ldd,
                                                     long long rows, int C) {
@@ -241,6 +288,7 @@ int mi355seg_prof_read(double* out, int n) {
 
 int mi355seg_ncdhw_to_ndhwc_f32(const float* src, float* dst, int lddst, long long N, int C, long long S, void* stream) {
     SEG_CHECK_ARG(src && dst && N > 0 && C > 0 && S > 0 && lddst >= C && N < 65536, "ncdhw_to_ndhwc: bad arguments");
+    if (narrow_layout<float, float, false>(src, dst, lddst, N, C, S, (hipStream_t)stream)) { SEG_CHECK_LAUNCH(); return MI355SEG_OK; }
     dim3 grid((unsigned)((S + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N);
     hipLaunchKernelGGL((ncs_to_nsc_kernel<float, float>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, lddst, C, S);
     SEG_CHECK_LAUNCH();
@@ -248,6 +296,7 @@ int mi355seg_ncdhw_to_ndhwc_f32(const float* src, float* dst, int lddst, long lo
 }
 int mi355seg_ncdhw_f32_to_ndhwc_bf16(const float* src, mi355seg_bf16* dst, int lddst, long long N, int C, long long S, void* stream) {
     SEG_CHECK_ARG(src && dst && N > 0 && C > 0 && S > 0 && lddst >= C && N < 65536, "ncdhw_f32_to_ndhwc_bf16: bad arguments");
+    if (narrow_layout<float, bf16, false>(src, dst, lddst, N, C, S, (hipStream_t)stream)) { SEG_CHECK_LAUNCH(); return MI355SEG_OK; }
     dim3 grid((unsigned)((S + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N);
     hipLaunchKernelGGL((ncs_to_nsc_kernel<float, bf16>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, lddst, C, S);
     SEG_CHECK_LAUNCH();
@@ -255,6 +304,7 @@ int mi355seg_ncdhw_f32_to_ndhwc_bf16(const float* src, mi355seg_bf16* dst, int l
 }
 int mi355seg_ndhwc_to_ncdhw_f32(const float* src, int ldsrc, float* dst, long long N, int C, long long S, void* stream) {
     SEG_CHECK_ARG(src && dst && N > 0 && C > 0 && S > 0 && ldsrc >= C && N < 65536, "ndhwc_to_ncdhw: bad arguments");
+    if (narrow_layout<float, float, true>(src, dst, ldsrc, N, C, S, (hipStream_t)stream)) { SEG_CHECK_LAUNCH(); return MI355SEG_OK; }
     dim3 grid((unsigned)((S + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N);
     hipLaunchKernelGGL((nsc_to_ncs_kernel<float, float>), grid, dim3(256), 0, (hipStream_t)stream, src, ldsrc, dst, C, S);
     SEG_CHECK_LAUNCH();
@@ -262,6 +312,7 @@ int mi355seg_ndhwc_to_ncdhw_f32(const float* src, int ldsrc, float* dst, long lo
 }
 int mi355seg_ndhwc_bf16_to_ncdhw_f32(const mi355seg_bf16* src, int ldsrc, float* dst, long long N, int C, long long S, void* stream) {
     SEG_CHECK_ARG(src && dst && N > 0 && C > 0 && S > 0 && ldsrc >= C && N < 65536, "ndhwc_bf16_to_ncdhw_f32: bad arguments");
+    if (narrow_layout<bf16, float, true>(src, dst, ldsrc, N, C, S, (hipStream_t)stream)) { SEG_CHECK_LAUNCH(); return MI355SEG_OK; }
     dim3 grid((unsigned)((S + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N);
     hipLaunchKernelGGL((nsc_to_ncs_kernel<bf16, float>), grid, dim3(256), 0, (hipStream_t)stream, src, ldsrc, dst, C, S);
     SEG_CHECK_LAUNCH();

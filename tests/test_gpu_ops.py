@@ -494,9 +494,11 @@ def test_split_precision_conv_is_fp32_accurate(seg, case):
         assert e6 < 4.0 * e32 + 2e-7 * max(1.0, sc), (what, e6, e32, sc)
 
 
-def test_layout_roundtrip(seg):
+@pytest.mark.parametrize("shape", [(2, 5, 4, 6, 7), (2, 2, 4, 6, 8), (1, 3, 4, 6, 8), (3, 4, 2, 6, 10), (2, 2, 3, 5, 7), (1, 1, 4, 4, 4)])
+def test_layout_roundtrip(seg, shape):
+    """32 x 32 transpose tiles, the narrow-channel kernel (C <= 4, S % 4 == 0) and its fall-back (S % 4 != 0)."""
     F = seg.functional
-    x = rnd(2, 5, 4, 6, 7, seed=1)
+    x = rnd(*shape, seed=1)
     y = F.to_channels_last(x.cuda())
     assert torch.equal(y.cpu(), x.permute(0, 2, 3, 4, 1).contiguous())
     assert torch.equal(F.to_channels_first(y).cpu(), x)
