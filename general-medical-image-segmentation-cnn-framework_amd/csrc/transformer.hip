@@ -360,6 +360,19 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __re
 
 using namespace seg;
 
+// column sums of a short matrix (the bias gradient of a token Linear): 64 columns per workgroup, four row groups whose
+// partial sums are added in fixed order
+__global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restrict__ x, int ldx, int rows, int C, float* __restrict__ out) {
+    __shared__ float sh[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < C)
+        for (int r = rg; r < rows; r += 4) s += x[(long long)r * ldx + c];
+    sh[rg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rg == 0 && c < C) out[c] = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
+}
+
 extern "C" {
 
 size_t mi355seg_gemm_ws_bytes(int M, int N, int K, int nb0, int nb1) {
@@ -445,6 +458,11 @@ int mi355seg_softmax_rows_bwd_f32(const float* y, const float* dy, float* dx, lo
 /* out[c] = sum_rows x[r, c]  (bias gradients of Linear layers) */
 int mi355seg_colsum_f32(const float* x, int ldx, long long rows, int C, float* out, void* ws, size_t ws_bytes, void* stream) {
     SEG_CHECK_ARG(x && out && rows > 0 && C > 0 && ldx >= C, "colsum: bad arguments");
+    if (rows <= 1024) {                        // token matrices (a few hundred rows): one launch, fixed summation order
+        hipLaunchKernelGGL(colsum_small_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)rows, C, out);
+        SEG_CHECK_LAUNCH();
+        return MI355SEG_OK;
+    }
     return channel_sums(x, ldx, rows, C, nullptr, nullptr, out, 0, ws, ws_bytes, (hipStream_t)stream);
 }
 
