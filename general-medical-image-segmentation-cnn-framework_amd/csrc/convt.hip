@@ -129,6 +129,8 @@ size_t mi355seg_convt3d_k2s2_ws_bytes(int N, int D, int H, int W, int Cin, int C
     size_t red = colsum_ws_bytes(Cout);
     size_t pw = pw_wgrad_ws_bytes((long long)N * D * H * W, Cin, Cout, 8);
     if (pw > part) part = pw;
+    const size_t lw = convt_wgrad_lowp_ws_bytes((long long)N * D * H * W, Cin, Cout);
+    if (lw > part) part = lw;
     return wb + (part > red ? part : red) + 1024;
 }
 
