@@ -83,6 +83,26 @@ __device__ __forceinline__ float4 ldf4(const bf16* p) {
     const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(p);
     return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
+// ld8 / st8: eight consecutive elements as floats (32 bytes of fp32, 16 of bf16; the pointer must be aligned to that)
+__device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void ld8(const bf16* p, float (&v)[8]) {
+    const bf16x8_t q = *reinterpret_cast<const bf16x8_t*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)q[j];
+}
+__device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void st8(bf16* p, const float (&v)[8]) {
+    bf16x8_t q;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] = (bf16)v[j];
+    *reinterpret_cast<bf16x8_t*>(p) = q;
+}
 __device__ __forceinline__ void stf4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ void stf4(bf16* p, float4 v) {
     bf16x4_t q;
