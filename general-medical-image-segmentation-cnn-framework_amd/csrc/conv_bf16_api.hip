@@ -36,10 +36,11 @@ static void cast_rows(const TS* src, int lds, TD* dst, int ldd, long long rows, 
 static int oext(int n, int k, int s, int p) { return (n + 2 * p - k) / s + 1; }
 
 // which native bf16 kernel serves a shape (0 = none: fp32 fallback)
-enum { NB_NONE = 0, NB_IGEMM, NB_GATHER, NB_STEM4, NB_STEM, NB_HEAD, NB_LOWP, NB_PW, NB_SMALLCIN, NB_SMALLCOUT, NB_GW, NB_TINY, NB_CONVT };
+enum { NB_NONE = 0, NB_IGEMM, NB_GATHER, NB_HEAD2, NB_STEM4, NB_STEM, NB_HEAD, NB_LOWP, NB_PW, NB_SMALLCIN, NB_SMALLCOUT, NB_GW, NB_TINY, NB_CONVT };
 static int native_fwd(int N, int D, int H, int W, int Cin, int Cout, int k, int s, int p, int ldx, int ldy) {
     if (conv_mfma_supported(MATH_B16, N, D, H, W, Cin, Cout, k, s, p, ldx, ldy)) return NB_IGEMM;
     if (conv_gather_fwd_supported(MATH_B16, N, D, H, W, Cin, Cout, k, s, p, ldx, ldy)) return NB_GATHER;
+    if (head2_lowp_supported(Cin, Cout, k, s, p, ldx, ldy)) return NB_HEAD2;
     if (stem4_lowp_supported(Cin, Cout, k, s, p, ldx, ldy)) return NB_STEM4;
     if (stem_supported(Cin, Cout, k, s, p, ldy)) return NB_STEM;
     if (head_supported(Cin, Cout, k, s, p, ldx)) return NB_HEAD;
@@ -49,6 +50,7 @@ static int native_fwd(int N, int D, int H, int W, int Cin, int Cout, int k, int 
 static int native_dgrad(int N, int D, int H, int W, int Cin, int Cout, int k, int s, int p, int lddy, int lddx) {
     if (conv_mfma_supported(MATH_B16, N, D, H, W, Cout, Cin, k, s, p, lddy, lddx)) return NB_IGEMM;
     if (conv_gather_dgrad_supported(MATH_B16, N, D, H, W, Cin, Cout, k, s, p, lddy, lddx)) return NB_GATHER;
+    if (head2_lowp_supported(Cin, Cout, k, s, p, lddx, lddy)) return NB_HEAD2;
     if (head_supported(Cin, Cout, k, s, p, lddx)) return NB_HEAD;
     if (tinypw_supported(Cin, Cout, k, s, p)) return NB_TINY;
     // k2 s2 p0: the input gradient is the forward of ConvTranspose3d k2 s2 with the same weight tensor (conv_generic.hip)
@@ -60,6 +62,7 @@ static int native_wgrad(int N, int D, int H, int W, int Cin, int Cout, int k, in
     if (wgrad_lowp_supported(MATH_B16, N, D, H, W, Cin, Cout, k, s, p, ldx, lddy)) return NB_LOWP;
     // V-Net's two-channel k5 head: the fp32 z-marching kernel (conv_headk.hip) behind the cast fall-back is 8x faster than the
     // generic small-channel wgrad below (the one-channel k5 stem has its own LDS-tiled kernel inside smallcin_wgrad)
+    if (head2_lowp_supported(Cin, Cout, k, s, p, ldx, lddy)) return NB_HEAD2;
     if (headk_wgrad_supported(Cin, Cout, k, s, p, Cin, Cout)) return NB_NONE;
     if (tinypw_supported(Cin, Cout, k, s, p)) return NB_TINY;
     if (k == 1 && s == 1 && p == 0 && pw_wgrad_supported((long long)N * D * H * W, Cin, Cout, 1, ldx, lddy)) return NB_PW;
@@ -86,6 +89,7 @@ size_t mi355seg_conv3d_ws_bytes_bf16(int N, int D, int H, int W, int Cin, int Co
     const bool fb = !native_fwd(N, D, H, W, Cin, Cout, k, stride, pad, Cin, Cout) || !native_dgrad(N, D, H, W, Cin, Cout, k, stride, pad, Cout, Cin) ||
                     !native_wgrad(N, D, H, W, Cin, Cout, k, stride, pad, Cin, Cout);
     if (stem4_lowp_supported(Cin, Cout, k, stride, pad, Cin, Cout) && base < stem4_lowp_ws_bytes(Cout)) base = stem4_lowp_ws_bytes(Cout);
+    if (head2_lowp_supported(Cin, Cout, k, stride, pad, Cin, Cout) && base < head2_lowp_ws_bytes(Cin)) base = head2_lowp_ws_bytes(Cin);
     if (fb) base += align_up((size_t)N * D * H * W * Cin * 4, 256) + align_up((size_t)N * Do * Ho * Wo * Cout * 4, 256) + 512;
     return base;
 }
@@ -106,6 +110,11 @@ int mi355seg_conv3d_fwd_bf16(const mi355seg_bf16* x, int ldx, const float* w, co
         return conv_fwd_mfma(MATH_B16, x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, /*dgrad=*/0, stats_sum, stats_sq, ws, ws_bytes, st);
     if (nb == NB_GATHER && al)
         return conv_gather_fwd_mfma(MATH_B16, x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, stride, pad, stats_sum, stats_sq, ws, ws_bytes, st);
+    if (nb == NB_HEAD2 && al && ((uintptr_t)y % 4) == 0) {
+        int rc = head2_fwd_lowp(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, ws, ws_bytes, st);
+        if (rc || !stats_sum) return rc;
+        return channel_sums(y, ldy, vout, Cout, stats_sum, stats_sq, nullptr, 0, ws, ws_bytes, st);
+    }
     if (nb == NB_STEM4 && ((uintptr_t)x % 8) == 0 && ((uintptr_t)y % 8) == 0) {
         int rc = stem4_fwd_lowp(x, w, bias, y, ldy, N, D, H, W, Cout, ws, ws_bytes, st);
         if (rc || !stats_sum) return rc;
@@ -153,6 +162,8 @@ int mi355seg_conv3d_dgrad_bf16(const mi355seg_bf16* dy, int lddy, const float* w
         return conv_fwd_mfma(MATH_B16, dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cout, Cin, k, /*dgrad=*/1, nullptr, nullptr, ws, ws_bytes, st);
     if (nb == NB_GATHER && al)
         return conv_gather_dgrad_mfma(MATH_B16, dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, k, stride, pad, ws, ws_bytes, st);
+    if (nb == NB_HEAD2 && ((uintptr_t)dy % 4) == 0 && ((uintptr_t)dx % 8) == 0)
+        return head2_dgrad_lowp(dy, lddy, w, dx, lddx, N, D, H, W, Cin, ws, ws_bytes, st);
     if (nb == NB_HEAD && ((uintptr_t)dx % 8) == 0)
         return head_dgrad(dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, st);
     if (nb == NB_TINY) return tinypw_dgrad(dy, lddy, w, dx, lddx, vin, Cin, Cout, st);
@@ -186,6 +197,8 @@ int mi355seg_conv3d_wgrad_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg
     }
     const bool al16 = ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, al8 = ((uintptr_t)x % 8) == 0 && ((uintptr_t)dy % 8) == 0;
     const int nb = native_wgrad(N, D, H, W, Cin, Cout, k, stride, pad, ldx, lddy);
+    if (nb == NB_HEAD2 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 4) == 0)
+        return head2_wgrad_lowp(dy, lddy, x, ldx, dw, N, D, H, W, Cin, accumulate, ws, ws_bytes, st);
     if (nb == NB_LOWP && al16) return conv_wgrad_lowp(MATH_B16, dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, stride, accumulate, ws, ws_bytes, st);
     if (nb == NB_PW && al8) {
         float* part; int nstrips;

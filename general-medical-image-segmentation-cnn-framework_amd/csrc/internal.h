@@ -44,6 +44,15 @@ template <typename T> int smallcin_wgrad(const T* dy, int lddy, const T* x, int 
                    int k, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 template <typename T> int smallcout_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
                     int k, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+// conv_head2_lowp.hip -- the two-channel k5 head on the bf16 matrix cores ((dx, co) as the GEMM's narrow axis), bf16 tensors
+bool head2_lowp_supported(int Cin, int Cout, int k, int stride, int pad, int ld_wide, int ld_narrow);
+size_t head2_lowp_ws_bytes(int Cin);
+int head2_fwd_lowp(const bf16* x, int ldx, const float* w, const float* bias, bf16* y, int ldy, int N, int D, int H, int W, int Cin,
+                   void* ws, size_t ws_bytes, hipStream_t st);
+int head2_dgrad_lowp(const bf16* dy, int lddy, const float* w, bf16* dx, int lddx, int N, int D, int H, int W, int Cin,
+                     void* ws, size_t ws_bytes, hipStream_t st);
+int head2_wgrad_lowp(const bf16* dy, int lddy, const bf16* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int accumulate,
+                     void* ws, size_t ws_bytes, hipStream_t st);
 // conv_headk.hip -- odd-kernel "same" convolutions with two output channels (V-Net head), z-marching VALU kernels
 bool headk_supported(int Cin, int Cout, int k, int stride, int pad, int ldx_in, int ld_out, bool dgrad);
 size_t headk_ws_bytes(int Cin, int Cout, int k);
