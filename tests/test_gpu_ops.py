@@ -331,6 +331,9 @@ GEMM_CASES = [
     (768, 768, 216, True, False, False, False, False),    # Linear wgrad (dy^T @ x), K = tokens
     (37, 53, 29, False, False, True, False, True),        # ragged, unaligned strides -> scalar reads, accumulate
     (130, 70, 260, True, True, False, False, True),       # ragged split-K with both operands transposed
+    (100, 72, 264, True, True, True, False, True),        # LDS-free 32x32 kernel, A along its outer index / B along k, edge tiles
+    (45, 40, 64, False, True, False, True, False),        # ... both along k, one k-block per wave, edge tiles in M and N
+    (33, 31, 8, False, False, True, False, False),        # ... a single k-block: three of the four waves have nothing to add
 ]
 
 
