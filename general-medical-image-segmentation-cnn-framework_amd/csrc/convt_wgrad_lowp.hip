@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void convt_wgrad_lowp_kernel(CwArgs a) {
         for (int it = 0; it < DIT; ++it) {
             const int pc = it * 256 + tid, part = pc % PPV, vl = (pc / PPV) % C::V, tap = pc / (PPV * C::V);
             stage_t dv = {};
-            if (v0 + vl < nvox) {
+            if (v0 + vl < nvox && co0 + part * EPP < a.Cout) {       // a ragged last co block (Cout % 32 == 16) stages zeros
                 long long v = v0 + vl;
                 const int xw = (int)(v % a.W); v /= a.W;
                 const int yh = (int)(v % a.H); v /= a.H;
@@ -174,18 +174,20 @@ __global__ __launch_bounds__(256, 2) void convt_wgrad_lowp_kernel(CwArgs a) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             float* dst = a.part + (((long long)strip * 8 + 2 * wave + tt) * a.Cin + ci0 + cb * 32) * a.Cout + co0 + i;
+            if (co0 + i < a.Cout) {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) dst[(long long)((v & 3) + 8 * (v >> 2) + 4 * h) * a.Cout] = acc[cb][tt][v];
+                for (int v = 0; v < 16; ++v) dst[(long long)((v & 3) + 8 * (v >> 2) + 4 * h) * a.Cout] = acc[cb][tt][v];
+            }
         }
 }
 
 struct CwPlan { int ntiles, nstrips, npairs; };
 
 static bool cw_plan(int NP, long long nvox, int Cin, int Cout, CwPlan* p) {
-    if (Cin % 64 || Cout % 32 || nvox < 1) return false;
+    if (Cin % 64 || Cout % 16 || nvox < 1) return false;          // 16-byte staged pieces; a half-empty last co block is allowed
     const int V = NP == 3 ? 32 : 64;
     p->ntiles = (int)((nvox + V - 1) / V);
-    p->npairs = (Cin / 64) * (Cout / 32);
+    p->npairs = (Cin / 64) * ((Cout + 31) / 32);
     int want = 512 / p->npairs;                        // two workgroups per CU
     long long cap = (long long)(64u << 20) / ((long long)8 * Cin * Cout * 4);
     if (cap < 1) cap = 1;
@@ -224,7 +226,7 @@ int convt_wgrad_lowp(const IN_T* dy, int lddy, const IN_T* x, int ldx, int N, in
     Carver cv(ws);
     float* part = cv.take<float>((size_t)p.nstrips * 8 * Cin * Cout);
     SEG_CHECK_WS(cv.used(), ws_bytes);
-    CwArgs a{x, dy, part, ldx, lddy, N, D, H, W, Cin, Cout, p.ntiles, p.nstrips, p.npairs, Cout / 32};
+    CwArgs a{x, dy, part, ldx, lddy, N, D, H, W, Cin, Cout, p.ntiles, p.nstrips, p.npairs, (Cout + 31) / 32};
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute((const void*)convt_wgrad_lowp_kernel<NP, IN_T>, hipFuncAttributeMaxDynamicSharedMemorySize, CwCfg<NP>::LDS_BYTES); set = true; }
     ProfScope ps(PF_CONVT, 2.0 * nvox * 8 * Cin * Cout, (double)sizeof(IN_T) * nvox * (Cin + 8.0 * Cout) + 32.0 * Cin * Cout, st);
