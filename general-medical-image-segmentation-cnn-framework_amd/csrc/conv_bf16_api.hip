@@ -36,7 +36,7 @@ static void cast_rows(const TS* src, int lds, TD* dst, int ldd, long long rows, 
 static int oext(int n, int k, int s, int p) { return (n + 2 * p - k) / s + 1; }
 
 // which native bf16 kernel serves a shape (0 = none: fp32 fallback)
-enum { NB_NONE = 0, NB_IGEMM, NB_GATHER, NB_HEAD2, NB_STEM4, NB_STEM, NB_HEAD, NB_LOWP, NB_PW, NB_SMALLCIN, NB_SMALLCOUT, NB_GW, NB_TINY, NB_CONVT };
+enum { NB_NONE = 0, NB_IGEMM, NB_GATHER, NB_K2S2W, NB_HEAD2, NB_STEM4, NB_STEM, NB_HEAD, NB_LOWP, NB_PW, NB_SMALLCIN, NB_SMALLCOUT, NB_GW, NB_TINY, NB_CONVT };
 static int native_fwd(int N, int D, int H, int W, int Cin, int Cout, int k, int s, int p, int ldx, int ldy) {
     if (conv_mfma_supported(MATH_B16, N, D, H, W, Cin, Cout, k, s, p, ldx, ldy)) return NB_IGEMM;
     if (conv_gather_fwd_supported(MATH_B16, N, D, H, W, Cin, Cout, k, s, p, ldx, ldy)) return NB_GATHER;
@@ -63,6 +63,10 @@ static int native_wgrad(int N, int D, int H, int W, int Cin, int Cout, int k, in
     // V-Net's two-channel k5 head: the fp32 z-marching kernel (conv_headk.hip) behind the cast fall-back is 8x faster than the
     // generic small-channel wgrad below (the one-channel k5 stem has its own LDS-tiled kernel inside smallcin_wgrad)
     if (head2_lowp_supported(Cin, Cout, k, s, p, ldx, lddy)) return NB_HEAD2;
+    // k2 s2 down-convolution (V-Net): its weight gradient IS a ConvTranspose k2 s2 weight gradient with the roles swapped
+    // (base voxels = the coarse dy, children = the fine x), and (Cout, Cin, 2, 2, 2) is that kernel's output layout
+    if (k == 2 && s == 2 && p == 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0 &&
+        convt_wgrad_lowp_supported((long long)N * (D / 2) * (H / 2) * (W / 2), Cout, Cin, lddy, ldx, 2)) return NB_K2S2W;
     if (headk_wgrad_supported(Cin, Cout, k, s, p, Cin, Cout)) return NB_NONE;
     if (tinypw_supported(Cin, Cout, k, s, p)) return NB_TINY;
     if (k == 1 && s == 1 && p == 0 && pw_wgrad_supported((long long)N * D * H * W, Cin, Cout, 1, ldx, lddy)) return NB_PW;
@@ -90,6 +94,8 @@ size_t mi355seg_conv3d_ws_bytes_bf16(int N, int D, int H, int W, int Cin, int Co
                     !native_wgrad(N, D, H, W, Cin, Cout, k, stride, pad, Cin, Cout);
     if (stem4_lowp_supported(Cin, Cout, k, stride, pad, Cin, Cout) && base < stem4_lowp_ws_bytes(Cout)) base = stem4_lowp_ws_bytes(Cout);
     if (head2_lowp_supported(Cin, Cout, k, stride, pad, Cin, Cout) && base < head2_lowp_ws_bytes(Cin)) base = head2_lowp_ws_bytes(Cin);
+    if (k == 2 && stride == 2 && pad == 0 && base < convt_wgrad_lowp_ws_bytes((long long)N * (D / 2) * (H / 2) * (W / 2), Cout, Cin))
+        base = convt_wgrad_lowp_ws_bytes((long long)N * (D / 2) * (H / 2) * (W / 2), Cout, Cin);
     if (fb) base += align_up((size_t)N * D * H * W * Cin * 4, 256) + align_up((size_t)N * Do * Ho * Wo * Cout * 4, 256) + 512;
     return base;
 }
@@ -197,6 +203,14 @@ int mi355seg_conv3d_wgrad_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg
     }
     const bool al16 = ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, al8 = ((uintptr_t)x % 8) == 0 && ((uintptr_t)dy % 8) == 0;
     const int nb = native_wgrad(N, D, H, W, Cin, Cout, k, stride, pad, ldx, lddy);
+    if (nb == NB_K2S2W && al16 && !accumulate) {
+        float* part; int nstrips;
+        int rc = convt_wgrad_lowp(x, ldx, dy, lddy, N, D / 2, H / 2, W / 2, Cout, Cin, &part, &nstrips, ws, ws_bytes, st);
+        if (rc) return rc;
+        convt_wgrad_reduce(part, dw, nstrips, Cout, Cin, st);
+        SEG_CHECK_LAUNCH();
+        return MI355SEG_OK;
+    }
     if (nb == NB_HEAD2 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 4) == 0)
         return head2_wgrad_lowp(dy, lddy, x, ldx, dw, N, D, H, W, Cin, accumulate, ws, ws_bytes, st);
     if (nb == NB_LOWP && al16) return conv_wgrad_lowp(MATH_B16, dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, stride, accumulate, ws, ws_bytes, st);

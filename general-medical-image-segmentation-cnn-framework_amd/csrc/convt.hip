@@ -104,6 +104,12 @@ __global__ void convt_wgrad_reduce_kernel(const float* __restrict__ part, float*
     }
 }
 
+void convt_wgrad_reduce(const float* part, float* dw, int splits, int Cin, int Cout, hipStream_t st) {
+    const long long total = (long long)8 * Cin * Cout;
+    const long long b = (total + 255) / 256;
+    hipLaunchKernelGGL(convt_wgrad_reduce_kernel, dim3((unsigned)(b > 4096 ? 4096 : b)), dim3(256), 0, st, part, dw, splits, Cin, Cout);
+}
+
 static int convt_splits(long long nvox, int Cin, int Cout) {
     int pairblocks = cdiv((long long)Cin * Cout, 256);
     long long want = 4096 / ((long long)pairblocks * 8) + 1;

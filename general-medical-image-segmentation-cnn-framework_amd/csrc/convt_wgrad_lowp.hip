@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void convt_wgrad_lowp_kernel(CwArgs a) {
         for (int it = 0; it < XIT; ++it) {
             const int pc = it * 256 + tid, vl = pc / (2 * PPV), part = pc % (2 * PPV);
             stage_t xv = {};
-            if (v0 + vl < nvox) xv = *reinterpret_cast<const stage_t*>(xin + (v0 + vl) * a.ldx + ci0 + part * EPP);
+            if (v0 + vl < nvox && ci0 + part * EPP < a.Cin) xv = *reinterpret_cast<const stage_t*>(xin + (v0 + vl) * a.ldx + ci0 + part * EPP);
             sx[it] = xv;
         }
 #pragma unroll
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void convt_wgrad_lowp_kernel(CwArgs a) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             float* dst = a.part + (((long long)strip * 8 + 2 * wave + tt) * a.Cin + ci0 + cb * 32) * a.Cout + co0 + i;
-            if (co0 + i < a.Cout) {
+            if (co0 + i < a.Cout && ci0 + cb * 32 < a.Cin) {
 #pragma unroll
                 for (int v = 0; v < 16; ++v) dst[(long long)((v & 3) + 8 * (v >> 2) + 4 * h) * a.Cout] = acc[cb][tt][v];
             }
@@ -184,10 +184,10 @@ __global__ __launch_bounds__(256, 2) void convt_wgrad_lowp_kernel(CwArgs a) {
 struct CwPlan { int ntiles, nstrips, npairs; };
 
 static bool cw_plan(int NP, long long nvox, int Cin, int Cout, CwPlan* p) {
-    if (Cin % 64 || Cout % 16 || nvox < 1) return false;          // 16-byte staged pieces; a half-empty last co block is allowed
+    if (Cin % 32 || Cout % 16 || nvox < 1) return false;          // 16-byte staged pieces; half-empty last ci / co blocks are allowed
     const int V = NP == 3 ? 32 : 64;
     p->ntiles = (int)((nvox + V - 1) / V);
-    p->npairs = (Cin / 64) * ((Cout + 31) / 32);
+    p->npairs = ((Cin + 63) / 64) * ((Cout + 31) / 32);
     int want = 512 / p->npairs;                        // two workgroups per CU
     long long cap = (long long)(64u << 20) / ((long long)8 * Cin * Cout * 4);
     if (cap < 1) cap = 1;

@@ -103,6 +103,7 @@ template <typename T> int conv_gwgrad(const T* dy, int lddy, const T* x, int ldx
                 int k, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 // conv_pw_wgrad.hip -- K = voxels GEMM wgrads (T = 1: Conv3d k1, T = 8: ConvTranspose3d k2 s2)
 // convt_wgrad_lowp.hip: ConvTranspose3d k2 s2 weight gradient on the bf16 matrix cores (fp32 tensors: bf16x6 planes)
+void convt_wgrad_reduce(const float* part, float* dw, int splits, int Cin, int Cout, hipStream_t st);   // convt.hip: dw[ci][co][tap] = sum of the slabs
 size_t convt_wgrad_lowp_ws_bytes(long long nvox, int Cin, int Cout);
 bool convt_wgrad_lowp_supported(long long nvox, int Cin, int Cout, int ldx, int lddy, int elem_bytes);
 template <typename IN_T> int convt_wgrad_lowp(const IN_T* dy, int lddy, const IN_T* x, int ldx, int N, int D, int H, int W, int Cin, int Cout,
