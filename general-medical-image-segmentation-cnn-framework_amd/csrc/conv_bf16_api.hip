@@ -36,13 +36,14 @@ static void cast_rows(const TS* src, int lds, TD* dst, int ldd, long long rows, 
 static int oext(int n, int k, int s, int p) { return (n + 2 * p - k) / s + 1; }
 
 // which native bf16 kernel serves a shape (0 = none: fp32 fallback)
-enum { NB_NONE = 0, NB_IGEMM, NB_GATHER, NB_K2S2W, NB_HEAD2, NB_STEM4, NB_STEM, NB_HEAD, NB_LOWP, NB_PW, NB_SMALLCIN, NB_SMALLCOUT, NB_GW, NB_TINY, NB_CONVT };
+enum { NB_NONE = 0, NB_IGEMM, NB_GATHER, NB_HEADPW, NB_K2S2W, NB_HEAD2, NB_STEM4, NB_STEM, NB_HEAD, NB_LOWP, NB_PW, NB_SMALLCIN, NB_SMALLCOUT, NB_GW, NB_TINY, NB_CONVT };
 static int native_fwd(int N, int D, int H, int W, int Cin, int Cout, int k, int s, int p, int ldx, int ldy) {
     if (conv_mfma_supported(MATH_B16, N, D, H, W, Cin, Cout, k, s, p, ldx, ldy)) return NB_IGEMM;
     if (conv_gather_fwd_supported(MATH_B16, N, D, H, W, Cin, Cout, k, s, p, ldx, ldy)) return NB_GATHER;
     if (head2_lowp_supported(Cin, Cout, k, s, p, ldx, ldy)) return NB_HEAD2;
     if (stem4_lowp_supported(Cin, Cout, k, s, p, ldx, ldy)) return NB_STEM4;
     if (stem_supported(Cin, Cout, k, s, p, ldy)) return NB_STEM;
+    if (headpw_lowp_supported(Cin, Cout, k, s, p, ldx, ldy)) return NB_HEADPW;
     if (head_supported(Cin, Cout, k, s, p, ldx)) return NB_HEAD;
     if (tinypw_supported(Cin, Cout, k, s, p)) return NB_TINY;
     return NB_NONE;
@@ -72,6 +73,7 @@ static int native_wgrad(int N, int D, int H, int W, int Cin, int Cout, int k, in
     if (k == 1 && s == 1 && p == 0 && pw_wgrad_supported((long long)N * D * H * W, Cin, Cout, 1, ldx, lddy)) return NB_PW;
     if (stem4_lowp_supported(Cin, Cout, k, s, p, ldx, lddy)) return NB_STEM4;
     if (stem_supported(Cin, Cout, k, s, p, lddy)) return NB_STEM;
+    if (headpw_lowp_supported(Cin, Cout, k, s, p, ldx, lddy)) return NB_HEADPW;
     if (head_supported(Cin, Cout, k, s, p, ldx)) return NB_HEAD;
     if (smallcin_wgrad_supported(Cin, Cout, k)) return NB_SMALLCIN;
     if (smallcout_wgrad_supported(Cin, Cout, k, ldx)) return NB_SMALLCOUT;
@@ -94,6 +96,7 @@ size_t mi355seg_conv3d_ws_bytes_bf16(int N, int D, int H, int W, int Cin, int Co
                     !native_wgrad(N, D, H, W, Cin, Cout, k, stride, pad, Cin, Cout);
     if (stem4_lowp_supported(Cin, Cout, k, stride, pad, Cin, Cout) && base < stem4_lowp_ws_bytes(Cout)) base = stem4_lowp_ws_bytes(Cout);
     if (head2_lowp_supported(Cin, Cout, k, stride, pad, Cin, Cout) && base < head2_lowp_ws_bytes(Cin)) base = head2_lowp_ws_bytes(Cin);
+    if (headpw_lowp_supported(Cin, Cout, k, stride, pad, Cin, Cout) && base < headpw_lowp_ws_bytes(Cin, Cout)) base = headpw_lowp_ws_bytes(Cin, Cout);
     if (k == 2 && stride == 2 && pad == 0 && base < convt_wgrad_lowp_ws_bytes((long long)N * (D / 2) * (H / 2) * (W / 2), Cout, Cin))
         base = convt_wgrad_lowp_ws_bytes((long long)N * (D / 2) * (H / 2) * (W / 2), Cout, Cin);
     if (fb) base += align_up((size_t)N * D * H * W * Cin * 4, 256) + align_up((size_t)N * Do * Ho * Wo * Cout * 4, 256) + 512;
@@ -128,7 +131,12 @@ int mi355seg_conv3d_fwd_bf16(const mi355seg_bf16* x, int ldx, const float* w, co
     }
     if ((nb == NB_STEM || nb == NB_STEM4) && ((uintptr_t)y % 8) == 0)
         return stem_fwd(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, stats_sum, stats_sq, ws, ws_bytes, st);
-    if (nb == NB_HEAD && ((uintptr_t)x % 8) == 0) {
+    if (nb == NB_HEADPW && al && ((uintptr_t)y % (2 * Cout)) == 0) {
+        int rc = headpw_fwd_lowp(x, ldx, w, bias, y, ldy, vout, Cin, Cout, st);
+        if (rc || !stats_sum) return rc;
+        return channel_sums(y, ldy, vout, Cout, stats_sum, stats_sq, nullptr, 0, ws, ws_bytes, st);
+    }
+    if ((nb == NB_HEAD || nb == NB_HEADPW) && ((uintptr_t)x % 8) == 0) {
         int rc = head_fwd(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, st);
         if (rc || !stats_sum) return rc;
         return channel_sums(y, ldy, vout, Cout, stats_sum, stats_sq, nullptr, 0, ws, ws_bytes, st);
@@ -225,7 +233,8 @@ int mi355seg_conv3d_wgrad_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg
     if (nb == NB_TINY) return tinypw_wgrad(dy, lddy, x, ldx, dw, vin, Cin, Cout, accumulate, ws, ws_bytes, st);
     if (nb == NB_STEM4 && al16) return stem4_wgrad_lowp(dy, lddy, x, dw, N, D, H, W, Cout, accumulate, ws, ws_bytes, st);
     if ((nb == NB_STEM || nb == NB_STEM4) && al8) return stem_wgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, st);
-    if (nb == NB_HEAD && al8) return head_wgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, st);
+    if (nb == NB_HEADPW && al16) return headpw_wgrad_lowp(dy, lddy, x, ldx, dw, vin, Cin, Cout, accumulate, ws, ws_bytes, st);
+    if ((nb == NB_HEAD || nb == NB_HEADPW) && al8) return head_wgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, st);
     if (nb == NB_SMALLCIN && al8) return smallcin_wgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, stride, pad, accumulate, ws, ws_bytes, st);
     if (nb == NB_SMALLCOUT && al8) return smallcout_wgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, stride, pad, accumulate, ws, ws_bytes, st);
     if (nb == NB_GW && al8) return conv_gwgrad(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, stride, pad, accumulate, ws, ws_bytes, st);

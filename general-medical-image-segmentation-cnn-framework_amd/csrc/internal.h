@@ -44,6 +44,12 @@ template <typename T> int smallcin_wgrad(const T* dy, int lddy, const T* x, int 
                    int k, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 template <typename T> int smallcout_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
                     int k, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+// conv_headpw_lowp.hip -- pointwise heads (k1, Cout = 2 | 4) for bf16 tensors: the matrix core contracts the channels
+bool headpw_lowp_supported(int Cin, int Cout, int k, int stride, int pad, int ldx, int ldy);
+size_t headpw_lowp_ws_bytes(int Cin, int Cout);
+int headpw_fwd_lowp(const bf16* x, int ldx, const float* w, const float* bias, bf16* y, int ldy, long long nvox, int Cin, int Cout, hipStream_t st);
+int headpw_wgrad_lowp(const bf16* dy, int lddy, const bf16* x, int ldx, float* dw, long long nvox, int Cin, int Cout, int accumulate,
+                      void* ws, size_t ws_bytes, hipStream_t st);
 // conv_head2_lowp.hip -- the two-channel k5 head on the bf16 matrix cores ((dx, co) as the GEMM's narrow axis), bf16 tensors
 bool head2_lowp_supported(int Cin, int Cout, int k, int stride, int pad, int ld_wide, int ld_narrow);
 size_t head2_lowp_ws_bytes(int Cin);
