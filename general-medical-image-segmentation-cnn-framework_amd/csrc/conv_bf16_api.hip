@@ -36,7 +36,7 @@ static void cast_rows(const TS* src, int lds, TD* dst, int ldd, long long rows, 
 static int oext(int n, int k, int s, int p) { return (n + 2 * p - k) / s + 1; }
 
 // which native bf16 kernel serves a shape (0 = none: fp32 fallback)
-enum { NB_NONE = 0, NB_IGEMM, NB_GATHER, NB_HEADPW, NB_K2S2W, NB_HEAD2, NB_STEM4, NB_STEM, NB_HEAD, NB_LOWP, NB_PW, NB_SMALLCIN, NB_SMALLCOUT, NB_GW, NB_TINY, NB_CONVT };
+enum { NB_NONE = 0, NB_IGEMM, NB_GATHER, NB_PWL, NB_HEADPW, NB_K2S2W, NB_HEAD2, NB_STEM4, NB_STEM, NB_HEAD, NB_LOWP, NB_PW, NB_SMALLCIN, NB_SMALLCOUT, NB_GW, NB_TINY, NB_CONVT };
 static int native_fwd(int N, int D, int H, int W, int Cin, int Cout, int k, int s, int p, int ldx, int ldy) {
     if (conv_mfma_supported(MATH_B16, N, D, H, W, Cin, Cout, k, s, p, ldx, ldy)) return NB_IGEMM;
     if (conv_gather_fwd_supported(MATH_B16, N, D, H, W, Cin, Cout, k, s, p, ldx, ldy)) return NB_GATHER;
@@ -70,6 +70,7 @@ static int native_wgrad(int N, int D, int H, int W, int Cin, int Cout, int k, in
         convt_wgrad_lowp_supported((long long)N * (D / 2) * (H / 2) * (W / 2), Cout, Cin, lddy, ldx, 2)) return NB_K2S2W;
     if (headk_wgrad_supported(Cin, Cout, k, s, p, Cin, Cout)) return NB_NONE;
     if (tinypw_supported(Cin, Cout, k, s, p)) return NB_TINY;
+    if (k == 1 && s == 1 && p == 0 && pw_wgrad_lowp_supported((long long)N * D * H * W, Cin, Cout, ldx, lddy, 2)) return NB_PWL;
     if (k == 1 && s == 1 && p == 0 && pw_wgrad_supported((long long)N * D * H * W, Cin, Cout, 1, ldx, lddy)) return NB_PW;
     if (stem4_lowp_supported(Cin, Cout, k, s, p, ldx, lddy)) return NB_STEM4;
     if (stem_supported(Cin, Cout, k, s, p, lddy)) return NB_STEM;
@@ -97,6 +98,7 @@ size_t mi355seg_conv3d_ws_bytes_bf16(int N, int D, int H, int W, int Cin, int Co
     if (stem4_lowp_supported(Cin, Cout, k, stride, pad, Cin, Cout) && base < stem4_lowp_ws_bytes(Cout)) base = stem4_lowp_ws_bytes(Cout);
     if (head2_lowp_supported(Cin, Cout, k, stride, pad, Cin, Cout) && base < head2_lowp_ws_bytes(Cin)) base = head2_lowp_ws_bytes(Cin);
     if (headpw_lowp_supported(Cin, Cout, k, stride, pad, Cin, Cout) && base < headpw_lowp_ws_bytes(Cin, Cout)) base = headpw_lowp_ws_bytes(Cin, Cout);
+    if (k == 1 && stride == 1 && pad == 0 && base < pw_wgrad_lowp_ws_bytes((long long)N * D * H * W, Cin, Cout)) base = pw_wgrad_lowp_ws_bytes((long long)N * D * H * W, Cin, Cout);
     if (k == 2 && stride == 2 && pad == 0 && base < convt_wgrad_lowp_ws_bytes((long long)N * (D / 2) * (H / 2) * (W / 2), Cout, Cin))
         base = convt_wgrad_lowp_ws_bytes((long long)N * (D / 2) * (H / 2) * (W / 2), Cout, Cin);
     if (fb) base += align_up((size_t)N * D * H * W * Cin * 4, 256) + align_up((size_t)N * Do * Ho * Wo * Cout * 4, 256) + 512;
@@ -222,7 +224,15 @@ int mi355seg_conv3d_wgrad_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg
     if (nb == NB_HEAD2 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 4) == 0)
         return head2_wgrad_lowp(dy, lddy, x, ldx, dw, N, D, H, W, Cin, accumulate, ws, ws_bytes, st);
     if (nb == NB_LOWP && al16) return conv_wgrad_lowp(MATH_B16, dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, stride, accumulate, ws, ws_bytes, st);
-    if (nb == NB_PW && al8) {
+    if (nb == NB_PWL && al16) {
+        float* part; int nstrips;
+        int rc = pw_wgrad_lowp(dy, lddy, x, ldx, N, D, H, W, Cin, Cout, &part, &nstrips, ws, ws_bytes, st);
+        if (rc) return rc;
+        wgrad_reduce(part, dw, nstrips, 1, Cin, Cout, accumulate, st);
+        SEG_CHECK_LAUNCH();
+        return MI355SEG_OK;
+    }
+    if ((nb == NB_PW || (nb == NB_PWL && pw_wgrad_supported((long long)N * D * H * W, Cin, Cout, 1, ldx, lddy))) && al8) {
         float* part; int nstrips;
         int rc = pw_wgrad_mfma(dy, lddy, x, ldx, N, D, H, W, Cin, Cout, 1, &part, &nstrips, ws, ws_bytes, st);
         if (rc) return rc;

@@ -424,6 +424,7 @@ size_t mi355seg_conv3d_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, i
     if (patch_embed_supported(D, H, W, Cin, k, stride, pad) && patch_embed_ws_bytes(N, D, H, W, Cin, Cout, k) > a) a = patch_embed_ws_bytes(N, D, H, W, Cin, Cout, k);
     if (stemk_supported(Cin, Cout, k, stride, pad, 2, 4) && headk_ws_bytes(Cout, Cin, k) > a) a = headk_ws_bytes(Cout, Cin, k);
     if (headk_wgrad_supported(Cin, Cout, k, stride, pad, 4, 2) && headk_wgrad_ws_bytes(N, D, H, W, Cin, k) > a) a = headk_wgrad_ws_bytes(N, D, H, W, Cin, k);
+    if (k == 1 && stride == 1 && pad == 0 && pw_wgrad_lowp_ws_bytes((long long)N * D * H * W, Cin, Cout) > a) a = pw_wgrad_lowp_ws_bytes((long long)N * D * H * W, Cin, Cout);
     return a > c ? a : c;
 }
 
@@ -533,6 +534,15 @@ int mi355seg_conv3d_wgrad_f32(const float* dy, int lddy, const float* x, int ldx
         return conv_wgrad_lowp(MATH_X3, dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, stride, accumulate, ws, ws_bytes, st);
     if (wgrad_mfma_supported(N, D, H, W, Cin, Cout, k, stride, pad, ldx, lddy) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0)
         return conv_wgrad_mfma(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, accumulate, ws, ws_bytes, st);
+    if (k == 1 && stride == 1 && pad == 0 && f32_conv_policy() == MATH_X3 && pw_wgrad_lowp_supported((long long)N * D * H * W, Cin, Cout, ldx, lddy, 4) &&
+        ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0) {
+        float* part; int nstrips;
+        rc = pw_wgrad_lowp(dy, lddy, x, ldx, N, D, H, W, Cin, Cout, &part, &nstrips, ws, ws_bytes, st);
+        if (rc) return rc;
+        wgrad_reduce(part, dw, nstrips, 1, Cin, Cout, accumulate, st);
+        SEG_CHECK_LAUNCH();
+        return MI355SEG_OK;
+    }
     if (k == 1 && stride == 1 && pad == 0 && pw_wgrad_supported((long long)N * D * H * W, Cin, Cout, 1, ldx, lddy)) {
         float* part; int nstrips;
         rc = pw_wgrad_mfma(dy, lddy, x, ldx, N, D, H, W, Cin, Cout, 1, &part, &nstrips, ws, ws_bytes, st);

@@ -114,6 +114,10 @@ size_t convt_wgrad_lowp_ws_bytes(long long nvox, int Cin, int Cout);
 bool convt_wgrad_lowp_supported(long long nvox, int Cin, int Cout, int ldx, int lddy, int elem_bytes);
 template <typename IN_T> int convt_wgrad_lowp(const IN_T* dy, int lddy, const IN_T* x, int ldx, int N, int D, int H, int W, int Cin, int Cout,
                                               float** part_out, int* nstrips_out, void* ws, size_t ws_bytes, hipStream_t st);
+size_t pw_wgrad_lowp_ws_bytes(long long nvox, int Cin, int Cout);                 // convt_wgrad_lowp.hip: k1 weight gradient, same operand path
+bool pw_wgrad_lowp_supported(long long nvox, int Cin, int Cout, int ldx, int lddy, int elem_bytes);
+template <typename IN_T> int pw_wgrad_lowp(const IN_T* dy, int lddy, const IN_T* x, int ldx, int N, int D, int H, int W, int Cin, int Cout,
+                                           float** part_out, int* nstrips_out, void* ws, size_t ws_bytes, hipStream_t st);
 size_t pw_wgrad_ws_bytes(long long nvox, int Cin, int Cout, int T);
 bool pw_wgrad_supported(long long nvox, int Cin, int Cout, int T, int ldx, int lddy);
 template <typename IN_T> int pw_wgrad_mfma(const IN_T* dy, int lddy, const IN_T* x, int ldx, int N, int D, int H, int W, int Cin, int Cout, int T,

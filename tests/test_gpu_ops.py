@@ -59,6 +59,7 @@ CONV_CASES = [
     (2, 8, 8, 8, 32, 2, 1, 1, 0),          # direct head kernel, Cout=2
     (1, 4, 4, 8, 256, 4, 1, 1, 0),         # direct head kernel, 64 lanes per voxel
     (1, 16, 16, 32, 64, 32, 1, 1, 0),      # k1 on the MFMA igemm + MFMA pointwise wgrad
+    (2, 5, 7, 9, 96, 48, 1, 1, 0),         # k1, ragged tile and half-empty channel blocks (bf16x6: pw_wgrad_lowp planes)
     (1, 8, 8, 64, 1, 16, 5, 1, 2),         # V-Net k5 stem: z-marching fwd + LDS-tiled k5 wgrad (TX = 64)
     (2, 6, 8, 10, 2, 2, 1, 1, 0),          # tiny pointwise 2 -> 2 (V-Net out_tr.conv2)
     (1, 4, 6, 8, 3, 4, 1, 1, 0),           # tiny pointwise 3 -> 4
