@@ -204,7 +204,7 @@ def main():
         args.no_prof = True
     else:
         assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the product path)"
-        from mi355seg.engine import train_step, weights_init_normal
+        from mi355seg.engine import make_adam, train_step, weights_init_normal
         from mi355seg.models.three_d.unet3d import UNet3D
         local = local % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
@@ -215,7 +215,8 @@ def main():
         model = UNet3D(in_channels=cin, out_channels=ncls, init_features=width)
         model.apply(weights_init_normal("kaiming"))
         model = model.to(dev).train()
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=bool(args.hip_graph))
+        # train.py:109's Adam as the framework's train.py builds it (engine.make_adam: torch's fused single-kernel Adam on the GPU)
+        opt = make_adam(model.parameters(), lr=1e-3, capturable=True) if args.hip_graph else make_adam(model.parameters(), lr=1e-3)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     x = torch.randn((B, cin, Dd, Hh, Ww), generator=g).to(dev)
     gt = (torch.rand((B, 1, Dd, Hh, Ww), generator=g) > 0.9).float().to(dev)
@@ -300,7 +301,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": MATH_DTYPE[args.conv_math], "data": "synthetic",
         "config": {"workload": f"{args.workload}: UNet3D(1,2,32) fwd+BCE+bwd+Adam+Dice, x=[{B},{cin},{Dd},{Hh},{Ww}] fp32 per GPU, "
                                f"random-init (kaiming) weights, data-parallel replicas with RCCL gradient all-reduce, conv math {args.conv_math}",
-                   "global_batch": B * world, "patch": [Dd, Hh, Ww], "parallelism": f"dp{world}", "conv_math": args.conv_math},
+                   "global_batch": B * world, "patch": [Dd, Hh, Ww], "parallelism": f"dp{world}", "conv_math": args.conv_math,
+                   "optimizer": "torch.optim.Adam" + ("(fused=True)" if getattr(opt, "defaults", {}).get("fused") else "")},
         "rccl_ranks": world, "dist_backend": (dist.get_backend() if world > 1 else None), "rank_devices": rank_devices,
         "loss": float(loss.item()), "dice": dice,
     }

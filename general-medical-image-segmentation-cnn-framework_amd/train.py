@@ -16,7 +16,7 @@ from torch.optim.lr_scheduler import StepLR
 from . import distributed as D
 from .config import compose, parse_patch_size
 from .data import make_loader
-from .engine import mixed_precision_dtype, train_step, weights_init_normal
+from .engine import make_adam, mixed_precision_dtype, train_step, weights_init_normal
 from .registry import build_model
 
 
@@ -47,7 +47,7 @@ def train(config, model, logger):
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     model = model.to(device)
-    optimizer = torch.optim.Adam(model.parameters(), lr=config.init_lr)          # train.py:109
+    optimizer = make_adam(model.parameters(), lr=config.init_lr)                 # train.py:109 (torch's fused single-kernel Adam on the GPU)
     scheduler = StepLR(optimizer, step_size=config.scheduler_step_size, gamma=config.scheduler_gamma) \
         if config.use_scheduler else None                                       # train.py:119-120
     elapsed_epochs = 0

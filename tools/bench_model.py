@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import mi355seg  # noqa: E402
 from mi355seg import functional as F  # noqa: E402
-from mi355seg.engine import weights_init_normal  # noqa: E402
+from mi355seg.engine import make_adam, weights_init_normal  # noqa: E402
 
 PEAK = {"bf16": 2500.0, "bf16x6": 2500.0 / 6.0, "fp32": 157.3}
 HBM_GBS = 8000.0
@@ -66,7 +66,7 @@ def main():
     m = build(a.name, C, a.classes, D, H, W)
     m.apply(weights_init_normal("kaiming"))
     m = m.cuda().train()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    opt = make_adam(m.parameters(), lr=1e-3)         # what train.py builds (torch's fused Adam on the GPU)
     x = torch.randn(N, C, D, H, W, device="cuda")
     lab = torch.randint(0, a.classes, (N, 1, D, H, W), device="cuda")
     tgt = torch.cat([(lab == i).float() for i in range(a.classes)], dim=1)
