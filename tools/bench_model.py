@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--conv-math", default=None, choices=["fp32", "bf16x6"])
     ap.add_argument("--json", default=None)
     ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="capture the whole step (fwd, loss, bwd, Adam) into one HIP graph and time its replays")
     a = ap.parse_args()
     N, C, D, H, W = a.shape
     L = mi355seg.lib()
@@ -66,7 +67,7 @@ def main():
     m = build(a.name, C, a.classes, D, H, W)
     m.apply(weights_init_normal("kaiming"))
     m = m.cuda().train()
-    opt = make_adam(m.parameters(), lr=1e-3)         # what train.py builds (torch's fused Adam on the GPU)
+    opt = make_adam(m.parameters(), lr=1e-3, **({"capturable": True} if a.graph else {}))    # what train.py builds (torch's fused Adam on the GPU)
     x = torch.randn(N, C, D, H, W, device="cuda")
     lab = torch.randint(0, a.classes, (N, 1, D, H, W), device="cuda")
     tgt = torch.cat([(lab == i).float() for i in range(a.classes)], dim=1)
@@ -80,6 +81,25 @@ def main():
         opt.step()
         return loss
 
+    if a.graph:                                      # stream capture: eager warm-up on a side stream, then one capture, then replays
+        a.no_prof = True
+        L.call("mi355seg_prof_enable", 0)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            static_loss = step()
+        eager_step = step
+
+        def step():                                   # noqa: F811
+            graph.replay()
+            return static_loss
     step()
     step()
     torch.cuda.synchronize()
@@ -92,7 +112,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     L.call("mi355seg_prof_enable", 0)
-    res = {"model": a.name, "x": [N, C, D, H, W], "classes": a.classes, "dtype": a.dtype, "conv_math": math, "steps": a.steps,
+    res = {"model": a.name, "x": [N, C, D, H, W], "classes": a.classes, "dtype": a.dtype, "conv_math": math, "steps": a.steps, "hip_graph": bool(a.graph),
            "ms_per_step": dt * 1e3, "voxels_per_s": N * D * H * W / dt, "loss": float(loss.item()),
            "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30, "families": {}}
     if not a.no_prof:
