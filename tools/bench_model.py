@@ -103,17 +103,26 @@ def main():
     step()
     step()
     torch.cuda.synchronize()
-    if not a.no_prof:
-        L.call("mi355seg_prof_reset")
-        L.call("mi355seg_prof_enable", 1)
+    # timed leg: the in-library profiler off (its event pairs around ~all launches cost 1-2 ms per step on the many-kernel
+    # models); then the same number of steps again with every family bracketed, for the per-family table only
+    L.call("mi355seg_prof_enable", 0)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
-    L.call("mi355seg_prof_enable", 0)
-    res = {"model": a.name, "x": [N, C, D, H, W], "classes": a.classes, "dtype": a.dtype, "conv_math": math, "steps": a.steps, "hip_graph": bool(a.graph),
-           "ms_per_step": dt * 1e3, "voxels_per_s": N * D * H * W / dt, "loss": float(loss.item()),
+    dt_prof = None
+    if not a.no_prof:
+        L.call("mi355seg_prof_reset")
+        L.call("mi355seg_prof_enable", 1)
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dt_prof = (time.perf_counter() - t1) / a.steps
+        L.call("mi355seg_prof_enable", 0)
+    res = {"model": a.name, "x": [N, C, D, H, W], "classes": a.classes, "dtype": a.dtype, "conv_math": math, "steps": a.steps, "hip_graph": bool(a.graph), "optimizer": "torch.optim.Adam" + ("(fused=True)" if opt.defaults.get("fused") else ""),
+           "ms_per_step": dt * 1e3, "ms_per_step_with_profiler": None if dt_prof is None else dt_prof * 1e3, "voxels_per_s": N * D * H * W / dt, "loss": float(loss.item()),
            "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30, "families": {}}
     if not a.no_prof:
         buf = (ctypes.c_double * 32)()
