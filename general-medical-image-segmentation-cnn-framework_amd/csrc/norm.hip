@@ -125,7 +125,19 @@ __global__ __launch_bounds__(kRedThreads) void colreduce2_kernel(F f, long long 
         float4 sa = make_float4(0, 0, 0, 0), sb = sa;
         if (active) {
             const typename F::State fst = f.prepC(g, lane * 4, 4, C);
-            for (long long r = (long long)blockIdx.x * rpi + rsub; r < rows; r += (long long)nblk * rpi) {
+            // two rows per trip: both rows' loads are issued before either is reduced (twice the bytes in flight per wave)
+            const long long stride = (long long)nblk * rpi;
+            long long r = (long long)blockIdx.x * rpi + rsub;
+            for (; r + stride < rows; r += 2 * stride) {
+                float4 a0, b0, a1, b1;
+                f.eval4(fst, rbase + r, g, lane * 4, C, a0, b0);
+                f.eval4(fst, rbase + r + stride, g, lane * 4, C, a1, b1);
+                sa.x += a0.x; sa.y += a0.y; sa.z += a0.z; sa.w += a0.w;
+                sb.x += b0.x; sb.y += b0.y; sb.z += b0.z; sb.w += b0.w;
+                sa.x += a1.x; sa.y += a1.y; sa.z += a1.z; sa.w += a1.w;
+                sb.x += b1.x; sb.y += b1.y; sb.z += b1.z; sb.w += b1.w;
+            }
+            if (r < rows) {
                 float4 a, b;
                 f.eval4(fst, rbase + r, g, lane * 4, C, a, b);
                 sa.x += a.x; sa.y += a.y; sa.z += a.z; sa.w += a.w;
