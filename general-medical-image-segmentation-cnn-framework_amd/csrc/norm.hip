@@ -290,18 +290,32 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const T* __restrict__
             al[j] = rstd[g * C + c + j] * (gamma ? gamma[c + j] : 1.f);
             be[j] = (beta ? beta[c + j] : 0.f) - mean[g * C + c + j] * al[j];
         }
+        if (VEC) {          // two adjacent rows per trip: both rows' loads are issued before either is normalised
+            for (long long r = 2 * ((long long)blockIdx.x * rpi + rsub); r < rows; r += 2 * (long long)gridDim.x * rpi) {
+                const int nr = r + 1 < rows ? 2 : 1;
+                float4 v[2], rr[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (u < nr) {
+                        v[u] = ldf4(x + (rbase + r + u) * ldx + c);
+                        rr[u] = res ? ldf4(res + (rbase + r + u) * ldres + c) : make_float4(0, 0, 0, 0);
+                    }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (u < nr) {
+                        float4 o;
+                        o.x = act_apply(fmaf(v[u].x, al[0], be[0]) + rr[u].x, act, slope);
+                        o.y = act_apply(fmaf(v[u].y, al[NJ > 1 ? 1 : 0], be[NJ > 1 ? 1 : 0]) + rr[u].y, act, slope);
+                        o.z = act_apply(fmaf(v[u].z, al[NJ > 1 ? 2 : 0], be[NJ > 1 ? 2 : 0]) + rr[u].z, act, slope);
+                        o.w = act_apply(fmaf(v[u].w, al[NJ > 1 ? 3 : 0], be[NJ > 1 ? 3 : 0]) + rr[u].w, act, slope);
+                        stf4(y + (rbase + r + u) * ldy + c, o);
+                    }
+            }
+            continue;
+        }
         for (long long r = (long long)blockIdx.x * rpi + rsub; r < rows; r += (long long)gridDim.x * rpi) {
             const long long row = rbase + r;
-            if (VEC) {
-                float4 v = ldf4(x + row * ldx + c);
-                float4 rr = res ? ldf4(res + row * ldres + c) : make_float4(0, 0, 0, 0);
-                float4 o;
-                o.x = act_apply(fmaf(v.x, al[0], be[0]) + rr.x, act, slope);
-                o.y = act_apply(fmaf(v.y, al[NJ > 1 ? 1 : 0], be[NJ > 1 ? 1 : 0]) + rr.y, act, slope);
-                o.z = act_apply(fmaf(v.z, al[NJ > 1 ? 2 : 0], be[NJ > 1 ? 2 : 0]) + rr.z, act, slope);
-                o.w = act_apply(fmaf(v.w, al[NJ > 1 ? 3 : 0], be[NJ > 1 ? 3 : 0]) + rr.w, act, slope);
-                stf4(y + row * ldy + c, o);
-            } else {
+            {
                 const float rv = res ? ld1(res + row * ldres + c) : 0.f;
                 st1(y + row * ldy + c, act_apply(fmaf(ld1(x + row * ldx + c), al[0], be[0]) + rv, act, slope));
             }
