@@ -39,7 +39,8 @@ class LUConv(nn.Module):
         self.bn1 = BatchNorm3d(width)
 
     def forward(self, x):
-        return _bn_elu(self.bn1, self.conv1(x))
+        # conv + batch statistics (conv epilogue) + BN + ELU as one autograd node; the bias gradient comes out of the BN backward
+        return F.conv_bn_act(x, self.conv1, self.bn1, F.ACT_ELU)
 
 
 def _make_nConv(width, units, elu):
@@ -73,7 +74,7 @@ class DownTransition(nn.Module):
         self.ops = _make_nConv(2 * cin, units, elu)
 
     def forward(self, x):
-        down = _bn_elu(self.bn1, self.down_conv(x))
+        down = F.conv_bn_act(x, self.down_conv, self.bn1, F.ACT_ELU)
         return F.activation(self.ops(self.do1(down)), F.ACT_ELU, residual=down)
 
 
@@ -108,7 +109,7 @@ class OutputTransition(nn.Module):
         self.relu1 = _act_module(elu)
 
     def forward(self, x):
-        return self.conv2(_bn_elu(self.bn1, self.conv1(x)))
+        return self.conv2(F.conv_bn_act(x, self.conv1, self.bn1, F.ACT_ELU))
 
 
 class VNet(nn.Module):
