@@ -138,3 +138,45 @@ def test_cfg4_strided_conv_norm_upsample_at_full_extent(seg, dtype):
     assert tuple(up.shape) == (1, 160, 192, 160, 64)
     assert torch.equal(up[0, -1, -1, -1], small[0, -1, -1, -1]) and torch.equal(up[0, 158, 191, 1], small[0, 79, 95, 0])
     assert torch.equal(up[0, ::2, ::2, ::2], small[0]) and torch.equal(up[0, 1::2, 1::2, 1::2], small[0])
+
+
+def test_cfg3_cfg4_narrow_layers_at_the_last_voxels(seg):
+    """The layers that run on the narrow-axis MFMA kernels, at BASELINE extents, crops incl. the far corner (bf16):
+    V-Net's k5 two-channel head at [2, 128^3] (conv_head2_lowp), the Residual U-Net's four-channel stem and its pointwise
+    four-channel head at [1, 160, 192, 160] (conv_stem4_lowp, conv_headpw_lowp) -- forward values against ATen-CPU on the
+    crop's receptive field, and the weight gradients against a chunked fp64 reduction over the whole volume."""
+    F = seg.functional
+    # V-Net head: Conv3d(32, 2, k5, p2)
+    x = _rnd((2, 128, 128, 128, 32), 11, "cuda").to(BF)
+    w = (_rnd((2, 32, 5, 5, 5), 12) * (2.0 / 4000) ** 0.5).cuda()
+    b = _rnd((2,), 13).cuda()
+    y = F.conv3d(x, w, b, 1, 2)
+    assert tuple(y.shape) == (2, 128, 128, 128, 2)
+    _crop_check(x, w, b, y, 5, 1, 2, [(0, 0, 0, 0), (1, 124, 124, 124), (0, 63, 1, 110), (1, 124, 0, 26)], True)
+    del x, y
+    # Residual U-Net stem: Conv3d(4, 32, k3, p1, bias=False)
+    x = _rnd((1, 160, 192, 160, 4), 14, "cuda").to(BF)
+    w = (_rnd((32, 4, 3, 3, 3), 15) * (2.0 / 108) ** 0.5).cuda()
+    y = F.conv3d(x, w, None, 1, 1)
+    _crop_check(x, w, None, y, 3, 1, 1, [(0, 0, 0, 0), (0, 156, 188, 156), (0, 77, 3, 129)], True)
+    # ... its weight gradient over all 4.9 M voxels: dW[co][ci][tap] = sum_v dy[v][co] x[v + tap][ci], by z-slabs in fp64
+    xr = x.detach().requires_grad_(True)
+    wr = w.detach().requires_grad_(True)
+    g = _rnd((1, 160, 192, 160, 32), 16, "cuda").to(BF)
+    F.conv3d(xr, wr, None, 1, 1).backward(g)
+    want = torch.zeros(32, 4, 3, 3, 3, dtype=torch.float64)
+    xp = TF.pad(x[0].float().permute(3, 0, 1, 2), (1, 1, 1, 1, 1, 1)).double().cpu()        # [4, 162, 194, 162]
+    gd = g[0].float().permute(3, 0, 1, 2).double().cpu()                                    # [32, 160, 192, 160]
+    for dz in range(3):
+        for dy in range(3):
+            for dx in range(3):
+                want[:, :, dz, dy, dx] = torch.einsum("ozyx,izyx->oi", gd, xp[:, dz:dz + 160, dy:dy + 192, dx:dx + 160])
+    err = (wr.grad.double().cpu() - want).abs().max()
+    assert err <= 2e-5 * max(float(want.abs().max()), (160 * 192 * 160) ** 0.5), float(err)
+    del x, y, xr, g, xp, gd
+    # Residual U-Net head: Conv3d(32, 4, k1)
+    x = _rnd((1, 160, 192, 160, 32), 17, "cuda").to(BF)
+    w = (_rnd((4, 32, 1, 1, 1), 18) * (2.0 / 32) ** 0.5).cuda()
+    b = _rnd((4,), 19).cuda()
+    y = F.conv3d(x, w, b, 1, 0)
+    _crop_check(x, w, b, y, 1, 1, 0, [(0, 0, 0, 0), (0, 156, 188, 156), (0, 5, 188, 77)], True)
