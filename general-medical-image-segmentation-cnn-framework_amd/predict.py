@@ -18,6 +18,7 @@ import torch
 
 from . import functional as F
 from .config import compose, parse_patch_size
+from .engine import mixed_precision_dtype
 from .registry import build_model
 from .utils.metric import metric_from_counts
 
@@ -49,8 +50,9 @@ def crop_window(loc, patch, size, overlap):
 
 
 @torch.no_grad()
-def sliding_window_predict(model, volume, patch_size, overlap=(4, 4, 36), batch_size=1):
-    """volume: float tensor [C, D, H, W] on the GPU -> int64 label volume [1, D, H, W] (argmax over classes)."""
+def sliding_window_predict(model, volume, patch_size, overlap=(4, 4, 36), batch_size=1, dtype=None):
+    """volume: float tensor [C, D, H, W] on the GPU -> int64 label volume [1, D, H, W] (argmax over classes).
+    ``dtype`` = torch.bfloat16 runs the forward under mi355seg.autocast (``config.mixed_precision=bf16``)."""
     C, D, H, W = volume.shape
     ps = (patch_size,) * 3 if isinstance(patch_size, int) else tuple(patch_size)
     size = (D, H, W)
@@ -62,11 +64,12 @@ def sliding_window_predict(model, volume, patch_size, overlap=(4, 4, 36), batch_
         chunk = locs[i:i + batch_size]
         x = torch.stack([volume[:, z:z + ps[0], y:y + ps[1], w:w + ps[2]] for (z, y, w) in chunk])
         x = x.contiguous()
-        if getattr(model, "takes_frequency_bands", False):               # predict.py:128-131 (IS: first output only)
-            from .models.three_d.IS import frequency_bands
-            logits, _ = model(x, *frequency_bands(x))
-        else:
-            logits = model(x)
+        with F.autocast(dtype or F.compute_dtype()):
+            if getattr(model, "takes_frequency_bands", False):           # predict.py:128-131 (IS: first output only)
+                from .models.three_d.IS import frequency_bands
+                logits, _ = model(x, *frequency_bands(x))
+            else:
+                logits = model(x)
         labels = F.argmax_channels(logits)                               # predict.py:133,139
         for j, loc in enumerate(chunk):
             src, dst = crop_window(loc, ps, size, overlap)
@@ -104,7 +107,7 @@ def predict(config, model, log=print):
     rows = []
     for name, x, gt in cases:
         vol = znorm(x.to(device))
-        mask = sliding_window_predict(model, vol, ps, overlap, batch_size=max(1, int(config.batch_size)))
+        mask = sliding_window_predict(model, vol, ps, overlap, batch_size=max(1, int(config.batch_size)), dtype=mixed_precision_dtype(config))
         counts = F.dice_counts(gt.to(device).to(torch.int64).reshape(mask.shape), mask)
         jac, dice = metric_from_counts(counts.cpu().tolist())
         np.save(os.path.join(config.hydra_path, f"{name}_pred.npy"), mask.cpu().numpy().astype(np.uint8))

@@ -162,6 +162,15 @@ def test_predict_cli_sliding_window(seg, tmp_path):
         b = m(vol[None]).argmax(1)
     assert torch.equal(a, b)
     assert not m.training
+    # mixed-precision inference (config.mixed_precision=bf16): eval-mode results do not depend on how patches are batched,
+    # and a one-patch volume equals the plain bf16 forward + argmax
+    big = make_input((1, 48, 40, 64)).cuda()
+    p1 = sliding_window_predict(m, big, (32, 32, 32), (4, 4, 4), batch_size=1, dtype=torch.bfloat16)
+    p3 = sliding_window_predict(m, big, (32, 32, 32), (4, 4, 4), batch_size=3, dtype=torch.bfloat16)
+    assert p1.shape == (1, 48, 40, 64) and torch.equal(p1, p3)
+    with torch.no_grad(), seg.autocast(torch.bfloat16):
+        bb = m(vol[None]).argmax(1)
+    assert torch.equal(sliding_window_predict(m, vol, (32, 32, 32), (4, 4, 4), dtype=torch.bfloat16), bb)
 
 
 def test_hip_graph_train_step_matches_eager(seg):
