@@ -36,11 +36,12 @@ static void cast_rows(const TS* src, int lds, TD* dst, int ldd, long long rows, 
 static int oext(int n, int k, int s, int p) { return (n + 2 * p - k) / s + 1; }
 
 // which native bf16 kernel serves a shape (0 = none: fp32 fallback)
-enum { NB_NONE = 0, NB_IGEMM, NB_GATHER, NB_PWL, NB_HEADPW, NB_K2S2W, NB_HEAD2, NB_STEM4, NB_STEM, NB_HEAD, NB_LOWP, NB_PW, NB_SMALLCIN, NB_SMALLCOUT, NB_GW, NB_TINY, NB_CONVT };
+enum { NB_NONE = 0, NB_IGEMM, NB_GATHER, NB_STEM1K5, NB_PWL, NB_HEADPW, NB_K2S2W, NB_HEAD2, NB_STEM4, NB_STEM, NB_HEAD, NB_LOWP, NB_PW, NB_SMALLCIN, NB_SMALLCOUT, NB_GW, NB_TINY, NB_CONVT };
 static int native_fwd(int N, int D, int H, int W, int Cin, int Cout, int k, int s, int p, int ldx, int ldy) {
     if (conv_mfma_supported(MATH_B16, N, D, H, W, Cin, Cout, k, s, p, ldx, ldy)) return NB_IGEMM;
     if (conv_gather_fwd_supported(MATH_B16, N, D, H, W, Cin, Cout, k, s, p, ldx, ldy)) return NB_GATHER;
     if (head2_lowp_supported(Cin, Cout, k, s, p, ldx, ldy)) return NB_HEAD2;
+    if (stem1k5_lowp_supported(Cin, Cout, k, s, p, ldx, ldy)) return NB_STEM1K5;
     if (stem4_lowp_supported(Cin, Cout, k, s, p, ldx, ldy)) return NB_STEM4;
     if (stem_supported(Cin, Cout, k, s, p, ldy)) return NB_STEM;
     if (headpw_lowp_supported(Cin, Cout, k, s, p, ldx, ldy)) return NB_HEADPW;
@@ -64,6 +65,7 @@ static int native_wgrad(int N, int D, int H, int W, int Cin, int Cout, int k, in
     // V-Net's two-channel k5 head: the fp32 z-marching kernel (conv_headk.hip) behind the cast fall-back is 8x faster than the
     // generic small-channel wgrad below (the one-channel k5 stem has its own LDS-tiled kernel inside smallcin_wgrad)
     if (head2_lowp_supported(Cin, Cout, k, s, p, ldx, lddy)) return NB_HEAD2;
+    if (stem1k5_lowp_supported(Cin, Cout, k, s, p, ldx, lddy)) return NB_STEM1K5;
     // k2 s2 down-convolution (V-Net): its weight gradient IS a ConvTranspose k2 s2 weight gradient with the roles swapped
     // (base voxels = the coarse dy, children = the fine x), and (Cout, Cin, 2, 2, 2) is that kernel's output layout
     if (k == 2 && s == 2 && p == 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0 &&
@@ -98,6 +100,7 @@ size_t mi355seg_conv3d_ws_bytes_bf16(int N, int D, int H, int W, int Cin, int Co
     if (stem4_lowp_supported(Cin, Cout, k, stride, pad, Cin, Cout) && base < stem4_lowp_ws_bytes(Cout)) base = stem4_lowp_ws_bytes(Cout);
     if (head2_lowp_supported(Cin, Cout, k, stride, pad, Cin, Cout) && base < head2_lowp_ws_bytes(Cin)) base = head2_lowp_ws_bytes(Cin);
     if (headpw_lowp_supported(Cin, Cout, k, stride, pad, Cin, Cout) && base < headpw_lowp_ws_bytes(Cin, Cout)) base = headpw_lowp_ws_bytes(Cin, Cout);
+    if (stem1k5_lowp_supported(Cin, Cout, k, stride, pad, Cin, Cout) && base < stem1k5_lowp_ws_bytes(Cout)) base = stem1k5_lowp_ws_bytes(Cout);
     if (k == 1 && stride == 1 && pad == 0 && base < pw_wgrad_lowp_ws_bytes((long long)N * D * H * W, Cin, Cout)) base = pw_wgrad_lowp_ws_bytes((long long)N * D * H * W, Cin, Cout);
     if (k == 2 && stride == 2 && pad == 0 && base < convt_wgrad_lowp_ws_bytes((long long)N * (D / 2) * (H / 2) * (W / 2), Cout, Cin))
         base = convt_wgrad_lowp_ws_bytes((long long)N * (D / 2) * (H / 2) * (W / 2), Cout, Cin);
@@ -123,6 +126,11 @@ int mi355seg_conv3d_fwd_bf16(const mi355seg_bf16* x, int ldx, const float* w, co
         return conv_gather_fwd_mfma(MATH_B16, x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, stride, pad, stats_sum, stats_sq, ws, ws_bytes, st);
     if (nb == NB_HEAD2 && al && ((uintptr_t)y % 4) == 0) {
         int rc = head2_fwd_lowp(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, ws, ws_bytes, st);
+        if (rc || !stats_sum) return rc;
+        return channel_sums(y, ldy, vout, Cout, stats_sum, stats_sq, nullptr, 0, ws, ws_bytes, st);
+    }
+    if (nb == NB_STEM1K5 && ((uintptr_t)y % 8) == 0) {
+        int rc = stem1k5_fwd_lowp(x, w, bias, y, ldy, N, D, H, W, Cout, ws, ws_bytes, st);
         if (rc || !stats_sum) return rc;
         return channel_sums(y, ldy, vout, Cout, stats_sum, stats_sq, nullptr, 0, ws, ws_bytes, st);
     }
@@ -221,6 +229,8 @@ int mi355seg_conv3d_wgrad_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg
         SEG_CHECK_LAUNCH();
         return MI355SEG_OK;
     }
+    if (nb == NB_STEM1K5 && ((uintptr_t)dy % 16) == 0)
+        return stem1k5_wgrad_lowp(dy, lddy, x, dw, N, D, H, W, Cout, accumulate, ws, ws_bytes, st);
     if (nb == NB_HEAD2 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 4) == 0)
         return head2_wgrad_lowp(dy, lddy, x, ldx, dw, N, D, H, W, Cin, accumulate, ws, ws_bytes, st);
     if (nb == NB_LOWP && al16) return conv_wgrad_lowp(MATH_B16, dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, stride, accumulate, ws, ws_bytes, st);

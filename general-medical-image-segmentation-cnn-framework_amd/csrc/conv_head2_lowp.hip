@@ -33,17 +33,23 @@ struct Head2Args {
     int ldx, lddy, ldo, N, D, H, W, Cin, ntx, nty, ntz, ntiles;
 };
 
-// NCOPY copies of the (two-channel) dy halo tile: copy c, row (hz, hy), slot j holds dy[z0 - 2 + hz][y0 - 2 + hy][x0 - 2 + j + c]
+// NCOPY copies of the (two-channel) dy halo tile: copy c, row (hz, hy), slot j holds dy[z0 - 2 + hz][y0 - 2 + hy][x0 - 2 + j + c].
+// Every source voxel is loaded once and written to the (up to NCOPY) slots that show it.
 template <int NCOPY>
 __device__ __forceinline__ void head2_stage_dy(unsigned char* ds, const bf16* __restrict__ dy, int lddy, int n, int z0, int y0, int x0,
                                                int D, int H, int W, int nthreads) {
-    for (int e = threadIdx.x; e < NCOPY * H2_HZ * H2_HY * H2_ROWW; e += nthreads) {
-        const int j = e % H2_ROWW, r = (e / H2_ROWW) % (H2_HZ * H2_HY), c = e / (H2_ROWW * H2_HZ * H2_HY);
-        const int gz = z0 - 2 + r / H2_HY, gy = y0 - 2 + r % H2_HY, gx = x0 - 2 + j + c;
+    constexpr int SRCW = H2_ROWW + NCOPY - 1;
+    for (int e = threadIdx.x; e < H2_HZ * H2_HY * SRCW; e += nthreads) {
+        const int t = e % SRCW, r = e / SRCW;
+        const int gz = z0 - 2 + r / H2_HY, gy = y0 - 2 + r % H2_HY, gx = x0 - 2 + t;
         unsigned v = 0u;
         if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
             v = *reinterpret_cast<const unsigned*>(dy + ((((long long)n * D + gz) * H + gy) * W + gx) * lddy);
-        *reinterpret_cast<unsigned*>(ds + c * H2_COPYB + r * H2_ROWB + j * 4) = v;
+#pragma unroll
+        for (int c = 0; c < NCOPY; ++c) {
+            const int j = t - c;
+            if (j >= 0 && j < H2_ROWW) *reinterpret_cast<unsigned*>(ds + c * H2_COPYB + r * H2_ROWB + j * 4) = v;
+        }
     }
 }
 

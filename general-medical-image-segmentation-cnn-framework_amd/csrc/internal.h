@@ -44,6 +44,13 @@ template <typename T> int smallcin_wgrad(const T* dy, int lddy, const T* x, int 
                    int k, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 template <typename T> int smallcout_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
                     int k, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+// conv_stem1k5_lowp.hip -- V-Net's one-channel k5 stem on the bf16 matrix cores (x-taps as the GEMM's narrow axis), bf16 tensors
+bool stem1k5_lowp_supported(int Cin, int Cout, int k, int stride, int pad, int ldx, int ldy);
+size_t stem1k5_lowp_ws_bytes(int Cout);
+int stem1k5_fwd_lowp(const bf16* x, const float* w, const float* bias, bf16* y, int ldy, int N, int D, int H, int W, int Cout,
+                     void* ws, size_t ws_bytes, hipStream_t st);
+int stem1k5_wgrad_lowp(const bf16* dy, int lddy, const bf16* x, float* dw, int N, int D, int H, int W, int Cout, int accumulate,
+                       void* ws, size_t ws_bytes, hipStream_t st);
 // conv_headpw_lowp.hip -- pointwise heads (k1, Cout = 2 | 4) for bf16 tensors: the matrix core contracts the channels
 bool headpw_lowp_supported(int Cin, int Cout, int k, int stride, int pad, int ldx, int ldy);
 size_t headpw_lowp_ws_bytes(int Cin, int Cout);
