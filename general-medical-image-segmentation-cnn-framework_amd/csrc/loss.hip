@@ -203,6 +203,63 @@ __global__ __launch_bounds__(256) void dice_sums_bwd_kernel(const float* __restr
     }
 }
 
+// ---- row-segmented form: R contiguous rows of L elements, all rows in ONE launch (BinaryDiceLoss: row = sample,
+// loss_function.py:78-83; DiceLossss: row = (sample, class), loss_function.py:160-183).  Denominator exponent p
+// (loss_function.py:82 takes any p): a^p = a*a for p == 2 (the bits of the single-row kernel), a for p == 1, powf otherwise.
+__device__ __forceinline__ float pow_p(float a, float p) { return p == 2.f ? a * a : (p == 1.f ? a : powf(a, p)); }
+__device__ __forceinline__ float dpow_p(float a, float p) {     // d a^p / da, torch's pow backward: p * a^(p-1), 0 for p == 0
+    return p == 2.f ? 2.f * a : (p == 1.f ? 1.f : (p == 0.f ? 0.f : p * powf(a, p - 1.f)));
+}
+__device__ __forceinline__ void dice_acc(double (&acc)[5], float a, float b, int apply_sigmoid, float p) {
+    if (apply_sigmoid) a = 1.f / (1.f + expf(-a));
+    acc[0] += (double)(a * b); acc[1] += (double)a; acc[2] += (double)b;
+    acc[3] += (double)pow_p(a, p); acc[4] += (double)pow_p(b, p);
+}
+// grid = (blocks per row, R); part[(row * gridDim.x + block) * 5 + j]
+__global__ __launch_bounds__(kLossThreads) void dice_rows_kernel(const float* __restrict__ x, const float* __restrict__ t,
+        long long L, int apply_sigmoid, float p, int vec, double* __restrict__ part) {
+    __shared__ double sh[20];
+    double acc[5] = {0, 0, 0, 0, 0};
+    const float* xr = x + (long long)blockIdx.y * L;
+    const float* tr = t + (long long)blockIdx.y * L;
+    const long long stride = (long long)gridDim.x * blockDim.x, first = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {                                        // rows 16-byte aligned: 16 B per lane
+        const long long n4 = L / 4;
+        for (long long i = first; i < n4; i += stride) {
+            const float4 a = reinterpret_cast<const float4*>(xr)[i], b = reinterpret_cast<const float4*>(tr)[i];
+            dice_acc(acc, a.x, b.x, apply_sigmoid, p); dice_acc(acc, a.y, b.y, apply_sigmoid, p);
+            dice_acc(acc, a.z, b.z, apply_sigmoid, p); dice_acc(acc, a.w, b.w, apply_sigmoid, p);
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (L & 3)) dice_acc(acc, xr[n4 * 4 + threadIdx.x], tr[n4 * 4 + threadIdx.x], apply_sigmoid, p);
+    } else {
+        for (long long i = first; i < L; i += stride) dice_acc(acc, xr[i], tr[i], apply_sigmoid, p);
+    }
+    block_sum<5>(acc, sh);
+    if (threadIdx.x == 0) for (int j = 0; j < 5; ++j) part[((long long)blockIdx.y * gridDim.x + blockIdx.x) * 5 + j] = acc[j];
+}
+// one block per row, fixed order
+__global__ __launch_bounds__(256) void dice_rows_finalize_kernel(const double* __restrict__ part, int nblk, double* __restrict__ out) {
+    __shared__ double sh[20];
+    double acc[5] = {0, 0, 0, 0, 0};
+    const double* pr = part + (long long)blockIdx.x * nblk * 5;
+    for (int i = threadIdx.x; i < nblk; i += 256)
+        for (int j = 0; j < 5; ++j) acc[j] += pr[(long long)i * 5 + j];
+    block_sum<5>(acc, sh);
+    if (threadIdx.x == 0) for (int j = 0; j < 5; ++j) out[(long long)blockIdx.x * 5 + j] = acc[j];
+}
+// dx[r][i] = (g[r][0]*t + g[r][1] + g[r][3] * d(a^p)/da) * da/dx
+__global__ __launch_bounds__(256) void dice_rows_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
+        const double* __restrict__ g5, long long L, int apply_sigmoid, float p, float* __restrict__ dx) {
+    const double* g = g5 + (long long)blockIdx.y * 5;
+    const float g0 = (float)g[0], g1 = (float)g[1], g3 = (float)g[3];
+    const long long base = (long long)blockIdx.y * L;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (long long)gridDim.x * blockDim.x) {
+        float a = x[base + i], d = 1.f;
+        if (apply_sigmoid) { a = 1.f / (1.f + expf(-a)); d = a * (1.f - a); }
+        dx[base + i] = (g0 * t[base + i] + g1 + g3 * dpow_p(a, p)) * d;
+    }
+}
+
 constexpr int kMaxClasses = 16;
 
 __global__ __launch_bounds__(256) void softmax_ch_kernel(const float* __restrict__ x, float* __restrict__ y, long long N, int K, long long S) {
@@ -364,6 +421,39 @@ int mi355seg_dice_sums_bwd_f32(const float* x, const float* t, const double* g5,
                                float* dx, void* stream) {
     SEG_CHECK_ARG(x && t && g5 && dx && numel > 0, "dice_sums_bwd: bad arguments");
     hipLaunchKernelGGL(dice_sums_bwd_kernel, dim3(loss_grid(numel) * 2), dim3(256), 0, (hipStream_t)stream, x, t, g5, numel, apply_sigmoid, dx);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+static int dice_rows_grid(long long rows, long long L) {
+    long long per = (L + (long long)kLossThreads * 16 - 1) / ((long long)kLossThreads * 16);      // >= 16 elements per thread
+    long long cap = kLossMaxBlocks / rows;
+    if (per > cap) per = cap;
+    return (int)(per < 1 ? 1 : per);
+}
+size_t mi355seg_dice_rows_ws_bytes(long long rows, long long len) {
+    if (rows < 1 || len < 1) return 0;
+    return (size_t)rows * dice_rows_grid(rows, len) * 5 * sizeof(double);
+}
+int mi355seg_dice_rows_f32(const float* x, const float* t, long long rows, long long len, int apply_sigmoid, float p,
+                           double* out, void* ws, size_t ws_bytes, void* stream) {
+    SEG_CHECK_ARG(x && t && out && rows > 0 && rows <= 65535 && len > 0, "dice_rows: bad arguments (1 <= rows <= 65535)");
+    const int nblk = dice_rows_grid(rows, len);
+    SEG_CHECK_WS((size_t)rows * nblk * 5 * sizeof(double), ws_bytes);
+    const int vec = ((uintptr_t)x % 16) == 0 && ((uintptr_t)t % 16) == 0 && (rows == 1 || len % 4 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(dice_rows_kernel, dim3(nblk, (unsigned)rows), dim3(kLossThreads), 0, st, x, t, len, apply_sigmoid, p, vec, (double*)ws);
+    SEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dice_rows_finalize_kernel, dim3((unsigned)rows), dim3(256), 0, st, (const double*)ws, nblk, out);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_dice_rows_bwd_f32(const float* x, const float* t, const double* g, long long rows, long long len, int apply_sigmoid,
+                               float p, float* dx, void* stream) {
+    SEG_CHECK_ARG(x && t && g && dx && rows > 0 && rows <= 65535 && len > 0, "dice_rows_bwd: bad arguments (1 <= rows <= 65535)");
+    long long per = (len + 256 * 8 - 1) / (256 * 8);
+    if (per > 4096) per = 4096;
+    hipLaunchKernelGGL(dice_rows_bwd_kernel, dim3((unsigned)per, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, t, g, len, apply_sigmoid, p, dx);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }

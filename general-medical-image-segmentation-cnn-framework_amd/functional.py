@@ -8,6 +8,8 @@ Activations inside the package are channel-last: a 5-D fp32 tensor of logical sh
 [N, D, H, W, C] whose last stride is 1 and whose voxel pitch (stride of W) may exceed C
 (a channel slice of a wider concat buffer).
 """
+import threading
+
 import torch
 from torch.autograd import Function
 
@@ -21,7 +23,14 @@ _WS = {}
 # (to_channels_last) produces bf16 activations and every op below follows its input's dtype: what
 # ``Accelerator(mixed_precision="bf16")`` / torch.autocast does for the reference (parameters, their gradients, norm
 # statistics and the loss stay fp32; conv products are bf16 MFMAs with fp32 accumulation).
-_COMPUTE_DTYPE = [torch.float32]
+class _AutocastState(threading.local):
+    """Per-thread stack (a worker thread's forward must not inherit or leak another thread's bf16 mode)."""
+
+    def __init__(self):
+        self.stack = [torch.float32]
+
+
+_AUTOCAST = _AutocastState()
 _SFX = {torch.float32: "f32", torch.bfloat16: "bf16"}
 
 
@@ -34,16 +43,16 @@ class autocast:
         self.dtype = dtype if enabled else torch.float32
 
     def __enter__(self):
-        _COMPUTE_DTYPE.append(self.dtype)
+        _AUTOCAST.stack.append(self.dtype)
         return self
 
     def __exit__(self, *exc):
-        _COMPUTE_DTYPE.pop()
+        _AUTOCAST.stack.pop()
         return False
 
 
 def compute_dtype():
-    return _COMPUTE_DTYPE[-1]
+    return _AUTOCAST.stack[-1]
 
 
 def _sfx(t):
@@ -816,6 +825,40 @@ class _DiceSums(Function):
 
 def dice_sums_autograd(x, t, apply_sigmoid=False):
     return _DiceSums.apply(x, t, apply_sigmoid)
+
+
+class _DiceRows(Function):
+    """S[r] = (sum a*t, sum a, sum t, sum a^p, sum t^p) over row r of a [R, L] view, every row in one launch, with autograd
+    w.r.t. x (a = sigmoid(x) or x)."""
+
+    @staticmethod
+    def forward(ctx, x, t, apply_sigmoid, p):
+        _require_cuda(x, "dice_rows input")
+        x, t = x.contiguous().to(torch.float32), t.contiguous().to(torch.float32)
+        R, Ln = x.shape
+        if tuple(t.shape) != (R, Ln):
+            raise Mi355SegError(f"dice_rows: target {tuple(t.shape)} must match input {tuple(x.shape)}")
+        L = lib()
+        ws = workspace(L.query("mi355seg_dice_rows_ws_bytes", R, Ln), x.device)
+        out = torch.empty((R, 5), dtype=torch.float64, device=x.device)
+        L.call("mi355seg_dice_rows_f32", _p(x), _p(t), R, Ln, int(bool(apply_sigmoid)), float(p), _p(out), _p(ws), ws.numel(), _stream())
+        ctx.save_for_backward(x, t)
+        ctx.cfg = (R, Ln, int(bool(apply_sigmoid)), float(p))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t = ctx.saved_tensors
+        R, Ln, sg, p = ctx.cfg
+        g = g.contiguous().to(torch.float64)
+        dx = torch.empty_like(x)
+        lib().call("mi355seg_dice_rows_bwd_f32", _p(x), _p(t), _p(g), R, Ln, sg, float(p), _p(dx), _stream())
+        return dx, None, None, None
+
+
+def dice_rows_autograd(x, t, apply_sigmoid=False, p=2.0):
+    """Per-row Dice sums of a [R, L] pair as float64 [R, 5] (one reduction launch + one finalise for all rows)."""
+    return _DiceRows.apply(x, t, apply_sigmoid, p)
 
 
 class _SoftmaxCh(Function):

@@ -38,8 +38,8 @@ def make_one_hot(input, num_classes):
 
 
 class BinaryDiceLoss(nn.Module):
-    """loss_function.py:61-99 -- per-sample 1 - (sum p*t + s) / (sum p^2 + sum t^2 + s); p must be 2
-    (the reference default) for the fused reduction kernel."""
+    """loss_function.py:61-99 -- per-sample 1 - (sum x*t + s) / (sum x^p + sum t^p + s), any exponent p; every sample's
+    sums come from one row-segmented reduction launch."""
 
     def __init__(self, smooth=1, p=2, reduction="mean"):
         super().__init__()
@@ -47,16 +47,9 @@ class BinaryDiceLoss(nn.Module):
 
     def forward(self, predict, target):
         assert predict.shape[0] == target.shape[0], "predict & target batch size don't match"
-        if self.p != 2:
-            raise NotImplementedError("BinaryDiceLoss: only p=2 is implemented")
         n = predict.shape[0]
-        pr = predict.contiguous().view(n, -1)
-        tg = target.contiguous().view(n, -1)
-        losses = []
-        for i in range(n):
-            s = F.dice_sums_autograd(pr[i], tg[i], False)
-            losses.append(1 - (s[0] + self.smooth) / (s[3] + s[4] + self.smooth))
-        loss = torch.stack(losses).to(torch.float32)
+        s = F.dice_rows_autograd(predict.contiguous().view(n, -1), target.contiguous().view(n, -1), False, self.p)
+        loss = (1 - (s[:, 0] + self.smooth) / (s[:, 3] + s[:, 4] + self.smooth)).to(torch.float32)
         if self.reduction == "mean":
             return loss.mean()
         elif self.reduction == "sum":
@@ -101,9 +94,9 @@ class DiceLossss(nn.Module):
         assert inputs.size() == target.size(), "predict & target shape do not match"
         smooth = 1e-5
         n = inputs.shape[0]
-        loss = 0.0
-        for i in range(self.n_classes):
-            s = sum(F.dice_sums_autograd(inputs[b, i], target[b, i], False) for b in range(n))
-            dice = 1 - (2 * s[0] + smooth) / (s[3] + s[4] + smooth)
-            loss = loss + dice * weight[i]
-        return (loss / self.n_classes).to(torch.float32)
+        # rows = (sample, class): one reduction launch for all of them, then the per-class sums over the batch
+        s = F.dice_rows_autograd(inputs.contiguous().view(n * self.n_classes, -1), target.view(n * self.n_classes, -1), False, 2.0)
+        s = s.view(n, self.n_classes, 5).sum(dim=0)
+        dice = 1 - (2 * s[:, 0] + smooth) / (s[:, 3] + s[:, 4] + smooth)
+        w = torch.as_tensor(weight, dtype=torch.float64, device=dice.device)
+        return ((dice * w).sum() / self.n_classes).to(torch.float32)

@@ -233,6 +233,16 @@ int mi355seg_dice_sums_f32(const float* x, const float* t, long long numel, int 
 int mi355seg_dice_sums_bwd_f32(const float* x, const float* t, const double* g5, long long numel, int apply_sigmoid,
                                float* dx, void* stream);
 
+/* The same five sums for `rows` contiguous rows of `len` elements in ONE launch: out[r*5 + j].  BinaryDiceLoss reduces per
+ * sample (loss_function.py:78-83: predict.view(N, -1)), DiceLossss per (sample, class) (loss_function.py:160-183).  `p` is
+ * BinaryDiceLoss's denominator exponent (loss_function.py:82, any value): out[r*5+3] = sum a^p, out[r*5+4] = sum b^p. */
+size_t mi355seg_dice_rows_ws_bytes(long long rows, long long len);
+int mi355seg_dice_rows_f32(const float* x, const float* t, long long rows, long long len, int apply_sigmoid, float p,
+                           double* out, void* ws, size_t ws_bytes, void* stream);
+/* dx[r][i] = (g[r*5+0]*t + g[r*5+1] + g[r*5+3] * p * a^(p-1)) * da/dx */
+int mi355seg_dice_rows_bwd_f32(const float* x, const float* t, const double* g, long long rows, long long len, int apply_sigmoid,
+                               float p, float* dx, void* stream);
+
 /* softmax over the channel dim of an NCDHW tensor [N,K,S] (DiceLossss softmax=True, loss_function.py:170-171) */
 int mi355seg_softmax_ch_f32(const float* x, float* y, long long N, int K, long long S, void* stream);
 /* dx = y * (dy - sum_k dy*y) */

@@ -116,3 +116,11 @@ def make_class_labels(shape, n_classes) -> torch.Tensor:
     i = np.arange(n, dtype=np.float64)
     f = 0.5 * (np.sin(0.002 * i) + 1.0) * 0.999
     return torch.from_numpy(np.floor(f * n_classes).astype(np.int64)).reshape(shape)
+
+
+def init_probe_modules():
+    """Fresh modules the init policy is applied to (every branch of train.py:33-61)."""
+    import torch.nn as nn
+    return [("conv3d", nn.Conv3d(3, 5, 3)), ("convT3d", nn.ConvTranspose3d(4, 6, 2, stride=2)), ("linear", nn.Linear(7, 9)),
+            ("conv3d_nobias", nn.Conv3d(2, 4, 1, bias=False)), ("bn3d", nn.BatchNorm3d(6)), ("bn2d", nn.BatchNorm2d(6)),
+            ("in3d_affine", nn.InstanceNorm3d(4, affine=True)), ("ln", nn.LayerNorm(8))]

@@ -51,3 +51,27 @@ def test_unet3d_surface_matches_reference_schema():
     b.apply(weights_init_normal("kaiming"))     # the reference's init policy applies unchanged
     assert float(b.encoder1.enc1conv1.bias.abs().max()) == 0.0
     assert float(b.encoder1.enc1norm1.weight.min()) == 1.0
+
+
+def test_autocast_state_is_per_thread():
+    """functional.autocast keeps its stack in threading.local: a bf16 region in one thread neither leaks into nor is
+    inherited by another thread's forward."""
+    import threading
+    import torch
+    import mi355seg
+    F = mi355seg.functional
+    seen = {}
+
+    def worker():
+        seen["inside_other_thread"] = F.compute_dtype()
+        with F.autocast(torch.bfloat16):
+            seen["worker_own"] = F.compute_dtype()
+
+    with F.autocast(torch.bfloat16):
+        assert F.compute_dtype() is torch.bfloat16
+        t = threading.Thread(target=worker)
+        t.start()
+        t.join()
+        assert F.compute_dtype() is torch.bfloat16
+    assert F.compute_dtype() is torch.float32
+    assert seen == {"inside_other_thread": torch.float32, "worker_own": torch.bfloat16}

@@ -207,6 +207,13 @@ def test_library_losses_vs_reference_fixture(seg, golden_dir):
     for red in ("mean", "sum", "none"):
         got = LF.BinaryDiceLoss(reduction=red)(pr, onehot[:, 1]).detach().cpu().numpy()
         assert np.abs(got - g["bdl_" + red]).max() < 2e-6
+    for pw in (1, 2, 3, 1.5):                      # loss_function.py:82: any exponent p -- value and input gradient
+        prg = torch.sigmoid(logits[:, 1]).clone().requires_grad_(True)
+        l = LF.BinaryDiceLoss(smooth=0.5, p=pw, reduction="sum")(prg, onehot[:, 1])
+        l.backward()
+        assert abs(l.item() - float(g[f"bdl_p{pw}"])) < 2e-6, (pw, l.item(), float(g[f"bdl_p{pw}"]))
+        ref = g[f"bdl_p{pw}_grad"]
+        assert np.abs(prg.grad.cpu().numpy() - ref).max() < 1e-9 + 2e-5 * np.abs(ref).max(), pw
     with pytest.raises(Exception):
         LF.BinaryDiceLoss(reduction="bogus")(pr, onehot[:, 1])
     with pytest.raises(AssertionError):

@@ -548,6 +548,23 @@ def test_bce_argmax_dice(seg):
     assert ((s - ref).abs() / ref.abs().clamp_min(1)).max() < 1e-6
 
 
+def test_dice_counters_bit_exact_against_reference_metric_fixture(seg, golden_dir):
+    """mi355seg_dice_counts_i64 (through utils.metric.metric and F.dice_counts) against what the reference's own
+    utils/metric.py:20-75 counted and returned for eleven mask pairs (tests/golden/metric.npz, generated by executing the
+    reference function lifted from its file): the four integer counters and the (jaccard, dice) doubles, bit for bit."""
+    import os
+    from mi355seg.utils.metric import metric
+    F = seg.functional
+    g = np.load(os.path.join(golden_dir, "metric.npz"))
+    names = sorted({k.split("/")[0] for k in g.files})
+    assert len(names) >= 8
+    for n in names:
+        gt, pred = torch.from_numpy(g[n + "/gt"]), torch.from_numpy(g[n + "/pred"])
+        cnt = F.dice_counts(gt.to(torch.int64).cuda(), pred.to(torch.int64).cuda()).cpu().tolist()
+        assert cnt == g[n + "/counts"].tolist(), n
+        assert list(metric(gt.cuda(), pred.cuda())) == g[n + "/jaccard_dice"].tolist(), n
+
+
 def test_missing_library_fails_loudly(seg, monkeypatch):
     import importlib
     L = importlib.import_module(seg.__name__ + "._lib")
