@@ -288,6 +288,7 @@ int mi355seg_prof_read(double* out, int n) {
 
 int mi355seg_ncdhw_to_ndhwc_f32(const float* src, float* dst, int lddst, long long N, int C, long long S, void* stream) {
     SEG_CHECK_ARG(src && dst && N > 0 && C > 0 && S > 0 && lddst >= C && N < 65536, "ncdhw_to_ndhwc: bad arguments");
+    ProfScope ps(PF_POOL, 0.0, 8.0 * N * C * S, (hipStream_t)stream);
     if (narrow_layout<float, float, false>(src, dst, lddst, N, C, S, (hipStream_t)stream)) { SEG_CHECK_LAUNCH(); return MI355SEG_OK; }
     dim3 grid((unsigned)((S + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N);
     hipLaunchKernelGGL((ncs_to_nsc_kernel<float, float>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, lddst, C, S);
@@ -296,6 +297,7 @@ int mi355seg_ncdhw_to_ndhwc_f32(const float* src, float* dst, int lddst, long lo
 }
 int mi355seg_ncdhw_f32_to_ndhwc_bf16(const float* src, mi355seg_bf16* dst, int lddst, long long N, int C, long long S, void* stream) {
     SEG_CHECK_ARG(src && dst && N > 0 && C > 0 && S > 0 && lddst >= C && N < 65536, "ncdhw_f32_to_ndhwc_bf16: bad arguments");
+    ProfScope ps(PF_POOL, 0.0, 6.0 * N * C * S, (hipStream_t)stream);
     if (narrow_layout<float, bf16, false>(src, dst, lddst, N, C, S, (hipStream_t)stream)) { SEG_CHECK_LAUNCH(); return MI355SEG_OK; }
     dim3 grid((unsigned)((S + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N);
     hipLaunchKernelGGL((ncs_to_nsc_kernel<float, bf16>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, lddst, C, S);
@@ -304,6 +306,7 @@ int mi355seg_ncdhw_f32_to_ndhwc_bf16(const float* src, mi355seg_bf16* dst, int l
 }
 int mi355seg_ndhwc_to_ncdhw_f32(const float* src, int ldsrc, float* dst, long long N, int C, long long S, void* stream) {
     SEG_CHECK_ARG(src && dst && N > 0 && C > 0 && S > 0 && ldsrc >= C && N < 65536, "ndhwc_to_ncdhw: bad arguments");
+    ProfScope ps(PF_POOL, 0.0, 8.0 * N * C * S, (hipStream_t)stream);
     if (narrow_layout<float, float, true>(src, dst, ldsrc, N, C, S, (hipStream_t)stream)) { SEG_CHECK_LAUNCH(); return MI355SEG_OK; }
     dim3 grid((unsigned)((S + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N);
     hipLaunchKernelGGL((nsc_to_ncs_kernel<float, float>), grid, dim3(256), 0, (hipStream_t)stream, src, ldsrc, dst, C, S);
@@ -312,6 +315,7 @@ int mi355seg_ndhwc_to_ncdhw_f32(const float* src, int ldsrc, float* dst, long lo
 }
 int mi355seg_ndhwc_bf16_to_ncdhw_f32(const mi355seg_bf16* src, int ldsrc, float* dst, long long N, int C, long long S, void* stream) {
     SEG_CHECK_ARG(src && dst && N > 0 && C > 0 && S > 0 && ldsrc >= C && N < 65536, "ndhwc_bf16_to_ncdhw_f32: bad arguments");
+    ProfScope ps(PF_POOL, 0.0, 6.0 * N * C * S, (hipStream_t)stream);
     if (narrow_layout<bf16, float, true>(src, dst, ldsrc, N, C, S, (hipStream_t)stream)) { SEG_CHECK_LAUNCH(); return MI355SEG_OK; }
     dim3 grid((unsigned)((S + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N);
     hipLaunchKernelGGL((nsc_to_ncs_kernel<bf16, float>), grid, dim3(256), 0, (hipStream_t)stream, src, ldsrc, dst, C, S);
@@ -324,6 +328,7 @@ static int rows_grid(long long total) {
 }
 int mi355seg_copy_rows_f32(const float* src, int ldsrc, float* dst, int lddst, long long rows, int C, void* stream) {
     SEG_CHECK_ARG(src && dst && rows > 0 && C > 0 && ldsrc >= C && lddst >= C, "copy_rows: bad arguments");
+    ProfScope ps(PF_POOL, 0.0, 8.0 * rows * C, (hipStream_t)stream);
     hipLaunchKernelGGL((rows_kernel<float, false>), dim3(rows_grid(rows * C / 4 + 1)), dim3(256), 0, (hipStream_t)stream, src, ldsrc,
                        dst, lddst, rows, C);
     SEG_CHECK_LAUNCH();
@@ -331,6 +336,7 @@ int mi355seg_copy_rows_f32(const float* src, int ldsrc, float* dst, int lddst, l
 }
 int mi355seg_copy_rows_bf16(const mi355seg_bf16* src, int ldsrc, mi355seg_bf16* dst, int lddst, long long rows, int C, void* stream) {
     SEG_CHECK_ARG(src && dst && rows > 0 && C > 0 && ldsrc >= C && lddst >= C, "copy_rows: bad arguments");
+    ProfScope ps(PF_POOL, 0.0, 4.0 * rows * C, (hipStream_t)stream);
     hipLaunchKernelGGL((rows_kernel<bf16, false>), dim3(rows_grid(rows * C / 4 + 1)), dim3(256), 0, (hipStream_t)stream, src, ldsrc,
                        dst, lddst, rows, C);
     SEG_CHECK_LAUNCH();
@@ -338,6 +344,7 @@ int mi355seg_copy_rows_bf16(const mi355seg_bf16* src, int ldsrc, mi355seg_bf16* 
 }
 int mi355seg_add_rows_f32(const float* src, int ldsrc, float* dst, int lddst, long long rows, int C, void* stream) {
     SEG_CHECK_ARG(src && dst && rows > 0 && C > 0 && ldsrc >= C && lddst >= C, "add_rows: bad arguments");
+    ProfScope ps(PF_POOL, 0.0, 12.0 * rows * C, (hipStream_t)stream);
     hipLaunchKernelGGL((rows_kernel<float, true>), dim3(rows_grid(rows * C / 4 + 1)), dim3(256), 0, (hipStream_t)stream, src, ldsrc,
                        dst, lddst, rows, C);
     SEG_CHECK_LAUNCH();
@@ -345,6 +352,7 @@ int mi355seg_add_rows_f32(const float* src, int ldsrc, float* dst, int lddst, lo
 }
 int mi355seg_add_rows_bf16(const mi355seg_bf16* src, int ldsrc, mi355seg_bf16* dst, int lddst, long long rows, int C, void* stream) {
     SEG_CHECK_ARG(src && dst && rows > 0 && C > 0 && ldsrc >= C && lddst >= C, "add_rows: bad arguments");
+    ProfScope ps(PF_POOL, 0.0, 6.0 * rows * C, (hipStream_t)stream);
     hipLaunchKernelGGL((rows_kernel<bf16, true>), dim3(rows_grid(rows * C / 4 + 1)), dim3(256), 0, (hipStream_t)stream, src, ldsrc,
                        dst, lddst, rows, C);
     SEG_CHECK_LAUNCH();

@@ -338,6 +338,7 @@ int mi355seg_bce_logits_fwd_f32(const float* logits, const float* target, long l
                                 float* loss, void* ws, size_t ws_bytes, void* stream) {
     SEG_CHECK_ARG(logits && target && loss && numel > 0, "bce_logits_fwd: bad arguments");
     SEG_CHECK_ARG(((uintptr_t)logits % 16) == 0 && ((uintptr_t)target % 16) == 0, "bce_logits_fwd: pointers must be 16-byte aligned");
+    ProfScope ps(PF_LOSS, 0.0, 8.0 * numel, (hipStream_t)stream);
     int nblk = loss_grid(numel / 4 + 1);
     SEG_CHECK_WS((size_t)nblk * sizeof(double), ws_bytes);
     hipStream_t st = (hipStream_t)stream;
@@ -353,6 +354,7 @@ int mi355seg_bce_logits_bwd_f32(const float* logits, const float* target, const 
     SEG_CHECK_ARG(logits && target && gscale && dlogits && numel > 0, "bce_logits_bwd: bad arguments");
     SEG_CHECK_ARG(((uintptr_t)logits % 16) == 0 && ((uintptr_t)target % 16) == 0 && ((uintptr_t)dlogits % 16) == 0,
                   "bce_logits_bwd: pointers must be 16-byte aligned");
+    ProfScope ps(PF_LOSS, 0.0, 12.0 * numel, (hipStream_t)stream);
     hipLaunchKernelGGL(bce_bwd_kernel, dim3(loss_grid(numel / 4 + 1) * 2), dim3(256), 0, (hipStream_t)stream, logits, target,
                        gscale, numel, dlogits);
     SEG_CHECK_LAUNCH();
@@ -361,6 +363,7 @@ int mi355seg_bce_logits_bwd_f32(const float* logits, const float* target, const 
 
 int mi355seg_argmax_ch_f32(const float* logits, long long N, int K, long long S, int64_t* mask, void* stream) {
     SEG_CHECK_ARG(logits && mask && N > 0 && K > 0 && S > 0, "argmax_ch: bad arguments");
+    ProfScope ps(PF_LOSS, 0.0, (4.0 * K + 8.0) * N * S, (hipStream_t)stream);
     hipLaunchKernelGGL(argmax_kernel, dim3(loss_grid(N * S) * 2), dim3(256), 0, (hipStream_t)stream, logits, N, K, S, mask);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
@@ -369,6 +372,7 @@ int mi355seg_argmax_ch_f32(const float* logits, long long N, int K, long long S,
 int mi355seg_dice_counts_i64(const int64_t* gt, const int64_t* pred, long long numel,
                              int64_t* counts, void* ws, size_t ws_bytes, void* stream) {
     SEG_CHECK_ARG(gt && pred && counts && numel > 0, "dice_counts: bad arguments");
+    ProfScope ps(PF_LOSS, 0.0, 16.0 * numel, (hipStream_t)stream);
     int nblk = loss_grid(numel);
     SEG_CHECK_WS((size_t)nblk * 4 * sizeof(long long), ws_bytes);
     hipStream_t st = (hipStream_t)stream;
@@ -381,6 +385,7 @@ int mi355seg_dice_counts_i64(const int64_t* gt, const int64_t* pred, long long n
 
 int mi355seg_two_channel_gt_f32(const float* gt, float* out, long long N, long long S, void* stream) {
     SEG_CHECK_ARG(gt && out && N > 0 && S > 0, "two_channel_gt: bad arguments");
+    ProfScope ps(PF_LOSS, 0.0, 12.0 * N * S, (hipStream_t)stream);
     hipLaunchKernelGGL(two_channel_gt_kernel, dim3(loss_grid(N * S) * 2), dim3(256), 0, (hipStream_t)stream, gt, out, N, S);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
@@ -390,6 +395,7 @@ int mi355seg_bce_argmax_dice_f32(const float* logits, const float* target, long 
                                  float* loss, int64_t* mask, int64_t* counts,
                                  void* ws, size_t ws_bytes, void* stream) {
     SEG_CHECK_ARG(logits && target && loss && mask && counts && N > 0 && K > 0 && S > 0, "bce_argmax_dice: bad arguments");
+    ProfScope ps(PF_LOSS, 0.0, (8.0 * K + 8.0) * N * S, (hipStream_t)stream);
     int nblk = loss_grid(N * S);
     SEG_CHECK_WS((size_t)nblk * 5 * sizeof(double), ws_bytes);
     hipStream_t st = (hipStream_t)stream;
@@ -407,6 +413,7 @@ int mi355seg_bce_argmax_dice_f32(const float* logits, const float* target, long 
 int mi355seg_dice_sums_f32(const float* x, const float* t, long long numel, int apply_sigmoid,
                            double* out5, void* ws, size_t ws_bytes, void* stream) {
     SEG_CHECK_ARG(x && t && out5 && numel > 0, "dice_sums: bad arguments");
+    ProfScope ps(PF_LOSS, 0.0, 8.0 * numel, (hipStream_t)stream);
     int nblk = loss_grid(numel);
     SEG_CHECK_WS((size_t)nblk * 5 * sizeof(double), ws_bytes);
     hipStream_t st = (hipStream_t)stream;
@@ -420,6 +427,7 @@ int mi355seg_dice_sums_f32(const float* x, const float* t, long long numel, int 
 int mi355seg_dice_sums_bwd_f32(const float* x, const float* t, const double* g5, long long numel, int apply_sigmoid,
                                float* dx, void* stream) {
     SEG_CHECK_ARG(x && t && g5 && dx && numel > 0, "dice_sums_bwd: bad arguments");
+    ProfScope ps(PF_LOSS, 0.0, 12.0 * numel, (hipStream_t)stream);
     hipLaunchKernelGGL(dice_sums_bwd_kernel, dim3(loss_grid(numel) * 2), dim3(256), 0, (hipStream_t)stream, x, t, g5, numel, apply_sigmoid, dx);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
@@ -438,6 +446,7 @@ size_t mi355seg_dice_rows_ws_bytes(long long rows, long long len) {
 int mi355seg_dice_rows_f32(const float* x, const float* t, long long rows, long long len, int apply_sigmoid, float p,
                            double* out, void* ws, size_t ws_bytes, void* stream) {
     SEG_CHECK_ARG(x && t && out && rows > 0 && rows <= 65535 && len > 0, "dice_rows: bad arguments (1 <= rows <= 65535)");
+    ProfScope ps(PF_LOSS, 0.0, 8.0 * rows * len, (hipStream_t)stream);
     const int nblk = dice_rows_grid(rows, len);
     SEG_CHECK_WS((size_t)rows * nblk * 5 * sizeof(double), ws_bytes);
     const int vec = ((uintptr_t)x % 16) == 0 && ((uintptr_t)t % 16) == 0 && (rows == 1 || len % 4 == 0);
@@ -451,6 +460,7 @@ int mi355seg_dice_rows_f32(const float* x, const float* t, long long rows, long 
 int mi355seg_dice_rows_bwd_f32(const float* x, const float* t, const double* g, long long rows, long long len, int apply_sigmoid,
                                float p, float* dx, void* stream) {
     SEG_CHECK_ARG(x && t && g && dx && rows > 0 && rows <= 65535 && len > 0, "dice_rows_bwd: bad arguments (1 <= rows <= 65535)");
+    ProfScope ps(PF_LOSS, 0.0, 12.0 * rows * len, (hipStream_t)stream);
     long long per = (len + 256 * 8 - 1) / (256 * 8);
     if (per > 4096) per = 4096;
     hipLaunchKernelGGL(dice_rows_bwd_kernel, dim3((unsigned)per, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, t, g, len, apply_sigmoid, p, dx);
@@ -460,12 +470,14 @@ int mi355seg_dice_rows_bwd_f32(const float* x, const float* t, const double* g, 
 
 int mi355seg_softmax_ch_f32(const float* x, float* y, long long N, int K, long long S, void* stream) {
     SEG_CHECK_ARG(x && y && N > 0 && K > 0 && K <= kMaxClasses && S > 0, "softmax_ch: bad arguments (K <= %d)", kMaxClasses);
+    ProfScope ps(PF_LOSS, 0.0, 8.0 * N * K * S, (hipStream_t)stream);
     hipLaunchKernelGGL(softmax_ch_kernel, dim3(loss_grid(N * S) * 2), dim3(256), 0, (hipStream_t)stream, x, y, N, K, S);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
 int mi355seg_softmax_ch_bwd_f32(const float* y, const float* dy, float* dx, long long N, int K, long long S, void* stream) {
     SEG_CHECK_ARG(y && dy && dx && N > 0 && K > 0 && S > 0, "softmax_ch_bwd: bad arguments");
+    ProfScope ps(PF_LOSS, 0.0, 12.0 * N * K * S, (hipStream_t)stream);
     hipLaunchKernelGGL(softmax_ch_bwd_kernel, dim3(loss_grid(N * S) * 2), dim3(256), 0, (hipStream_t)stream, y, dy, dx, N, K, S);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
@@ -474,6 +486,7 @@ int mi355seg_softmax_ch_bwd_f32(const float* y, const float* dy, float* dx, long
 int mi355seg_ce3d_fwd_f32(const float* logits, const int64_t* labels, const float* weight, long long N, int K, long long S,
                           int size_average, float* loss, void* ws, size_t ws_bytes, void* stream) {
     SEG_CHECK_ARG(logits && labels && loss && N > 0 && K > 0 && S > 0, "ce3d_fwd: bad arguments");
+    ProfScope ps(PF_LOSS, 0.0, (4.0 * K + 8.0) * N * S, (hipStream_t)stream);
     int nblk = loss_grid(N * S);
     SEG_CHECK_WS((size_t)nblk * sizeof(double), ws_bytes);
     hipStream_t st = (hipStream_t)stream;
@@ -486,6 +499,7 @@ int mi355seg_ce3d_fwd_f32(const float* logits, const int64_t* labels, const floa
 int mi355seg_ce3d_bwd_f32(const float* logits, const int64_t* labels, const float* weight, const float* gscale,
                           long long N, int K, long long S, int size_average, float* dlogits, void* stream) {
     SEG_CHECK_ARG(logits && labels && gscale && dlogits && N > 0 && K > 0 && S > 0, "ce3d_bwd: bad arguments");
+    ProfScope ps(PF_LOSS, 0.0, (8.0 * K + 8.0) * N * S, (hipStream_t)stream);
     hipLaunchKernelGGL(ce3d_bwd_kernel, dim3(loss_grid(N * S) * 2), dim3(256), 0, (hipStream_t)stream, logits, labels, weight, gscale,
                        N, K, S, size_average ? 1.f / (float)(N * S) : 1.f, dlogits);
     SEG_CHECK_LAUNCH();
