@@ -23,4 +23,13 @@ def get_conv_math():
     return next(k for k, v in _MATH.items() if v == code)
 
 
-__all__ = ["functional", "autocast", "lib", "LIB_PATH", "Mi355SegError", "set_conv_math", "get_conv_math"]
+def set_x3_shape(shape):
+    """MFMA shape of the bf16x6 forward / input-gradient kernels: 16 (v_mfma_f32_16x16x32_bf16, default) or 32."""
+    lib().call("mi355seg_set_x3_shape", int(shape))
+
+
+def get_x3_shape():
+    return lib().query("mi355seg_get_x3_shape")
+
+
+__all__ = ["set_x3_shape", "get_x3_shape", "functional", "autocast", "lib", "LIB_PATH", "Mi355SegError", "set_conv_math", "get_conv_math"]

@@ -12,7 +12,8 @@ import re
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 HEADER = os.path.join(_ROOT, "include", "mi355seg.h")
-LIB_PATH = os.path.join(_PKG, "libmi355seg.so")
+# MI355SEG_LIB_PATH: load another build of the same library (A/B timing of kernel variants); it must export every symbol too
+LIB_PATH = os.environ.get("MI355SEG_LIB_PATH") or os.path.join(_PKG, "libmi355seg.so")
 
 _CTYPE = {
     "int": ctypes.c_int,

@@ -351,7 +351,10 @@ static int conv_math_from_env() {
     return MI355SEG_MATH_DEFAULT;
 }
 static int g_conv_math = conv_math_from_env();
+static int x3_shape_from_env() { const char* e = getenv("MI355SEG_X3_SHAPE"); return (e && !strcmp(e, "32")) ? 32 : 16; }
+static int g_x3_shape = x3_shape_from_env();
 namespace seg {
+int x3_shape() { return g_x3_shape; }
 // policy for a convolution on fp32 tensors: the split-precision kernels where the selected math asks for them
 int f32_conv_policy() { return g_conv_math == MI355SEG_MATH_BF16X6 ? MATH_X3 : MATH_F32; }
 }
@@ -407,6 +410,12 @@ int mi355seg_set_conv_math(int mode) {
     return MI355SEG_OK;
 }
 int mi355seg_get_conv_math(void) { return g_conv_math; }
+int mi355seg_set_x3_shape(int shape) {
+    SEG_CHECK_ARG(shape == 16 || shape == 32, "set_x3_shape: 16 or 32, got %d", shape);
+    g_x3_shape = shape;
+    return MI355SEG_OK;
+}
+int mi355seg_get_x3_shape(void) { return g_x3_shape; }
 
 size_t mi355seg_conv3d_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
     size_t a = conv_generic_ws_bytes(N, D, H, W, Cin, Cout, k, stride, pad);

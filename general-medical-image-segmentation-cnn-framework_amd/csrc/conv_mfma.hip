@@ -88,8 +88,32 @@ __global__ void pack_wq_lowp_kernel(const float* __restrict__ w, bf16* __restric
     }
 }
 
+// conv_x3s.hip layout: wq[nt][chunk][unit = (K-step s, 32-channel half nh)][plane][16-channel tile t2][lane][8]; lane = (c, g):
+// element e = plane of W[co = nt*NT + nh*32 + t2*16 + c][ci = chunk*16 + 8*(g&1) + e][tap = x3s_pair_tap(s, g>>1)]  (tap 27: zero)
+__global__ void pack_wq_x3s_kernel(const float* __restrict__ w, bf16* __restrict__ wq, int K, int Nn, int NBW, int mode) {
+    const int NT = 32 * NBW, NU = X3S_NPAIR * NBW, nch = K / 16;
+    const long long total = (long long)(Nn / NT) * nch * NU * 1024;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        long long q = idx;
+        const int e = (int)(q % 8); q /= 8;
+        const int lane = (int)(q % 64); q /= 64;
+        const int t2 = (int)(q % 2); q /= 2;
+        const int u = (int)(q % NU); q /= NU;
+        const int chunk = (int)(q % nch); q /= nch;
+        const int nt = (int)q;
+        const int s = u / NBW, nh = u % NBW, g = lane >> 4, c = lane & 15;
+        const int tap = x3s_pair_tap(s, g >> 1);
+        const float v = tap < 27 ? pack_src(w, mode, nt * NT + nh * 32 + t2 * 16 + c, chunk * 16 + 8 * (g & 1) + e, tap, K, Nn, 27, 0, 27, TapList{}) : 0.f;
+        bf16 bh, bm, bl;
+        split3(v, bh, bm, bl);
+        const long long base = (((long long)nt * nch + chunk) * NU + u) * 3072 + t2 * 512 + lane * 8 + e;
+        wq[base] = bh; wq[base + 1024] = bm; wq[base + 2048] = bl;
+    }
+}
+
 static int pack_grid(long long total) { return (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256); }
-static size_t wq_bytes(int math, size_t nelem) { return math == MATH_F32 ? nelem * 4 : (math == MATH_X3 ? nelem * 6 : nelem * 2); }
+// MATH_X3: sized for the 28-tap layout of conv_x3s.hip (27 taps + one zero tap), which is the larger of its two packings
+static size_t wq_bytes(int math, size_t nelem) { return math == MATH_F32 ? nelem * 4 : (math == MATH_X3 ? (nelem + nelem / 27 + 64) * 6 : nelem * 2); }
 static void launch_pack(int math, const float* w, void* wq, int K, int Nn, int T, int NT, int mode, int aux, int CK, int TW, const TapList& taps,
                         hipStream_t st) {
     const int grid = pack_grid((long long)K * Nn * T);
@@ -285,7 +309,10 @@ static void dispatch_igemm_ck(const IgemmPlan& p, const IgemmArgs& a, int nwg, h
 
 static int tile_block(int nt) { return nt % 4 == 0 ? 4 : (nt % 2 == 0 ? 2 : 1); }
 
-static void dispatch_igemm(int math, const IgemmPlan& p, const IgemmArgs& a_in, int nwg, hipStream_t st) {
+// mi355seg_set_x3_shape(32) keeps the bf16x6 convolutions on the 32x32x16-MFMA tiles of the generic kernel
+static bool x3s_enabled() { return x3_shape() == 16; }
+
+static void dispatch_igemm(int math, const IgemmPlan& p, const IgemmArgs& a_in, int nwg, hipStream_t st, bool x3s = false) {
     IgemmArgs a = a_in;
     a.total = nwg;
 #ifdef MI355SEG_TUNE
@@ -295,6 +322,7 @@ static void dispatch_igemm(int math, const IgemmPlan& p, const IgemmArgs& a_in, 
 #endif
     a.by = flat_walk ? 1 : tile_block(a.nty);
     a.bz = flat_walk ? 1 : (a.ntz >= 4 ? 4 : tile_block(a.ntz));      // z may be ragged (last brick row shorter), y must divide
+    if (x3s) { dispatch_x3s(p, a, nwg, st); return; }
     if (math != MATH_F32) { dispatch_igemm_lowp(math, p, a, nwg, st); return; }
     if (p.KS == 3) dispatch_igemm_ck<3, 16, true>(p, a, nwg, st);
     else if (p.KS == 5) dispatch_igemm_ck<5, 8, false>(p, a, nwg, st);
@@ -338,7 +366,10 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
     float* slabs = ksplit > 1 ? cv.take<float>((size_t)ksplit * nvox * Cout) : nullptr;
     size_t tail = cv.used();
     SEG_CHECK_WS(tail + ((ssum && ksplit > 1) ? colsum_ws_bytes(Cout) : 0), ws_bytes);
-    launch_pack(math, w, wq, Cin, Cout, T, p.NT, dgrad ? 1 : 0, 0, p.CK, T, TapList{}, st);
+    // fp32 tensors, bf16x6, 16-wide tiles: the 16x16x32-MFMA kernel (conv_x3s.hip) with its own weight packing
+    const bool x3s = math == MATH_X3 && x3s_enabled() && x3s_plan_ok(p, x, ldx, ksplit > 1 ? (void*)slabs : y, ksplit > 1 ? Cout : ldy, (long long)D * H * W);
+    if (x3s) hipLaunchKernelGGL(pack_wq_x3s_kernel, dim3(pack_grid((long long)28 * Cin * Cout)), dim3(256), 0, st, w, (bf16*)wq, Cin, Cout, p.NBW, dgrad ? 1 : 0);
+    else launch_pack(math, w, wq, Cin, Cout, T, p.NT, dgrad ? 1 : 0, 0, p.CK, T, TapList{}, st);
     SEG_CHECK_LAUNCH();
     IgemmArgs a{x, wq, ksplit > 1 ? nullptr : bias, ksplit > 1 ? (void*)slabs : y, spart, ldx, ksplit > 1 ? Cout : ldy, N, D, H, W, Cout,
                 p.ntx, p.nty, p.ntz, p.nN, nchunks, nchunks, p.nN, 1, 1, p.nM, ksplit, nchunks / ksplit, nvox * Cout, dbg_flags()};
@@ -347,7 +378,7 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
     const double vox = (double)nvox;
     {
         ProfScope ps(PF_IGEMM, 2.0 * vox * T * Cin * Cout, matrix_bytes(math, vox * (Cin + Cout), (double)T * Cin * Cout), st);
-        dispatch_igemm(math, p, a, nwg, st);
+        dispatch_igemm(math, p, a, nwg, st, x3s);
         SEG_CHECK_LAUNCH();
         if (ksplit > 1) {
             long long tot = nvox * (Cout / 4);

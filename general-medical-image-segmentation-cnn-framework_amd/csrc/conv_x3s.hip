@@ -1,0 +1,337 @@
+// conv_x3s.hip -- Conv3d k3 s1 p1 forward / input gradient for fp32 tensors on the bf16 matrix cores with the "bf16x6"
+// split (x = h + m + l, six bf16 products per fp32 product, fp32 accumulate: see igemm_kernel.h, MATH_X3), built on
+// v_mfma_f32_16x16x32_bf16 instead of the 32x32x16 shape of the generic kernel.
+//
+// Why a second kernel: the bf16x6 loop is power-limited (r2 PMC: MFMA busy 0.65-0.69 at an effective 1.85 GHz).  A timing
+// probe that replaced every 32x32x16 MFMA of the generic loop by two 16x16x32 MFMAs on the same operands (same FLOPs, same
+// LDS and L2 traffic) ran 10-21 % faster on the cfg-2 layers (profiles/r03_mfma_shape_probe.log): the chip holds a higher
+// clock on the smaller shape (MI355X_MICROARCH.md, DVFS give-back (7)).
+//
+//   D^T orientation: A operand = weights (16 output channels x K), B operand = voxels (K x 16 voxels of one x-line), so a
+//   lane ends up with FOUR CONSECUTIVE CHANNELS of one voxel per accumulator: the epilogue stores 16 bytes per lane.
+//   K = 32 per MFMA = two taps x 16 input channels (CK = 16 keeps the 3-plane halo tile at 63 KB: two workgroups per CU);
+//   the 27 taps form 13 pairs + one tap paired with zero weights (14 K-steps per 16-channel chunk, 3.7 % padding).
+//   LDS tile: piece-major -- six arrays (plane h/m/l x channel half) of 16-byte voxel slots -- so that the four k-groups of a
+//   fragment read (lane = (voxel r, k-group g): g&1 = channel half, g>>1 = first / second tap of the pair) are one
+//   conflict-free ds_read_b128: piece stride = 0 mod 256 B puts the two halves of a 32-lane group on the 16 distinct
+//   slots r, and a tap shift only rotates them.
+//   Tile = the generic kernel's BX = 16 tile (4 x 4 x 16 or 2 x 4 x 16 voxels, 32 or 64 channels, same walk, same split-K,
+//   same BatchNorm-statistics epilogue), so the host-side plan is shared (conv_mfma.hip).
+#include "common.h"
+#include "internal.h"
+#include "igemm_kernel.h"
+
+namespace seg {
+
+namespace {
+
+constexpr int XBX = 16, XTY = 4, XHX = XBX + 2, XHY = XTY + 2;
+
+template <int LW>
+struct Geo {
+    static constexpr int LINES = 4 * LW, TZ = LINES / XTY, HZ = TZ + 2;
+    static constexpr int NVOX = XHX * XHY * HZ;
+    static constexpr int PS = (NVOX + 15) / 16 * 16;            // 16-byte slots per piece; a multiple of 16 slots (256 B)
+    static constexpr int LDS_BYTES = 6 * PS * 16;
+    static constexpr int NPIECE = NVOX * 4;                     // staged 16-byte pieces (4 fp32 channels) per chunk
+    static constexpr int NITER = (NPIECE + 255) / 256;
+};
+
+__device__ __forceinline__ constexpr int tap_slot(int t) { return ((t / 9) * XHY + (t / 3) % 3) * XHX + t % 3; }
+// which per-lane base a K-step uses: the second tap of the pair is +1 slot (x), +HX (y), +HY*HX (z) or the same voxel (zero weights)
+__device__ __forceinline__ constexpr int pair_kind(int s) { return s < 9 ? 0 : (s < 12 ? 1 : (s == 12 ? 2 : 3)); }
+
+// sum over the 16 lanes of a DPP row (lanes with equal lane >> 4); result in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
+
+// LW = x-lines (16 voxels each) per wave: 4 -> tile 4 (z) x 4 (y) x 16, wave w owns z-slab w; 2 -> tile 2 x 4 x 16.
+// NBW = 32-channel blocks of the tile (NT = 32 * NBW output channels).
+template <int LW, int NBW>
+__global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
+    using G = Geo<LW>;
+    constexpr int NT = 32 * NBW;
+    constexpr int NTW = 2 * NBW;                                 // 16-channel MFMA tiles per wave
+    constexpr int NU = X3S_NPAIR * NBW;                          // (K-step, 32-channel half) units per chunk
+    constexpr int UNIT = 6 * 512;                                // bf16 elements of one unit of packed weights: [plane][t2][lane][8]
+    constexpr int PS = G::PS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+
+    // ---- block -> tile map: identical to conv_igemm_kernel (XCD-contiguous ranges, (y, z) bricks of M-tiles)
+    int ks, ntile, mtile, n, x0, y0, z0;
+    {
+        const int total = (int)gridDim.x, bid = blockIdx.x;
+        const int q8 = total >> 3, r8 = total & 7, xcd = bid & 7;
+        const int xstart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, xcnt = q8 + (xcd < r8 ? 1 : 0);
+        const int local = bid >> 3;
+        if (local >= xcnt) return;
+        int t = xstart + local;
+        ks = t % a.ksplit; t /= a.ksplit;
+        ntile = t % a.nN;
+        mtile = t / a.nN;
+        int mt = mtile;
+        const int per_n = a.ntx * a.nty * a.ntz;
+        n = mt / per_n; mt -= n * per_n;
+        const int zfull = a.ntz / a.bz;
+        const int rowtiles = a.ntx * a.nty * a.bz;
+        int zrow = mt / rowtiles, bzz = a.bz;
+        if (zrow >= zfull) { zrow = zfull; bzz = a.ntz - zfull * a.bz; }
+        mt -= zrow * rowtiles;
+        const int blk = a.ntx * a.by * bzz;
+        const int b = mt / blk; mt -= b * blk;
+        const int txi = mt % a.ntx; mt /= a.ntx;
+        const int tyi = b * a.by + mt % a.by;
+        const int tzi = zrow * a.bz + mt / a.by;
+        x0 = txi * XBX; y0 = tyi * XTY; z0 = tzi * G::TZ;
+    }
+    const int n0 = ntile * NT;
+    const int c0 = ks * a.cps, c1 = c0 + a.cps;
+    const float* __restrict__ xin = reinterpret_cast<const float*>(a.x);
+
+    // ---- halo staging: global -> registers (issue early) -> split3 -> LDS (write late).
+    // Piece p = it * 256 + tid is (halo voxel p / 4, four channels p % 4) of the chunk.  Its byte offset inside sample n is the
+    // same for every chunk, so it is computed once per tile; the loads are buffer loads on a per-chunk descriptor
+    // (base = sample + 16 * chunk channels) whose range check returns zeros for the pieces outside the volume (offset
+    // 0x7FFFFFF0 >= num_records): no address arithmetic and no select in the K loop.
+    int voff[G::NITER];
+#pragma unroll
+    for (int it = 0; it < G::NITER; ++it) {
+        const int p = it * 256 + tid;
+        const int vox = p >> 2, part = p & 3;
+        const int hz = vox / (XHY * XHX), rem = vox % (XHY * XHX);
+        const int hy = rem / XHX, hx = rem % XHX;
+        const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool ok = (p < G::NPIECE) && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        voff[it] = ok ? (((gz * a.H + gy) * a.W + gx) * a.ldx + part * 4) * 4 : 0x7FFFFFF0;
+    }
+    const float* xsample = xin + (long long)n * a.D * a.H * a.W * a.ldx;
+    const int sample_bytes = a.D * a.H * a.W * a.ldx * 4;        // < 2^31: checked on the host (x3s_plan_ok)
+    f32x4 stage[G::NITER];
+    auto load_stage = [&](int chunk) {
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xsample + chunk * 16), 0, sample_bytes, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < G::NITER; ++it)
+            stage[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[it], 0, 0));
+    };
+    // x = h + m + l for a pair of values: three packed conversions, the remainders formed from the packed words
+    auto split_pair = [](float x0_, float x1_, unsigned& h2, unsigned& m2, unsigned& l2) {
+        using f32x2 = __attribute__((ext_vector_type(2))) float;
+        h2 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0_, x1_}, bf16x2_t));
+        const float r0 = x0_ - __builtin_bit_cast(float, h2 << 16), r1 = x1_ - __builtin_bit_cast(float, h2 & 0xFFFF0000u);
+        m2 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2_t));
+        const float q0 = r0 - __builtin_bit_cast(float, m2 << 16), q1 = r1 - __builtin_bit_cast(float, m2 & 0xFFFF0000u);
+        l2 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{q0, q1}, bf16x2_t));
+    };
+    // piece p = it * 256 + tid sits at LDS byte  ((part >> 1) * PS + tid / 4) * 16 + (part & 1) * 8  +  it * 1024
+    unsigned char* const wdst = lds_raw + (((tid & 3) >> 1) * PS + (tid >> 2)) * 16 + (tid & 1) * 8;
+    auto write_stage = [&]() {
+#pragma unroll
+        for (int it = 0; it < G::NITER; ++it) {
+            if (it * 256 + tid < G::NPIECE) {
+                using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+                unsigned h0, m0, l0, h1, m1, l1;
+                split_pair(stage[it][0], stage[it][1], h0, m0, l0);
+                split_pair(stage[it][2], stage[it][3], h1, m1, l1);
+                const u32x2 qh = {h0, h1}, qm = {m0, m1}, ql = {l0, l1};
+                unsigned char* dst = wdst + it * 1024;
+                *reinterpret_cast<u32x2*>(dst) = qh;
+                *reinterpret_cast<u32x2*>(dst + 2 * PS * 16) = qm;
+                *reinterpret_cast<u32x2*>(dst + 4 * PS * 16) = ql;
+            }
+        }
+    };
+
+    // per-lane LDS byte bases of the voxel fragments: line 0 of this wave, tap (0, 0, 0), plane h; one per pair kind
+    const int line0 = wave * LW;
+    const int lane_slot = ((line0 / XTY) * XHY + (line0 % XTY)) * XHX + r + (g & 1) * PS;
+    const int hi = g >> 1;
+    const int xb0 = (lane_slot + hi) * 16, xb1 = (lane_slot + hi * XHX) * 16, xb2 = (lane_slot + hi * XHY * XHX) * 16, xb3 = lane_slot * 16;
+    auto xaddr = [&](int s, int j, int pl) {                     // s, j, pl are compile-time after unrolling: the rest folds into the offset field
+        const int base = pair_kind(s) == 0 ? xb0 : (pair_kind(s) == 1 ? xb1 : (pair_kind(s) == 2 ? xb2 : xb3));
+        return base + (j * XHX + tap_slot(x3s_pair_tap(s, 0)) + 2 * pl * PS) * 16;
+    };
+
+    f32x4 acc[LW][NTW];
+#pragma unroll
+    for (int j = 0; j < LW; ++j)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const bf16* wlane = reinterpret_cast<const bf16*>(a.wq) + (long long)ntile * a.nchunks * (NU * UNIT) + lane * 8;
+    load_stage(c0);
+    for (int chunk = c0; chunk < c1; ++chunk) {
+        const bf16* wp = wlane + (long long)chunk * (NU * UNIT);
+        constexpr int WD = NBW == 2 && LW == 4 ? 1 : 2;          // weight units in flight ahead of the MFMAs (the 64-channel 4-line tile is register-bound)
+        bf16x8_t wf[WD + 1][2][3], xf[2][3];
+        auto load_w = [&](int u) {
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wf[u % (WD + 1)][t2][pl] = *reinterpret_cast<const bf16x8_t*>(wp + u * UNIT + (pl * 2 + t2) * 512);
+        };
+        // the first weight units are requested BEFORE the next chunk's halo: vmcnt retires in order
+#pragma unroll
+        for (int u = 0; u < WD; ++u) load_w(u);
+        __syncthreads();                                         // every wave is done reading the previous chunk
+        write_stage();
+        __syncthreads();
+        if (chunk + 1 < c1) load_stage(chunk + 1);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) xf[0][pl] = *reinterpret_cast<const bf16x8_t*>(lds_raw + xaddr(0, 0, pl));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int s = u / NBW, nh = u % NBW;
+#pragma unroll
+            for (int j = 0; j < LW; ++j) {
+                const int q = u * LW + j, cur = q & 1, nxt = cur ^ 1;
+                if (j == 0 && u + WD < NU) load_w(u + WD);
+                if (q + 1 < NU * LW) {
+                    const int u2 = (q + 1) / LW, j2 = (q + 1) % LW;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) xf[nxt][pl] = *reinterpret_cast<const bf16x8_t*>(lds_raw + xaddr(u2 / NBW, j2, pl));
+                }
+                // planes 0 / 1 / 2 = h / m / l; the small cross terms go in first; the two channel tiles alternate
+                constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2)
+                        acc[j][nh * 2 + t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u % (WD + 1)][t2][PW[pr]], xf[cur][PX[pr]], acc[j][nh * 2 + t2], 0, 0, 0);
+                // interleave: the next line's voxels (DS, needed first) behind the first MFMAs, then the weights two units ahead
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+                if (j == 0) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);               // one scheduling region per (unit, line)
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue: bias, 16-byte stores, optional BatchNorm partial statistics
+    // acc[j][t][e] = y[voxel (line j, x = r)][channel n0 + 16 t + 4 g + e]
+    float* yslab = reinterpret_cast<float*>(a.y) + (long long)ks * a.split_stride;     // ksplit > 1: raw partial sums of this split (split_stride 0 otherwise)
+    const int gx = x0 + r;
+    float ssum[NTW][4];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ssum[t][e] = 0.f;
+    f32x4 bv[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) bv[t] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n0 + 16 * t + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < LW; ++j) {
+        const int line = line0 + j;
+        const int gz = z0 + line / XTY, gy = y0 + line % XTY;
+        const bool inside = gz < a.D && gy < a.H && gx < a.W;
+        float* dst = yslab + ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.ldy + n0 + 4 * g;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const f32x4 v = acc[j][t] + bv[t];
+            if (inside) {
+                *reinterpret_cast<f32x4*>(dst + 16 * t) = v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ssum[t][e] += v[e];
+            }
+        }
+    }
+    if (a.spart) {
+        // per channel (sum, M2 about the tile mean, n) of this tile, as conv_igemm_kernel: spart[mtile][c] = {sum, M2, n}
+        float* lds = reinterpret_cast<float*>(lds_raw);
+        __syncthreads();                 // LDS halo no longer needed
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float s1 = row16_sum(ssum[t][e]);
+                if (r == 0) lds[wave * NT + 16 * t + 4 * g + e] = s1;
+            }
+        const int vz = min(G::TZ, a.D - z0), vy = min(XTY, a.H - y0), vx = min(XBX, a.W - x0);
+        const float cnt = (float)(vz * vy * vx);
+        __syncthreads();
+        float tmean[NTW][4];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 16 * t + 4 * g + e;
+                tmean[t][e] = (lds[c] + lds[NT + c] + lds[2 * NT + c] + lds[3 * NT + c]) / cnt;
+            }
+        __syncthreads();
+        float m2[NTW][4];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m2[t][e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < LW; ++j) {
+            const int line = line0 + j;
+            const bool inside = (z0 + line / XTY) < a.D && (y0 + line % XTY) < a.H && gx < a.W;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = acc[j][t][e] + bv[t][e] - tmean[t][e];
+                    if (inside) m2[t][e] += d * d;
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = row16_sum(m2[t][e]);
+                if (r == 0) lds[(4 + wave) * NT + 16 * t + 4 * g + e] = v;
+            }
+        __syncthreads();
+        if (tid < NT) {
+            float s1 = 0.f, mm = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s1 += lds[w * NT + tid]; mm += lds[(4 + w) * NT + tid]; }
+            float* dst = a.spart + ((long long)mtile * a.Cout + n0 + tid) * 3;
+            dst[0] = s1; dst[1] = mm; dst[2] = cnt;
+        }
+    }
+}
+
+template <int LW, int NBW>
+void launch_x3s(const IgemmArgs& a, int nwg, hipStream_t st) {
+    constexpr int LDSB = Geo<LW>::LDS_BYTES;
+    static_assert(LDSB >= 8 * 64 * 4, "the statistics epilogue needs 8 x NT floats");
+    // set on every call: cheap, and correct for a process that drives more than one device
+    (void)hipFuncSetAttribute((const void*)conv_x3s_kernel<LW, NBW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+    hipLaunchKernelGGL((conv_x3s_kernel<LW, NBW>), dim3(nwg), dim3(256), LDSB, st, a);
+}
+
+}  // namespace
+
+// the generic plan's BX = 16 tiles (MB = 2 <-> four lines per wave, MB = 1 <-> two) map one to one onto this kernel
+bool x3s_plan_ok(const IgemmPlan& p, const void* x, int ldx, const void* y, int ldy, long long sample_voxels) {
+    if (sample_voxels * ldx * 4 >= 0x7FFFFFF0LL) return false;        // the halo loads address one sample through a 32-bit buffer offset
+    return p.KS == 3 && p.CK == 16 && p.BX == 16 && (p.MB == 1 || p.MB == 2) && (p.NBW == 1 || p.NBW == 2) && p.WN == 1 && p.TY == 4 &&
+           (ldx % 4) == 0 && (ldy % 4) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0;
+}
+
+void dispatch_x3s(const IgemmPlan& p, const IgemmArgs& a, int nwg, hipStream_t st) {
+    if (p.MB == 2) { if (p.NBW == 2) launch_x3s<4, 2>(a, nwg, st); else launch_x3s<4, 1>(a, nwg, st); }
+    else { if (p.NBW == 2) launch_x3s<2, 2>(a, nwg, st); else launch_x3s<2, 1>(a, nwg, st); }
+}
+
+}  // namespace seg

@@ -36,6 +36,23 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 #define SEG_DBG(a, bit) 0
 #endif
 
+#ifdef MI355SEG_PROBE16
+// timing probe only (garbage results): one 32x32x16 MFMA replaced by two 16x16x32 MFMAs on quarters of its accumulator --
+// same FLOPs, same operand registers -- to see which clock the chip holds under the other MFMA shape in THIS loop
+template <int Q>
+__device__ __forceinline__ f32x16 probe16(bf16x8_t a, bf16x8_t b, f32x16 c) {
+    f32x4 s = {c[4 * Q], c[4 * Q + 1], c[4 * Q + 2], c[4 * Q + 3]};
+    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, s, 0, 0, 0);
+    c[4 * Q] = s[0]; c[4 * Q + 1] = s[1]; c[4 * Q + 2] = s[2]; c[4 * Q + 3] = s[3];
+    return c;
+}
+#endif
+
+#ifdef MI355SEG_PROBE16
+#define SEG_MFQ 2
+#else
+#define SEG_MFQ 1
+#endif
 template <int MATH> struct MathTraits;
 template <> struct MathTraits<MATH_F32> { using in_t = float; using out_t = float; static constexpr int NP = 1, EPP = 4, LDS_ELEM = 4, KGRAN = 8; };
 template <> struct MathTraits<MATH_X3> { using in_t = float; using out_t = float; static constexpr int NP = 3, EPP = 4, LDS_ELEM = 2, KGRAN = 16; };
@@ -433,19 +450,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
 #pragma unroll
                         for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
-                            for (int nb = 0; nb < NBW; ++nb)
+                            for (int nb = 0; nb < NBW; ++nb) {
+#ifdef MI355SEG_PROBE16
+                                if (pr & 1) { acc[mb][nb] = probe16<2>(av[cur][PA[pr]], bq[step & 1][nb][PB[pr]], acc[mb][nb]);
+                                              acc[mb][nb] = probe16<3>(av[cur][PA[pr]], bq[step & 1][nb][PB[pr]], acc[mb][nb]); }
+                                else { acc[mb][nb] = probe16<0>(av[cur][PA[pr]], bq[step & 1][nb][PB[pr]], acc[mb][nb]);
+                                       acc[mb][nb] = probe16<1>(av[cur][PA[pr]], bq[step & 1][nb][PB[pr]], acc[mb][nb]); }
+#else
                                 acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cur][PA[pr]], bq[step & 1][nb][PB[pr]], acc[mb][nb], 0, 0, 0);
+#endif
+                            }
                         // interleave: the next block's voxels (DS, needed first) behind the first MFMAs, then the next step's weights
 #pragma unroll
                         for (int g = 0; g < 3; ++g) {
                             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, SEG_MFQ, 0);
                         }
                         if (mb == 0) {
 #pragma unroll
                             for (int g = 0; g < 3 * NBW; ++g) {
                                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x008, SEG_MFQ, 0);
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);      // one scheduling region per (k-step, M-block)
@@ -625,6 +650,18 @@ static void launch_igemm(const IgemmArgs& a, int nwg, hipStream_t st) {
     const int grid = (T::PERSIST && nwg > 512) ? 512 : nwg;   // persistent variants: two workgroups per CU walk the tiles
     hipLaunchKernelGGL((conv_igemm_kernel<MATH, KS, BX, MB, NBW, CK, WN>), dim3(grid), dim3(256), LDSB, st, a);
 }
+
+// conv_x3s.hip: the bf16x6 k3 kernel on v_mfma_f32_16x16x32_bf16 (fp32 tensors, BX = 16 tiles of the plan above).
+// K-step s of a 16-channel chunk contracts the tap pair (x3s_pair_tap(s, 0), x3s_pair_tap(s, 1)); tap 27 = zero weights.
+constexpr int X3S_NPAIR = 14;
+__host__ __device__ constexpr int x3s_pair_tap(int s, int which) {
+    if (s < 9) return (s / 3) * 9 + (s % 3) * 3 + which;           // (dz, dy, dx = 0 | 1)
+    if (s < 12) return (s - 9) * 9 + which * 3 + 2;                 // (dz, dy = 0 | 1, dx = 2)
+    if (s == 12) return which * 9 + 8;                              // (dz = 0 | 1, dy = 2, dx = 2)
+    return which == 0 ? 26 : 27;                                    // (2, 2, 2) + zero
+}
+bool x3s_plan_ok(const IgemmPlan& p, const void* x, int ldx, const void* y, int ldy, long long sample_voxels);
+void dispatch_x3s(const IgemmPlan& p, const IgemmArgs& a, int nwg, hipStream_t st);
 
 // conv_igemm_lowp.hip: the MATH_X3 / MATH_B16 instantiations (their own translation unit: they compile in parallel)
 void dispatch_igemm_lowp(int math, const IgemmPlan& p, const IgemmArgs& a, int nwg, hipStream_t st);

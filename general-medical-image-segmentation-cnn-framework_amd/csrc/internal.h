@@ -83,6 +83,7 @@ template <typename T> int head_wgrad(const T* dy, int lddy, const T* x, int ldx,
 
 // conv_generic.hip
 int f32_conv_policy();     // MATH_X3 when the bf16x6 conv math is selected, else MATH_F32
+int x3_shape();            // 16 | 32: MFMA shape of the bf16x6 forward / dgrad kernels (mi355seg_set_x3_shape)
 void pack_w_fwd(const float* w, float* wp, int Cout, int Cin, int T, hipStream_t st);
 void pack_w_dgrad(const float* w, float* wd, int Cout, int Cin, int T, int flip, hipStream_t st);
 void wgrad_reduce(const float* part, float* dw, int splits, int T, int Cin, int Cout, int accumulate, hipStream_t st);

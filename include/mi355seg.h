@@ -65,6 +65,12 @@ int mi355seg_version(void);
 #define MI355SEG_MATH_DEFAULT MI355SEG_MATH_BF16X6
 int mi355seg_set_conv_math(int mode);
 int mi355seg_get_conv_math(void);
+/* MFMA shape of the BF16X6 forward / input-gradient kernels: 16 = v_mfma_f32_16x16x32_bf16 (conv_x3s.hip; the default: the
+ * chip holds a higher clock under it, +8-12 % on the cfg-2 layers), 32 = v_mfma_f32_32x32x16_bf16 (the generic kernel).  Same six
+ * products per fp32 product either way; layers the 16-wide tiles do not cover use 32 regardless.  Process-wide, read at each
+ * launch.  Initial value: environment MI355SEG_X3_SHAPE = 16 | 32. */
+int mi355seg_set_x3_shape(int shape);
+int mi355seg_get_x3_shape(void);
 
 /* ------------------------------------------------------------------ Conv3d
  * Replaces nn.Conv3d forward/backward (ATen convolution / convolution_backward):

@@ -481,21 +481,79 @@ def test_split_precision_conv_is_fp32_accurate(seg, case):
     want.backward(g.double())
     errs = {}
     try:
-        for math in ("fp32", "bf16x6"):
+        # bf16x6 on both MFMA shapes: 16 = conv_x3s.hip (v_mfma_f32_16x16x32_bf16, where its 16-wide tiles apply), 32 = the generic kernel
+        for math, shape in (("fp32", 16), ("bf16x6", 32), ("bf16x6", 16)):
             seg.set_conv_math(math)
-            assert seg.get_conv_math() == math
+            seg.set_x3_shape(shape)
+            assert seg.get_conv_math() == math and seg.get_x3_shape() == shape
             xg = cl(x).requires_grad_(True)
             wg = w.cuda().requires_grad_(True)
             y = F.conv3d(xg, wg, b.cuda(), 1, pad)
             y.backward(cl(g))
-            errs[math] = ((cf(y).double() - want.detach()).abs().max().item(), (cf(xg.grad).double() - xd.grad).abs().max().item(),
-                          (wg.grad.cpu().double() - wd.grad).abs().max().item())
+            errs[(math, shape)] = ((cf(y).double() - want.detach()).abs().max().item(), (cf(xg.grad).double() - xd.grad).abs().max().item(),
+                                   (wg.grad.cpu().double() - wd.grad).abs().max().item())
     finally:
         seg.set_conv_math(DEFAULT_MATH)
+        seg.set_x3_shape(16)
     scales = (float(want.abs().max()), float(xd.grad.abs().max()), float(wd.grad.abs().max()))
-    for what, e6, e32, sc in zip(("fwd", "dgrad", "wgrad"), errs["bf16x6"], errs["fp32"], scales):
-        assert e6 < 3e-6 * max(1.0, sc), (what, e6, e32, sc)
-        assert e6 < 4.0 * e32 + 2e-7 * max(1.0, sc), (what, e6, e32, sc)
+    for shape in (32, 16):
+        for what, e6, e32, sc in zip(("fwd", "dgrad", "wgrad"), errs[("bf16x6", shape)], errs[("fp32", 16)], scales):
+            assert e6 < 3e-6 * max(1.0, sc), (shape, what, e6, e32, sc)
+            assert e6 < 4.0 * e32 + 2e-7 * max(1.0, sc), (shape, what, e6, e32, sc)
+
+
+@pytest.mark.parametrize("case", [(1, 32, 32, 32, 32, 32, 0), (1, 16, 16, 16, 32, 64, 0), (1, 16, 16, 16, 64, 64, 0), (2, 16, 16, 16, 128, 128, 0),
+                                  (1, 9, 7, 20, 32, 64, 0), (2, 5, 6, 17, 64, 32, 0), (1, 16, 16, 48, 64, 32, 32), (1, 12, 8, 16, 32, 32, 16)])
+def test_bf16x6_16x16x32_kernel_against_fp64_and_the_32x32x16_kernel(seg, case):
+    """conv_x3s.hip (bf16x6 on v_mfma_f32_16x16x32_bf16: tap-paired K = 32 steps, piece-major LDS tile) through the C-ABI on every
+    variant it has -- four / two lines per wave, 32- / 64-channel tiles, split-K slabs (few tiles), ragged extents, channel-slice
+    pitches (ld > C) -- forward with bias + BatchNorm statistics and input gradient: error statistics against an fp64 convolution
+    must match the generic 32x32x16 kernel's (same six products: the two are the same arithmetic in a different summation
+    order) and the exact-fp32 MFMA path's."""
+    N, D, H, W, Cin, Cout, extra = case
+    F, L = seg.functional, seg.lib()
+    ldx, ldy = Cin + extra, Cout + extra
+    xw = rnd(N, D, H, W, ldx, seed=1)
+    w = rnd(Cout, Cin, 3, 3, 3, seed=2, scale=(2.0 / (27 * Cin)) ** 0.5)
+    b = rnd(Cout, seed=3, scale=0.1)
+    gw = rnd(N, D, H, W, ldy, seed=4)
+    x, g = xw[..., :Cin], gw[..., :Cout]
+    want = TF.conv3d(x.permute(0, 4, 1, 2, 3).double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 4, 1)
+    want_dx = torch.nn.grad.conv3d_input((N, Cin, D, H, W), w.double(), g.permute(0, 4, 1, 2, 3).double(), padding=1).permute(0, 2, 3, 4, 1)
+    xg, gg, wg, bg = xw.cuda(), gw.cuda(), w.cuda(), b.cuda()
+    ws = F.workspace(L.query("mi355seg_conv3d_ws_bytes", N, D, H, W, Cin, Cout, 3, 1, 1), xg.device)
+    st = torch.cuda.current_stream().cuda_stream
+    res = {}
+    try:
+        for math, shape in (("fp32", 16), ("bf16x6", 32), ("bf16x6", 16)):
+            seg.set_conv_math(math)
+            seg.set_x3_shape(shape)
+            y = torch.full((N, D, H, W, ldy), 7.0, device="cuda")
+            dx = torch.full((N, D, H, W, ldx), 7.0, device="cuda")
+            ssum = torch.zeros(Cout, dtype=torch.float64, device="cuda")
+            ssq = torch.zeros_like(ssum)
+            L.call("mi355seg_conv3d_fwd_f32", xg.data_ptr(), ldx, wg.data_ptr(), bg.data_ptr(), y.data_ptr(), ldy, N, D, H, W, Cin, Cout, 3, 1, 1,
+                   ssum.data_ptr(), ssq.data_ptr(), ws.data_ptr(), ws.numel(), st)
+            L.call("mi355seg_conv3d_dgrad_f32", gg.data_ptr(), ldy, wg.data_ptr(), dx.data_ptr(), ldx, N, D, H, W, Cin, Cout, 3, 1, 1,
+                   ws.data_ptr(), ws.numel(), st)
+            torch.cuda.synchronize()
+            if extra:                                            # the channels beyond C of a slice pitch are not the kernel's to touch
+                assert bool((y[..., Cout:] == 7.0).all()) and bool((dx[..., Cin:] == 7.0).all())
+            ey, ed = y[..., :Cout].cpu().double() - want, dx[..., :Cin].cpu().double() - want_dx
+            res[(math, shape)] = (ey, ed, ssum.cpu(), ssq.cpu())
+    finally:
+        seg.set_conv_math(DEFAULT_MATH)
+        seg.set_x3_shape(16)
+    sy, sd = float(want.abs().max()), float(want_dx.abs().max())
+    rms = lambda e: float(e.pow(2).mean().sqrt())
+    e16, e32, ef = res[("bf16x6", 16)], res[("bf16x6", 32)], res[("fp32", 16)]
+    for i, sc in ((0, sy), (1, sd)):
+        assert float(e16[i].abs().max()) < 3e-6 * sc
+        assert rms(e16[i]) <= 1.25 * max(rms(e32[i]), rms(ef[i])) + 1e-9 * sc          # same error level as the other two maths
+        assert abs(float(e16[i].mean())) <= 2e-7 * sc                                  # no systematic offset
+    nvox = N * D * H * W
+    assert torch.allclose(e16[2], want.sum(dim=(0, 1, 2, 3)), rtol=0, atol=2e-6 * sy * nvox)
+    assert torch.allclose(e16[3], want.pow(2).sum(dim=(0, 1, 2, 3)), rtol=2e-6, atol=1e-9)
 
 
 @pytest.mark.parametrize("shape", [(2, 5, 4, 6, 7), (2, 2, 4, 6, 8), (1, 3, 4, 6, 8), (3, 4, 2, 6, 10), (2, 2, 3, 5, 7), (1, 1, 4, 4, 4)])
