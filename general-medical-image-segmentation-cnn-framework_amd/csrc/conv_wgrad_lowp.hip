@@ -2,8 +2,9 @@
 //
 //   dW[tap][ci][co] = sum over voxels v of  x[v + tap][ci] * dy[v][co]
 //
-// i.e. one GEMM per tap with M = Cin, N = Cout and K = all output voxels, on v_mfma_f32_32x32x16_bf16 with fp32
-// accumulation.  Two arithmetic policies (common.h):
+// i.e. one GEMM per tap with M = Cin, N = Cout and K = all output voxels, on v_mfma_f32_16x16x32_bf16 (2 x 2 MFMA tiles per
+// 32 x 32 channel block and 32-voxel k-step; the chip holds a higher clock under this shape than under 32x32x16, see
+// conv_x3s.hip) with fp32 accumulation.  Two arithmetic policies (common.h):
 //   MATH_X3  fp32 tensors ("bf16x6"): x and dy are split once, while they are staged, into three bf16 planes each
 //            (v = h + m + l, 24 mantissa bits) and six MFMAs (lh, hl, mm, mh, hm, hh) form each product -- fp32-level
 //            accuracy at 2.7x the fp32 matrix rate;
@@ -53,7 +54,7 @@ struct LTile {
     static_assert(S == 1 || KS == 3, "strided tiles are built for k3");
     static constexpr int NVOX = HX * HY * HZ;
     static constexpr int ROW = 64 * NP;                           // bytes per voxel row: NP planes of 32 bf16 channels
-    static constexpr int KSTEPS = VOX / 16;
+    static constexpr int KSTEPS = VOX / 32;                       // 32-voxel k-steps
     static constexpr int X_BYTES = NVOX * ROW, D_BYTES = VOX * ROW;
     static constexpr int LDS_BYTES = X_BYTES + D_BYTES;
     static_assert(TZ >= 1 && LINES % TY == 0, "tile lines must fill whole y-rows");
@@ -89,8 +90,6 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5, i = lane & 31;
-
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
@@ -101,13 +100,14 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
     const IN_T* __restrict__ xin = reinterpret_cast<const IN_T*>(a.x);
     const IN_T* __restrict__ din = reinterpret_cast<const IN_T*>(a.dy);
 
-    // transposing-read lane geometry: lane 4q+p of a 16-lane group addresses voxel row q, channels 4p..4p+3 of the group's
-    // 16-channel half; group (h, cg) covers k = 8h .. 8h+7 (two reads of 4) and channels 16cg .. 16cg+15
-    const int li = lane & 15, q = li >> 2, p = li & 3, cg = (lane >> 4) & 1;
-    const int chan_off = (16 * cg + 4 * p) * 2;
-    const int kq_x = (BX >= 16 ? (8 * h + q) * S : h * S * T::HX + q * S);    // BX = 8: the two halves of a k-step are two x-lines
+    // transposing-read lane geometry: lane 4q+p of a 16-lane group addresses voxel row q, channels 4p..4p+3 of the fragment's
+    // 16 channels and receives the four voxels of channel 4q+p; group g = lane / 16 covers k = 8g .. 8g+7 of the 32-voxel k-step
+    // (two reads of 4).  A k-step is one x-line (BX = 32), two (BX = 16: g / 2 picks the line) or four (BX = 8: g picks it).
+    const int li = lane & 15, q = li >> 2, p = li & 3, g = lane >> 4;
+    const int chan_off = 4 * p * 2;
+    const int kq_x = BX == 32 ? (8 * g + q) * S : (BX == 16 ? (g >> 1) * S * T::HX + (8 * (g & 1) + q) * S : g * S * T::HX + q * S);
     const int lane_x = kq_x * T::ROW + chan_off;
-    const int lane_d = (8 * h + q) * T::ROW + chan_off;
+    const int lane_d = (8 * g + q) * T::ROW + chan_off;
 
     // the taps of this wave: wave, wave + 8, wave + 16 (, wave + 24 for the first waves)
     const bool has_last = wave + LW_WAVES * (LW_TPW - 1) <= T::NTAPS - 1;       // wave-uniform
@@ -120,11 +120,11 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
         abase[tt] = ((dz * T::HY + dy) * T::HX + dx) * T::ROW + lane_x;
     }
 
-    f32x16 acc[LW_TPW];
+    f32x4 acc[LW_TPW][2][2];                                      // [tap-tile][ci half][co half]
 #pragma unroll
     for (int tt = 0; tt < LW_TPW; ++tt)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[tt][v] = 0.f;
+        for (int ab = 0; ab < 4; ++ab) acc[tt][ab >> 1][ab & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     using stage_t = typename std::conditional<EPP == 4, f32x4, bf16x8_t>::type;
     stage_t sx[XITER], sd[DITER];
@@ -189,43 +189,77 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
         for (int it = 0; it < DITER; ++it) put(ds, it * LW_THREADS + tid, sd[it]);
     };
 
-    // byte offset of k-step ks, half-read t inside the x halo / the dy tile (lane part excluded)
+    // byte offset of 32-voxel k-step ks, half-read t inside the x halo / the dy tile (lane part excluded)
     auto xoff = [](int ks, int t) {
-        if constexpr (BX >= 16) {
-            const int line = ks / (BX / 16), xp = ks % (BX / 16);
-            return ((((line / T::TY) * S * T::HY + (line % T::TY) * S) * T::HX) + (xp * 16 + 4 * t) * S) * T::ROW;
-        } else {
-            const int line = 2 * ks;
-            return ((((line / T::TY) * S * T::HY + (line % T::TY) * S) * T::HX) + 4 * t * S) * T::ROW;
-        }
+        const int line = ks * (32 / BX);
+        return ((((line / T::TY) * S * T::HY + (line % T::TY) * S) * T::HX) + 4 * t * S) * T::ROW;
     };
-    auto doff = [](int ks, int t) { return (ks * 16 + 4 * t) * T::ROW; };
+    auto doff = [](int ks, int t) { return (ks * 32 + 4 * t) * T::ROW; };
 
+    // bf16 tensors (one MFMA per fragment pair): one scheduling region per (k-step, tap-tile); the x fragments of the NEXT region
+    // are requested behind the first MFMAs of the current one (left alone the compiler sinks the transposing reads next to
+    // their first use and every tap-tile starts with an exposed LDS latency).  The MFMAs of a region run co-half 0 first: the
+    // dy fragments are single-buffered, half 0 of the next k-step is requested behind the last region's half-0 MFMAs and
+    // half 1 at the start of the next region.
     auto tile_mfma = [&](auto ntc) {
         constexpr int NTT = decltype(ntc)::value;
-        bf16x8_t ac[NTT][NP], bc[NP];
+        constexpr int NREG = T::KSTEPS * NTT;
+        bf16x8_t bc[2][NP], ac[2][2][NP];
+        auto load_b = [&](int ks, int b) {
 #pragma unroll
-        for (int ks = 0; ks < T::KSTEPS; ++ks) {
+            for (int pl = 0; pl < NP; ++pl) bc[b][pl] = tr_frag(ds, lane_d + doff(ks, 0) + b * 32 + pl * 64, lane_d + doff(ks, 1) + b * 32 + pl * 64);
+        };
+        auto load_a = [&](int buf, int ks, int tt) {
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl) bc[pl] = tr_frag(ds, lane_d + doff(ks, 0) + pl * 64, lane_d + doff(ks, 1) + pl * 64);
+            for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-            for (int tt = 0; tt < NTT; ++tt)
+                for (int pl = 0; pl < NP; ++pl) ac[buf][a2][pl] = tr_frag(xs, abase[tt] + xoff(ks, 0) + a2 * 32 + pl * 64, abase[tt] + xoff(ks, 1) + a2 * 32 + pl * 64);
+        };
+        auto mfma_half = [&](int cur, int tt, int b) {
+            if constexpr (NP == 3) {                // planes 0 / 1 / 2 = h / m / l; the small cross terms go in first; the two ci tiles alternate
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl) ac[tt][pl] = tr_frag(xs, abase[tt] + xoff(ks, 0) + pl * 64, abase[tt] + xoff(ks, 1) + pl * 64);
+                for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
-            for (int tt = 0; tt < NTT; ++tt) {
-                f32x16 c = acc[tt];
-                if constexpr (NP == 3) {                // planes 0 / 1 / 2 = h / m / l; the small cross terms go in first
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[tt][2], bc[0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[tt][0], bc[2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[tt][1], bc[1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[tt][1], bc[0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[tt][0], bc[1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[tt][0], bc[0], c, 0, 0, 0);
-                } else {
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[tt][0], bc[0], c, 0, 0, 0);
+                    for (int a2 = 0; a2 < 2; ++a2)
+                        acc[tt][a2][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[cur][a2][PA[pr]], bc[b][PB[pr]], acc[tt][a2][b], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int a2 = 0; a2 < 2; ++a2)
+                    acc[tt][a2][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[cur][a2][0], bc[b][0], acc[tt][a2][b], 0, 0, 0);
+            }
+        };
+        if constexpr (NP == 3 || S == 2) {
+            // (the strided tiles are register-bound too.)  bf16x6: 24 MFMAs per tap-tile hide the reads of the next one by themselves (two waves per SIMD); pinning the order by
+            // hand costs registers the three-plane fragments do not leave (measured: 42 spilled VGPRs, 0.68x) -- compiler order
+#pragma unroll
+            for (int ks = 0; ks < T::KSTEPS; ++ks) {
+                load_b(ks, 0); load_b(ks, 1);
+#pragma unroll
+                for (int tt = 0; tt < NTT; ++tt) {
+                    load_a(0, ks, tt);
+                    mfma_half(0, tt, 0);
+                    mfma_half(0, tt, 1);
                 }
-                acc[tt] = c;
+            }
+        } else {
+            load_b(0, 0); load_b(0, 1);
+            load_a(0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < NREG; ++u) {
+                const int ks = u / NTT, tt = u % NTT, cur = u & 1;
+                if (tt == 0 && ks > 0) load_b(ks, 1);
+                if (u + 1 < NREG) load_a(cur ^ 1, (u + 1) / NTT, (u + 1) % NTT);
+                mfma_half(cur, tt, 0);
+                if (tt == NTT - 1 && ks + 1 < T::KSTEPS) load_b(ks + 1, 0);
+                mfma_half(cur, tt, 1);
+                // spread the region's reads over its MFMAs (groups that find no read left are no-ops)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) { __builtin_amdgcn_sched_group_barrier(0x100, 3, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
@@ -243,17 +277,16 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
         else tile_mfma(std::integral_constant<int, LW_TPW - 1>{});
     }
 
-    // slab store: part[strip][tap][ci][co]; rows of the 32x32 tile = ci, lanes (cols) = co
+    // slab store: part[strip][tap][ci][co]; a 16 x 16 tile holds ci = 4 (lane / 16) + e in its four registers, co on the lanes
 #pragma unroll
     for (int tt = 0; tt < LW_TPW; ++tt) {
         const int tap = wave + LW_WAVES * tt;
         if (tap > T::NTAPS - 1) break;
-        float* dst = a.part + (((long long)strip * a.ntaps_total + plane * T::NTAPS + tap) * a.Cin + ci0) * a.Cout + co0 + i;
+        float* dst = a.part + (((long long)strip * a.ntaps_total + plane * T::NTAPS + tap) * a.Cin + ci0 + 4 * g) * a.Cout + co0 + li;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int r = (v & 3) + 8 * (v >> 2) + 4 * h;
-            dst[(long long)r * a.Cout] = acc[tt][v];
-        }
+        for (int ab = 0; ab < 4; ++ab)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[(long long)(16 * (ab >> 1) + e) * a.Cout + 16 * (ab & 1)] = acc[tt][ab >> 1][ab & 1][e];
     }
 }
 

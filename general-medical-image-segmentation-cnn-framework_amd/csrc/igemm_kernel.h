@@ -36,23 +36,6 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 #define SEG_DBG(a, bit) 0
 #endif
 
-#ifdef MI355SEG_PROBE16
-// timing probe only (garbage results): one 32x32x16 MFMA replaced by two 16x16x32 MFMAs on quarters of its accumulator --
-// same FLOPs, same operand registers -- to see which clock the chip holds under the other MFMA shape in THIS loop
-template <int Q>
-__device__ __forceinline__ f32x16 probe16(bf16x8_t a, bf16x8_t b, f32x16 c) {
-    f32x4 s = {c[4 * Q], c[4 * Q + 1], c[4 * Q + 2], c[4 * Q + 3]};
-    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, s, 0, 0, 0);
-    c[4 * Q] = s[0]; c[4 * Q + 1] = s[1]; c[4 * Q + 2] = s[2]; c[4 * Q + 3] = s[3];
-    return c;
-}
-#endif
-
-#ifdef MI355SEG_PROBE16
-#define SEG_MFQ 2
-#else
-#define SEG_MFQ 1
-#endif
 template <int MATH> struct MathTraits;
 template <> struct MathTraits<MATH_F32> { using in_t = float; using out_t = float; static constexpr int NP = 1, EPP = 4, LDS_ELEM = 4, KGRAN = 8; };
 template <> struct MathTraits<MATH_X3> { using in_t = float; using out_t = float; static constexpr int NP = 3, EPP = 4, LDS_ELEM = 2, KGRAN = 16; };
@@ -450,27 +433,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
 #pragma unroll
                         for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
-                            for (int nb = 0; nb < NBW; ++nb) {
-#ifdef MI355SEG_PROBE16
-                                if (pr & 1) { acc[mb][nb] = probe16<2>(av[cur][PA[pr]], bq[step & 1][nb][PB[pr]], acc[mb][nb]);
-                                              acc[mb][nb] = probe16<3>(av[cur][PA[pr]], bq[step & 1][nb][PB[pr]], acc[mb][nb]); }
-                                else { acc[mb][nb] = probe16<0>(av[cur][PA[pr]], bq[step & 1][nb][PB[pr]], acc[mb][nb]);
-                                       acc[mb][nb] = probe16<1>(av[cur][PA[pr]], bq[step & 1][nb][PB[pr]], acc[mb][nb]); }
-#else
+                            for (int nb = 0; nb < NBW; ++nb)
                                 acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cur][PA[pr]], bq[step & 1][nb][PB[pr]], acc[mb][nb], 0, 0, 0);
-#endif
-                            }
                         // interleave: the next block's voxels (DS, needed first) behind the first MFMAs, then the next step's weights
 #pragma unroll
                         for (int g = 0; g < 3; ++g) {
                             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x008, SEG_MFQ, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         }
                         if (mb == 0) {
 #pragma unroll
                             for (int g = 0; g < 3 * NBW; ++g) {
                                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                                __builtin_amdgcn_sched_group_barrier(0x008, SEG_MFQ, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);      // one scheduling region per (k-step, M-block)
