@@ -32,4 +32,13 @@ def get_x3_shape():
     return lib().query("mi355seg_get_x3_shape")
 
 
-__all__ = ["set_x3_shape", "get_x3_shape", "functional", "autocast", "lib", "LIB_PATH", "Mi355SegError", "set_conv_math", "get_conv_math"]
+def set_b16_tiles(mode):
+    """Tiling of the k3 / k5 convolutions on bf16 tensors: 0 automatic, 1 the 16x16x32 kernel wherever possible, 2 generic tiles only."""
+    lib().call("mi355seg_set_b16_tiles", int(mode))
+
+
+def get_b16_tiles():
+    return lib().query("mi355seg_get_b16_tiles")
+
+
+__all__ = ["set_b16_tiles", "get_b16_tiles", "set_x3_shape", "get_x3_shape", "functional", "autocast", "lib", "LIB_PATH", "Mi355SegError", "set_conv_math", "get_conv_math"]

@@ -10,6 +10,7 @@
 // write of tensors that are a few channels wide -- correct for every geometry, never the hot layers.
 #include "common.h"
 #include "internal.h"
+#include "igemm_kernel.h"
 
 namespace seg {
 
@@ -89,6 +90,13 @@ static int native_wgrad(int N, int D, int H, int W, int Cin, int Cout, int k, in
 using namespace seg;
 
 extern "C" {
+
+int mi355seg_set_b16_tiles(int mode) {
+    SEG_CHECK_ARG(mode >= 0 && mode <= 2, "set_b16_tiles: 0 (auto), 1 (16x16x32 tiles wherever possible) or 2 (generic tiles), got %d", mode);
+    set_b16_tiles(mode);
+    return MI355SEG_OK;
+}
+int mi355seg_get_b16_tiles(void) { return get_b16_tiles(); }
 
 // workspace of the three bf16 Conv3d entry points for one layer geometry (contiguous tensors assumed for the fallback test)
 size_t mi355seg_conv3d_ws_bytes_bf16(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad) {

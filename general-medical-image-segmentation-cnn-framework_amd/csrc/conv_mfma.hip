@@ -111,9 +111,30 @@ __global__ void pack_wq_x3s_kernel(const float* __restrict__ w, bf16* __restrict
     }
 }
 
+// conv_b16s.hip layout: wq[nt][chunk][K-step s][16-channel tile tt][lane][8]; lane = (c, g), c = 4 g' + e':
+// element e = bf16 of W[co = nt*NT + 32 (tt / 2) + 8 g' + 4 (tt % 2) + e'][ci = chunk*16 + 8 (g & 1) + e][tap = 2 s + (g >> 1)]  (tap >= T: zero)
+__global__ void pack_wq_b16s_kernel(const float* __restrict__ w, bf16* __restrict__ wq, int K, int Nn, int T, int NT, int mode) {
+    const int nstep = (T + 1) / 2, nch = K / 16, ntt = NT / 16;
+    const long long total = (long long)(Nn / NT) * nch * nstep * ntt * 512;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        long long q = idx;
+        const int e = (int)(q % 8); q /= 8;
+        const int lane = (int)(q % 64); q /= 64;
+        const int tt = (int)(q % ntt); q /= ntt;
+        const int s = (int)(q % nstep); q /= nstep;
+        const int chunk = (int)(q % nch); q /= nch;
+        const int nt = (int)q;
+        const int g = lane >> 4, c = lane & 15;
+        const int tap = 2 * s + (g >> 1);
+        const int co = nt * NT + 32 * (tt >> 1) + 8 * (c >> 2) + 4 * (tt & 1) + (c & 3);
+        wq[idx] = tap < T ? (bf16)pack_src(w, mode, co, chunk * 16 + 8 * (g & 1) + e, tap, K, Nn, T, 0, T, TapList{}) : (bf16)0.f;
+    }
+}
+
 static int pack_grid(long long total) { return (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256); }
 // MATH_X3: sized for the 28-tap layout of conv_x3s.hip (27 taps + one zero tap), which is the larger of its two packings
-static size_t wq_bytes(int math, size_t nelem) { return math == MATH_F32 ? nelem * 4 : (math == MATH_X3 ? (nelem + nelem / 27 + 64) * 6 : nelem * 2); }
+// MATH_B16 likewise for conv_b16s.hip (taps paired: one zero tap when the tap count is odd)
+static size_t wq_bytes(int math, size_t nelem) { return math == MATH_F32 ? nelem * 4 : (math == MATH_X3 ? (nelem + nelem / 27 + 64) * 6 : (nelem + nelem / 27 + 64) * 2); }
 static void launch_pack(int math, const float* w, void* wq, int K, int Nn, int T, int NT, int mode, int aux, int CK, int TW, const TapList& taps,
                         hipStream_t st) {
     const int grid = pack_grid((long long)K * Nn * T);
@@ -288,6 +309,10 @@ size_t conv_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, 
                           (ks > 1 ? align_up((size_t)ks * N * D * H * W * co * sizeof(float), 256) + colsum_ws_bytes(co) : 0) + 1024;
             if (need > best) best = need;
         }
+    for (int pass = 0; pass < 2; ++pass) {            // the bf16 16x16x32 tiles (conv_b16s.hip) cut more, smaller M-tiles
+        const size_t need = b16s_ws_bytes(N, D, H, W, pass ? Cout : Cin, pass ? Cin : Cout, k);
+        if (need > best) best = need;
+    }
     size_t wg = (k == 3 || k == 5) ? wgrad_mfma_ws_bytes(N, D, H, W, Cin, Cout, k) : (k == 1 ? pw_wgrad_ws_bytes((long long)N * D * H * W, Cin, Cout, 1) : 0);
     if ((k == 3 || k == 5) && wgrad_lowp_ws_bytes(N, D, H, W, Cin, Cout, k) > wg) wg = wgrad_lowp_ws_bytes(N, D, H, W, Cin, Cout, k);
     return best > wg ? best : wg;
@@ -357,9 +382,13 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
     SEG_CHECK_ARG(igemm_plan(math, k, N, D, H, W, Cin, Cout, 1, &p), "conv_fwd_mfma: unsupported shape");
     SEG_CHECK_ARG(((uintptr_t)x % 16) == 0, "conv_fwd_mfma: input pointer must be 16-byte aligned");
     const int T = k * k * k;
+    // bf16 tensors, k3 / k5, enough tiles: the 16x16x32-MFMA kernel (conv_b16s.hip) with its own tiling and weight packing
+    B16sPlan bp;
+    const bool b16s = math == MATH_B16 && b16s_plan(k, N, D, H, W, Cin, Cout, x, ldx, y, ldy, &bp);
+    if (b16s) { p.CK = 16; p.nM = bp.nM; p.nN = bp.nN; p.ntx = bp.ntx; p.nty = bp.nty; p.ntz = bp.ntz; p.NT = bp.NT; }
     const int nchunks = Cin / p.CK;
     const long long nvox = (long long)N * D * H * W;
-    const int ksplit = (ldy % 4 == 0) ? pick_ksplit(p.nM * p.nN, nchunks) : 1;
+    const int ksplit = b16s ? 1 : ((ldy % 4 == 0) ? pick_ksplit(p.nM * p.nN, nchunks) : 1);
     Carver cv(ws);
     void* wq = cv.take<char>(wq_bytes(math, (size_t)T * Cin * Cout));
     float* spart = (ssum && ksplit == 1) ? cv.take<float>((size_t)p.nM * Cout * 3) : nullptr;
@@ -368,7 +397,8 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
     SEG_CHECK_WS(tail + ((ssum && ksplit > 1) ? colsum_ws_bytes(Cout) : 0), ws_bytes);
     // fp32 tensors, bf16x6, 16-wide tiles: the 16x16x32-MFMA kernel (conv_x3s.hip) with its own weight packing
     const bool x3s = math == MATH_X3 && x3s_enabled() && x3s_plan_ok(p, x, ldx, ksplit > 1 ? (void*)slabs : y, ksplit > 1 ? Cout : ldy, (long long)D * H * W);
-    if (x3s) hipLaunchKernelGGL(pack_wq_x3s_kernel, dim3(pack_grid((long long)28 * Cin * Cout)), dim3(256), 0, st, w, (bf16*)wq, Cin, Cout, p.NBW, dgrad ? 1 : 0);
+    if (b16s) hipLaunchKernelGGL(pack_wq_b16s_kernel, dim3(pack_grid((long long)(T + 1) * Cin * Cout)), dim3(256), 0, st, w, (bf16*)wq, Cin, Cout, T, bp.NT, dgrad ? 1 : 0);
+    else if (x3s) hipLaunchKernelGGL(pack_wq_x3s_kernel, dim3(pack_grid((long long)28 * Cin * Cout)), dim3(256), 0, st, w, (bf16*)wq, Cin, Cout, p.NBW, dgrad ? 1 : 0);
     else launch_pack(math, w, wq, Cin, Cout, T, p.NT, dgrad ? 1 : 0, 0, p.CK, T, TapList{}, st);
     SEG_CHECK_LAUNCH();
     IgemmArgs a{x, wq, ksplit > 1 ? nullptr : bias, ksplit > 1 ? (void*)slabs : y, spart, ldx, ksplit > 1 ? Cout : ldy, N, D, H, W, Cout,
@@ -378,7 +408,8 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
     const double vox = (double)nvox;
     {
         ProfScope ps(PF_IGEMM, 2.0 * vox * T * Cin * Cout, matrix_bytes(math, vox * (Cin + Cout), (double)T * Cin * Cout), st);
-        dispatch_igemm(math, p, a, nwg, st, x3s);
+        if (b16s) { a.total = nwg; a.by = tile_block(a.nty); a.bz = a.ntz >= 4 ? 4 : tile_block(a.ntz); dispatch_b16s(bp, a, nwg, st); }
+        else dispatch_igemm(math, p, a, nwg, st, x3s);
         SEG_CHECK_LAUNCH();
         if (ksplit > 1) {
             long long tot = nvox * (Cout / 4);

@@ -53,7 +53,10 @@ struct LTile {
     static constexpr int HX = (BX - 1) * S + KS, HY = (TY - 1) * S + KS, HZ = KS == 3 ? (TZ - 1) * S + 3 : TZ;
     static_assert(S == 1 || KS == 3, "strided tiles are built for k3");
     static constexpr int NVOX = HX * HY * HZ;
-    static constexpr int ROW = 64 * NP;                           // bytes per voxel row: NP planes of 32 bf16 channels
+    // bytes per voxel row: NP planes of 32 bf16 channels + 32 bytes of padding.  A transposing read serves 32 lanes per LDS
+    // cycle = eight voxel rows x 32 bytes; with the padding, row pitch / 32 is odd, so ANY eight consecutive rows fall on the
+    // eight distinct 32-byte bank spans (unpadded, rows four apart share one: 0.44 conflict cycles per LDS cycle, r3 PMC)
+    static constexpr int ROW = 64 * NP + (S == 1 ? 32 : 0);     // (the strided halo is too large to pad and reads every second row anyway)
     static constexpr int KSTEPS = VOX / 32;                       // 32-voxel k-steps
     static constexpr int X_BYTES = NVOX * ROW, D_BYTES = VOX * ROW;
     static constexpr int LDS_BYTES = X_BYTES + D_BYTES;
@@ -101,13 +104,15 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
     const IN_T* __restrict__ din = reinterpret_cast<const IN_T*>(a.dy);
 
     // transposing-read lane geometry: lane 4q+p of a 16-lane group addresses voxel row q, channels 4p..4p+3 of the fragment's
-    // 16 channels and receives the four voxels of channel 4q+p; group g = lane / 16 covers k = 8g .. 8g+7 of the 32-voxel k-step
-    // (two reads of 4).  A k-step is one x-line (BX = 32), two (BX = 16: g / 2 picks the line) or four (BX = 8: g picks it).
+    // 16 channels and receives the four voxels of channel 4q+p.  Group g = lane / 16 holds k = {4g .. 4g+3} (first read) and
+    // {16+4g .. 16+4g+3} (second read) of the 32-voxel k-step -- the same assignment for x and dy -- so the two groups that share
+    // an LDS cycle (g = 0, 1 / g = 2, 3) read eight CONSECUTIVE voxels of one x-line.  A k-step is one x-line (BX = 32: a
+    // read covers 16 of its voxels), two (BX = 16: one line per read) or four (BX = 8: g / 2 picks the line of the pair).
     const int li = lane & 15, q = li >> 2, p = li & 3, g = lane >> 4;
     const int chan_off = 4 * p * 2;
-    const int kq_x = BX == 32 ? (8 * g + q) * S : (BX == 16 ? (g >> 1) * S * T::HX + (8 * (g & 1) + q) * S : g * S * T::HX + q * S);
+    const int kq_x = BX == 8 ? (g >> 1) * S * T::HX + (4 * (g & 1) + q) * S : (4 * g + q) * S;
     const int lane_x = kq_x * T::ROW + chan_off;
-    const int lane_d = (8 * g + q) * T::ROW + chan_off;
+    const int lane_d = (4 * g + q) * T::ROW + chan_off;
 
     // the taps of this wave: wave, wave + 8, wave + 16 (, wave + 24 for the first waves)
     const bool has_last = wave + LW_WAVES * (LW_TPW - 1) <= T::NTAPS - 1;       // wave-uniform
@@ -189,12 +194,12 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
         for (int it = 0; it < DITER; ++it) put(ds, it * LW_THREADS + tid, sd[it]);
     };
 
-    // byte offset of 32-voxel k-step ks, half-read t inside the x halo / the dy tile (lane part excluded)
+    // byte offset of 32-voxel k-step ks, read t inside the x halo / the dy tile (lane part excluded)
     auto xoff = [](int ks, int t) {
-        const int line = ks * (32 / BX);
-        return ((((line / T::TY) * S * T::HY + (line % T::TY) * S) * T::HX) + 4 * t * S) * T::ROW;
+        const int line = BX == 32 ? ks : (BX == 16 ? 2 * ks + t : 4 * ks + 2 * t);
+        return ((((line / T::TY) * S * T::HY + (line % T::TY) * S) * T::HX) + (BX == 32 ? 16 * t * S : 0)) * T::ROW;
     };
-    auto doff = [](int ks, int t) { return (ks * 32 + 4 * t) * T::ROW; };
+    auto doff = [](int ks, int t) { return (ks * 32 + 16 * t) * T::ROW; };
 
     // bf16 tensors (one MFMA per fragment pair): one scheduling region per (k-step, tap-tile); the x fragments of the NEXT region
     // are requested behind the first MFMAs of the current one (left alone the compiler sinks the transposing reads next to

@@ -638,6 +638,16 @@ __host__ __device__ constexpr int x3s_pair_tap(int s, int which) {
 bool x3s_plan_ok(const IgemmPlan& p, const void* x, int ldx, const void* y, int ldy, long long sample_voxels);
 void dispatch_x3s(const IgemmPlan& p, const IgemmArgs& a, int nwg, hipStream_t st);
 
+// conv_b16s.hip: bf16 tensors, k3 / k5 stride 1, on v_mfma_f32_16x16x32_bf16 (eight x-lines of 16 voxels x 32 channels per wave).
+// K-step s of a 16-channel chunk contracts taps 2s and 2s + 1 (the odd last tap pairs with zero weights).
+struct B16sPlan { int KS, WMG, NT, TZ, ntx, nty, ntz, nM, nN, nsteps; };
+bool b16s_geom(int KS, int N, int D, int H, int W, int Cin, int Cout, B16sPlan* p);
+bool b16s_plan(int KS, int N, int D, int H, int W, int Cin, int Cout, const void* x, int ldx, const void* y, int ldy, B16sPlan* p);
+size_t b16s_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k);
+void dispatch_b16s(const B16sPlan& p, const IgemmArgs& a, int nwg, hipStream_t st);
+void set_b16_tiles(int mode);
+int get_b16_tiles();
+
 // conv_igemm_lowp.hip: the MATH_X3 / MATH_B16 instantiations (their own translation unit: they compile in parallel)
 void dispatch_igemm_lowp(int math, const IgemmPlan& p, const IgemmArgs& a, int nwg, hipStream_t st);
 bool igemm_lowp_has(int math, int KS, int CK, int BX, int MB);

@@ -15,6 +15,8 @@ if "--conv-math" in argv:
     i = argv.index("--conv-math"); math = argv[i + 1]; del argv[i:i + 2]
 if math:
     mi355seg.set_conv_math(math)
+if os.environ.get("MI355SEG_B16_TILES"):
+    mi355seg.set_b16_tiles(int(os.environ["MI355SEG_B16_TILES"]))
 N, D, H, W, Cin, Cout = [int(v) for v in argv[:6]]
 k = int(argv[6]) if len(argv) > 6 else 3
 reps = int(argv[7]) if len(argv) > 7 else 10

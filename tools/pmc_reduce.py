@@ -11,7 +11,7 @@ import sys
 
 
 def short(name):
-    return re.sub(r"\(.*", "", name).replace("void ", "").replace("(anonymous namespace)::", "")[:80]
+    return re.sub(r"\(seg::.*", "", name.replace("void ", "").replace("(anonymous namespace)::", ""))[:80]
 
 
 def main():
