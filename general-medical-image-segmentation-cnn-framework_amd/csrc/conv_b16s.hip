@@ -66,8 +66,8 @@ __global__ __launch_bounds__(256, 2) void conv_b16s_kernel(IgemmArgs a) {
     const int r = lane & 15, g = lane >> 4;
     const int wm = wave / WNG, wn = wave % WNG;
 
-    // ---- block -> tile map: as conv_igemm_kernel (XCD-contiguous ranges, (y, z) bricks of M-tiles); no split-K here
-    int ntile, mtile, n, x0, y0, z0;
+    // ---- block -> tile map: as conv_igemm_kernel (XCD-contiguous ranges, (y, z) bricks of M-tiles, K-splits of a tile adjacent)
+    int ks, ntile, mtile, n, x0, y0, z0;
     {
         const int total = (int)gridDim.x, bid = blockIdx.x;
         const int q8 = total >> 3, r8 = total & 7, xcd = bid & 7;
@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256, 2) void conv_b16s_kernel(IgemmArgs a) {
         const int local = bid >> 3;
         if (local >= xcnt) return;
         int t = xstart + local;
+        ks = t % a.ksplit; t /= a.ksplit;
         ntile = t % a.nN;
         mtile = t / a.nN;
         int mt = mtile;
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(256, 2) void conv_b16s_kernel(IgemmArgs a) {
         x0 = txi * SBX; y0 = tyi * STY; z0 = tzi * G::TZ;
     }
     const int n0 = ntile * NT;
+    const int c0 = ks * a.cps, c1 = c0 + a.cps;                   // this split's chunk range
     const bf16* __restrict__ xin = reinterpret_cast<const bf16*>(a.x);
 
     // ---- halo staging: buffer loads at per-tile offsets (zero fill by the range check) -> registers -> LDS
@@ -139,8 +141,8 @@ __global__ __launch_bounds__(256, 2) void conv_b16s_kernel(IgemmArgs a) {
     for (int j = 0; j < SRV; ++j) { acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     const bf16* wlane = reinterpret_cast<const bf16*>(a.wq) + (long long)ntile * a.nchunks * (NSTEP * UNIT) + wn * 1024 + lane * 8;
-    load_stage(0);
-    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+    load_stage(c0);
+    for (int chunk = c0; chunk < c1; ++chunk) {
         const bf16* wp = wlane + (long long)chunk * (NSTEP * UNIT);
         constexpr int WD = 2;                                    // K-steps of weights in flight ahead of the MFMAs
         bf16x8_t wf[WD + 1][2], xf[2][4];
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv_b16s_kernel(IgemmArgs a) {
         __syncthreads();                                         // every wave is done reading the previous chunk
         write_stage();
         __syncthreads();
-        if (chunk + 1 < a.nchunks) load_stage(chunk + 1);
+        if (chunk + 1 < c1) load_stage(chunk + 1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) xf[0][j] = *reinterpret_cast<const bf16x8_t*>(lds_raw + xaddr(0, j));
         __builtin_amdgcn_sched_barrier(0);
@@ -191,6 +193,8 @@ __global__ __launch_bounds__(256, 2) void conv_b16s_kernel(IgemmArgs a) {
     // ---- epilogue: bias, one 16-byte bf16 store per line, optional BatchNorm partial statistics
     // acc[j][t][e] = y[voxel (line j, x = r)][channel n0 + 32 wn + 8 g + 4 t + e]
     bf16* yout = reinterpret_cast<bf16*>(a.y);
+    float* yslab = reinterpret_cast<float*>(a.y) + (long long)ks * a.split_stride;     // ksplit > 1: raw fp32 partial sums of this split
+    const bool slab = a.ksplit > 1;
     const int gx = x0 + r, cbase = n0 + wn * 32 + 8 * g;
     float bv[8];
 #pragma unroll
@@ -203,10 +207,16 @@ __global__ __launch_bounds__(256, 2) void conv_b16s_kernel(IgemmArgs a) {
         const int line = line0 + j;
         const int gz = z0 + line / STY, gy = y0 + line % STY;
         if (gz < a.D && gy < a.H && gx < a.W) {
-            bf16x8_t o;
+            const long long off = ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.ldy + cbase;
+            if (slab) {                                          // bias and statistics belong to the reduce pass
+                *reinterpret_cast<f32x4*>(yslab + off) = acc[j][0];
+                *reinterpret_cast<f32x4*>(yslab + off + 4) = acc[j][1];
+            } else {
+                bf16x8_t o;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) { const float v = acc[j][c >> 2][c & 3] + bv[c]; o[c] = (bf16)v; ssum[c] += v; }
-            *reinterpret_cast<bf16x8_t*>(yout + ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.ldy + cbase) = o;
+                for (int c = 0; c < 8; ++c) { const float v = acc[j][c >> 2][c & 3] + bv[c]; o[c] = (bf16)v; ssum[c] += v; }
+                *reinterpret_cast<bf16x8_t*>(yout + off) = o;
+            }
         }
     }
     if (a.spart) {
@@ -282,6 +292,7 @@ bool b16s_geom(int KS, int N, int D, int H, int W, int Cin, int Cout, B16sPlan* 
     p->ntx = (W + SBX - 1) / SBX; p->nty = (H + STY - 1) / STY; p->ntz = (D + p->TZ - 1) / p->TZ;
     p->nM = N * p->ntz * p->nty * p->ntx; p->nN = Cout / p->NT;
     p->nsteps = (KS * KS * KS + 1) / 2;
+    p->ksplit = pick_ksplit(p->nM * p->nN, Cin / 16);
     return true;
 }
 bool b16s_plan(int KS, int N, int D, int H, int W, int Cin, int Cout, const void* x, int ldx, const void* y, int ldy, B16sPlan* p) {
@@ -290,12 +301,13 @@ bool b16s_plan(int KS, int N, int D, int H, int W, int Cin, int Cout, const void
     if ((long long)D * H * W * ldx * 2 >= 0x7FFFFFF0LL) return false;       // one sample is addressed through a 32-bit buffer offset
     if (g_b16_tiles == 1) return true;
     const double waste = (double)p->ntx * SBX * p->nty * STY * p->ntz * p->TZ / ((double)W * H * D);
-    return waste <= 1.2 && (long long)p->nM * p->nN >= 384;
+    return waste <= 1.35 && (long long)p->nM * p->nN * p->ksplit >= 192;
 }
 size_t b16s_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k) {
     B16sPlan p;
     if (!b16s_geom(k, N, D, H, W, Cin, Cout, &p)) return 0;
-    return align_up((size_t)2 * p.nsteps * 16 * (Cin / 16) * Cout * 2, 256) + align_up((size_t)p.nM * Cout * 3 * sizeof(float), 256) + 1024;
+    return align_up((size_t)2 * p.nsteps * 16 * (Cin / 16) * Cout * 2, 256) + align_up((size_t)p.nM * Cout * 3 * sizeof(float), 256) +
+           (p.ksplit > 1 ? align_up((size_t)p.ksplit * N * D * H * W * Cout * sizeof(float), 256) + colsum_ws_bytes(Cout) : 0) + 1024;
 }
 
 void dispatch_b16s(const B16sPlan& p, const IgemmArgs& a, int nwg, hipStream_t st) {

@@ -293,7 +293,6 @@ bool conv_mfma_supported(int math, int N, int D, int H, int W, int Cin, int Cout
     return igemm_plan(math, k, N, D, H, W, Cin, Cout, 1, &p);
 }
 
-static int pick_ksplit(int tiles, int nchunks);
 size_t conv_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
     if (!igemm_shape_ok(k, stride, pad)) return 0;
     size_t best = 0;
@@ -361,16 +360,6 @@ static int dbg_flags() { static const char* e = getenv("MI355SEG_DBG"); return e
 static constexpr int dbg_flags() { return 0; }
 #endif
 
-// K-split factor for layers with too few tiles to fill 2 x 256 workgroup slots
-static int pick_ksplit(int tiles, int nchunks) {
-    int best = 1;
-    for (int k = 2; k <= 16; k *= 2) {
-        if (nchunks % k || nchunks / k < 2) break;
-        if (tiles * (k / 2) >= 512) break;
-        best = k;
-    }
-    return best;
-}
 
 static size_t esize(int math) { return math == MATH_B16 ? 2 : 4; }
 static double matrix_bytes(int math, double act_elems, double w_elems) { return esize(math) * act_elems + 4.0 * w_elems; }
@@ -388,7 +377,7 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
     if (b16s) { p.CK = 16; p.nM = bp.nM; p.nN = bp.nN; p.ntx = bp.ntx; p.nty = bp.nty; p.ntz = bp.ntz; p.NT = bp.NT; }
     const int nchunks = Cin / p.CK;
     const long long nvox = (long long)N * D * H * W;
-    const int ksplit = b16s ? 1 : ((ldy % 4 == 0) ? pick_ksplit(p.nM * p.nN, nchunks) : 1);
+    const int ksplit = b16s ? bp.ksplit : ((ldy % 4 == 0) ? pick_ksplit(p.nM * p.nN, nchunks) : 1);
     Carver cv(ws);
     void* wq = cv.take<char>(wq_bytes(math, (size_t)T * Cin * Cout));
     float* spart = (ssum && ksplit == 1) ? cv.take<float>((size_t)p.nM * Cout * 3) : nullptr;
@@ -507,8 +496,13 @@ size_t conv_gather_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k
     const size_t T = (size_t)k * k * k;
     size_t need = align_up(T * Cin * Cout * sizeof(float), 256) + 2048;
     IgemmPlan p;
-    if (igemm_plan(MATH_F32, 1, N, out_extent(D, k, stride, pad), out_extent(H, k, stride, pad), out_extent(W, k, stride, pad), Cin, Cout, 1, &p))
-        need += align_up((size_t)p.nM * Cout * 3 * sizeof(float), 256);
+    for (int math : {MATH_F32, MATH_B16}) {
+        if (!igemm_plan(math, 1, N, out_extent(D, k, stride, pad), out_extent(H, k, stride, pad), out_extent(W, k, stride, pad), Cin, Cout, 1, &p)) continue;
+        const int ks = pick_ksplit(p.nM * p.nN, (int)T * (Cin / p.CK));
+        const size_t extra = align_up((size_t)p.nM * Cout * 3 * sizeof(float), 256) +
+                             (ks > 1 ? align_up((size_t)ks * N * out_extent(D, k, stride, pad) * out_extent(H, k, stride, pad) * out_extent(W, k, stride, pad) * Cout * sizeof(float), 256) + colsum_ws_bytes(Cout) : 0);
+        if (align_up(T * Cin * Cout * sizeof(float), 256) + 2048 + extra > need) need = align_up(T * Cin * Cout * sizeof(float), 256) + 2048 + extra;
+    }
     return need;
 }
 
@@ -519,23 +513,39 @@ int conv_gather_fwd_mfma(int math, const void* x, int ldx, const float* w, const
     SEG_CHECK_ARG(igemm_plan(math, 1, N, Do, Ho, Wo, Cin, Cout, 1, &p), "conv_gather_fwd_mfma: unsupported shape");
     SEG_CHECK_ARG(((uintptr_t)x % 16) == 0, "conv_gather_fwd_mfma: input pointer must be 16-byte aligned");
     const int T = k * k * k, cpt = Cin / p.CK, nchunks = T * cpt;
+    // few output tiles and a long K (the deep down-convolutions: 256 -> 512 at 10 x 12 x 10 is 9 tiles x 432 chunks): split K
+    const int ksplit = (ldy % 4 == 0) ? pick_ksplit(p.nM * p.nN, nchunks) : 1;
+    const long long nvo = (long long)N * Do * Ho * Wo;
     Carver cv(ws);
     void* wq = cv.take<char>(wq_bytes(math, (size_t)T * Cin * Cout));
-    float* spart = ssum ? cv.take<float>((size_t)p.nM * Cout * 3) : nullptr;
-    SEG_CHECK_WS(cv.used(), ws_bytes);
+    float* spart = (ssum && ksplit == 1) ? cv.take<float>((size_t)p.nM * Cout * 3) : nullptr;
+    float* slabs = ksplit > 1 ? cv.take<float>((size_t)ksplit * nvo * Cout) : nullptr;
+    const size_t tail = cv.used();
+    SEG_CHECK_WS(tail + ((ssum && ksplit > 1) ? colsum_ws_bytes(Cout) : 0), ws_bytes);
     launch_pack(math, w, wq, T * Cin, Cout, 1, p.NT, 5, Cin, p.CK, T, TapList{}, st);
     SEG_CHECK_LAUNCH();
-    IgemmArgs a{x, wq, bias, y, spart, ldx, ldy, N, Do, Ho, Wo, Cout, p.ntx, p.nty, p.ntz, p.nN, nchunks, cpt, p.nN, stride, 1,
-                p.nM, 1, nchunks, 0, 0};
+    IgemmArgs a{x, wq, ksplit > 1 ? nullptr : bias, ksplit > 1 ? (void*)slabs : y, spart, ldx, ksplit > 1 ? Cout : ldy, N, Do, Ho, Wo, Cout, p.ntx, p.nty, p.ntz, p.nN, nchunks, cpt, p.nN, stride, 1,
+                p.nM, ksplit, nchunks / ksplit, nvo * Cout, 0};
     a.Di = D; a.Hi = H; a.Wi = W; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
     for (int t = 0; t < T; ++t) { a.toff[t][0] = (signed char)(t / (k * k) - pad); a.toff[t][1] = (signed char)((t / k) % k - pad); a.toff[t][2] = (signed char)(t % k - pad); }
-    const double vox = (double)N * Do * Ho * Wo;
+    const double vox = (double)nvo;
     {
         ProfScope ps(PF_IGEMM, 2.0 * vox * T * Cin * Cout, matrix_bytes(math, (double)N * D * H * W * Cin + vox * Cout, (double)T * Cin * Cout), st);
-        dispatch_igemm(math, p, a, p.nM * p.nN, st);
+        dispatch_igemm(math, p, a, p.nM * p.nN * ksplit, st);
         SEG_CHECK_LAUNCH();
+        if (ksplit > 1) {
+            const long long tot = nvo * (Cout / 4);
+            const int grid = (int)((tot + 255) / 256 > 2048 ? 2048 : (tot + 255) / 256);
+            if (math == MATH_B16) hipLaunchKernelGGL(splitk_reduce_kernel<bf16>, dim3(grid), dim3(256), 0, st, slabs, ksplit, nvo * Cout, bias, (bf16*)y, ldy, nvo, Cout);
+            else hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(grid), dim3(256), 0, st, slabs, ksplit, nvo * Cout, bias, (float*)y, ldy, nvo, Cout);
+            SEG_CHECK_LAUNCH();
+        }
     }
     if (ssum) {
+        if (ksplit > 1) {
+            if (math == MATH_B16) return channel_sums((const bf16*)y, ldy, nvo, Cout, ssum, ssq, nullptr, 0, (char*)ws + tail, ws_bytes - tail, st);
+            return channel_sums((const float*)y, ldy, nvo, Cout, ssum, ssq, nullptr, 0, (char*)ws + tail, ws_bytes - tail, st);
+        }
         hipLaunchKernelGGL(igemm_stats_finalize_kernel, dim3(Cout), dim3(256), 0, st, spart, p.nM, Cout, ssum, ssq);
         SEG_CHECK_LAUNCH();
     }

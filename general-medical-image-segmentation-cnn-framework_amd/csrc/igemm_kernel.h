@@ -626,6 +626,18 @@ static void launch_igemm(const IgemmArgs& a, int nwg, hipStream_t st) {
     hipLaunchKernelGGL((conv_igemm_kernel<MATH, KS, BX, MB, NBW, CK, WN>), dim3(grid), dim3(256), LDSB, st, a);
 }
 
+// K-split factor for layers with too few tiles to fill 2 x 256 workgroup slots (every split writes an fp32 slab, a second
+// kernel adds them in fixed order)
+inline int pick_ksplit(int tiles, int nchunks) {
+    int best = 1;
+    for (int k = 2; k <= 16; k *= 2) {
+        if (nchunks % k || nchunks / k < 2) break;
+        if (tiles * (k / 2) >= 512) break;
+        best = k;
+    }
+    return best;
+}
+
 // conv_x3s.hip: the bf16x6 k3 kernel on v_mfma_f32_16x16x32_bf16 (fp32 tensors, BX = 16 tiles of the plan above).
 // K-step s of a 16-channel chunk contracts the tap pair (x3s_pair_tap(s, 0), x3s_pair_tap(s, 1)); tap 27 = zero weights.
 constexpr int X3S_NPAIR = 14;
@@ -640,7 +652,7 @@ void dispatch_x3s(const IgemmPlan& p, const IgemmArgs& a, int nwg, hipStream_t s
 
 // conv_b16s.hip: bf16 tensors, k3 / k5 stride 1, on v_mfma_f32_16x16x32_bf16 (eight x-lines of 16 voxels x 32 channels per wave).
 // K-step s of a 16-channel chunk contracts taps 2s and 2s + 1 (the odd last tap pairs with zero weights).
-struct B16sPlan { int KS, WMG, NT, TZ, ntx, nty, ntz, nM, nN, nsteps; };
+struct B16sPlan { int KS, WMG, NT, TZ, ntx, nty, ntz, nM, nN, nsteps, ksplit; };
 bool b16s_geom(int KS, int N, int D, int H, int W, int Cin, int Cout, B16sPlan* p);
 bool b16s_plan(int KS, int N, int D, int H, int W, int Cin, int Cout, const void* x, int ldx, const void* y, int ldy, B16sPlan* p);
 size_t b16s_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k);

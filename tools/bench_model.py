@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--conv-math", default=None, choices=["fp32", "bf16x6"])
     ap.add_argument("--json", default=None)
     ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--dump-launches", default=None, help="write (family, ms, GFLOP, TFLOP/s, GB, GB/s) of every profiled launch of the last step")
     ap.add_argument("--graph", action="store_true", help="capture the whole step (fwd, loss, bwd, Adam) into one HIP graph and time its replays")
     a = ap.parse_args()
     N, C, D, H, W = a.shape
@@ -141,6 +142,17 @@ def main():
                 ent["roofline"] = {"peak_gbs": HBM_GBS, "frac": gb / HBM_GBS}
             res["families"][nm] = ent
         res["ms_in_profiled_families"] = covered
+        if a.dump_launches:
+            nmax = 65536
+            rec = (ctypes.c_double * (4 * nmax))()
+            nrec = ctypes.c_int(0)
+            L.call("mi355seg_prof_records", rec, nmax, ctypes.byref(nrec))
+            per = nrec.value // a.steps
+            with open(a.dump_launches, "w") as fh:
+                fh.write("family,ms,gflop,tflops,alg_gbytes,alg_gbs\n")
+                for r in range(nrec.value - per, nrec.value):
+                    f_, ms_, fl_, by_ = int(rec[4 * r]), rec[4 * r + 1], rec[4 * r + 2], rec[4 * r + 3]
+                    fh.write(f"{FAMILIES[f_]},{ms_:.4f},{fl_ / 1e9:.2f},{fl_ / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0:.2f},{by_ / 1e9:.4f},{by_ / (ms_ * 1e-3) / 1e9 if ms_ > 0 else 0:.1f}\n")
     print(f"{a.name} x=[{N},{C},{D},{H},{W}] classes={a.classes} {a.dtype} (conv math {math}): {dt * 1e3:.1f} ms/step, "
           f"{N * D * H * W / dt / 1e6:.1f} Mvoxel/s, loss {loss.item():.4f}, peak mem {res['peak_mem_gib']:.1f} GiB")
     for nm, e in res["families"].items():
