@@ -452,6 +452,9 @@ def main():
     sync()
     if world > 1:
         dist.barrier()
+    if reducer is not None:                 # the `comm` block counts the timed steps only
+        reducer.timer.reset()
+    D.BUFFER_BROADCAST_TIMER.reset()
     if not args.no_prof:
         L.call("mi355seg_prof_reset")
         # default: bracket only the two MFMA conv families (51 launches per step); --prof-all brackets all ~400
@@ -470,6 +473,7 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    comm = D.comm_report(reducer, args.steps) if world > 1 else None
     counts, loss = D.all_reduce_metric(out["counts"], out["loss"])
 
     if rank != 0:
@@ -493,6 +497,9 @@ def main():
         "rccl_ranks": world, "dist_backend": (dist.get_backend() if world > 1 else None), "rank_devices": rank_devices,
         "loss": float(loss.item()), "dice": dice,
     }
+    if comm is not None:                    # what a step sends and how long it waited for it (attribution of a scaling shortfall)
+        comm["allreduce_wait_frac_of_step"] = comm["allreduce_wait_ms_per_step"] / ms
+        res["comm"] = comm
     if args.rehearse_cpu:
         res["rehearsal"] = "CPU plumbing rehearsal on a toy torch.nn model (tests/test_bench_launch.py); not a measurement"
         res["data"] = "rehearsal"

@@ -35,6 +35,22 @@ void set_error(const char* fmt, ...);
         }                                                                    \
     } while (0)
 
+// Raise a kernel's dynamic-LDS limit (kernels that need more than 48 KB), once per DEVICE: the attribute belongs to the device's
+// code object, and a process may drive several GPUs.  A failure is recorded and surfaces at the launch that follows.
+inline void set_max_dynamic_lds(const void* fn, int bytes, unsigned long long& done_mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 64;
+    if (dev < 64 && ((done_mask >> dev) & 1ull)) return;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed: %s", bytes, hipGetErrorString(e));
+    else if (dev < 64) done_mask |= 1ull << dev;
+}
+#define SEG_SET_LDS(fn, bytes)                                                  \
+    do {                                                                        \
+        static unsigned long long seg_lds_done__ = 0;                           \
+        seg::set_max_dynamic_lds((const void*)(fn), (int)(bytes), seg_lds_done__); \
+    } while (0)
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_b16s_kernel(IgemmArgs a) {
 template <int KS, int WMG>
 void launch_b16s(const IgemmArgs& a, int nwg, hipStream_t st) {
     constexpr int LDSB = SGeo<KS, WMG>::LDS_BYTES;
-    (void)hipFuncSetAttribute((const void*)conv_b16s_kernel<KS, WMG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+    SEG_SET_LDS((conv_b16s_kernel<KS, WMG>), LDSB);
     hipLaunchKernelGGL((conv_b16s_kernel<KS, WMG>), dim3(nwg), dim3(256), LDSB, st, a);
 }
 

@@ -112,7 +112,11 @@ size_t mi355seg_conv3d_ws_bytes_bf16(int N, int D, int H, int W, int Cin, int Co
     if (k == 1 && stride == 1 && pad == 0 && base < pw_wgrad_lowp_ws_bytes((long long)N * D * H * W, Cin, Cout)) base = pw_wgrad_lowp_ws_bytes((long long)N * D * H * W, Cin, Cout);
     if (k == 2 && stride == 2 && pad == 0 && base < convt_wgrad_lowp_ws_bytes((long long)N * (D / 2) * (H / 2) * (W / 2), Cout, Cin))
         base = convt_wgrad_lowp_ws_bytes((long long)N * (D / 2) * (H / 2) * (W / 2), Cout, Cin);
-    if (fb) base += align_up((size_t)N * D * H * W * Cin * 4, 256) + align_up((size_t)N * Do * Ho * Wo * Cout * 4, 256) + 512;
+    // the fp32 staging copies of the fall-back: for shapes without a native kernel, and -- while they stay under 512 MB -- for
+    // every shape, because an entry point also falls back when a POINTER is not 16-byte aligned (a bf16 channel slice at an
+    // 8-byte offset) or a k2 s2 weight gradient is asked not to accumulate, which this query cannot see
+    const size_t stage = align_up((size_t)N * D * H * W * Cin * 4, 256) + align_up((size_t)N * Do * Ho * Wo * Cout * 4, 256) + 512;
+    if (fb || stage <= ((size_t)512 << 20)) base += stage;
     return base;
 }
 

@@ -169,8 +169,7 @@ int conv_gwgrad(const IN_T* dy, int lddy, const IN_T* x, int ldx, float* dw, int
     const double vox = (double)N * Do * Ho * Wo;
     {
         ProfScope ps(PF_WGRAD, 2.0 * vox * p.T * Cin * Cout, (double)sizeof(IN_T) * vox * ((double)p.T * Cin + Cout) + 4.0 * p.T * Cin * Cout, st);
-        static bool set = false;
-        if (!set) { (void)hipFuncSetAttribute((const void*)conv_gwgrad_kernel<IN_T>, hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS); set = true; }
+        SEG_SET_LDS((conv_gwgrad_kernel<IN_T>), GW_LDS);
         hipLaunchKernelGGL(conv_gwgrad_kernel<IN_T>, dim3(nwg), dim3(256), GW_LDS, st, a);
         SEG_CHECK_LAUNCH();
     }

@@ -308,8 +308,7 @@ int head2_fwd_lowp(const bf16* x, int ldx, const float* w, const float* bias, bf
     SEG_CHECK_LAUNCH();
     Head2Args a{x, nullptr, wq, bias, y, nullptr, ldx, 0, ldy, 0, 0, 0, 0, Cin, 0, 0, 0, 0};
     head2_geom(a, N, D, H, W, HF_OX, HF_TY, HF_TZ);
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)head2_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, HF_XBYTES); set = true; }
+    SEG_SET_LDS((head2_fwd_kernel), HF_XBYTES);
     const double vox = (double)N * D * H * W;
     ProfScope ps(PF_DIRECT, 2.0 * vox * 125.0 * Cin * 2, 2.0 * vox * (Cin + 2), st);
     hipLaunchKernelGGL(head2_fwd_kernel, dim3(a.ntiles), dim3(256), HF_XBYTES, st, a);
@@ -328,8 +327,7 @@ int head2_dgrad_lowp(const bf16* dy, int lddy, const float* w, bf16* dx, int ldd
     Head2Args a{nullptr, dy, wq, nullptr, dx, nullptr, 0, lddy, lddx, 0, 0, 0, 0, Cin, 0, 0, 0, 0};
     head2_geom(a, N, D, H, W, H2_BX, H2_TY, H2_TZ);
     const int ldsb = 4 * H2_COPYB;
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)head2_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb); set = true; }
+    SEG_SET_LDS((head2_dgrad_kernel), ldsb);
     const int grid = a.ntiles < 2048 ? a.ntiles : 2048;
     const double vox = (double)N * D * H * W;
     ProfScope ps(PF_DIRECT, 2.0 * vox * 125.0 * Cin * 2, 2.0 * vox * (Cin + 2), st);
@@ -348,8 +346,7 @@ int head2_wgrad_lowp(const bf16* dy, int lddy, const bf16* x, int ldx, float* dw
     a.part = cv.take<float>((size_t)nblk * 125 * Cin * 2);
     SEG_CHECK_WS(cv.used(), ws_bytes);
     const int ldsb = 512 * 64 + 2 * H2_COPYB;
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)head2_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb); set = true; }
+    SEG_SET_LDS((head2_wgrad_kernel), ldsb);
     const double vox = (double)N * D * H * W;
     {
         ProfScope ps(PF_DIRECT, 2.0 * vox * 125.0 * Cin * 2, 2.0 * vox * (Cin + 2), st);

@@ -392,8 +392,7 @@ static void headk_launch(bool dgrad, const float* in, const float* wp, const flo
     constexpr int R = KS / 2, HY = HK_TY + 2 * R;
     if (!dgrad) {
         const size_t ldsb = (size_t)KS * 4 * HY * 40 * 16 + 4 * 64 * 8 * 4;
-        static bool set = false;
-        if (!set) { (void)hipFuncSetAttribute((const void*)headk_fwd_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); set = true; }
+        SEG_SET_LDS((headk_fwd_kernel<KS>), (int)ldsb);
         hipLaunchKernelGGL(headk_fwd_kernel<KS>, dim3(nwg), dim3(256), ldsb, st, in, wp, bias, out, a);
     } else {
         const size_t ldsb = (size_t)KS * HY * 40 * 8;
@@ -473,13 +472,11 @@ int headk_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, i
         ProfScope ps(PF_DIRECT, 2.0 * vox * NT * Cin * 2, 4.0 * vox * (Cin + 2), st);
         if (k == 5) {
             const size_t ldsb = ((size_t)5 * (HK_TY + 4) * 16 * 40 + HK_TY * HK_TX * 2) * 4;
-            static bool set = false;
-            if (!set) { (void)hipFuncSetAttribute((const void*)headk_wgrad_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); set = true; }
+            SEG_SET_LDS((headk_wgrad_kernel<5>), (int)ldsb);
             hipLaunchKernelGGL(headk_wgrad_kernel<5>, dim3(nwg), dim3(448), ldsb, st, x, dy, part, a);
         } else {
             const size_t ldsb = ((size_t)3 * (HK_TY + 2) * 16 * 40 + HK_TY * HK_TX * 2) * 4;
-            static bool set = false;
-            if (!set) { (void)hipFuncSetAttribute((const void*)headk_wgrad_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); set = true; }
+            SEG_SET_LDS((headk_wgrad_kernel<3>), (int)ldsb);
             hipLaunchKernelGGL(headk_wgrad_kernel<3>, dim3(nwg), dim3(448), ldsb, st, x, dy, part, a);
         }
         SEG_CHECK_LAUNCH();

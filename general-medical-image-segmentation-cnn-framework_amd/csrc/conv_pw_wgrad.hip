@@ -181,12 +181,10 @@ int pw_wgrad_mfma(const IN_T* dy, int lddy, const IN_T* x, int ldx, int N, int D
     const int nwg = p.nstrips * p.npairs;
     ProfScope ps(T == 8 ? PF_CONVT : PF_WGRAD, 2.0 * nvox * T * Cin * Cout, (double)sizeof(IN_T) * nvox * (Cin + (double)T * Cout) + 4.0 * T * Cin * Cout, st);
     if (T == 8) {
-        static bool set8 = false;
-        if (!set8) { (void)hipFuncSetAttribute((const void*)pw_wgrad_kernel<8, IN_T>, hipFuncAttributeMaxDynamicSharedMemorySize, PwCfg<8>::LDS_BYTES); set8 = true; }
+        SEG_SET_LDS((pw_wgrad_kernel<8, IN_T>), PwCfg<8>::LDS_BYTES);
         hipLaunchKernelGGL((pw_wgrad_kernel<8, IN_T>), dim3(nwg), dim3(256), PwCfg<8>::LDS_BYTES, st, a);
     } else {
-        static bool set1 = false;
-        if (!set1) { (void)hipFuncSetAttribute((const void*)pw_wgrad_kernel<1, IN_T>, hipFuncAttributeMaxDynamicSharedMemorySize, PwCfg<1>::LDS_BYTES); set1 = true; }
+        SEG_SET_LDS((pw_wgrad_kernel<1, IN_T>), PwCfg<1>::LDS_BYTES);
         hipLaunchKernelGGL((pw_wgrad_kernel<1, IN_T>), dim3(nwg), dim3(256), PwCfg<1>::LDS_BYTES, st, a);
     }
     SEG_CHECK_LAUNCH();

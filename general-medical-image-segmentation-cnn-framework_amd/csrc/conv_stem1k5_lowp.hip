@@ -215,8 +215,7 @@ int stem1k5_fwd_lowp(const bf16* x, const float* w, const float* bias, bf16* y, 
     Stem1Args a{x, nullptr, wq, bias, y, nullptr, ldy, 0, 0, 0, 0, Cout, 0, 0, 0, 0};
     stem1_geom(a, N, D, H, W);
     const int ldsb = 8 * S1_COPYB;
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)stem1_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb); set = true; }
+    SEG_SET_LDS((stem1_fwd_kernel), ldsb);
     const double vox = (double)N * D * H * W;
     ProfScope ps(PF_DIRECT, 2.0 * vox * 125.0 * Cout, 2.0 * vox * (1 + Cout), st);
     hipLaunchKernelGGL(stem1_fwd_kernel, dim3(a.ntiles < 2048 ? a.ntiles : 2048), dim3(256), ldsb, st, a);
@@ -234,8 +233,7 @@ int stem1k5_wgrad_lowp(const bf16* dy, int lddy, const bf16* x, float* dw, int N
     a.part = cv.take<float>((size_t)nblk * 125 * Cout);
     SEG_CHECK_WS(cv.used(), ws_bytes);
     const int ldsb = 512 * 32 + 4 * S1_COPYB;
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)stem1_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb); set = true; }
+    SEG_SET_LDS((stem1_wgrad_kernel), ldsb);
     const double vox = (double)N * D * H * W;
     {
         ProfScope ps(PF_DIRECT, 2.0 * vox * 125.0 * Cout, 2.0 * vox * (1 + Cout), st);

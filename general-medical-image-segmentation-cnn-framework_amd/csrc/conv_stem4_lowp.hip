@@ -233,8 +233,7 @@ int stem4_wgrad_lowp(const bf16* dy, int lddy, const bf16* x, float* dw, int N, 
     SEG_CHECK_ARG(((uintptr_t)x % 8) == 0 && ((uintptr_t)dy % 16) == 0, "stem4_wgrad: pointers must be 8 / 16-byte aligned");
     a.part = (float*)ws;
     const size_t ldsb = S4_XBYTES + 512 * 64;
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)stem4_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); set = true; }
+    SEG_SET_LDS((stem4_wgrad_kernel), (int)ldsb);
     const double vox = (double)N * D * H * W;
     {
         ProfScope ps(PF_DIRECT, 2.0 * vox * 108.0 * Cout, 2.0 * vox * (4 + Cout), st);

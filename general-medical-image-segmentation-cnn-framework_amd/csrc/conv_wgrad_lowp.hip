@@ -360,11 +360,7 @@ size_t wgrad_lowp_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k)
 template <int BX, int KS, int NP, typename IN_T, int S = 1>
 static void launch_lwgrad(const LWgradArgs& a, int nwg, hipStream_t st) {
     using T = LTile<BX, KS, NP, S>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_lowp_kernel<BX, KS, NP, IN_T, S>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
-        attr_set = true;
-    }
+    SEG_SET_LDS((conv_wgrad_lowp_kernel<BX, KS, NP, IN_T, S>), T::LDS_BYTES);
     hipLaunchKernelGGL((conv_wgrad_lowp_kernel<BX, KS, NP, IN_T, S>), dim3(nwg), dim3(LW_THREADS), T::LDS_BYTES, st, a);
 }
 

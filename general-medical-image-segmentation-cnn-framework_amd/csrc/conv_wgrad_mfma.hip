@@ -227,11 +227,7 @@ size_t wgrad_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k)
 template <int BX, int KS>
 static void launch_wgrad(const WgradArgs& a, int nwg, hipStream_t st) {
     using T = WTile<BX, KS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<BX, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
-        attr_set = true;
-    }
+    SEG_SET_LDS((conv_wgrad_kernel<BX, KS>), T::LDS_BYTES);
     hipLaunchKernelGGL((conv_wgrad_kernel<BX, KS>), dim3(nwg), dim3(WG_THREADS), T::LDS_BYTES, st, a);
 }
 

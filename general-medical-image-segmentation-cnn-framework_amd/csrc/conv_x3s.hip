@@ -315,8 +315,7 @@ template <int LW, int NBW>
 void launch_x3s(const IgemmArgs& a, int nwg, hipStream_t st) {
     constexpr int LDSB = Geo<LW>::LDS_BYTES;
     static_assert(LDSB >= 8 * 64 * 4, "the statistics epilogue needs 8 x NT floats");
-    // set on every call: cheap, and correct for a process that drives more than one device
-    (void)hipFuncSetAttribute((const void*)conv_x3s_kernel<LW, NBW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+    SEG_SET_LDS((conv_x3s_kernel<LW, NBW>), LDSB);
     hipLaunchKernelGGL((conv_x3s_kernel<LW, NBW>), dim3(nwg), dim3(256), LDSB, st, a);
 }
 

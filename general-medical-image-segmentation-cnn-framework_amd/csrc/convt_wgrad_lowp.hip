@@ -359,8 +359,7 @@ int pw_wgrad_lowp(const IN_T* dy, int lddy, const IN_T* x, int ldx, int N, int D
     float* part = cv.take<float>((size_t)p.nstrips * Cin * Cout);
     SEG_CHECK_WS(cv.used(), ws_bytes);
     CwArgs a{x, dy, part, ldx, lddy, N, D, H, W, Cin, Cout, p.ntiles, p.nstrips, p.npairs, (Cout + 31) / 32};
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)pw_wgrad_lowp_kernel<NP, IN_T>, hipFuncAttributeMaxDynamicSharedMemorySize, PwlCfg<NP>::LDS_BYTES); set = true; }
+    SEG_SET_LDS((pw_wgrad_lowp_kernel<NP, IN_T>), PwlCfg<NP>::LDS_BYTES);
     ProfScope ps(PF_WGRAD, 2.0 * nvox * Cin * Cout, (double)sizeof(IN_T) * nvox * (Cin + (double)Cout) + 4.0 * Cin * Cout, st);
     hipLaunchKernelGGL((pw_wgrad_lowp_kernel<NP, IN_T>), dim3(p.nstrips * p.npairs), dim3(256), PwlCfg<NP>::LDS_BYTES, st, a);
     SEG_CHECK_LAUNCH();
@@ -415,8 +414,7 @@ int convt_wgrad_lowp(const IN_T* dy, int lddy, const IN_T* x, int ldx, int N, in
     float* part = cv.take<float>((size_t)p.nstrips * 8 * Cin * Cout);
     SEG_CHECK_WS(cv.used(), ws_bytes);
     CwArgs a{x, dy, part, ldx, lddy, N, D, H, W, Cin, Cout, p.ntiles, p.nstrips, p.npairs, (Cout + 31) / 32};
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)convt_wgrad_lowp_kernel<NP, IN_T>, hipFuncAttributeMaxDynamicSharedMemorySize, CwCfg<NP>::LDS_BYTES); set = true; }
+    SEG_SET_LDS((convt_wgrad_lowp_kernel<NP, IN_T>), CwCfg<NP>::LDS_BYTES);
     ProfScope ps(PF_CONVT, 2.0 * nvox * 8 * Cin * Cout, (double)sizeof(IN_T) * nvox * (Cin + 8.0 * Cout) + 32.0 * Cin * Cout, st);
     hipLaunchKernelGGL((convt_wgrad_lowp_kernel<NP, IN_T>), dim3(p.nstrips * p.npairs), dim3(256), CwCfg<NP>::LDS_BYTES, st, a);
     SEG_CHECK_LAUNCH();

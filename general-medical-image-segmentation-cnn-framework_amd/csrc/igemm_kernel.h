@@ -617,11 +617,7 @@ template <int MATH, int KS, int BX, int MB, int NBW, int CK, int WN = 1>
 static void launch_igemm(const IgemmArgs& a, int nwg, hipStream_t st) {
     using T = Tile<MATH, KS, BX, MB, CK, WN>;
     constexpr int LDSB = T::LDS_BYTES < 8 * 64 * 4 ? 8 * 64 * 4 : T::LDS_BYTES;      // the statistics epilogue needs 8 x NT floats
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<MATH, KS, BX, MB, NBW, CK, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-        attr_set = true;
-    }
+    SEG_SET_LDS((conv_igemm_kernel<MATH, KS, BX, MB, NBW, CK, WN>), LDSB);
     const int grid = (T::PERSIST && nwg > 512) ? 512 : nwg;   // persistent variants: two workgroups per CU walk the tiles
     hipLaunchKernelGGL((conv_igemm_kernel<MATH, KS, BX, MB, NBW, CK, WN>), dim3(grid), dim3(256), LDSB, st, a);
 }

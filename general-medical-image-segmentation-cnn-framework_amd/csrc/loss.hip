@@ -260,6 +260,46 @@ __global__ __launch_bounds__(256) void dice_rows_bwd_kernel(const float* __restr
     }
 }
 
+// ---- ZNormalization of one volume (dataloader.py:94, torchio: (x - mean) / std over all voxels, unbiased std).
+// Sums of d = x - x[0] and d^2 in fp64 (the pivot keeps sum d^2 - (sum d)^2 / n well conditioned for CT-like offsets),
+// two-stage and fixed-order; the apply pass turns them into mean and 1 / std.
+__global__ __launch_bounds__(kLossThreads) void znorm_sums_kernel(const float* __restrict__ x, long long n, double* __restrict__ part) {
+    __shared__ double sh[8];
+    const float pv = x[0];
+    double acc[2] = {0.0, 0.0};
+    const long long n4 = n / 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float a = v.x - pv, b = v.y - pv, c = v.z - pv, d = v.w - pv;
+        acc[0] += (double)a + (double)b + (double)c + (double)d;
+        acc[1] += (double)a * a + (double)b * b + (double)c * c + (double)d * d;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float a = x[n4 * 4 + threadIdx.x] - pv; acc[0] += a; acc[1] += (double)a * a; }
+    block_sum<2>(acc, sh);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = acc[0]; part[2 * blockIdx.x + 1] = acc[1]; }
+}
+__global__ __launch_bounds__(256) void znorm_finalize_kernel(const double* __restrict__ part, int nblk, const float* __restrict__ x, long long n, float* __restrict__ mr) {
+    __shared__ double sh[8];
+    double acc[2] = {0.0, 0.0};
+    for (int i = threadIdx.x; i < nblk; i += 256) { acc[0] += part[2 * i]; acc[1] += part[2 * i + 1]; }
+    block_sum<2>(acc, sh);
+    if (threadIdx.x == 0) {
+        const double md = acc[0] / (double)n, var = (acc[1] - acc[0] * md) / (double)(n - 1);
+        mr[0] = (float)((double)x[0] + md);
+        mr[1] = (float)(1.0 / sqrt(var));
+    }
+}
+__global__ __launch_bounds__(256) void znorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ mr, long long n, float* __restrict__ y) {
+    const float m = mr[0], r = mr[1];
+    const long long n4 = n / 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        v.x = (v.x - m) * r; v.y = (v.y - m) * r; v.z = (v.z - m) * r; v.w = (v.w - m) * r;
+        reinterpret_cast<float4*>(y)[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[n4 * 4 + threadIdx.x] = (x[n4 * 4 + threadIdx.x] - m) * r;
+}
+
 constexpr int kMaxClasses = 16;
 
 __global__ __launch_bounds__(256) void softmax_ch_kernel(const float* __restrict__ x, float* __restrict__ y, long long N, int K, long long S) {
@@ -464,6 +504,25 @@ int mi355seg_dice_rows_bwd_f32(const float* x, const float* t, const double* g, 
     long long per = (len + 256 * 8 - 1) / (256 * 8);
     if (per > 4096) per = 4096;
     hipLaunchKernelGGL(dice_rows_bwd_kernel, dim3((unsigned)per, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, t, g, len, apply_sigmoid, p, dx);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+size_t mi355seg_znorm_ws_bytes(long long n) { (void)n; return (size_t)kLossMaxBlocks * 2 * sizeof(double) + 64; }
+int mi355seg_znorm_f32(const float* x, long long n, float* y, void* ws, size_t ws_bytes, void* stream) {
+    SEG_CHECK_ARG(x && y && n > 1, "znorm: bad arguments (n > 1)");
+    SEG_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0, "znorm: pointers must be 16-byte aligned");
+    SEG_CHECK_WS(mi355seg_znorm_ws_bytes(n), ws_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(PF_LOSS, 0.0, 12.0 * n, st);
+    float* mr = (float*)ws;                                    // mean, 1 / std; the block partials behind them
+    double* part = (double*)((char*)ws + 64);
+    const int nblk = loss_grid(n / 4 + 1);
+    hipLaunchKernelGGL(znorm_sums_kernel, dim3(nblk), dim3(kLossThreads), 0, st, x, n, part);
+    SEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(znorm_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)part, nblk, x, n, mr);
+    SEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(znorm_apply_kernel, dim3(loss_grid(n / 4 + 1) * 2), dim3(256), 0, st, x, (const float*)mr, n, y);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }

@@ -78,6 +78,60 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+class CommTimer:
+    """Accumulates how long the step spent WAITING on communication, measured where the step waits: HIP events on the compute
+    stream (the collectives run on the communicator's stream; ``work.wait()`` only makes the compute stream wait for them, so
+    the time between the two events is the exposed part -- what backward did not hide -- plus the scatter-back copy), or the
+    host clock for the CPU (gloo) rehearsal.  ``total_ms()`` synchronises once, at the end of the timed region."""
+
+    def __init__(self):
+        self.pairs, self.host_ms, self.calls = [], 0.0, 0
+
+    def start(self, device):
+        import time
+        self.calls += 1
+        if device.type == "cuda":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            return (e0, e1)
+        return time.perf_counter()
+
+    def stop(self, token):
+        import time
+        if isinstance(token, tuple):
+            token[1].record()
+            self.pairs.append(token)
+        else:
+            self.host_ms += (time.perf_counter() - token) * 1e3
+
+    def reset(self):
+        self.pairs, self.host_ms, self.calls = [], 0.0, 0
+
+    def total_ms(self):
+        if self.pairs:
+            self.pairs[-1][1].synchronize()
+        return self.host_ms + sum(a.elapsed_time(b) for a, b in self.pairs)
+
+
+BUFFER_BROADCAST_TIMER = CommTimer()
+
+
+def comm_report(reducer, steps):
+    """The `comm` block of bench.py's line (rank 0): what one step sends and how long it waited for it."""
+    params = reducer.params if reducer is not None else []
+    dev = params[0].device.type if params else "cpu"
+    return {
+        "grad_bytes_per_step": int(sum(p.numel() * p.element_size() for p in params)),
+        "buckets": len(reducer.buckets) if reducer is not None else 0,
+        "bucket_cap_mb": getattr(reducer, "bucket_mb", None),
+        "allreduce_wait_ms_per_step": (reducer.timer.total_ms() / max(1, steps)) if reducer is not None else 0.0,
+        "broadcast_buffers_ms_per_step": BUFFER_BROADCAST_TIMER.total_ms() / max(1, steps),
+        "buffer_broadcast_collectives_per_step": BUFFER_BROADCAST_TIMER.calls / max(1, steps),
+        "timer": "HIP events on the compute stream of rank 0: time the step waited in GradAllReducer.__call__ (exposed all-reduce + scatter-back) "
+                 "and in broadcast_buffers" if dev == "cuda" else "host clock (CPU / gloo rehearsal)",
+    }
+
+
 class GradAllReducer:
     """Mean all-reduce of every parameter gradient through flat fp32 buckets, overlapped with backward.
 
@@ -93,6 +147,8 @@ class GradAllReducer:
     def __init__(self, model, bucket_mb=32.0, overlap=True, always=False):
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.always = always
+        self.bucket_mb = bucket_mb
+        self.timer = CommTimer()
         cap = int(bucket_mb * (1 << 20) / 4)
         self.buckets, cur, n = [], [], 0
         for p in reversed(self.params):
@@ -149,6 +205,7 @@ class GradAllReducer:
         for bi in range(len(self.buckets)):
             if self._works[bi] is None:
                 self._launch(bi)
+        token = self.timer.start(self.params[0].device)
         inv = 1.0 / world_size()
         for bi, bucket in enumerate(self.buckets):
             self._works[bi].wait()
@@ -169,6 +226,7 @@ class GradAllReducer:
                 torch._foreach_copy_(dsts, srcs)              # one multi-tensor launch per bucket instead of one copy per parameter
             self._works[bi] = None
             self._pending[bi] = len(bucket)
+        self.timer.stop(token)
 
 
 def broadcast_parameters(model, src=0):
@@ -206,46 +264,45 @@ def setup_replica(model, bucket_mb=32.0, overlap=True):
 
 
 def flatten_buffers(model):
-    """Re-seat every module buffer as a view into one flat tensor per dtype class (float / integer), so that
-    ``broadcast_buffers`` is two collectives with no gather / scatter copies around them.  The kernels update running
-    statistics through ``data_ptr()``, so views are transparent to them.  Idempotent; returns the flat tensors."""
+    """Re-seat every module buffer as a typed view into ONE flat byte tensor (each buffer at a 16-byte aligned offset), so that
+    ``broadcast_buffers`` is a single collective with no gather / scatter copies around it -- float running statistics and the
+    int64 ``num_batches_tracked`` counters travel together.  The kernels update running statistics through ``data_ptr()``, so
+    views are transparent to them.  Idempotent; returns the flat tensor (None for a model without buffers)."""
     if getattr(model, "_mi355seg_flat_buffers", None) is not None:
         return model._mi355seg_flat_buffers
     owners = [(mod, name, b) for mod in model.modules() for name, b in mod._buffers.items() if b is not None]
-    flats = []
-    for floating in (True, False):
-        group = [(m, n, b) for (m, n, b) in owners if b.is_floating_point() == floating]
-        if not group:
-            flats.append(None)
-            continue
-        flat = torch.cat([b.detach().reshape(-1) for (_, _, b) in group])
-        off = 0
-        for m, n, b in group:
-            k = b.numel()
-            m._buffers[n] = flat[off:off + k].view_as(b)
-            off += k
-        flats.append(flat)
-    model._mi355seg_flat_buffers = tuple(flats)
-    return model._mi355seg_flat_buffers
+    if not owners:
+        model._mi355seg_flat_buffers = None
+        return None
+    offs, total = [], 0
+    for _, _, b in owners:
+        offs.append(total)
+        total += (b.numel() * b.element_size() + 15) // 16 * 16
+    flat = torch.zeros(total, dtype=torch.uint8, device=owners[0][2].device)
+    for (m, n, b), off in zip(owners, offs):
+        nbytes = b.numel() * b.element_size()
+        view = flat[off:off + nbytes].view(b.dtype).view(b.shape)
+        view.copy_(b.detach())
+        m._buffers[n] = view
+    model._mi355seg_flat_buffers = flat
+    return flat
 
 
 def broadcast_buffers(model, src=0):
     """DDP(broadcast_buffers=True): rank ``src``'s BatchNorm running statistics (and
-    num_batches_tracked) overwrite every rank's before the forward."""
+    num_batches_tracked) overwrite every rank's before the forward -- one collective on the flattened buffers."""
     if world_size() == 1:
         return
-    flats = getattr(model, "_mi355seg_flat_buffers", None)
-    if flats is not None:
-        live = {b.untyped_storage().data_ptr() for b in model.buffers()}
-        if live <= {f.untyped_storage().data_ptr() for f in flats if f is not None}:
-            for flat in flats:
-                if flat is not None:
-                    dist.broadcast(flat, src=src)
-            return
-        model._mi355seg_flat_buffers = None           # the module was moved / re-created since: fall back to gather + scatter
     bufs = [b for b in model.buffers()]
     if not bufs:
         return
+    token = BUFFER_BROADCAST_TIMER.start(bufs[0].device)
+    flat = getattr(model, "_mi355seg_flat_buffers", None)
+    if flat is not None and {b.untyped_storage().data_ptr() for b in bufs} == {flat.untyped_storage().data_ptr()}:
+        dist.broadcast(flat, src=src)
+        BUFFER_BROADCAST_TIMER.stop(token)
+        return
+    model._mi355seg_flat_buffers = None           # the module was moved / re-created since: gather + scatter, one collective per dtype class
     fl = [b for b in bufs if b.is_floating_point()]
     it = [b for b in bufs if not b.is_floating_point()]
     for group in (fl, it):
@@ -258,6 +315,7 @@ def broadcast_buffers(model, src=0):
             n = b.numel()
             b.copy_(flat[off:off + n].view_as(b))
             off += n
+    BUFFER_BROADCAST_TIMER.stop(token)
 
 
 def all_reduce_metric(counts, loss):

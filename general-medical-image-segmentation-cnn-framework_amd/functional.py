@@ -792,6 +792,17 @@ def two_channel_gt(gt):
     return out
 
 
+def znormalize(x):
+    """tio.ZNormalization() of one volume on the device: (x - mean) / std over all voxels (unbiased std)."""
+    _require_cuda(x, "znormalize input")
+    x = x.contiguous().to(torch.float32)
+    L = lib()
+    ws = workspace(L.query("mi355seg_znorm_ws_bytes", x.numel()), x.device)
+    y = torch.empty_like(x)
+    L.call("mi355seg_znorm_f32", _p(x), x.numel(), _p(y), _p(ws), ws.numel(), _stream())
+    return y
+
+
 def dice_sums(x, t, apply_sigmoid=False):
     """(sum a*b, sum a, sum b, sum a*a, sum b*b) as float64[5], a = sigmoid(x) if asked."""
     _require_cuda(x, "dice_sums input")

@@ -111,7 +111,9 @@ def main(argv=None, conf_dir=None):
     # ranks from here when no launcher did (WORLD_SIZE unset) -- before this process has made any GPU call -- and waits
     gpus = int(config.get("gpus", os.environ.get("MI355SEG_GPUS", 1)) or 1)
     if gpus > 1 and "WORLD_SIZE" not in os.environ:
-        script = os.path.abspath(sys.argv[0]) if sys.argv and sys.argv[0].endswith(".py") else os.path.abspath(__file__)
+        # always the repo-level wrapper (it puts the package on the path; this file uses relative imports and whatever
+        # sys.argv[0] is -- pytest, ``python -c``, another driver script -- is not the train entry point)
+        script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "train.py")
         rc = D.self_launch(gpus, [script] + argv)
         if rc:
             raise SystemExit(rc)

@@ -255,6 +255,11 @@ int mi355seg_dice_rows_f32(const float* x, const float* t, long long rows, long 
 int mi355seg_dice_rows_bwd_f32(const float* x, const float* t, const double* g, long long rows, long long len, int apply_sigmoid,
                                float p, float* dx, void* stream);
 
+/* tio.ZNormalization() of one volume (dataloader.py:94): y = (x - mean) / std over all n voxels, unbiased std, fp64 sums;
+ * in place (y == x) allowed.  The device patch queue normalises each uploaded volume once with it. */
+size_t mi355seg_znorm_ws_bytes(long long n);
+int mi355seg_znorm_f32(const float* x, long long n, float* y, void* ws, size_t ws_bytes, void* stream);
+
 /* softmax over the channel dim of an NCDHW tensor [N,K,S] (DiceLossss softmax=True, loss_function.py:170-171) */
 int mi355seg_softmax_ch_f32(const float* x, float* y, long long N, int K, long long S, void* stream);
 /* dx = y * (dy - sum_k dy*y) */

@@ -30,11 +30,16 @@ def test_bench_self_launches_two_ranks():
     assert len(r["rank_devices"]) == 2 and r["rank_devices"][0].startswith("rank0:") and r["rank_devices"][1].startswith("rank1:")
     assert r["steps"] == 3 and r["warmup"] == 1 and r["value"] > 0 and r["scaling"] == "weak"
     assert "rehearsal" in r
+    # the `comm` block: what a step sends and how long it waited for it (so that a scaling shortfall can be attributed)
+    c = r["comm"]
+    assert c["grad_bytes_per_step"] == 4 * (4 * 27 + 4 + 4 + 4 + 2 * 4 + 2) and c["buckets"] >= 1
+    assert c["allreduce_wait_ms_per_step"] > 0.0 and c["broadcast_buffers_ms_per_step"] > 0.0
+    assert c["buffer_broadcast_collectives_per_step"] == 1.0 and 0.0 < c["allreduce_wait_frac_of_step"] < 1.0
 
 
 def test_bench_single_rank_does_not_launch():
     r = _run(["--gpus", "1"])
-    assert r["n_gpus"] == 1 and r["rccl_ranks"] == 1 and r["dist_backend"] is None
+    assert r["n_gpus"] == 1 and r["rccl_ranks"] == 1 and r["dist_backend"] is None and "comm" not in r
 
 
 def test_bench_under_an_external_launcher_is_one_of_the_ranks():

@@ -55,3 +55,24 @@ def test_registry_builds_in_scope_networks_with_reference_constructors():
         build_model({"network": "densenet", "in_classes": 1, "out_classes": 2})
     with pytest.raises(ValueError):
         build_model({"network": "nope", "in_classes": 1, "out_classes": 2})
+
+
+def test_train_gpus_n_launches_the_repo_level_entry_point(monkeypatch):
+    """``train.py config.gpus=N`` (accelerate launch of the reference, train.py:167-169): the N ranks are started on the
+    repo-level ``train.py`` wrapper whatever ``sys.argv[0]`` is (pytest here), with the original overrides."""
+    import sys
+    from mi355seg import distributed as D
+    from mi355seg import train as T
+    seen = {}
+
+    def fake_launch(nproc, argv, env=None):
+        seen["nproc"], seen["argv"] = nproc, list(argv)
+        return 0
+    monkeypatch.setattr(D, "self_launch", fake_launch)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["/usr/bin/pytest"])
+    cfg, res = T.main(["config=unet", "config.gpus=2", "config.epochs=1"])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert res is None and seen["nproc"] == 2
+    assert seen["argv"][0] == os.path.join(root, "train.py") and os.path.exists(seen["argv"][0])
+    assert seen["argv"][1:] == ["config=unet", "config.gpus=2", "config.epochs=1"]

@@ -55,3 +55,36 @@ def test_queue_is_seeded(tmp_path):
     mk = lambda: DevicePatchQueue(str(tmp_path / "x"), str(tmp_path / "y"), 8, 1, 5, "cpu", seed=3)
     a, b = list(mk()), list(mk())
     assert all(torch.equal(p["source"]["data"], q["source"]["data"]) for p, q in zip(a, b))
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_device_patch_queue_on_the_gpu(tmp_path):
+    """DevicePatchQueue on cuda:0 (the configuration the train loop uses): batch dicts of the reference's shape on the device,
+    ZNormalization by the HIP kernels (mi355seg_znorm_f32) equal to numpy's (x - mean) / std(ddof=1), the same seeded patch
+    order as a CPU-resident queue, labels cut with the same windows."""
+    import mi355seg
+    from mi355seg.data import DevicePatchQueue
+    assert torch.cuda.is_available()
+    vols = _write(tmp_path, n=3, shape=(20, 18, 24))
+    mk = lambda dev: DevicePatchQueue(str(tmp_path / "x"), str(tmp_path / "y"), (8, 8, 8), batch_size=2, iters=7, device=dev, seed=11,
+                                      queue_length=6, samples_per_volume=3)
+    qg, qc = mk("cuda:0"), mk("cpu")
+    bg, bc = list(qg), list(qc)
+    assert len(bg) == 7
+    for g, c in zip(bg, bc):
+        xg, yg = g["source"]["data"], g["gt"]["data"]
+        assert xg.is_cuda and yg.is_cuda and xg.dtype == torch.float32 and xg.shape == (2, 1, 8, 8, 8) and yg.shape == (2, 1, 8, 8, 8)
+        assert torch.equal(yg.cpu(), c["gt"]["data"])                              # same windows, same order
+        assert (xg.cpu() - c["source"]["data"]).abs().max() < 2e-5
+    for idx, (x, _) in enumerate(vols):                                            # the cached volumes are z-normalised
+        xn = qg.cache[idx][0].cpu().numpy()[0]
+        ref = (x.astype(np.float64) - x.astype(np.float64).mean()) / x.astype(np.float64).std(ddof=1)
+        assert np.abs(xn - ref).max() < 2e-5 and abs(float(xn.mean())) < 1e-5 and abs(float(xn.std(ddof=1)) - 1.0) < 1e-5
+    # the op itself on an odd-length volume (tail elements) and a large offset (cancellation in sum x^2 - n mean^2 stays in fp64)
+    v = torch.randn(100003) * 3.0 + 1000.0
+    got = mi355seg.functional.znormalize(v.cuda()).cpu().double()
+    want = (v.double() - v.double().mean()) / v.double().std()
+    assert (got - want).abs().max() < 2e-4

@@ -42,13 +42,16 @@ def _worker(rank, world, port, out):
     if rank == 1:
         for b in model.buffers():
             b.add_(2)
-    flats = D.flatten_buffers(model)                           # buffers become views of two flat tensors
-    assert flats[0] is not None and flats[1] is not None and D.flatten_buffers(model) is flats
-    D.broadcast_buffers(model)                                 # two collectives, no copies
+    flat = D.flatten_buffers(model)                            # every buffer (float statistics AND the int64 counter) a view of ONE byte tensor
+    assert flat is not None and flat.dtype == torch.uint8 and D.flatten_buffers(model) is flat
+    assert all(b.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() and b.data_ptr() % 16 == 0 for b in model.buffers())
+    D.BUFFER_BROADCAST_TIMER.reset()
+    D.broadcast_buffers(model)                                 # one collective, no copies
+    assert D.BUFFER_BROADCAST_TIMER.calls == 1 and D.BUFFER_BROADCAST_TIMER.total_ms() > 0.0
     for (k, a), b in zip(model.named_buffers(), ref.buffers()):
-        assert torch.equal(a, b), k
+        assert torch.equal(a, b) and a.dtype == b.dtype, k
     model.train()(torch.zeros(2, 1, 4, 4, 4))                  # BatchNorm keeps updating the (view) buffers in place
-    assert int(model[1].num_batches_tracked) == 1 and flats[1].sum() == 1
+    assert int(model[1].num_batches_tracked) == 1 and model[1].num_batches_tracked.dtype == torch.int64
     model[1].reset_running_stats()
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.randn(2, 1, 4, 4, 4, generator=g)
@@ -62,6 +65,9 @@ def _worker(rank, world, port, out):
         assert all(w is not None for w in hooked._works)       # every bucket went out during backward
         hooked(model)
         results.append((local, [p.grad.clone() for p in model.parameters()]))
+    rep = D.comm_report(hooked, steps=2)                       # the `comm` block of bench.py's line
+    assert rep["grad_bytes_per_step"] == sum(p.numel() * 4 for p in model.parameters()) and rep["buckets"] == len(hooked.buckets) > 1
+    assert rep["allreduce_wait_ms_per_step"] > 0.0 and "host clock" in rep["timer"] and rep["buffer_broadcast_collectives_per_step"] >= 0
     hooked.detach()
     for p in model.parameters():
         p.grad = None
