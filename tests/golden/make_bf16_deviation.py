@@ -29,6 +29,16 @@ from oracle.step import two_channel_gt  # noqa: E402
 torch.set_num_threads(8)
 
 
+SAMPLES = {}
+
+
+def _sample(t, k=32768):
+    """Evenly strided sample of the logits (the GPU test samples its own logits the same way)."""
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // k)
+    return f[::step][:k].float().numpy().copy()
+
+
 def deviation(build, x, target, seed=11):
     runs = []
     for autocast in (False, True):
@@ -41,6 +51,7 @@ def deviation(build, x, target, seed=11):
         loss.backward()
         runs.append((pred.detach().double(), float(loss), {k: p.grad.double() for k, p in m.named_parameters() if p.grad is not None}))
     (p32, l32, g32), (p16, l16, g16) = runs
+    SAMPLES[len(SAMPLES)] = (_sample(p32), _sample(p16))
     num = sum(float((g16[k] - g32[k]).norm() ** 2) for k in g32)
     den = sum(float(g32[k].norm() ** 2) for k in g32)
     return {"logits_rel_l2": float((p16 - p32).norm() / p32.norm()), "logits_max_abs": float((p16 - p32).abs().max()),
@@ -71,6 +82,12 @@ def main():
     out["unet3d_f8_32"] = deviation(lambda: fill_module_(UNet3D(in_channels=1, out_channels=2, init_features=8)), make_input((2, 1, 32, 32, 32)),
                                     two_channel_gt(make_labels((2, 1, 32, 32, 32))).float())
     json.dump(out, open(os.path.join(HERE, "bf16_reference_deviation.json"), "w"), indent=1)
+    # the reference's OWN logits, fp32 and autocast-bf16, on a strided sample per fixture: the GPU bf16 path is placed next to
+    # the reference's bf16 result directly (tests/test_gpu_bf16.py), not only next to its own fp32 result
+    import numpy as np
+    names = ["vnet_32", "resunet_f4_96", "unetr_small", "unet3d_f8_32"]
+    np.savez_compressed(os.path.join(HERE, "bf16_reference_logits.npz"),
+                        **{f"{n}/fp32": SAMPLES[i][0] for i, n in enumerate(names)}, **{f"{n}/bf16": SAMPLES[i][1] for i, n in enumerate(names)})
     print(json.dumps(out, indent=1))
 
 

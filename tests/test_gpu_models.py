@@ -144,6 +144,7 @@ def test_resunet_well_conditioned_fixture_plain_tolerance(seg, golden_dir):
     train forward with the reference's dropout masks, loss, and six weight gradients incl. the weight-shared block."""
     from mi355seg.models.three_d.residual_unet3d import UNet
     from oracle.fill import RESUNET96_HEAD_SCALE, fill_module_hash_, make_input_rough
+    from oracle.nets import ResUNet
     g = np.load(os.path.join(golden_dir, "resunet_f4_96.npz"))
     K = 1 << 18
     x = make_input_rough((1, 4, 96, 96, 96), seed=2.0).cuda()
@@ -165,17 +166,26 @@ def test_resunet_well_conditioned_fixture_plain_tolerance(seg, golden_dir):
               f" (reference thread spread {float(g['thread_spread']):.1e}, |logit| max {np.abs(ref).max():.2f})")
         assert d.max() < TOL, (name, d.max(), int((d > TOL).sum()))
     assert abs(loss.item() - float(g["loss"])) < 1e-5
+    # Weight gradients: the forward is smooth in the weights, the backward is not (LeakyReLU kinks under 20+ InstanceNorm backward
+    # passes), so the bound is MEASURED here, not assumed: the same step in fp64 (the oracle with the reference's dropout masks) is the
+    # truth, the reference's own fp32 gradients (the fixture) sit some distance e_ref from it, and the GPU must sit within twice that.
+    o = fill_module_hash_(ResUNet(in_channels=4, n_classes=4, base_n_filter=4), RESUNET96_HEAD_SCALE).double().train()
+    queue = [mk.double() / 0.4 for mk in _masks(g)]
+    o.dropout3d.forward = lambda t: t * queue.pop(0).reshape(t.shape[0], t.shape[1], 1, 1, 1)
+    t_loss = torch.nn.functional.binary_cross_entropy_with_logits(o(x.cpu().double()), onehot.cpu().double())
+    t_loss.backward()
+    assert abs(float(t_loss) - float(g["loss"])) < 1e-5
+    t_grads = {k: p.grad for k, p in o.named_parameters()}
     params = dict(m.named_parameters())
     for k in g.files:
         if k.startswith("grad/"):
+            truth = _sample(t_grads[k[5:]].float(), 4096).astype(np.float64)
             ref, got = g[k].astype(np.float64), _sample(params[k[5:]].grad).astype(np.float64)
-            d = np.abs(got - ref).max()
-            print(f"resunet96 {k}: max |dGPU - dref| = {d:.3e} of {np.abs(ref).max():.3e} (relative {d / np.abs(ref).max():.2e})")
-            # the forward is smooth in the weights, the backward is not: LeakyReLU kinks and 20+ InstanceNorm backward passes
-            # put the REFERENCE's own fp32 gradients 0.5e-3 ... 2.7e-3 (relative to the tensor max) from an fp64 run of the
-            # same step (measured with the oracle in fp64; the head gradients, which see no kink, agree to 3e-7)
-            assert d <= 5e-3 * max(1e-6, np.abs(ref).max()), (k, d)
-            if "1x1" in k or k.endswith("conv3d_l4.weight"):
+            scale = max(1e-6, np.abs(truth).max())
+            e_ref, e_gpu, d = np.abs(ref - truth).max(), np.abs(got - truth).max(), np.abs(got - ref).max()
+            print(f"resunet96 {k}: vs fp64 -- reference fp32 {e_ref / scale:.2e}, GPU {e_gpu / scale:.2e} of the tensor max; direct |dGPU - dref| {d / scale:.2e}")
+            assert e_gpu <= 2.0 * e_ref + 1e-5 * scale, (k, e_gpu, e_ref)
+            if "1x1" in k or k.endswith("conv3d_l4.weight"):          # the heads see no kink: plain agreement
                 assert d <= 1e-5 * np.abs(ref).max(), (k, d)
 
 
