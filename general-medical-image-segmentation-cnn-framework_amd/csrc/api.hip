@@ -253,6 +253,38 @@ __global__ __launch_bounds__(256) void add_bias_kernel(T* __restrict__ y, int ld
     }
 }
 
+// ---- sliding-window inference (predict.py:98-147): grid patches of one volume as a device-resident batch, and the crop-mode
+// aggregation of their label maps.  table[p] = {origin z, y, x, crop lo z, y, x, crop hi z, y, x} (crop window inside the patch,
+// hi exclusive): torchio GridSampler locations and GridAggregator(overlap_mode='crop') windows, built once per volume on the host.
+__global__ __launch_bounds__(256) void gather_patches_kernel(const float* __restrict__ vol, int C, int D, int H, int W, const int* __restrict__ table,
+        int first, int count, int pd, int ph, int pw, float* __restrict__ out) {
+    const long long per = (long long)C * pd * ph * pw, total = per * count;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / per);
+        long long r = i - (long long)b * per;
+        const int x = (int)(r % pw); r /= pw;
+        const int y = (int)(r % ph); r /= ph;
+        const int z = (int)(r % pd);
+        const int c = (int)(r / pd);
+        const int* t = table + (long long)(first + b) * 9;
+        out[i] = vol[(((long long)c * D + t[0] + z) * H + t[1] + y) * W + t[2] + x];
+    }
+}
+__global__ __launch_bounds__(256) void paste_labels_kernel(const long long* __restrict__ labels, const int* __restrict__ table, int first, int count,
+        int pd, int ph, int pw, long long* __restrict__ out, int D, int H, int W) {
+    const long long per = (long long)pd * ph * pw, total = per * count;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / per);
+        long long r = i - (long long)b * per;
+        const int x = (int)(r % pw); r /= pw;
+        const int y = (int)(r % ph);
+        const int z = (int)(r / ph);
+        const int* t = table + (long long)(first + b) * 9;
+        if (z >= t[3] && z < t[6] && y >= t[4] && y < t[7] && x >= t[5] && x < t[8])
+            out[((long long)(t[0] + z) * H + t[1] + y) * W + t[2] + x] = labels[i];
+    }
+}
+
 extern "C" {
 
 const char* mi355seg_last_error(void) { return g_err; }
@@ -325,6 +357,27 @@ int mi355seg_ndhwc_bf16_to_ncdhw_f32(const mi355seg_bf16* src, int ldsrc, float*
 static int rows_grid(long long total) {
     long long b = (total + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+int mi355seg_gather_patches_f32(const float* vol, int C, int D, int H, int W, const int* table, int first, int count,
+                                int pd, int ph, int pw, float* out, void* stream) {
+    SEG_CHECK_ARG(vol && table && out && C > 0 && count > 0 && first >= 0 && pd > 0 && ph > 0 && pw > 0 && pd <= D && ph <= H && pw <= W,
+                  "gather_patches: bad arguments (patch %dx%dx%d in volume %dx%dx%d)", pd, ph, pw, D, H, W);
+    const long long total = (long long)count * C * pd * ph * pw;
+    ProfScope ps(PF_POOL, 0.0, 8.0 * total, (hipStream_t)stream);
+    hipLaunchKernelGGL(gather_patches_kernel, dim3(rows_grid(total)), dim3(256), 0, (hipStream_t)stream, vol, C, D, H, W, table, first, count, pd, ph, pw, out);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_paste_labels_i64(const int64_t* labels, const int* table, int first, int count, int pd, int ph, int pw,
+                              int64_t* out, int D, int H, int W, void* stream) {
+    SEG_CHECK_ARG(labels && table && out && count > 0 && first >= 0 && pd > 0 && ph > 0 && pw > 0 && pd <= D && ph <= H && pw <= W,
+                  "paste_labels: bad arguments");
+    const long long total = (long long)count * pd * ph * pw;
+    ProfScope ps(PF_POOL, 0.0, 16.0 * total, (hipStream_t)stream);
+    hipLaunchKernelGGL(paste_labels_kernel, dim3(rows_grid(total)), dim3(256), 0, (hipStream_t)stream, (const long long*)labels, table, first, count,
+                       pd, ph, pw, (long long*)out, D, H, W);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
 }
 int mi355seg_copy_rows_f32(const float* src, int ldsrc, float* dst, int lddst, long long rows, int C, void* stream) {
     SEG_CHECK_ARG(src && dst && rows > 0 && C > 0 && ldsrc >= C && lddst >= C, "copy_rows: bad arguments");

@@ -214,7 +214,11 @@ __global__ __launch_bounds__(256, 2) void conv_b16s_kernel(IgemmArgs a) {
             } else {
                 bf16x8_t o;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) { const float v = acc[j][c >> 2][c & 3] + bv[c]; o[c] = (bf16)v; ssum[c] += v; }
+                for (int c = 0; c < 8; ++c) {
+                    float v = acc[j][c >> 2][c & 3] + bv[c];
+                    if (a.act) v = act_apply(v, a.act, a.slope);
+                    o[c] = (bf16)v; ssum[c] += v;
+                }
                 *reinterpret_cast<bf16x8_t*>(yout + off) = o;
             }
         }

@@ -120,6 +120,18 @@ size_t mi355seg_conv3d_ws_bytes_bf16(int N, int D, int H, int W, int Cin, int Co
     return base;
 }
 
+int mi355seg_conv3d_fused_supported_bf16(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int ldy) {
+    return native_fwd(N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy) == NB_IGEMM;
+}
+int mi355seg_conv3d_fwd_fused_bf16(const mi355seg_bf16* x, int ldx, const float* w, const float* oscale, const float* oshift, int act, float slope,
+                                   mi355seg_bf16* y, int ldy, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                                   void* ws, size_t ws_bytes, void* stream) {
+    SEG_CHECK_ARG(x && w && y && oscale && oshift && N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ldx >= Cin && ldy >= Cout, "conv3d_fwd_fused_bf16: bad arguments");
+    SEG_CHECK_ARG(mi355seg_conv3d_fused_supported_bf16(N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy) && ((uintptr_t)x % 16) == 0,
+                  "conv3d_fwd_fused_bf16: no fused form for this shape / alignment (ask mi355seg_conv3d_fused_supported_bf16)");
+    return conv_fwd_mfma(MATH_B16, x, ldx, w, oshift, y, ldy, N, D, H, W, Cin, Cout, k, /*dgrad=*/0, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream, oscale, act, slope);
+}
+
 int mi355seg_conv3d_fwd_bf16(const mi355seg_bf16* x, int ldx, const float* w, const float* bias, mi355seg_bf16* y, int ldy,
                              int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad,
                              double* stats_sum, double* stats_sq, void* ws, size_t ws_bytes, void* stream) {

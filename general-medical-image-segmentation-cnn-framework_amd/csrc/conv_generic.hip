@@ -437,6 +437,28 @@ size_t mi355seg_conv3d_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, i
     return a > c ? a : c;
 }
 
+// ---- inference forward with eval-mode BatchNorm and the activation folded in (predict.py:79-81,133: model.eval() forward):
+// y = act(conv(x, w) * oscale[co] + oshift[co]); oscale goes into the packed weights, oshift takes the bias slot, the
+// activation runs in the MFMA kernel's epilogue -- no normalise pass.  Only the matrix-core layers have this form; the caller
+// asks first and keeps the two-pass form (convolution, then norm_act_fwd with the running statistics) for the rest.
+int mi355seg_conv3d_fused_supported_f32(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int ldy) {
+    const int pol = f32_conv_policy();
+    return (pol != MATH_F32 && conv_mfma_supported(pol, N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy)) ||
+           conv_mfma_supported(MATH_F32, N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy);
+}
+int mi355seg_conv3d_fwd_fused_f32(const float* x, int ldx, const float* w, const float* oscale, const float* oshift, int act, float slope,
+                                  float* y, int ldy, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                                  void* ws, size_t ws_bytes, void* stream) {
+    ConvGeom g{N, D, H, W, Cin, Cout, k, stride, pad, 0, 0, 0};
+    int rc = check_geom(&g, "conv3d_fwd_fused");
+    if (rc) return rc;
+    SEG_CHECK_ARG(x && w && y && oscale && oshift && ldx >= Cin && ldy >= Cout, "conv3d_fwd_fused: null pointer or pitch < channels");
+    SEG_CHECK_ARG(mi355seg_conv3d_fused_supported_f32(N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy), "conv3d_fwd_fused: no fused form for this shape (ask mi355seg_conv3d_fused_supported_f32)");
+    const int pol = f32_conv_policy();
+    const int math = (pol != MATH_F32 && conv_mfma_supported(pol, N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy)) ? pol : MATH_F32;
+    return conv_fwd_mfma(math, x, ldx, w, oshift, y, ldy, N, D, H, W, Cin, Cout, k, /*dgrad=*/0, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream, oscale, act, slope);
+}
+
 int mi355seg_conv3d_fwd_f32(const float* x, int ldx, const float* w, const float* bias,
                             float* y, int ldy, int N, int D, int H, int W, int Cin, int Cout,
                             int k, int stride, int pad, double* stats_sum, double* stats_sq,

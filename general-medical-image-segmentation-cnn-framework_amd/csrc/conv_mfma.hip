@@ -46,8 +46,10 @@ __device__ __forceinline__ float pack_src(const float* __restrict__ w, int mode,
     return w[((long long)co * Nn + n) * TW + taps.t[slot]];
 }
 
+// oscale (optional): per-output-channel factor folded into the packed weights -- eval-mode BatchNorm (gamma / sqrt(var + eps))
+// for the fused inference forward; n is the GEMM column = output channel in the modes that use it (0: conv forward)
 __global__ void pack_wq_kernel(const float* __restrict__ w, float* __restrict__ wq, int K, int Nn, int T, int NT, int mode, int aux, int CK,
-                               int TW, TapList taps) {
+                               int TW, TapList taps, const float* __restrict__ oscale) {
     const long long total = (long long)K * Nn * T;        // K = channels in the GEMM K dim (taps of mode 3 included)
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         long long r = idx;
@@ -58,13 +60,13 @@ __global__ void pack_wq_kernel(const float* __restrict__ w, float* __restrict__ 
         int tap = (int)(r % T); r /= T;
         int chunk = (int)(r % (K / CK)); r /= (K / CK);
         int nt = (int)r;
-        wq[idx] = pack_src(w, mode, nt * NT + j, chunk * CK + kk * 8 + h * 4 + s, tap, K, Nn, T, aux, TW, taps);
+        wq[idx] = pack_src(w, mode, nt * NT + j, chunk * CK + kk * 8 + h * 4 + s, tap, K, Nn, T, aux, TW, taps) * (oscale ? oscale[nt * NT + j] : 1.f);
     }
 }
 
 template <int NP>
 __global__ void pack_wq_lowp_kernel(const float* __restrict__ w, bf16* __restrict__ wq, int K, int Nn, int T, int NT, int mode, int aux, int CK,
-                                    int TW, TapList taps) {
+                                    int TW, TapList taps, const float* __restrict__ oscale) {
     const long long total = (long long)K * Nn * T;
     const int plane = 2 * NT * 8;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -76,7 +78,7 @@ __global__ void pack_wq_lowp_kernel(const float* __restrict__ w, bf16* __restric
         const int tap = (int)(r % T); r /= T;
         const int chunk = (int)(r % (K / CK)); r /= (K / CK);
         const int nt = (int)r;
-        const float v = pack_src(w, mode, nt * NT + j, chunk * CK + kst * 16 + 8 * h + e, tap, K, Nn, T, aux, TW, taps);
+        const float v = pack_src(w, mode, nt * NT + j, chunk * CK + kst * 16 + 8 * h + e, tap, K, Nn, T, aux, TW, taps) * (oscale ? oscale[nt * NT + j] : 1.f);
         const long long base = ((((long long)nt * (K / CK) + chunk) * T + tap) * (CK / 16) + kst) * (NP * plane) + ((long long)h * NT + j) * 8 + e;
         if (NP == 3) {
             bf16 bh, bm, bl;
@@ -90,7 +92,7 @@ __global__ void pack_wq_lowp_kernel(const float* __restrict__ w, bf16* __restric
 
 // conv_x3s.hip layout: wq[nt][chunk][unit = (K-step s, 32-channel half nh)][plane][16-channel tile t2][lane][8]; lane = (c, g):
 // element e = plane of W[co = nt*NT + nh*32 + t2*16 + c][ci = chunk*16 + 8*(g&1) + e][tap = x3s_pair_tap(s, g>>1)]  (tap 27: zero)
-__global__ void pack_wq_x3s_kernel(const float* __restrict__ w, bf16* __restrict__ wq, int K, int Nn, int NBW, int mode) {
+__global__ void pack_wq_x3s_kernel(const float* __restrict__ w, bf16* __restrict__ wq, int K, int Nn, int NBW, int mode, const float* __restrict__ oscale) {
     const int NT = 32 * NBW, NU = X3S_NPAIR * NBW, nch = K / 16;
     const long long total = (long long)(Nn / NT) * nch * NU * 1024;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -103,7 +105,8 @@ __global__ void pack_wq_x3s_kernel(const float* __restrict__ w, bf16* __restrict
         const int nt = (int)q;
         const int s = u / NBW, nh = u % NBW, g = lane >> 4, c = lane & 15;
         const int tap = x3s_pair_tap(s, g >> 1);
-        const float v = tap < 27 ? pack_src(w, mode, nt * NT + nh * 32 + t2 * 16 + c, chunk * 16 + 8 * (g & 1) + e, tap, K, Nn, 27, 0, 27, TapList{}) : 0.f;
+        const int co = nt * NT + nh * 32 + t2 * 16 + c;
+        const float v = tap < 27 ? pack_src(w, mode, co, chunk * 16 + 8 * (g & 1) + e, tap, K, Nn, 27, 0, 27, TapList{}) * (oscale ? oscale[co] : 1.f) : 0.f;
         bf16 bh, bm, bl;
         split3(v, bh, bm, bl);
         const long long base = (((long long)nt * nch + chunk) * NU + u) * 3072 + t2 * 512 + lane * 8 + e;
@@ -113,7 +116,7 @@ __global__ void pack_wq_x3s_kernel(const float* __restrict__ w, bf16* __restrict
 
 // conv_b16s.hip layout: wq[nt][chunk][K-step s][16-channel tile tt][lane][8]; lane = (c, g), c = 4 g' + e':
 // element e = bf16 of W[co = nt*NT + 32 (tt / 2) + 8 g' + 4 (tt % 2) + e'][ci = chunk*16 + 8 (g & 1) + e][tap = 2 s + (g >> 1)]  (tap >= T: zero)
-__global__ void pack_wq_b16s_kernel(const float* __restrict__ w, bf16* __restrict__ wq, int K, int Nn, int T, int NT, int mode) {
+__global__ void pack_wq_b16s_kernel(const float* __restrict__ w, bf16* __restrict__ wq, int K, int Nn, int T, int NT, int mode, const float* __restrict__ oscale) {
     const int nstep = (T + 1) / 2, nch = K / 16, ntt = NT / 16;
     const long long total = (long long)(Nn / NT) * nch * nstep * ntt * 512;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -127,7 +130,7 @@ __global__ void pack_wq_b16s_kernel(const float* __restrict__ w, bf16* __restric
         const int g = lane >> 4, c = lane & 15;
         const int tap = 2 * s + (g >> 1);
         const int co = nt * NT + 32 * (tt >> 1) + 8 * (c >> 2) + 4 * (tt & 1) + (c & 3);
-        wq[idx] = tap < T ? (bf16)pack_src(w, mode, co, chunk * 16 + 8 * (g & 1) + e, tap, K, Nn, T, 0, T, TapList{}) : (bf16)0.f;
+        wq[idx] = tap < T ? (bf16)(pack_src(w, mode, co, chunk * 16 + 8 * (g & 1) + e, tap, K, Nn, T, 0, T, TapList{}) * (oscale ? oscale[co] : 1.f)) : (bf16)0.f;
     }
 }
 
@@ -136,17 +139,17 @@ static int pack_grid(long long total) { return (int)((total + 255) / 256 > 2048 
 // MATH_B16 likewise for conv_b16s.hip (taps paired: one zero tap when the tap count is odd)
 static size_t wq_bytes(int math, size_t nelem) { return math == MATH_F32 ? nelem * 4 : (math == MATH_X3 ? (nelem + nelem / 27 + 64) * 6 : (nelem + nelem / 27 + 64) * 2); }
 static void launch_pack(int math, const float* w, void* wq, int K, int Nn, int T, int NT, int mode, int aux, int CK, int TW, const TapList& taps,
-                        hipStream_t st) {
+                        hipStream_t st, const float* oscale = nullptr) {
     const int grid = pack_grid((long long)K * Nn * T);
-    if (math == MATH_F32) hipLaunchKernelGGL(pack_wq_kernel, dim3(grid), dim3(256), 0, st, w, (float*)wq, K, Nn, T, NT, mode, aux, CK, TW, taps);
-    else if (math == MATH_X3) hipLaunchKernelGGL(pack_wq_lowp_kernel<3>, dim3(grid), dim3(256), 0, st, w, (bf16*)wq, K, Nn, T, NT, mode, aux, CK, TW, taps);
-    else hipLaunchKernelGGL(pack_wq_lowp_kernel<1>, dim3(grid), dim3(256), 0, st, w, (bf16*)wq, K, Nn, T, NT, mode, aux, CK, TW, taps);
+    if (math == MATH_F32) hipLaunchKernelGGL(pack_wq_kernel, dim3(grid), dim3(256), 0, st, w, (float*)wq, K, Nn, T, NT, mode, aux, CK, TW, taps, oscale);
+    else if (math == MATH_X3) hipLaunchKernelGGL(pack_wq_lowp_kernel<3>, dim3(grid), dim3(256), 0, st, w, (bf16*)wq, K, Nn, T, NT, mode, aux, CK, TW, taps, oscale);
+    else hipLaunchKernelGGL(pack_wq_lowp_kernel<1>, dim3(grid), dim3(256), 0, st, w, (bf16*)wq, K, Nn, T, NT, mode, aux, CK, TW, taps, oscale);
 }
 
 // y[r][c] = bias[c] + sum_k part[k][r][c]   (split-K second stage; fixed order)
 template <typename OT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int ksplit, long long stride,
-        const float* __restrict__ bias, OT* __restrict__ y, int ldy, long long rows, int C) {
+        const float* __restrict__ bias, OT* __restrict__ y, int ldy, long long rows, int C, int act, float slope) {
     const int cw = C / 4;
     const long long total = rows * cw;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -155,6 +158,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         if (bias) s = *reinterpret_cast<const f32x4*>(bias + c);
         for (int k = 0; k < ksplit; ++k) s += *reinterpret_cast<const f32x4*>(part + k * stride + r * C + c);
+        if (act) { s[0] = act_apply(s[0], act, slope); s[1] = act_apply(s[1], act, slope); s[2] = act_apply(s[2], act, slope); s[3] = act_apply(s[3], act, slope); }
         st4(y + r * ldy + c, s);
     }
 }
@@ -365,8 +369,11 @@ static size_t esize(int math) { return math == MATH_B16 ? 2 : 4; }
 static double matrix_bytes(int math, double act_elems, double w_elems) { return esize(math) * act_elems + 4.0 * w_elems; }
 
 // k in {1, 3, 5}, pad = k/2, stride 1.  x / y are fp32 (MATH_F32, MATH_X3) or bf16 (MATH_B16) NDHWC tensors.
+// oscale / act / slope (inference): y = act(conv(x, w * oscale[co]) + bias[co]) -- eval-mode BatchNorm folded into the packed weights
+// and the bias vector, the activation applied in the epilogue (or in the split-K reduce), no normalise pass
 int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int N, int D, int H, int W,
-                  int Cin, int Cout, int k, int dgrad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st) {
+                  int Cin, int Cout, int k, int dgrad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st,
+                  const float* oscale, int act, float slope) {
     IgemmPlan p;
     SEG_CHECK_ARG(igemm_plan(math, k, N, D, H, W, Cin, Cout, 1, &p), "conv_fwd_mfma: unsupported shape");
     SEG_CHECK_ARG(((uintptr_t)x % 16) == 0, "conv_fwd_mfma: input pointer must be 16-byte aligned");
@@ -386,13 +393,14 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
     SEG_CHECK_WS(tail + ((ssum && ksplit > 1) ? colsum_ws_bytes(Cout) : 0), ws_bytes);
     // fp32 tensors, bf16x6, 16-wide tiles: the 16x16x32-MFMA kernel (conv_x3s.hip) with its own weight packing
     const bool x3s = math == MATH_X3 && x3s_enabled() && x3s_plan_ok(p, x, ldx, ksplit > 1 ? (void*)slabs : y, ksplit > 1 ? Cout : ldy, (long long)D * H * W);
-    if (b16s) hipLaunchKernelGGL(pack_wq_b16s_kernel, dim3(pack_grid((long long)(T + 1) * Cin * Cout)), dim3(256), 0, st, w, (bf16*)wq, Cin, Cout, T, bp.NT, dgrad ? 1 : 0);
-    else if (x3s) hipLaunchKernelGGL(pack_wq_x3s_kernel, dim3(pack_grid((long long)28 * Cin * Cout)), dim3(256), 0, st, w, (bf16*)wq, Cin, Cout, p.NBW, dgrad ? 1 : 0);
-    else launch_pack(math, w, wq, Cin, Cout, T, p.NT, dgrad ? 1 : 0, 0, p.CK, T, TapList{}, st);
+    if (b16s) hipLaunchKernelGGL(pack_wq_b16s_kernel, dim3(pack_grid((long long)(T + 1) * Cin * Cout)), dim3(256), 0, st, w, (bf16*)wq, Cin, Cout, T, bp.NT, dgrad ? 1 : 0, oscale);
+    else if (x3s) hipLaunchKernelGGL(pack_wq_x3s_kernel, dim3(pack_grid((long long)28 * Cin * Cout)), dim3(256), 0, st, w, (bf16*)wq, Cin, Cout, p.NBW, dgrad ? 1 : 0, oscale);
+    else launch_pack(math, w, wq, Cin, Cout, T, p.NT, dgrad ? 1 : 0, 0, p.CK, T, TapList{}, st, oscale);
     SEG_CHECK_LAUNCH();
     IgemmArgs a{x, wq, ksplit > 1 ? nullptr : bias, ksplit > 1 ? (void*)slabs : y, spart, ldx, ksplit > 1 ? Cout : ldy, N, D, H, W, Cout,
                 p.ntx, p.nty, p.ntz, p.nN, nchunks, nchunks, p.nN, 1, 1, p.nM, ksplit, nchunks / ksplit, nvox * Cout, dbg_flags()};
     a.Di = a.Do = D; a.Hi = a.Ho = H; a.Wi = a.Wo = W;
+    a.act = ksplit > 1 ? 0 : act; a.slope = slope;
     const int nwg = p.nM * p.nN * ksplit;
     const double vox = (double)nvox;
     {
@@ -403,8 +411,8 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
         if (ksplit > 1) {
             long long tot = nvox * (Cout / 4);
             int grid = (int)((tot + 255) / 256 > 2048 ? 2048 : (tot + 255) / 256);
-            if (math == MATH_B16) hipLaunchKernelGGL(splitk_reduce_kernel<bf16>, dim3(grid), dim3(256), 0, st, slabs, ksplit, nvox * Cout, bias, (bf16*)y, ldy, nvox, Cout);
-            else hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(grid), dim3(256), 0, st, slabs, ksplit, nvox * Cout, bias, (float*)y, ldy, nvox, Cout);
+            if (math == MATH_B16) hipLaunchKernelGGL(splitk_reduce_kernel<bf16>, dim3(grid), dim3(256), 0, st, slabs, ksplit, nvox * Cout, bias, (bf16*)y, ldy, nvox, Cout, act, slope);
+            else hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(grid), dim3(256), 0, st, slabs, ksplit, nvox * Cout, bias, (float*)y, ldy, nvox, Cout, act, slope);
             SEG_CHECK_LAUNCH();
         }
     }
@@ -536,8 +544,8 @@ int conv_gather_fwd_mfma(int math, const void* x, int ldx, const float* w, const
         if (ksplit > 1) {
             const long long tot = nvo * (Cout / 4);
             const int grid = (int)((tot + 255) / 256 > 2048 ? 2048 : (tot + 255) / 256);
-            if (math == MATH_B16) hipLaunchKernelGGL(splitk_reduce_kernel<bf16>, dim3(grid), dim3(256), 0, st, slabs, ksplit, nvo * Cout, bias, (bf16*)y, ldy, nvo, Cout);
-            else hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(grid), dim3(256), 0, st, slabs, ksplit, nvo * Cout, bias, (float*)y, ldy, nvo, Cout);
+            if (math == MATH_B16) hipLaunchKernelGGL(splitk_reduce_kernel<bf16>, dim3(grid), dim3(256), 0, st, slabs, ksplit, nvo * Cout, bias, (bf16*)y, ldy, nvo, Cout, 0, 0.f);
+            else hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(grid), dim3(256), 0, st, slabs, ksplit, nvo * Cout, bias, (float*)y, ldy, nvo, Cout, 0, 0.f);
             SEG_CHECK_LAUNCH();
         }
     }

@@ -245,7 +245,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
         float* dst = yslab + ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.ldy + n0 + 4 * g;
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
-            const f32x4 v = acc[j][t] + bv[t];
+            f32x4 v = acc[j][t] + bv[t];
+            if (a.act) { v[0] = act_apply(v[0], a.act, a.slope); v[1] = act_apply(v[1], a.act, a.slope); v[2] = act_apply(v[2], a.act, a.slope); v[3] = act_apply(v[3], a.act, a.slope); }
             if (inside) {
                 *reinterpret_cast<f32x4*>(dst + 16 * t) = v;
 #pragma unroll

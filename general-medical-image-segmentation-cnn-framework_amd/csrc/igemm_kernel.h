@@ -107,6 +107,7 @@ struct IgemmArgs {
     int by, bz;         // (y, z) tile-block shape of the M-tile walk (divisors of nty, ntz)
     int total;          // virtual tiles = nM * nN * ksplit (the persistent variants walk them with a smaller grid); set by dispatch
     signed char toff[64][4];   // per K-tap input offset (z, y, x); all zero for the stride-1 halo modes
+    int act; float slope;      // activation applied after the bias in the epilogue (0 = none): the fused inference forward
 };
 
 struct TapList { unsigned char t[64]; };
@@ -531,7 +532,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
                 const int gz = (z0 + line / T::TY) * out_mul + oz;
                 const int gy = (y0 + line % T::TY) * out_mul + oy;
                 const int gx = (x0 + xx) * out_mul + ox;
-                const float val = acc[mb][nb][v] + bv;
+                float val = acc[mb][nb][v] + bv;
+                if (a.act) val = act_apply(val, a.act, a.slope);
                 // partial tiles (extents that are not tile multiples): rows outside the volume are dropped
                 const bool inside = (z0 + line / T::TY) < a.D && (y0 + line % T::TY) < a.H && (x0 + xx) < a.W &&
                                     gz < Do && gy < Ho && gx < Wo;

@@ -650,6 +650,25 @@ int mi355seg_norm_stats_from_sums_f32(const double* sum, const double* sq, long 
     return MI355SEG_OK;
 }
 
+// eval-mode BatchNorm as a per-channel affine map of the convolution's raw output: scale = gamma / sqrt(var + eps),
+// shift = beta + (conv_bias - mean) * scale
+__global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                               const float* __restrict__ var, const float* __restrict__ cbias, float eps, int C,
+                               float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = (gamma ? gamma[c] : 1.f) * (float)(1.0 / sqrt((double)var[c] + (double)eps));     // the rstd of rstd_from_var_kernel
+    scale[c] = sc;
+    shift[c] = (beta ? beta[c] : 0.f) + ((cbias ? cbias[c] : 0.f) - mean[c]) * sc;
+}
+int mi355seg_bn_fold_f32(const float* gamma, const float* beta, const float* mean, const float* var, const float* conv_bias,
+                         float eps, int C, float* scale, float* shift, void* stream) {
+    SEG_CHECK_ARG(mean && var && scale && shift && C > 0, "bn_fold: bad arguments");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta, mean, var, conv_bias, eps, C, scale, shift);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
 int mi355seg_rstd_from_var_f32(const float* var, float eps, float* rstd, int C, void* stream) {
     SEG_CHECK_ARG(var && rstd && C > 0, "rstd_from_var: bad arguments");
     hipLaunchKernelGGL(rstd_from_var_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, var, eps, rstd, C);

@@ -463,7 +463,7 @@ class _ConvBnAct(Function):
     pass (no separate pass over dy).  Training mode only updates running stats exactly as nn.BatchNorm3d."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, rmean, rvar, stride, pad, training, momentum, eps, act, slope, left_pad):
+    def forward(ctx, x, w, b, gamma, beta, rmean, rvar, stride, pad, training, momentum, eps, act, slope, left_pad, inference=False):
         x, ldx = cl_view(x, "conv3d input")
         N, D, H, W, Cin = x.shape
         Cout, k = w.shape[0], w.shape[2]
@@ -472,11 +472,13 @@ class _ConvBnAct(Function):
         w = w.contiguous()
         Do, Ho, Wo = [(e + 2 * pad - k) // stride + 1 for e in (D, H, W)]
         dev = x.device
-        y = torch.empty((N, Do, Ho, Wo, Cout), dtype=x.dtype, device=dev)
         L = lib()
         ws = workspace(max(_conv_ws(L, x, N, D, H, W, Cin, Cout, k, stride, pad),
                            L.query("mi355seg_norm_ws_bytes", N * Do * Ho * Wo, 1, Cout)), dev)
         rows = N * Do * Ho * Wo
+        fused = (not training) and inference and x.data_ptr() % 16 == 0 and \
+            L.query("mi355seg_conv3d_fused_supported_" + _sfx(x), N, D, H, W, Cin, Cout, k, stride, pad, ldx, left_pad + Cout)
+        y = None if fused else torch.empty((N, Do, Ho, Wo, Cout), dtype=x.dtype, device=dev)
         if training:
             sums = torch.empty(2 * Cout, dtype=torch.float64, device=dev)
             L.call("mi355seg_conv3d_fwd_" + _sfx(x), _p(x), ldx, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
@@ -485,6 +487,16 @@ class _ConvBnAct(Function):
             rstd = torch.empty(Cout, dtype=torch.float32, device=dev)
             L.call("mi355seg_norm_stats_from_sums_f32", sums.data_ptr(), sums.data_ptr() + 8 * Cout, rows, Cout, eps,
                    _p(mean), _p(rstd), _p(rmean), _p(rvar), momentum, _stream())
+        elif fused:
+            # inference (model.eval() under no_grad, predict.py:79-81,133): eval-mode BatchNorm folded into the packed weights and
+            # the bias slot, the activation in the convolution's epilogue -- one pass, nothing saved for a backward
+            fold = torch.empty(2 * Cout, dtype=torch.float32, device=dev)
+            L.call("mi355seg_bn_fold_f32", _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(b), eps, Cout, fold.data_ptr(), fold.data_ptr() + 4 * Cout, _stream())
+            full = torch.empty((N, Do, Ho, Wo, left_pad + Cout), dtype=x.dtype, device=dev)
+            a = full[..., left_pad:] if left_pad else full
+            L.call("mi355seg_conv3d_fwd_fused_" + _sfx(x), _p(x), ldx, _p(w), fold.data_ptr(), fold.data_ptr() + 4 * Cout, act, slope,
+                   a.data_ptr(), left_pad + Cout, N, D, H, W, Cin, Cout, k, stride, pad, _p(ws), ws.numel(), _stream())
+            return a
         else:
             L.call("mi355seg_conv3d_fwd_" + _sfx(x), _p(x), ldx, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
                    None, None, _p(ws), ws.numel(), _stream())
@@ -530,7 +542,7 @@ class _ConvBnAct(Function):
             dw = torch.empty_like(w)
             L.call("mi355seg_conv3d_wgrad_" + _sfx(x), _p(dy), Cout, _p(x), ldx, _p(dw), None, N, D, H, W, Cin, Cout, k, stride, pad,
                    0, _p(ws), ws.numel(), _stream())
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
 
 
 def conv_bn_act(x, conv, bn, act=ACT_NONE, slope=0.01, left_pad=0):
@@ -541,8 +553,10 @@ def conv_bn_act(x, conv, bn, act=ACT_NONE, slope=0.01, left_pad=0):
     pad = conv.padding[0] if isinstance(conv.padding, (tuple, list)) else conv.padding
     if bn.training:
         bn.num_batches_tracked.add_(1)
+    # eval mode under torch.no_grad() (predict.py:79-81,133) takes the folded one-pass form where the layer has one
     return _ConvBnAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, int(stride), int(pad),
-                            bool(bn.training), float(bn.momentum), float(bn.eps), int(act), float(slope), int(left_pad))
+                            bool(bn.training), float(bn.momentum), float(bn.eps), int(act), float(slope), int(left_pad),
+                            not torch.is_grad_enabled())
 
 
 class _Act(Function):

@@ -49,21 +49,53 @@ def crop_window(loc, patch, size, overlap):
     return tuple(src), tuple(dst)
 
 
+def window_table(size, patch, overlap):
+    """int32 [P, 9] rows (origin z, y, x, crop lo z, y, x, crop hi z, y, x -- the crop window in PATCH coordinates, hi exclusive) for
+    the device-side gather / paste kernels, patches in torchio's order.  torchio's aggregator adds the cropped patches one after the
+    other, so where two crop windows overlap (only the border-flush last patch of an axis overlaps its predecessor by more than
+    ``overlap``) the LATER patch wins; the table clips every window at the start of its successor's window instead, which gives
+    the same volume with disjoint windows -- the paste is then one launch with no ordering between patches."""
+    axes = []
+    for s, p, o in zip(size, patch, overlap):
+        if p > s:
+            raise ValueError(f"patch size {p} larger than the volume extent {s}")
+        if o >= p or o % 2:
+            raise ValueError(f"patch overlap {o} must be even and smaller than the patch size {p}")
+        idx = list(range(0, s + 1 - p, p - o))
+        if idx[-1] != s - p:
+            idx.append(s - p)
+        lo = [l + (o // 2 if l != 0 else 0) for l in idx]
+        hi = [l + p - (o // 2 if l + p != s else 0) for l in idx]
+        for i in range(len(idx) - 1):
+            hi[i] = min(hi[i], lo[i + 1])
+        axes.append([(l, a - l, b - l) for l, a, b in zip(idx, lo, hi)])
+    rows = [(z[0], y[0], x[0], z[1], y[1], x[1], z[2], y[2], x[2]) for z in axes[0] for y in axes[1] for x in axes[2]]
+    return np.asarray(rows, dtype=np.int32)
+
+
 @torch.no_grad()
 def sliding_window_predict(model, volume, patch_size, overlap=(4, 4, 36), batch_size=1, dtype=None):
     """volume: float tensor [C, D, H, W] on the GPU -> int64 label volume [1, D, H, W] (argmax over classes).
-    ``dtype`` = torch.bfloat16 runs the forward under mi355seg.autocast (``config.mixed_precision=bf16``)."""
+    ``dtype`` = torch.bfloat16 runs the forward under mi355seg.autocast (``config.mixed_precision=bf16``).
+    Device-resident: the window table is uploaded once, each batch is one gather launch (mi355seg_gather_patches_f32), the
+    eval-mode forward (BatchNorm folded into the convolutions), the channel argmax and one paste launch
+    (mi355seg_paste_labels_i64); no host loop over patches, no host copies."""
+    from ._lib import lib
     C, D, H, W = volume.shape
     ps = (patch_size,) * 3 if isinstance(patch_size, int) else tuple(patch_size)
-    size = (D, H, W)
-    locs = grid_locations(size, ps, overlap)
-    out = torch.zeros((1, D, H, W), dtype=torch.int64, device=volume.device)
+    table_h = window_table((D, H, W), ps, overlap)
+    P = table_h.shape[0]
+    dev = volume.device
+    table = torch.from_numpy(table_h).to(dev)
+    volume = volume.contiguous().to(torch.float32)
+    out = torch.zeros((1, D, H, W), dtype=torch.int64, device=dev)
+    L, st = lib(), torch.cuda.current_stream().cuda_stream
     was_training = model.training
     model.eval()
-    for i in range(0, len(locs), batch_size):
-        chunk = locs[i:i + batch_size]
-        x = torch.stack([volume[:, z:z + ps[0], y:y + ps[1], w:w + ps[2]] for (z, y, w) in chunk])
-        x = x.contiguous()
+    for i in range(0, P, batch_size):
+        nb = min(batch_size, P - i)
+        x = torch.empty((nb, C) + ps, dtype=torch.float32, device=dev)
+        L.call("mi355seg_gather_patches_f32", volume.data_ptr(), C, D, H, W, table.data_ptr(), i, nb, ps[0], ps[1], ps[2], x.data_ptr(), st)
         with F.autocast(dtype or F.compute_dtype()):
             if getattr(model, "takes_frequency_bands", False):           # predict.py:128-131 (IS: first output only)
                 from .models.three_d.IS import frequency_bands
@@ -71,9 +103,7 @@ def sliding_window_predict(model, volume, patch_size, overlap=(4, 4, 36), batch_
             else:
                 logits = model(x)
         labels = F.argmax_channels(logits)                               # predict.py:133,139
-        for j, loc in enumerate(chunk):
-            src, dst = crop_window(loc, ps, size, overlap)
-            out[(0,) + dst] = labels[j, 0][src]
+        L.call("mi355seg_paste_labels_i64", labels.data_ptr(), table.data_ptr(), i, nb, ps[0], ps[1], ps[2], out.data_ptr(), D, H, W, st)
     model.train(was_training)
     return out
 

@@ -94,6 +94,22 @@ int mi355seg_conv3d_fwd_f32(const float* x, int ldx, const float* w, const float
                             int k, int stride, int pad, double* stats_sum, double* stats_sq,
                             void* ws, size_t ws_bytes, void* stream);
 
+/* Inference forward (predict.py:79-81,133: model.eval()): eval-mode BatchNorm and the activation that follows it folded into the
+ * convolution -- y = act(conv(x, w) * oscale[co] + oshift[co]).  oscale is multiplied into the packed weights, oshift takes the
+ * bias slot and the activation runs in the MFMA kernel's epilogue: no normalise pass over y.  mi355seg_bn_fold_f32 builds the two
+ * vectors from the BatchNorm parameters, running statistics and the convolution's bias.  Matrix-core layers only: ask
+ * *_fused_supported_* first (non-zero = yes) and keep convolution + norm_act_fwd for the other layers. */
+int mi355seg_bn_fold_f32(const float* gamma, const float* beta, const float* mean, const float* var, const float* conv_bias,
+                         float eps, int C, float* scale, float* shift, void* stream);
+int mi355seg_conv3d_fused_supported_f32(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int ldy);
+int mi355seg_conv3d_fwd_fused_f32(const float* x, int ldx, const float* w, const float* oscale, const float* oshift, int act, float slope,
+                                  float* y, int ldy, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                                  void* ws, size_t ws_bytes, void* stream);
+int mi355seg_conv3d_fused_supported_bf16(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int ldy);
+int mi355seg_conv3d_fwd_fused_bf16(const mi355seg_bf16* x, int ldx, const float* w, const float* oscale, const float* oshift, int act, float slope,
+                                   mi355seg_bf16* y, int ldy, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                                   void* ws, size_t ws_bytes, void* stream);
+
 /* dx = conv_backward_input(dy, w).  D,H,W are the INPUT extents (of x/dx). */
 int mi355seg_conv3d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
                               int N, int D, int H, int W, int Cin, int Cout,
@@ -312,6 +328,17 @@ int mi355seg_prof_read(double* out_host, int n_doubles);
 /* per-launch records: writes up to max_records rows of 4 doubles (family, ms, flops, bytes); returns the
  * number of rows through *n_host (call after prof_read, which synchronises). */
 int mi355seg_prof_records(double* out_host, int max_records, int* n_host);
+
+/* ------------------------------------------------------------------ Sliding-window inference (predict.py:98-147)
+ * tio.inference.GridSampler patches of one volume [C,D,H,W] as a device-resident batch [count,C,pd,ph,pw], and
+ * tio.inference.GridAggregator(overlap_mode='crop') of their int64 label maps [count,pd,ph,pw] into the output volume [D,H,W]: one
+ * launch each.  table = int32 [P][9] on the device: patch origin z,y,x, then the crop window inside the patch, lo z,y,x and
+ * hi z,y,x (exclusive); the launch handles patches first .. first+count-1.  (Overlapping crop windows are disjoint by
+ * construction, so the paste needs no ordering.) */
+int mi355seg_gather_patches_f32(const float* vol, int C, int D, int H, int W, const int* table, int first, int count,
+                                int pd, int ph, int pw, float* out, void* stream);
+int mi355seg_paste_labels_i64(const int64_t* labels, const int* table, int first, int count, int pd, int ph, int pw,
+                              int64_t* out, int D, int H, int W, void* stream);
 
 /* ------------------------------------------------------------------ Layout helpers */
 int mi355seg_ncdhw_to_ndhwc_f32(const float* src, float* dst, int lddst, long long N, int C, long long S, void* stream);

@@ -173,6 +173,51 @@ def test_predict_cli_sliding_window(seg, tmp_path):
     assert torch.equal(sliding_window_predict(m, vol, (32, 32, 32), (4, 4, 4), dtype=torch.bfloat16), bb)
 
 
+def test_inference_path_against_the_oracle_eval_forward(seg, golden_dir):
+    """predict.py:79-81,98-147 as a kernel path.  (1) model.eval() under no_grad runs the FOLDED form (eval-mode BatchNorm inside the
+    packed weights and the bias slot, activation in the conv epilogue): logits against the pinned oracle's eval forward (itself
+    bit-identical to the reference, tests/test_oracle_vs_reference.py) and the reference fixture's eval logits at 1e-4, and against
+    the two-pass form (conv, then norm_act with running statistics), under both conv maths (module fixture) and in bf16 within
+    the bf16 rounding of the two-pass bf16 result.  (2) The device-resident sliding window (gather launch, folded forward, argmax,
+    paste launch) against torchio-order aggregation done on the host FROM THE ORACLE'S logits of every patch: identical labels
+    wherever the oracle's logit margin is decisive.  (The grid itself is restated from torchio, which is absent: that part stays
+    unpinned, see DESIGN.)"""
+    from mi355seg.models.three_d.unet3d import UNet3D
+    from mi355seg.predict import crop_window, grid_locations, sliding_window_predict
+    from oracle.nets import UNet3D as OracleUNet
+    o = fill_module_(OracleUNet(1, 2, 8)).eval()
+    m = fill_module_(UNet3D(1, 2, 8)).cuda().eval()
+    x = make_input((2, 1, 32, 32, 32))
+    with torch.no_grad():
+        want = o(x)
+        got = m(x.cuda())                                   # folded one-pass form
+    with torch.enable_grad():
+        two_pass = m(x.cuda()).detach()                     # grad mode on: the conv + norm_act form (eval statistics)
+    assert (got.cpu() - want).abs().max() < TOL and (two_pass.cpu() - want).abs().max() < TOL
+    assert (got - two_pass).abs().max() < 2e-5
+    with torch.no_grad(), seg.autocast(torch.bfloat16):
+        g16 = m(x.cuda())
+    with torch.enable_grad(), seg.autocast(torch.bfloat16):
+        t16 = m(x.cuda()).detach()
+    assert (g16 - t16).abs().max() <= 0.05 * float(want.abs().max()) and (g16.cpu() - want).abs().max() <= 0.08 * float(want.abs().max())
+    # sliding window over a volume of several patches per axis, ragged last patch, batches of 3
+    size, ps, ov = (40, 48, 72), (32, 32, 32), (4, 4, 12)
+    vol = make_input((1,) + size, freq=0.017)
+    labels = sliding_window_predict(m, vol.cuda(), ps, ov, batch_size=3).cpu()
+    ref = torch.full((1,) + size, -1, dtype=torch.int64)
+    margin = torch.full((1,) + size, 0.0)
+    with torch.no_grad():
+        for loc in grid_locations(size, ps, ov):
+            z, y, w = loc
+            lg = o(vol[None, :, z:z + 32, y:y + 32, w:w + 32])[0]
+            src, dst = crop_window(loc, ps, size, ov)
+            ref[(0,) + dst] = lg.argmax(0)[src]
+            margin[(0,) + dst] = (lg[0] - lg[1]).abs()[src]
+    assert int((ref < 0).sum()) == 0
+    decisive = margin > 2 * TOL
+    assert float(decisive.float().mean()) > 0.95 and torch.equal(labels[decisive], ref[decisive])
+
+
 def test_hip_graph_train_step_matches_eager(seg):
     """The captured-and-replayed step (engine.GraphedTrainStep) is the same arithmetic as the eager one: identical
     loss, Dice counters and parameters after the same number of optimiser steps."""
