@@ -543,7 +543,8 @@ def main():
             elif rec is not None:
                 note = f"PMC passes were taken with conv math {rec.get('conv_math', 'fp32')}, this run uses {args.conv_math}"
             kern = {"fp32": "conv_igemm_kernel<MATH_F32> (Conv3d k3 fwd+dgrad, v_mfma_f32_32x32x2_f32)",
-                    "bf16x6": "conv_igemm_kernel<MATH_X3> (Conv3d k3 fwd+dgrad, six v_mfma_f32_32x32x16_bf16 per fp32 product)"}[args.conv_math]
+                    "bf16x6": "conv_x3s_kernel (Conv3d k3 fwd+dgrad on fp32 tensors, six v_mfma_f32_16x16x32_bf16 per fp32 product; the W = 8 "
+                              "bottleneck layers on conv_igemm_kernel<MATH_X3>, 32x32x16)"}[args.conv_math]
             res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                                "frac": ach / peak, "traffic": traffic, "traffic_source": note,
                                "kernel": kern, "launches": int(n), "avg_launch_ms": tms / n,

@@ -121,6 +121,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
         for (int it = 0; it < G::NITER; ++it)
             stage[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[it], 0, 0));
     };
+    // one piece of the NEXT chunk's halo (the main loop requests one per scheduling region: a burst of all of them in front
+    // of the loop would sit in front of every weight fragment requested after it -- vmcnt retires in order)
+    auto load_piece = [&](int chunk, int it) {
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xsample + chunk * 16), 0, sample_bytes, 0x00020000);
+        stage[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[it], 0, 0));
+    };
     // x = h + m + l for a pair of values: three packed conversions, the remainders formed from the packed words
     auto split_pair = [](float x0_, float x1_, unsigned& h2, unsigned& m2, unsigned& l2) {
         using f32x2 = __attribute__((ext_vector_type(2))) float;
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
         __syncthreads();                                         // every wave is done reading the previous chunk
         write_stage();
         __syncthreads();
-        if (chunk + 1 < c1) load_stage(chunk + 1);
+        const bool more = chunk + 1 < c1;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) xf[0][pl] = *reinterpret_cast<const bf16x8_t*>(lds_raw + xaddr(0, 0, pl));
         __builtin_amdgcn_sched_barrier(0);
@@ -194,6 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
             for (int j = 0; j < LW; ++j) {
                 const int q = u * LW + j, cur = q & 1, nxt = cur ^ 1;
                 if (j == 0 && u + WD < NU) load_w(u + WD);
+                if (q < G::NITER && more) load_piece(chunk + 1, q);
                 if (q + 1 < NU * LW) {
                     const int u2 = (q + 1) / LW, j2 = (q + 1) % LW;
 #pragma unroll
@@ -212,9 +219,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 }
-                if (j == 0) {
+                if (j == 0 || q < G::NITER) {
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) {
+                    for (int k = 0; k < 7; ++k) {
                         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     }

@@ -1,4 +1,3 @@
-set -e
-mkdir -p gpurun_out/r3w
-timeout -k 10 600 python -m pytest tests/test_custom_ops.py -m gpu -x -q > gpurun_out/r3w/pytest.log 2>&1 || (tail -60 gpurun_out/r3w/pytest.log; exit 1)
-tail -2 gpurun_out/r3w/pytest.log
+mkdir -p gpurun_out/r3y
+python tools/_ab.py general-medical-image-segmentation-cnn-framework_amd/libmi355seg_old.so --what wgrad -- "2 128 128 128 32 32 3" "2 128 128 128 64 32 3" "2 64 64 64 64 64 3" "2 32 32 32 128 128 3" 2>&1 | tee gpurun_out/r3y/ab.log
+python tools/_ab.py general-medical-image-segmentation-cnn-framework_amd/libmi355seg_old.so --what wgrad --dtype bf16 -- "1 160 192 160 64 64 3" "2 128 128 128 32 32 5" "1 160 192 160 32 64 3 30 2 1" 2>&1 | tee -a gpurun_out/r3y/ab.log
