@@ -168,7 +168,7 @@ def run_leg(L, dev, name, net, shape, classes, loss_kind, flop_per_vox, steps, w
     n, tms, fl, by = buf[0], buf[1], buf[2], buf[3]
     if n > 0 and tms > 0:
         ach = fl / (tms * 1e-3) / 1e12
-        leg["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<MATH_B16> (Conv3d fwd + dgrad, bf16 MFMA, fp32 accumulate)",
+        leg["roofline"] = {"bound": "mfma", "kernel": "conv_b16s_kernel (Conv3d k3/k5 s1 fwd + dgrad, v_mfma_f32_16x16x32_bf16, fp32 accumulate; other shapes on conv_igemm_kernel<MATH_B16>)",
                            "launches": int(n), "launches_per_step": n / steps, "avg_launch_ms": tms / n, "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS, "algorithmic_gflop_per_launch": fl / n / 1e9}
     if "conv_wgrad_mfma" in fam:
