@@ -221,12 +221,47 @@ __global__ void wgrad_reduce_flat_kernel(const float* __restrict__ part, float* 
     }
 }
 
+// many strips (the narrow full-resolution layers: 256 strips of 27 x 32 x 32): the slab stack as a [splits][T * Cin * Cout] matrix, a
+// workgroup owns 32 consecutive columns (128-byte row pieces, same tap and input channel), its 8 row lanes walk the strips 8 apart with
+// two accumulators each, LDS combines the lanes in a fixed order.  (wgrad_reduce_flat_kernel walked all strips in every thread:
+// 27-36 us per layer whatever its size, 0.46 ms of a cfg-2 step.)
+__global__ __launch_bounds__(256) void wgrad_reduce_cols_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits, int T, int Cin,
+                                                                int Cout, int accumulate) {
+    __shared__ double sh[8][32];
+    const long long total = (long long)T * Cin * Cout;
+    const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const long long col = (long long)blockIdx.x * 32 + c;
+    double s0 = 0.0, s1 = 0.0;
+    if (col < total) {
+        const float* p = part + col;
+        int k = q;
+        for (; k + 8 < splits; k += 16) { s0 += (double)p[(long long)k * total]; s1 += (double)p[(long long)(k + 8) * total]; }
+        if (k < splits) s0 += (double)p[(long long)k * total];
+    }
+    sh[q][c] = s0 + s1;
+    __syncthreads();
+    if (q == 0 && col < total) {
+        double s = sh[0][c];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) s += sh[j][c];
+        const int co = (int)(col % Cout); const long long r = col / Cout;
+        const int ci = (int)(r % Cin), t = (int)(r / Cin);
+        const long long o = ((long long)co * Cin + ci) * T + t;
+        dw[o] = accumulate ? dw[o] + (float)s : (float)s;
+    }
+}
+
 void wgrad_reduce(const float* part, float* dw, int splits, int T, int Cin, int Cout, int accumulate, hipStream_t st) {
     const int TT = T > 256 ? 256 : T;
     int CIT = 256 / TT;
     CIT = CIT < 1 ? 1 : (CIT > 32 ? 32 : CIT);
     if (CIT > Cin) CIT = Cin;
     auto blocks = [&](int cit) { return (long long)((Cout + 31) / 32) * ((Cin + cit - 1) / cit) * ((T + TT - 1) / TT); };
+    if (splits >= 8) {
+        const long long total = (long long)T * Cin * Cout;
+        hipLaunchKernelGGL(wgrad_reduce_cols_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, part, dw, splits, T, Cin, Cout, accumulate);
+        return;
+    }
     while (CIT > 1 && blocks(CIT) < 256) CIT = (CIT + 1) / 2;       // wide layers: enough blocks for every CU
     if (blocks(CIT) < 256) {
         long long total = (long long)T * Cin * Cout;

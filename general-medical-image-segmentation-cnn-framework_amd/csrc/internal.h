@@ -117,6 +117,12 @@ bool gwgrad_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int 
 template <typename T> int conv_gwgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
                 int k, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 // conv_pw_wgrad.hip -- K = voxels GEMM wgrads (T = 1: Conv3d k1, T = 8: ConvTranspose3d k2 s2)
+// convt_direct.hip: ConvTranspose3d k2 s2 forward (gather = false) / input gradient (gather = true) as one GEMM on the bf16 matrix
+// cores (fp32 tensors: bf16x6 planes); coarse = the low-resolution tensor, fine = the 2x one
+bool convt_direct_supported(int elem_bytes, bool gather, int N, int D, int H, int W, int Cin, int Cout, int ld_coarse, int ld_fine);
+size_t convt_direct_ws_bytes(int Cin, int Cout);
+template <typename TT> int convt_direct(bool gather, const TT* x, int ldx, const float* w, const float* bias, TT* y, int ldy, int N, int D, int H, int W,
+                                        int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t st);
 // convt_wgrad_lowp.hip: ConvTranspose3d k2 s2 weight gradient on the bf16 matrix cores (fp32 tensors: bf16x6 planes)
 void convt_wgrad_reduce(const float* part, float* dw, int splits, int Cin, int Cout, hipStream_t st);   // convt.hip: dw[ci][co][tap] = sum of the slabs
 size_t convt_wgrad_lowp_ws_bytes(long long nvox, int Cin, int Cout);

@@ -1,8 +1,9 @@
 """The RCCL code path on a one-GPU box: a single-rank "nccl" group, with the gradient reducer forced on
 (``always=True``) so the flat-bucket all-reduces, the hook-driven overlap with backward, the buffer broadcast
 and the metric reduction all run through RCCL on device tensors.  With one rank the mean is the identity, so
-the train step must be bit-identical to the undistributed one.  (The two-rank arithmetic is covered on CPU by
-tests/test_distributed.py; N > 1 GPUs are the driver's to launch.)"""
+the train step must be bit-identical to the undistributed one.  The two-rank arithmetic of the HIP path runs here as two
+replicas sharing the box's one GPU over gloo (device gradients, staged by the backend); the same arithmetic of the oracle network
+is covered on CPU by tests/test_distributed.py; N > 1 GPUs over RCCL are the driver's to launch."""
 import os
 import socket
 
@@ -55,3 +56,65 @@ def test_single_rank_rccl_train_step_is_identity():
             assert torch.equal(a, b), k
     finally:
         dist.destroy_process_group()
+
+
+def _hip_ddp_worker(rank, world, port, out):
+    """One data-parallel train step of the HIP U-Net on this rank's shard, both ranks on cuda:0 (the box has one GPU), gradients
+    mean-all-reduced by the product's reducer over gloo (device tensors staged through the host by the backend)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import mi355seg
+    from mi355seg import distributed as D
+    from mi355seg.engine import train_step
+    from mi355seg.models.three_d.unet3d import UNet3D
+    from oracle.fill import fill_module_, make_input, make_labels
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = fill_module_(UNet3D(1, 2, 4)).cuda().train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)           # the gradients are what is compared: leave the weights alone
+    reducer = D.GradAllReducer(model, bucket_mb=0.05)
+    x = make_input((2, 1, 16, 16, 16), freq=0.05, phase=float(rank)).cuda()
+    gt = make_labels((2, 1, 16, 16, 16), thresh=0.8 - 0.3 * rank).cuda()
+    D.broadcast_buffers(model)
+    res = train_step(model, opt, x, gt, grad_hook=reducer)
+    counts, loss = D.all_reduce_metric(res["counts"], res["loss"].detach())
+    out[rank] = ({k: p.grad.detach().cpu() for k, p in model.named_parameters()}, len(reducer.buckets), counts.cpu(), float(loss),
+                 res["counts"].cpu(), float(res["loss"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_hip_path_gradients_equal_the_mean_of_per_shard_oracle_gradients():
+    """SURVEY section 8(e) on the HIP path: two replicas (sharing the box's one GPU) each run the library's forward / backward on
+    their own shard with rank-local BatchNorm statistics; the reducer's bucketed mean all-reduce must leave, on both ranks, the mean of
+    the CPU oracle's per-shard gradients; the Dice counters and the loss reduce to the global values."""
+    import torch.multiprocessing as mp
+    from oracle.fill import fill_module_, make_input, make_labels
+    from oracle.losses import bce_with_logits
+    from oracle.nets import UNet3D
+    from oracle.step import two_channel_gt
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_hip_ddp_worker, args=(world, port, out), nprocs=world, join=True)
+    shard = []
+    for rank in range(world):
+        m = fill_module_(UNet3D(1, 2, 4)).train()
+        x = make_input((2, 1, 16, 16, 16), freq=0.05, phase=float(rank))
+        gt = make_labels((2, 1, 16, 16, 16), thresh=0.8 - 0.3 * rank)
+        loss = bce_with_logits(m(x), two_channel_gt(gt).float())
+        loss.backward()
+        shard.append(({k: p.grad for k, p in m.named_parameters()}, float(loss.detach())))
+    scale = max(float(g.abs().max()) for g in shard[0][0].values())
+    assert out[0][1] > 1                                                   # several buckets went out
+    for k, g0 in shard[0][0].items():
+        want = (g0 + shard[1][0][k]) / 2
+        for rank in range(world):
+            got = out[rank][0][k]
+            assert (got - want).abs().max() <= 2e-4 * max(float(want.abs().max()), 1e-3 * scale), (k, rank)
+        assert torch.equal(out[0][0][k], out[1][0][k]), k                  # both replicas hold the same reduced gradient
+    assert torch.equal(out[0][2], out[0][4] + out[1][4]) and torch.equal(out[0][2], out[1][2])      # global integer Dice counters
+    assert abs(out[0][3] - (shard[0][1] + shard[1][1]) / 2) < 1e-5
