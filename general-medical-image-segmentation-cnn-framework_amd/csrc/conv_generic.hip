@@ -575,6 +575,36 @@ int mi355seg_conv3d_dgrad_f32(const float* dy, int lddy, const float* w, float* 
     return conv_dgrad_generic(dy, lddy, w, dx, lddx, g, ws, ws_bytes, st);
 }
 
+// Input gradient of a convolution whose INPUT was act(norm(bn_x)) of the layer in front, together with the two column sums that
+// layer's norm backward starts with (s1 = sum dz, s2 = sum dz * xhat, dz = dx * act'(z); dgamma = s2, dbeta = s1): on the bf16x6
+// k3 path they are reduced in the epilogue of the input-gradient kernel from the tile it has just computed (one read of bn_x instead
+// of a separate pass over dx and bn_x); every other path runs the plain input gradient and mi355seg_norm_act_bwd_sums_f32.
+// The layer in front then finishes with mi355seg_norm_act_bwd_apply_f32(dx, bn_x, ..., s1, s2).  groups == 1 (BatchNorm).
+int mi355seg_conv3d_dgrad_bnsums_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
+                                     int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                                     const float* bn_x, int ld_bnx, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                     int act, float slope, float* s1, float* s2, float* dgamma, float* dbeta,
+                                     void* ws, size_t ws_bytes, void* stream) {
+    ConvGeom g{N, D, H, W, Cin, Cout, k, stride, pad, 0, 0, 0};
+    int rc = check_geom(&g, "conv3d_dgrad_bnsums");
+    if (rc) return rc;
+    SEG_CHECK_ARG(dy && w && dx && lddy >= Cout && lddx >= Cin, "conv3d_dgrad_bnsums: null pointer or pitch < channels");
+    SEG_CHECK_ARG(bn_x && mean && rstd && gamma && beta && s1 && s2 && ld_bnx >= Cin, "conv3d_dgrad_bnsums: the norm in front needs x, mean, rstd, gamma, beta");
+    SEG_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "conv3d_dgrad_bnsums: dgamma/dbeta must come together");
+    hipStream_t st = (hipStream_t)stream;
+    const int pol = f32_conv_policy();
+    if (pol == MATH_X3 && conv_mfma_supported(pol, N, D, H, W, Cout, Cin, k, stride, pad, lddy, lddx)) {
+        BnBwdEpi e{bn_x, ld_bnx, mean, rstd, gamma, beta, act, slope, s1, s2, dgamma, dbeta, 0};
+        rc = conv_fwd_mfma(pol, dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cout, Cin, k, /*dgrad=*/1, nullptr, nullptr, ws, ws_bytes, st, nullptr, 0, 0.f, &e);
+        if (rc || e.done) return rc;
+    } else {
+        rc = mi355seg_conv3d_dgrad_f32(dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, k, stride, pad, ws, ws_bytes, stream);
+        if (rc) return rc;
+    }
+    return mi355seg_norm_act_bwd_sums_f32(dx, lddx, bn_x, ld_bnx, mean, rstd, gamma, beta, nullptr, 0, s1, s2, dgamma, dbeta,
+                                          (long long)N * D * H * W, 1, Cin, act, slope, ws, ws_bytes, stream);
+}
+
 int mi355seg_conv3d_wgrad_f32(const float* dy, int lddy, const float* x, int ldx,
                               float* dw, float* db, int N, int D, int H, int W, int Cin, int Cout,
                               int k, int stride, int pad, int accumulate,

@@ -373,7 +373,7 @@ static double matrix_bytes(int math, double act_elems, double w_elems) { return 
 // and the bias vector, the activation applied in the epilogue (or in the split-K reduce), no normalise pass
 int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int N, int D, int H, int W,
                   int Cin, int Cout, int k, int dgrad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st,
-                  const float* oscale, int act, float slope) {
+                  const float* oscale, int act, float slope, BnBwdEpi* bne) {
     IgemmPlan p;
     SEG_CHECK_ARG(igemm_plan(math, k, N, D, H, W, Cin, Cout, 1, &p), "conv_fwd_mfma: unsupported shape");
     SEG_CHECK_ARG(((uintptr_t)x % 16) == 0, "conv_fwd_mfma: input pointer must be 16-byte aligned");
@@ -389,10 +389,13 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
     void* wq = cv.take<char>(wq_bytes(math, (size_t)T * Cin * Cout));
     float* spart = (ssum && ksplit == 1) ? cv.take<float>((size_t)p.nM * Cout * 3) : nullptr;
     float* slabs = ksplit > 1 ? cv.take<float>((size_t)ksplit * nvox * Cout) : nullptr;
-    size_t tail = cv.used();
-    SEG_CHECK_WS(tail + ((ssum && ksplit > 1) ? colsum_ws_bytes(Cout) : 0), ws_bytes);
     // fp32 tensors, bf16x6, 16-wide tiles: the 16x16x32-MFMA kernel (conv_x3s.hip) with its own weight packing
     const bool x3s = math == MATH_X3 && x3s_enabled() && x3s_plan_ok(p, x, ldx, ksplit > 1 ? (void*)slabs : y, ksplit > 1 ? Cout : ldy, (long long)D * H * W);
+    // the BatchNorm-backward sums of the layer in front ride in that kernel's epilogue (whole-K launches only)
+    const bool bn_epi = bne && x3s && ksplit == 1 && !ssum && !bias && !act && (bne->ldx % 4) == 0 && ((uintptr_t)bne->x % 16) == 0 && Cout % 4 == 0;
+    float* bnpart = bn_epi ? cv.take<float>((size_t)p.nM * Cout * 2) : nullptr;
+    size_t tail = cv.used();
+    SEG_CHECK_WS(tail + ((ssum && ksplit > 1) ? colsum_ws_bytes(Cout) : 0), ws_bytes);
     if (b16s) hipLaunchKernelGGL(pack_wq_b16s_kernel, dim3(pack_grid((long long)(T + 1) * Cin * Cout)), dim3(256), 0, st, w, (bf16*)wq, Cin, Cout, T, bp.NT, dgrad ? 1 : 0, oscale);
     else if (x3s) hipLaunchKernelGGL(pack_wq_x3s_kernel, dim3(pack_grid((long long)28 * Cin * Cout)), dim3(256), 0, st, w, (bf16*)wq, Cin, Cout, p.NBW, dgrad ? 1 : 0, oscale);
     else launch_pack(math, w, wq, Cin, Cout, T, p.NT, dgrad ? 1 : 0, 0, p.CK, T, TapList{}, st, oscale);
@@ -401,6 +404,10 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
                 p.ntx, p.nty, p.ntz, p.nN, nchunks, nchunks, p.nN, 1, 1, p.nM, ksplit, nchunks / ksplit, nvox * Cout, dbg_flags()};
     a.Di = a.Do = D; a.Hi = a.Ho = H; a.Wi = a.Wo = W;
     a.act = ksplit > 1 ? 0 : act; a.slope = slope;
+    if (bn_epi) {
+        a.bnx = bne->x; a.ldbnx = bne->ldx; a.bn_mean = bne->mean; a.bn_rstd = bne->rstd; a.bn_gamma = bne->gamma; a.bn_beta = bne->beta;
+        a.bn_act = bne->act; a.bn_slope = bne->slope; a.bnpart = bnpart;
+    }
     const int nwg = p.nM * p.nN * ksplit;
     const double vox = (double)nvox;
     {
@@ -415,6 +422,11 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
             else hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(grid), dim3(256), 0, st, slabs, ksplit, nvox * Cout, bias, (float*)y, ldy, nvox, Cout, act, slope);
             SEG_CHECK_LAUNCH();
         }
+    }
+    if (bn_epi) {
+        norm_bwd_finalize(bnpart, p.nM, Cout, bne->s1, bne->s2, bne->dgamma, bne->dbeta, st);
+        SEG_CHECK_LAUNCH();
+        bne->done = 1;
     }
     if (ssum) {
         if (ksplit > 1) {

@@ -261,6 +261,50 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
             }
         }
     }
+    if (a.bnpart) {
+        // BatchNorm-backward column sums of the layer in front (input-gradient launch, no bias / activation / split): the tile just
+        // stored is d(activation); read that layer's pre-norm tensor at the same voxels and reduce dz and dz * xhat per channel
+        float sa[NTW][4], sb[NTW][4];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int c = n0 + 16 * t + 4 * g;
+            const f32x4 mu = *reinterpret_cast<const f32x4*>(a.bn_mean + c), rs = *reinterpret_cast<const f32x4*>(a.bn_rstd + c);
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(a.bn_gamma + c), be = *reinterpret_cast<const f32x4*>(a.bn_beta + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sa[t][e] = 0.f; sb[t][e] = 0.f; }
+#pragma unroll
+            for (int j = 0; j < LW; ++j) {
+                const int line = line0 + j;
+                const int gz = z0 + line / XTY, gy = y0 + line % XTY;
+                if (gz < a.D && gy < a.H && gx < a.W) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(a.bnx + ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.ldbnx + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xh = (xv[e] - mu[e]) * rs[e];
+                        const float dz = acc[j][t][e] * act_grad(fmaf(xh, ga[e], be[e]), a.bn_act, a.bn_slope);
+                        sa[t][e] += dz; sb[t][e] = fmaf(dz, xh, sb[t][e]);
+                    }
+                }
+            }
+        }
+        float* lds = reinterpret_cast<float*>(lds_raw);
+        __syncthreads();                 // LDS halo no longer needed
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v1 = row16_sum(sa[t][e]), v2 = row16_sum(sb[t][e]);
+                if (r == 0) { lds[wave * NT + 16 * t + 4 * g + e] = v1; lds[(4 + wave) * NT + 16 * t + 4 * g + e] = v2; }
+            }
+        __syncthreads();
+        if (tid < NT) {
+            float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { v1 += lds[w * NT + tid]; v2 += lds[(4 + w) * NT + tid]; }
+            float* dst = a.bnpart + ((long long)mtile * a.Cout + n0 + tid) * 2;
+            dst[0] = v1; dst[1] = v2;
+        }
+    }
     if (a.spart) {
         // per channel (sum, M2 about the tile mean, n) of this tile, as conv_igemm_kernel: spart[mtile][c] = {sum, M2, n}
         float* lds = reinterpret_cast<float*>(lds_raw);

@@ -108,7 +108,15 @@ struct IgemmArgs {
     int total;          // virtual tiles = nM * nN * ksplit (the persistent variants walk them with a smaller grid); set by dispatch
     signed char toff[64][4];   // per K-tap input offset (z, y, x); all zero for the stride-1 halo modes
     int act; float slope;      // activation applied after the bias in the epilogue (0 = none): the fused inference forward
+    // ---- BatchNorm-backward column sums in the epilogue of an input-gradient launch (conv_x3s.hip): y is then d(activation) of the
+    // norm + activation that produced this convolution's input; bnx = that norm's input (same voxels, pitch ldbnx), per channel
+    // bn_mean / bn_rstd / bn_gamma / bn_beta; bnpart[mtile][channel] = {sum dz, sum dz * xhat} with dz = y * act'(z)
+    const float* bnx; int ldbnx;
+    const float* bn_mean; const float* bn_rstd; const float* bn_gamma; const float* bn_beta;
+    int bn_act; float bn_slope;
+    float* bnpart;
 };
+
 
 struct TapList { unsigned char t[64]; };
 struct IgemmPlan { int KS, CK, BX, MB, NBW, TZ, nM, nN, ntx, nty, ntz, flat, WN, NT, TY; };     // NT = 32 * NBW * WN: tile width in channels

@@ -103,9 +103,16 @@ int conv_gather_fwd_mfma(int math, const void* x, int ldx, const float* w, const
                          int Cin, int Cout, int k, int stride, int pad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st);
 int conv_gather_dgrad_mfma(int math, const void* dy, int lddy, const float* w, void* dx, int lddx, int N, int D, int H, int W,
                            int Cin, int Cout, int k, int stride, int pad, void* ws, size_t ws_bytes, hipStream_t st);
+// what the caller of an input-gradient launch hands over to get the BatchNorm-backward column sums of the layer in front out of the
+// kernel's epilogue (done = 1 when the launch produced them; otherwise mi355seg_norm_act_bwd_sums_f32 has to)
+struct BnBwdEpi {
+    const float* x; int ldx; const float* mean; const float* rstd; const float* gamma; const float* beta; int act; float slope;
+    float* s1; float* s2; float* dgamma; float* dbeta; int done;
+};
+void norm_bwd_finalize(const float* part, int nblk, int C, float* s1, float* s2, float* dgamma, float* dbeta, hipStream_t st);   // norm.hip
 int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int N, int D, int H, int W,
                   int Cin, int Cout, int k, int dgrad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st,
-                  const float* oscale = nullptr, int act = 0, float slope = 0.f);
+                  const float* oscale = nullptr, int act = 0, float slope = 0.f, BnBwdEpi* bne = nullptr);
 bool convt_mfma_supported(int math, int N, int D, int H, int W, int Cin, int Cout, int ldx, int ldy);
 int convt_fwd_mfma(int math, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int N, int D, int H, int W,
                    int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t st);

@@ -7,6 +7,7 @@
 // = biased variance for the output, unbiased for running_var, momentum 0.1, eps 1e-5;
 // nn.InstanceNorm3d (residual_unet3d.py:27...) = the same per (n, c), no affine.
 #include "common.h"
+#include "internal.h"
 #include <initializer_list>
 
 namespace seg {
@@ -626,6 +627,11 @@ int channel_sums(const float* x, int ldx, long long rows, int C, double* sum, do
 int channel_sums(const bf16* x, int ldx, long long rows, int C, double* sum, double* sq, float* fsum, int accumulate,
                  void* ws, size_t ws_bytes, hipStream_t st) {
     return channel_sums_t(x, ldx, rows, C, sum, sq, fsum, accumulate, ws, ws_bytes, st);
+}
+
+// s1 / s2 (+ dgamma / dbeta) from per-tile {sum dz, sum dz * xhat} pairs produced by a convolution's epilogue (conv_x3s.hip)
+void norm_bwd_finalize(const float* part, int nblk, int C, float* s1, float* s2, float* dgamma, float* dbeta, hipStream_t st) {
+    hipLaunchKernelGGL(bwd_finalize_kernel, dim3(C), dim3(64), 0, st, part, nblk, C, 1, s1, s2, dgamma, dbeta);
 }
 
 }  // namespace seg

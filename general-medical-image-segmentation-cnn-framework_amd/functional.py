@@ -559,6 +559,117 @@ def conv_bn_act(x, conv, bn, act=ACT_NONE, slope=0.01, left_pad=0):
                             not torch.is_grad_enabled())
 
 
+class _DoubleConvBnAct(Function):
+    """act(BN2(conv2(act(BN1(conv1(x)))))) -- the double-conv block of unet3d.py:73-104 -- as ONE autograd node (training mode, fp32
+    tensors).  Forward is the two fused layers of _ConvBnAct back to back.  Because the activation between the two convolutions
+    has exactly one consumer here, the backward can let conv2's input-gradient kernel reduce BN1's two backward column sums in its
+    epilogue (mi355seg_conv3d_dgrad_bnsums_f32) instead of a separate pass over d(act) and y1."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, g1, be1, rm1, rv1, w2, b2, g2, be2, rm2, rv2, geo1, geo2, mom1, eps1, mom2, eps2, act, slope, left_pad):
+        x, ldx = cl_view(x, "conv3d input")
+        L = lib()
+        dev = x.device
+        N = x.shape[0]
+
+        def layer(inp, ldin, w, b, g, be, rm, rv, geo, mom, eps, lp):
+            D, H, W, Cin = inp.shape[1:]
+            Cout, k = w.shape[0], w.shape[2]
+            stride, pad = geo
+            if w.shape[1] != Cin:
+                raise Mi355SegError(f"conv3d: weight {tuple(w.shape)} does not match input channels {Cin}")
+            Do, Ho, Wo = [(e + 2 * pad - k) // stride + 1 for e in (D, H, W)]
+            rows = N * Do * Ho * Wo
+            ws = workspace(max(_conv_ws(L, inp, N, D, H, W, Cin, Cout, k, stride, pad), L.query("mi355seg_norm_ws_bytes", rows, 1, Cout)), dev)
+            y = torch.empty((N, Do, Ho, Wo, Cout), dtype=inp.dtype, device=dev)
+            sums = torch.empty(2 * Cout, dtype=torch.float64, device=dev)
+            L.call("mi355seg_conv3d_fwd_f32", _p(inp), ldin, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
+                   sums.data_ptr(), sums.data_ptr() + 8 * Cout, _p(ws), ws.numel(), _stream())
+            mean = torch.empty(Cout, dtype=torch.float32, device=dev)
+            rstd = torch.empty(Cout, dtype=torch.float32, device=dev)
+            L.call("mi355seg_norm_stats_from_sums_f32", sums.data_ptr(), sums.data_ptr() + 8 * Cout, rows, Cout, eps,
+                   _p(mean), _p(rstd), _p(rm), _p(rv), mom, _stream())
+            full = torch.empty((N, Do, Ho, Wo, lp + Cout), dtype=inp.dtype, device=dev)
+            a = full[..., lp:] if lp else full
+            L.call("mi355seg_norm_act_fwd_f32", _p(y), Cout, _p(mean), _p(rstd), _p(g), _p(be), None, 0,
+                   a.data_ptr(), lp + Cout, rows, 1, Cout, act, slope, _stream())
+            return y, mean, rstd, a, (N, D, H, W, Cin, Cout, k, stride, pad, ldin, b is not None, rows)
+
+        w1, w2 = w1.contiguous(), w2.contiguous()
+        y1, mean1, rstd1, a1, cfg1 = layer(x, ldx, w1, b1, g1, be1, rm1, rv1, geo1, mom1, eps1, 0)
+        y2, mean2, rstd2, a2, cfg2 = layer(a1, a1.shape[-1], w2, b2, g2, be2, rm2, rv2, geo2, mom2, eps2, left_pad)
+        ctx.save_for_backward(x, w1, y1, mean1, rstd1, g1, be1, a1, w2, y2, mean2, rstd2, g2, be2)
+        ctx.cfg = (cfg1, cfg2, act, slope)
+        return a2
+
+    @staticmethod
+    def backward(ctx, da2):
+        x, w1, y1, mean1, rstd1, g1, be1, a1, w2, y2, mean2, rstd2, g2, be2 = ctx.saved_tensors
+        cfg1, cfg2, act, slope = ctx.cfg
+        N, D1, H1, W1, Cin1, C1, k1, st1, pd1, ldx, has_b1, rows1 = cfg1
+        _, D2, H2, W2, _, C2, k2, st2, pd2, lda1, has_b2, rows2 = cfg2
+        L = lib()
+        dev = x.device
+        da2, ldda2 = cl_view(_like(da2, x), "conv+norm grad")
+        ws = workspace(max(_conv_ws(L, x, N, D1, H1, W1, Cin1, C1, k1, st1, pd1), _conv_ws(L, a1, N, D2, H2, W2, C1, C2, k2, st2, pd2),
+                           L.query("mi355seg_norm_ws_bytes", rows1, 1, C1), L.query("mi355seg_norm_ws_bytes", rows2, 1, C2)), dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        # layer 2: BatchNorm + activation backward (its dx column sums are conv2's bias gradient)
+        dy2 = torch.empty_like(y2)
+        dg2, dbe2 = torch.empty(C2, **f32), torch.empty(C2, **f32)
+        db2 = torch.empty(C2, **f32) if has_b2 else None
+        L.call("mi355seg_norm_act_bwd_colsum_f32", _p(da2), ldda2, _p(y2), C2, _p(mean2), _p(rstd2), _p(g2), _p(be2), None, 0,
+               _p(dy2), C2, _p(dg2), _p(dbe2), None, 0, _p(db2), rows2, 1, C2, act, slope, _p(ws), ws.numel(), _stream())
+        # conv2 input gradient = d(act1); BN1's two column sums come out of the same kernel
+        da1 = torch.empty((N, D2, H2, W2, C1), dtype=x.dtype, device=dev)
+        s12 = torch.empty(2 * C1, **f32)
+        dg1, dbe1 = torch.empty(C1, **f32), torch.empty(C1, **f32)
+        L.call("mi355seg_conv3d_dgrad_bnsums_f32", _p(dy2), C2, _p(w2), _p(da1), C1, N, D2, H2, W2, C1, C2, k2, st2, pd2,
+               _p(y1), C1, _p(mean1), _p(rstd1), _p(g1), _p(be1), act, slope, s12.data_ptr(), s12.data_ptr() + 4 * C1, _p(dg1), _p(dbe1),
+               _p(ws), ws.numel(), _stream())
+        dw2 = torch.empty_like(w2)
+        L.call("mi355seg_conv3d_wgrad_f32", _p(dy2), C2, _p(a1), lda1, _p(dw2), None, N, D2, H2, W2, C1, C2, k2, st2, pd2,
+               0, _p(ws), ws.numel(), _stream())
+        del dy2
+        # layer 1: the apply half of the norm backward (+ conv1's bias gradient), then conv1's gradients
+        dy1 = torch.empty_like(y1)
+        db1 = torch.empty(C1, **f32) if has_b1 else None
+        L.call("mi355seg_norm_act_bwd_apply_f32", _p(da1), C1, _p(y1), C1, _p(mean1), _p(rstd1), _p(g1), _p(be1), None, 0,
+               s12.data_ptr(), s12.data_ptr() + 4 * C1, _p(dy1), C1, None, 0, _p(db1), rows1, 1, C1, act, slope, _p(ws), ws.numel(), _stream())
+        del da1
+        dx = dw1 = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((N, D1, H1, W1, Cin1), dtype=x.dtype, device=dev)
+            L.call("mi355seg_conv3d_dgrad_f32", _p(dy1), C1, _p(w1), _p(dx), Cin1, N, D1, H1, W1, Cin1, C1, k1, st1, pd1,
+                   _p(ws), ws.numel(), _stream())
+        if ctx.needs_input_grad[1]:
+            dw1 = torch.empty_like(w1)
+            L.call("mi355seg_conv3d_wgrad_f32", _p(dy1), C1, _p(x), ldx, _p(dw1), None, N, D1, H1, W1, Cin1, C1, k1, st1, pd1,
+                   0, _p(ws), ws.numel(), _stream())
+        return (dx, dw1, db1, dg1, dbe1, None, None, dw2, db2, dg2, dbe2, None, None) + (None,) * 9
+
+
+def double_conv_bn_act(x, conv1, bn1, conv2, bn2, act=ACT_NONE, slope=0.01, left_pad=0):
+    """act(bn2(conv2(act(bn1(conv1(x)))))): training mode on fp32 tensors runs as one autograd node (_DoubleConvBnAct), everything
+    else as two conv_bn_act layers."""
+    fused = bn1.training and bn2.training and torch.is_grad_enabled() and compute_dtype() == torch.float32 and x.dtype == torch.float32
+    for bn in (bn1, bn2):
+        fused = fused and bn.momentum is not None and bn.affine and bn.track_running_stats
+    if not fused:
+        return conv_bn_act(conv_bn_act(x, conv1, bn1, act, slope), conv2, bn2, act, slope, left_pad=left_pad)
+
+    def geo(conv):
+        st = conv.stride[0] if isinstance(conv.stride, (tuple, list)) else conv.stride
+        pd = conv.padding[0] if isinstance(conv.padding, (tuple, list)) else conv.padding
+        return int(st), int(pd)
+    bn1.num_batches_tracked.add_(1)
+    bn2.num_batches_tracked.add_(1)
+    return _DoubleConvBnAct.apply(x, conv1.weight, conv1.bias, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
+                                  conv2.weight, conv2.bias, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var,
+                                  geo(conv1), geo(conv2), float(bn1.momentum), float(bn1.eps), float(bn2.momentum), float(bn2.eps),
+                                  int(act), float(slope), int(left_pad))
+
+
 class _Act(Function):
     @staticmethod
     def forward(ctx, x, res, act, slope):

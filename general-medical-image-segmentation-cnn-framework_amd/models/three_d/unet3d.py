@@ -23,8 +23,9 @@ class _DoubleConv(nn.Sequential):
         """``left_pad`` > 0: the block's output is the right channel slice of a buffer with ``left_pad`` free channels
         on its left, ready for the decoder's concat-free up-convolution (encoder blocks only)."""
         conv1, norm1, _r1, conv2, norm2, _r2 = self.children()
-        x = F.conv_bn_act(x, conv1, norm1, F.ACT_RELU)          # conv + batch statistics + BN + ReLU, one autograd node
-        return F.conv_bn_act(x, conv2, norm2, F.ACT_RELU, left_pad=left_pad)
+        # (conv + batch statistics + BN + ReLU) x 2; in training the whole block is one autograd node whose backward takes norm1's
+        # column sums out of conv2's input-gradient kernel
+        return F.double_conv_bn_act(x, conv1, norm1, conv2, norm2, F.ACT_RELU, left_pad=left_pad)
 
 
 class UNet3D(nn.Module):

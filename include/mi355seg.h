@@ -115,6 +115,17 @@ int mi355seg_conv3d_dgrad_f32(const float* dy, int lddy, const float* w, float* 
                               int N, int D, int H, int W, int Cin, int Cout,
                               int k, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
 
+/* The same input gradient for a convolution whose input was act(BatchNorm(bn_x)) of the layer in front (conv2 of a double-conv
+ * block, unet3d.py:92-101 behind :80-89), plus the two column sums that layer's norm backward starts with: s1[c] = sum dz,
+ * s2[c] = sum dz * xhat with dz = dx * act'(z) (dgamma = s2, dbeta = s1; may be NULL).  On the bf16x6 k3 path the sums come out of
+ * the input-gradient kernel's epilogue (one read of bn_x, no pass over dx); elsewhere this is conv3d_dgrad followed by
+ * norm_act_bwd_sums.  Finish the layer in front with mi355seg_norm_act_bwd_apply_f32.  ws: max(conv3d_ws_bytes, norm_ws_bytes). */
+int mi355seg_conv3d_dgrad_bnsums_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
+                                     int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                                     const float* bn_x, int ld_bnx, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                     int act, float slope, float* s1, float* s2, float* dgamma, float* dbeta,
+                                     void* ws, size_t ws_bytes, void* stream);
+
 /* dw (Cout,Cin,k,k,k) and db (Cout, may be NULL) = conv_backward_weight(dy, x).
  * Deterministic (two-stage reduction, no atomics).  accumulate!=0 adds into dw/db
  * (weight sharing, residual_unet3d.py:126,128). */
@@ -184,6 +195,22 @@ int mi355seg_norm_act_bwd_colsum_f32(const float* dy, int lddy, const float* x, 
                                      float* dx, int lddx, float* dgamma, float* dbeta, float* dres, int lddres, float* dx_colsum,
                                      long long rows, int groups, int C, int act, float slope,
                                      void* ws, size_t ws_bytes, void* stream);
+
+/* The same backward in its two halves (the conv -> BN -> ReLU -> conv chains of unet3d.py:73-104: the first half can ride in the
+ * epilogue of the kernel that produces dy, see mi355seg_conv3d_dgrad_bnsums_f32):
+ *   sums:  s1[g, c] = sum_rows dz, s2[g, c] = sum_rows dz * xhat, dz = dy * act'(z)  (+ dgamma = s2, dbeta = s1; groups == 1)
+ *   apply: dx = rstd * gamma * (dz - s1 / rows - xhat * s2 / rows)  (+ dres = dz; + dx_colsum[c] = sum_rows dx[r, c]) */
+int mi355seg_norm_act_bwd_sums_f32(const float* dy, int lddy, const float* x, int ldx,
+                                   const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                   const float* res, int ldres, float* s1, float* s2, float* dgamma, float* dbeta,
+                                   long long rows, int groups, int C, int act, float slope,
+                                   void* ws, size_t ws_bytes, void* stream);
+int mi355seg_norm_act_bwd_apply_f32(const float* dy, int lddy, const float* x, int ldx,
+                                    const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                    const float* res, int ldres, const float* s1, const float* s2,
+                                    float* dx, int lddx, float* dres, int lddres, float* dx_colsum,
+                                    long long rows, int groups, int C, int act, float slope,
+                                    void* ws, size_t ws_bytes, void* stream);
 
 /* Eval-mode BatchNorm (running stats) is norm_act_fwd with mean=running_mean and
  * rstd = 1/sqrt(running_var+eps) computed by: */
@@ -385,6 +412,8 @@ int mi355seg_norm_stats_bf16(const mi355seg_bf16* x, int ldx, long long rows, in
 int mi355seg_norm_act_fwd_bf16(const mi355seg_bf16* x, int ldx, const float* mean, const float* rstd, const float* gamma, const float* beta, const mi355seg_bf16* res, int ldres, mi355seg_bf16* y, int ldy, long long rows, int groups, int C, int act, float slope, void* stream);
 int mi355seg_norm_act_bwd_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, const float* mean, const float* rstd, const float* gamma, const float* beta, const mi355seg_bf16* res, int ldres, mi355seg_bf16* dx, int lddx, float* dgamma, float* dbeta, mi355seg_bf16* dres, int lddres, long long rows, int groups, int C, int act, float slope, void* ws, size_t ws_bytes, void* stream);
 int mi355seg_norm_act_bwd_colsum_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, const float* mean, const float* rstd, const float* gamma, const float* beta, const mi355seg_bf16* res, int ldres, mi355seg_bf16* dx, int lddx, float* dgamma, float* dbeta, mi355seg_bf16* dres, int lddres, float* dx_colsum, long long rows, int groups, int C, int act, float slope, void* ws, size_t ws_bytes, void* stream);
+int mi355seg_norm_act_bwd_sums_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, const float* mean, const float* rstd, const float* gamma, const float* beta, const mi355seg_bf16* res, int ldres, float* s1, float* s2, float* dgamma, float* dbeta, long long rows, int groups, int C, int act, float slope, void* ws, size_t ws_bytes, void* stream);
+int mi355seg_norm_act_bwd_apply_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, const float* mean, const float* rstd, const float* gamma, const float* beta, const mi355seg_bf16* res, int ldres, const float* s1, const float* s2, mi355seg_bf16* dx, int lddx, mi355seg_bf16* dres, int lddres, float* dx_colsum, long long rows, int groups, int C, int act, float slope, void* ws, size_t ws_bytes, void* stream);
 int mi355seg_scale_channels_bf16(const mi355seg_bf16* x, int ldx, const float* scale, mi355seg_bf16* y, int ldy, long long rows, int groups, int C, void* stream);
 int mi355seg_act_fwd_bf16(const mi355seg_bf16* x, int ldx, const mi355seg_bf16* res, int ldres, mi355seg_bf16* y, int ldy, long long rows, int C, int act, float slope, void* stream);
 int mi355seg_act_bwd_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, const mi355seg_bf16* res, int ldres, mi355seg_bf16* dx, int lddx, long long rows, int C, int act, float slope, void* stream);
