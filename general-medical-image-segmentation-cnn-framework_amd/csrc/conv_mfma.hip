@@ -134,6 +134,77 @@ __global__ void pack_wq_b16s_kernel(const float* __restrict__ w, bf16* __restric
     }
 }
 
+// The two hot packings above, tiled: a workgroup owns NB (8; 4 for k5 and for narrow layers) GEMM columns x one 16-channel K chunk x all taps, reads that block of W
+// with full-width coalesced loads (the per-element kernels read W at a stride of T floats -- one 64-byte sector per 4 bytes used;
+// 10-16 us per layer, 0.4-0.8 ms of a V-Net / Res-U-Net step) into LDS and emits whole 16-byte fragment slots.
+// LAYOUT 0: conv_b16s.hip (P = NT), 1: conv_x3s.hip (P = NBW).  mode 0 / 1 as pack_src.
+template <int LAYOUT, int NB>
+__global__ __launch_bounds__(256) void pack_tiled_kernel(const float* __restrict__ w, bf16* __restrict__ wq, int K, int Nn, int T, int P, int mode,
+                                                         const float* __restrict__ oscale) {
+    extern __shared__ float tile[];
+    const int nnb = Nn / NB;
+    const int n0 = (blockIdx.x % nnb) * NB, chunk = blockIdx.x / nnb, k0 = chunk * 16;
+    const int tid = threadIdx.x;
+    // phase 1: mode 0: NB runs (n) of 16 T floats at W[n][k0 ..][.]; mode 1: 16 runs (k) of NB T floats at W[k][n0 ..][.]
+    const int nrun = mode == 0 ? NB : 16, rlen = (mode == 0 ? 16 : NB) * T;
+    for (int i = tid * 4; i < nrun * rlen; i += 1024) {
+        const int run = i / rlen, off = i - run * rlen;
+        const float* src = mode == 0 ? w + ((long long)(n0 + run) * K + k0) * T : w + ((long long)(k0 + run) * Nn + n0) * T;
+        *reinterpret_cast<f32x4*>(tile + i) = *reinterpret_cast<const f32x4*>(src + off);
+    }
+    __syncthreads();
+    const int nstep = LAYOUT == 0 ? (T + 1) / 2 : X3S_NPAIR, nch = K / 16;
+    constexpr int LB = NB == 8 ? 3 : (NB == 4 ? 2 : 1);
+    for (int q = tid; q < nstep * 4 * NB; q += 256) {
+        const int half = q & 1, nl = (q >> 1) & (NB - 1), gh = (q >> (1 + LB)) & 1, s = q >> (2 + LB);
+        const int tap = LAYOUT == 0 ? 2 * s + gh : x3s_pair_tap(s, gh);
+        const int n = n0 + nl, g = 2 * gh + half;
+        float v[8];
+        if (tap < T) {
+            const float sc = (oscale && mode == 0) ? oscale[n] : 1.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int kl = 8 * half + e;
+                v[e] = (mode == 0 ? tile[(nl * 16 + kl) * T + tap] : tile[(kl * NB + nl) * T + (T - 1 - tap)]) * sc;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+        if (LAYOUT == 0) {
+            const int NT = P, ntt = NT / 16, nt = n / NT, nin = n - nt * NT;
+            const int tt = 2 * (nin / 32) + ((nin >> 2) & 1), c = 4 * ((nin & 31) >> 3) + (nin & 3);
+            bf16x8_t o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+            reinterpret_cast<bf16x8_t*>(wq)[((((long long)nt * nch + chunk) * nstep + s) * ntt + tt) * 64 + c + 16 * g] = o;
+        } else {
+            const int NBW = P, NT = 32 * NBW, nt = n / NT, nin = n - nt * NT;
+            const int nh = nin / 32, t2 = (nin & 31) >> 4, c = nin & 15;
+            bf16x8_t oh, om, ol;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { bf16 a, b, d; split3(v[e], a, b, d); oh[e] = a; om[e] = b; ol[e] = d; }
+            bf16* dst = wq + (((long long)nt * nch + chunk) * (X3S_NPAIR * NBW) + s * NBW + nh) * 3072 + t2 * 512 + (c + 16 * g) * 8;
+            *reinterpret_cast<bf16x8_t*>(dst) = oh;
+            *reinterpret_cast<bf16x8_t*>(dst + 1024) = om;
+            *reinterpret_cast<bf16x8_t*>(dst + 2048) = ol;
+        }
+    }
+}
+
+template <int LAYOUT, int NB>
+static void launch_pack_tiled_nb(const float* w, bf16* wq, int K, int Nn, int T, int P, int mode, const float* oscale, hipStream_t st) {
+    const size_t lds = (size_t)16 * NB * T * sizeof(float);
+    SEG_SET_LDS((pack_tiled_kernel<LAYOUT, NB>), lds);
+    hipLaunchKernelGGL((pack_tiled_kernel<LAYOUT, NB>), dim3((unsigned)((Nn / NB) * (K / 16))), dim3(256), lds, st, w, wq, K, Nn, T, P, mode, oscale);
+}
+template <int LAYOUT>
+static void launch_pack_tiled(const float* w, bf16* wq, int K, int Nn, int T, int P, int mode, const float* oscale, hipStream_t st) {
+    // enough workgroups for the narrow layers, short serial work per workgroup for the 125-tap ones
+    if (T > 27 || (long long)(Nn / 8) * (K / 16) < 256) launch_pack_tiled_nb<LAYOUT, 4>(w, wq, K, Nn, T, P, mode, oscale, st);   // (runs of 4 T floats keep the 16-byte alignment)
+    else launch_pack_tiled_nb<LAYOUT, 8>(w, wq, K, Nn, T, P, mode, oscale, st);
+}
+
 static int pack_grid(long long total) { return (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256); }
 // MATH_X3: sized for the 28-tap layout of conv_x3s.hip (27 taps + one zero tap), which is the larger of its two packings
 // MATH_B16 likewise for conv_b16s.hip (taps paired: one zero tap when the tap count is odd)
@@ -396,7 +467,10 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
     float* bnpart = bn_epi ? cv.take<float>((size_t)p.nM * Cout * 2) : nullptr;
     size_t tail = cv.used();
     SEG_CHECK_WS(tail + ((ssum && ksplit > 1) ? colsum_ws_bytes(Cout) : 0), ws_bytes);
-    if (b16s) hipLaunchKernelGGL(pack_wq_b16s_kernel, dim3(pack_grid((long long)(T + 1) * Cin * Cout)), dim3(256), 0, st, w, (bf16*)wq, Cin, Cout, T, bp.NT, dgrad ? 1 : 0, oscale);
+    const bool w16 = ((uintptr_t)w % 16) == 0;                     // the tiled packings read W in 16-byte pieces
+    if (b16s && w16) launch_pack_tiled<0>(w, (bf16*)wq, Cin, Cout, T, bp.NT, dgrad ? 1 : 0, oscale, st);
+    else if (b16s) hipLaunchKernelGGL(pack_wq_b16s_kernel, dim3(pack_grid((long long)(T + 1) * Cin * Cout)), dim3(256), 0, st, w, (bf16*)wq, Cin, Cout, T, bp.NT, dgrad ? 1 : 0, oscale);
+    else if (x3s && w16) launch_pack_tiled<1>(w, (bf16*)wq, Cin, Cout, 27, p.NBW, dgrad ? 1 : 0, oscale, st);
     else if (x3s) hipLaunchKernelGGL(pack_wq_x3s_kernel, dim3(pack_grid((long long)28 * Cin * Cout)), dim3(256), 0, st, w, (bf16*)wq, Cin, Cout, p.NBW, dgrad ? 1 : 0, oscale);
     else launch_pack(math, w, wq, Cin, Cout, T, p.NT, dgrad ? 1 : 0, 0, p.CK, T, TapList{}, st, oscale);
     SEG_CHECK_LAUNCH();
