@@ -111,6 +111,25 @@ struct BwdF {       // sum dz, sum dz*xhat  with dz = dy*act'(z), z = xhat*gamma
     }
 };
 
+template <typename T>
+struct PreluF {     // column sum of dy * min(z, 0), z = x (+ res): the gradient of a PReLU slope (second sum unused)
+    const T* dy; int lddy; const T* x; int ldx; const T* res; int ldres;
+    struct State { };
+    __device__ __forceinline__ State prep(int g, int c, int nj) const { return State(); }
+    __device__ __forceinline__ State prepC(int g, int c, int nj, int C) const { return State(); }
+    __device__ __forceinline__ void eval(const State&, long long r, int g, int c, int C, float& a, float& b) const {
+        const float z = ld1(x + r * ldx + c) + (res ? ld1(res + r * ldres + c) : 0.f);
+        a = ld1(dy + r * lddy + c) * fminf(z, 0.f); b = 0.f;
+    }
+    __device__ __forceinline__ void eval4(const State&, long long r, int g, int c, int C, float4& a, float4& b) const {
+        const float4 d = ldf4(dy + r * lddy + c);
+        float4 v = ldf4(x + r * ldx + c);
+        if (res) { const float4 q = ldf4(res + r * ldres + c); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+        a = make_float4(d.x * fminf(v.x, 0.f), d.y * fminf(v.y, 0.f), d.z * fminf(v.z, 0.f), d.w * fminf(v.w, 0.f));
+        b = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+};
+
 template <typename F, bool VEC>
 __global__ __launch_bounds__(kRedThreads) void colreduce2_kernel(F f, long long rows, int C, int lanes, int rpi,
                                                                  float* __restrict__ part) {
@@ -438,12 +457,15 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(const T* __rest
 template <typename T, bool VEC, bool BWD>
 __global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx,
         const T* __restrict__ res, int ldres, T* __restrict__ out, int ldo, long long rows, int C, int lanes, int rpi,
-        int act, float slope) {
+        int act, float slope, const float* __restrict__ slope_c) {
+    // slope_c != null: PReLU -- the leaky slope of channel c is slope_c[c] (act = LRELU)
     const int cw = VEC ? C / 4 : C;
     const int rsub = threadIdx.x / lanes;
     if (rsub >= rpi) return;
     for (int cc = threadIdx.x % lanes; cc < cw; cc += lanes) {
         const int c = cc * (VEC ? 4 : 1);
+        float4 sl = make_float4(slope, slope, slope, slope);
+        if (slope_c) { sl.x = slope_c[c]; if (VEC) { sl.y = slope_c[c + 1]; sl.z = slope_c[c + 2]; sl.w = slope_c[c + 3]; } }
         for (long long r = (long long)blockIdx.x * rpi + rsub; r < rows; r += (long long)gridDim.x * rpi) {
             if (VEC) {
                 float4 v = ldf4(x + r * ldx + c);
@@ -454,16 +476,16 @@ __global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ dy, int 
                 float4 o;
                 if (BWD) {
                     float4 d = ldf4(dy + r * lddy + c);
-                    o = make_float4(d.x * act_grad(v.x, act, slope), d.y * act_grad(v.y, act, slope),
-                                    d.z * act_grad(v.z, act, slope), d.w * act_grad(v.w, act, slope));
+                    o = make_float4(d.x * act_grad(v.x, act, sl.x), d.y * act_grad(v.y, act, sl.y),
+                                    d.z * act_grad(v.z, act, sl.z), d.w * act_grad(v.w, act, sl.w));
                 } else {
-                    o = make_float4(act_apply(v.x, act, slope), act_apply(v.y, act, slope),
-                                    act_apply(v.z, act, slope), act_apply(v.w, act, slope));
+                    o = make_float4(act_apply(v.x, act, sl.x), act_apply(v.y, act, sl.y),
+                                    act_apply(v.z, act, sl.z), act_apply(v.w, act, sl.w));
                 }
                 stf4(out + r * ldo + c, o);
             } else {
                 float v = ld1(x + r * ldx + c) + (res ? ld1(res + r * ldres + c) : 0.f);
-                st1(out + r * ldo + c, BWD ? ld1(dy + r * lddy + c) * act_grad(v, act, slope) : act_apply(v, act, slope));
+                st1(out + r * ldo + c, BWD ? ld1(dy + r * lddy + c) * act_grad(v, act, sl.x) : act_apply(v, act, sl.x));
             }
         }
     }

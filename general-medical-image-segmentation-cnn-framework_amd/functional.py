@@ -701,6 +701,44 @@ def activation(x, act, slope=0.01, residual=None):
     return _Act.apply(x, residual, int(act), float(slope))
 
 
+class _PReLU(Function):
+    @staticmethod
+    def forward(ctx, x, res, slope):
+        x, ldx = cl_view(x, "prelu input")
+        N, D, H, W, C = x.shape
+        if res is not None:
+            res, ldres = cl_view(res, "prelu residual")
+        else:
+            ldres = 0
+        slope = slope.contiguous().to(torch.float32)
+        if slope.numel() != C:
+            raise Mi355SegError(f"prelu: {slope.numel()} slopes for {C} channels")
+        y = torch.empty((N, D, H, W, C), dtype=x.dtype, device=x.device)
+        rows = N * D * H * W
+        lib().call("mi355seg_prelu_fwd_" + _sfx(x), _p(x), ldx, _p(res), ldres, _p(slope), _p(y), C, rows, C, _stream())
+        ctx.save_for_backward(x, res, slope)
+        ctx.cfg = (ldx, ldres, rows, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, res, slope = ctx.saved_tensors
+        ldx, ldres, rows, C = ctx.cfg
+        dy, lddy = cl_view(_like(dy, x), "prelu grad")
+        L = lib()
+        dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        dslope = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = workspace(L.query("mi355seg_norm_ws_bytes", rows, 1, C), x.device)
+        L.call("mi355seg_prelu_bwd_" + _sfx(x), _p(dy), lddy, _p(x), ldx, _p(res), ldres, _p(slope), _p(dx), C, _p(dslope), rows, C,
+               _p(ws), ws.numel(), _stream())
+        return dx, (dx if res is not None else None), dslope
+
+
+def prelu(x, weight, residual=None):
+    """nn.PReLU(C)(x [+ residual]) with one learnable slope per channel (vnet3d.py:14-18, elu=False)."""
+    return _PReLU.apply(x, residual, weight)
+
+
 class _ScaleChannels(Function):
     @staticmethod
     def forward(ctx, x, scale):

@@ -114,6 +114,13 @@ class ELU(nn.ELU):
         return F.activation(x, F.ACT_ELU)
 
 
+class PReLU(nn.PReLU):
+    """nn.PReLU(num_parameters = channels): same parameter (``weight``), one HIP launch forward, two backward."""
+
+    def forward(self, x, residual=None):
+        return F.prelu(x, self.weight, residual=residual)
+
+
 class LeakyReLU(nn.LeakyReLU):
     def forward(self, x):
         return F.activation(x, F.ACT_LRELU, self.negative_slope)

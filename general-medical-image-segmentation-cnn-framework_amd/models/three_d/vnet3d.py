@@ -4,13 +4,13 @@ Interface contract kept from the reference: ``VNet(elu=True, in_channels=1, clas
 ``state_dict`` keys ``in_tr.conv1.weight`` ... ``out_tr.conv2.bias`` and the forward
 semantics of vnet3d.py:146-157.  Everything else is organised for the kernels: activations stay channel-last,
 every BatchNorm is one fused launch with the residual add and the ELU that follow it (vnet3d.py:57-58,79,103),
-and the channel concat / repeat are strided slice copies.  Only the default ``elu=True`` branch exists (the
-PReLU branch is dead at the reference's defaults).
+and the channel concat / repeat are strided slice copies.  ``elu=False`` (nn.PReLU per unit, vnet3d.py:14-18) keeps the same
+kernels with the activation un-fused: BatchNorm without activation, then the per-channel-slope PReLU launch.
 """
 import torch.nn as nn
 
 from ... import functional as F
-from ...layers import BatchNorm3d, Conv3d, ConvTranspose3d, Dropout3d, ELU
+from ...layers import BatchNorm3d, Conv3d, ConvTranspose3d, Dropout3d, ELU, PReLU
 
 _K5 = dict(kernel_size=5, padding=2)
 _STEM_WIDTH = 16
@@ -19,14 +19,29 @@ _ENCODER = (("down_tr32", 16, 1), ("down_tr64", 32, 2), ("down_tr128", 64, 3), (
 _DECODER = (("up_tr256", 256, 256, 2), ("up_tr128", 256, 128, 2), ("up_tr64", 128, 64, 1), ("up_tr32", 64, 32, 1))
 
 
-def _act_module(elu):
-    if not elu:
-        raise NotImplementedError("VNet(elu=False) (PReLU) is not implemented; the reference default is elu=True")
-    return ELU(inplace=True)
+def _act_module(elu, nchan):
+    """ELUCons of vnet3d.py:14-18."""
+    return ELU(inplace=True) if elu else PReLU(nchan)
 
 
-def _bn_elu(bn, conv_out, residual=None):
-    return bn.forward_act(conv_out, F.ACT_ELU, residual=residual)
+def _bn_act(bn, conv_out, relu, residual=None):
+    """relu(bn(conv_out) [+ residual]): one fused launch for ELU; BatchNorm, then the PReLU launch otherwise."""
+    if isinstance(relu, ELU):
+        return bn.forward_act(conv_out, F.ACT_ELU, residual=residual)
+    return relu(bn.forward_act(conv_out, F.ACT_NONE), residual=residual)
+
+
+def _conv_bn_act(x, conv, bn, relu):
+    """relu(bn(conv(x))) with the batch statistics out of the convolution's epilogue."""
+    if isinstance(relu, ELU):
+        return F.conv_bn_act(x, conv, bn, F.ACT_ELU)
+    return relu(F.conv_bn_act(x, conv, bn, F.ACT_NONE))
+
+
+def _add_act(x, residual, relu):
+    if isinstance(relu, ELU):
+        return F.activation(x, F.ACT_ELU, residual=residual)
+    return relu(x, residual=residual)
 
 
 class LUConv(nn.Module):
@@ -34,13 +49,13 @@ class LUConv(nn.Module):
 
     def __init__(self, width, elu):
         super().__init__()
-        self.relu1 = _act_module(elu)
+        self.relu1 = _act_module(elu, width)
         self.conv1 = Conv3d(width, width, **_K5)
         self.bn1 = BatchNorm3d(width)
 
     def forward(self, x):
         # conv + batch statistics (conv epilogue) + BN + ELU as one autograd node; the bias gradient comes out of the BN backward
-        return F.conv_bn_act(x, self.conv1, self.bn1, F.ACT_ELU)
+        return _conv_bn_act(x, self.conv1, self.bn1, self.relu1)
 
 
 def _make_nConv(width, units, elu):
@@ -55,11 +70,11 @@ class InputTransition(nn.Module):
         self.in_channels, self.num_features = in_channels, _STEM_WIDTH
         self.conv1 = Conv3d(in_channels, _STEM_WIDTH, **_K5)
         self.bn1 = BatchNorm3d(_STEM_WIDTH)
-        self.relu1 = _act_module(elu)
+        self.relu1 = _act_module(elu, _STEM_WIDTH)
 
     def forward(self, x):
         tiled = F.repeat_channels(x, self.num_features // self.in_channels)
-        return _bn_elu(self.bn1, self.conv1(x), residual=tiled)
+        return _bn_act(self.bn1, self.conv1(x), self.relu1, residual=tiled)
 
 
 class DownTransition(nn.Module):
@@ -69,13 +84,13 @@ class DownTransition(nn.Module):
         super().__init__()
         self.down_conv = Conv3d(cin, 2 * cin, kernel_size=2, stride=2)
         self.bn1 = BatchNorm3d(2 * cin)
-        self.relu1, self.relu2 = _act_module(elu), _act_module(elu)
+        self.relu1, self.relu2 = _act_module(elu, 2 * cin), _act_module(elu, 2 * cin)
         self.do1 = Dropout3d() if dropout else nn.Identity()
         self.ops = _make_nConv(2 * cin, units, elu)
 
     def forward(self, x):
-        down = F.conv_bn_act(x, self.down_conv, self.bn1, F.ACT_ELU)
-        return F.activation(self.ops(self.do1(down)), F.ACT_ELU, residual=down)
+        down = _conv_bn_act(x, self.down_conv, self.bn1, self.relu1)
+        return _add_act(self.ops(self.do1(down)), down, self.relu2)
 
 
 class UpTransition(nn.Module):
@@ -87,14 +102,14 @@ class UpTransition(nn.Module):
         self.bn1 = BatchNorm3d(cout // 2)
         self.do1 = Dropout3d() if dropout else nn.Identity()
         self.do2 = Dropout3d()
-        self.relu1, self.relu2 = _act_module(elu), _act_module(elu)
+        self.relu1, self.relu2 = _act_module(elu, cout // 2), _act_module(elu, cout)
         self.ops = _make_nConv(cout, units, elu)
 
     def forward(self, x, skipx):
         kept_skip = self.do2(skipx)                      # the reference draws the skip mask first (vnet3d.py:99)
-        up = _bn_elu(self.bn1, self.up_conv(self.do1(x)))
+        up = _bn_act(self.bn1, self.up_conv(self.do1(x)), self.relu1)
         both = F.cat_channels(up, kept_skip)
-        return F.activation(self.ops(both), F.ACT_ELU, residual=both)
+        return _add_act(self.ops(both), both, self.relu2)
 
 
 class OutputTransition(nn.Module):
@@ -106,10 +121,10 @@ class OutputTransition(nn.Module):
         self.conv1 = Conv3d(in_channels, classes, **_K5)
         self.bn1 = BatchNorm3d(classes)
         self.conv2 = Conv3d(classes, classes, kernel_size=1)
-        self.relu1 = _act_module(elu)
+        self.relu1 = _act_module(elu, classes)
 
     def forward(self, x):
-        return self.conv2(F.conv_bn_act(x, self.conv1, self.bn1, F.ACT_ELU))
+        return self.conv2(_conv_bn_act(x, self.conv1, self.bn1, self.relu1))
 
 
 class VNet(nn.Module):

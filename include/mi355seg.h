@@ -223,6 +223,14 @@ int mi355seg_act_fwd_f32(const float* x, int ldx, const float* res, int ldres, f
 int mi355seg_act_bwd_f32(const float* dy, int lddy, const float* x, int ldx, const float* res, int ldres,
                          float* dx, int lddx, long long rows, int C, int act, float slope, void* stream);
 
+/* nn.PReLU(C) -- V-Net's elu=False branch (vnet3d.py:14-18): y = max(z, 0) + slope[c] * min(z, 0), z = x [+ res].
+ * Backward: dx = dy * (z > 0 ? 1 : slope[c]); dslope[c] = sum over rows of dy * min(z, 0) (two-stage, deterministic).
+ * ws for the backward: mi355seg_norm_ws_bytes(rows, 1, C). */
+int mi355seg_prelu_fwd_f32(const float* x, int ldx, const float* res, int ldres, const float* slope, float* y, int ldy,
+                           long long rows, int C, void* stream);
+int mi355seg_prelu_bwd_f32(const float* dy, int lddy, const float* x, int ldx, const float* res, int ldres, const float* slope,
+                           float* dx, int lddx, float* dslope, long long rows, int C, void* ws, size_t ws_bytes, void* stream);
+
 /* nn.Dropout3d (vnet3d.py:90,99; residual_unet3d.py:18): y[r,c] = x[r,c] * scale[g*C + c], the per-(sample,
  * channel) keep-mask / (1-p) being supplied by the caller (device RNG in production, the oracle's mask in
  * parity tests).  The backward is the same call on dy. */
@@ -417,6 +425,8 @@ int mi355seg_norm_act_bwd_apply_bf16(const mi355seg_bf16* dy, int lddy, const mi
 int mi355seg_scale_channels_bf16(const mi355seg_bf16* x, int ldx, const float* scale, mi355seg_bf16* y, int ldy, long long rows, int groups, int C, void* stream);
 int mi355seg_act_fwd_bf16(const mi355seg_bf16* x, int ldx, const mi355seg_bf16* res, int ldres, mi355seg_bf16* y, int ldy, long long rows, int C, int act, float slope, void* stream);
 int mi355seg_act_bwd_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, const mi355seg_bf16* res, int ldres, mi355seg_bf16* dx, int lddx, long long rows, int C, int act, float slope, void* stream);
+int mi355seg_prelu_fwd_bf16(const mi355seg_bf16* x, int ldx, const mi355seg_bf16* res, int ldres, const float* slope, mi355seg_bf16* y, int ldy, long long rows, int C, void* stream);
+int mi355seg_prelu_bwd_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, const mi355seg_bf16* res, int ldres, const float* slope, mi355seg_bf16* dx, int lddx, float* dslope, long long rows, int C, void* ws, size_t ws_bytes, void* stream);
 int mi355seg_maxpool2_fwd_bf16(const mi355seg_bf16* x, int ldx, mi355seg_bf16* y, int ldy, uint8_t* idx, int N, int D, int H, int W, int C, void* stream);
 int mi355seg_maxpool2_bwd_bf16(const mi355seg_bf16* dy, int lddy, const uint8_t* idx, mi355seg_bf16* dx, int lddx, int N, int D, int H, int W, int C, void* stream);
 int mi355seg_maxpool2_bwd_add_bf16(const mi355seg_bf16* dy, int lddy, const uint8_t* idx, const mi355seg_bf16* add, int ldadd, mi355seg_bf16* dx, int lddx, int N, int D, int H, int W, int C, void* stream);

@@ -31,6 +31,8 @@ def fill_module_(module: torch.nn.Module) -> torch.nn.Module:
             v = 1.0 + 0.1 * np.cos(0.23 * idx + ph)
         elif t.dim() == 1 and ("norm" in name or "bn" in name) and name.endswith("weight"):
             v = 1.0 + 0.1 * np.sin(0.61 * idx + ph)                 # norm gamma
+        elif t.dim() == 1 and "relu" in name and name.endswith("weight"):
+            v = 0.25 + 0.15 * np.sin(0.53 * idx + ph)               # nn.PReLU slopes (default 0.25)
         elif t.dim() == 1:
             v = 0.05 * np.sin(0.71 * idx + ph)                      # biases / norm beta
         else:
@@ -73,6 +75,8 @@ def fill_module_hash_(module: torch.nn.Module, scale_by_name=None) -> torch.nn.M
             v = 1.0 + 0.1 * np.cos(0.23 * idx + ph)
         elif t.dim() == 1 and ("norm" in name or "bn" in name) and name.endswith("weight"):
             v = 1.0 + 0.1 * np.sin(0.61 * idx + ph)
+        elif t.dim() == 1 and "relu" in name and name.endswith("weight"):
+            v = 0.25 + 0.15 * np.sin(0.53 * idx + ph)
         elif t.dim() == 1:
             v = 0.05 * np.sin(0.71 * idx + ph)
         else:

@@ -71,6 +71,47 @@ def test_vnet_train_step_vs_reference_fixture(seg, golden_dir):
     assert np.abs(gn - g["gradnorm"]).max() <= 3e-4 * g["gradnorm"].max()
 
 
+def test_vnet_prelu_branch_vs_reference_fixture(seg, golden_dir):
+    """VNet(elu=False): nn.PReLU per unit (vnet3d.py:14-18).  Same schema as the reference (the slopes are `relu*.weight`); logits and
+    loss against the fixture of the imported reference.  The gradients of this variant are ill-conditioned at 32^3 (BatchNorm over
+    16 voxels at the bottom): the reference's own fp32 gradients sit up to 3.5e-4 (relative) from an fp64 run of the same network,
+    so they are graded against that fp64 run -- never further from it than twice the reference is, and within the plain 3e-4."""
+    from mi355seg.models.three_d.vnet3d import VNet
+    from oracle.nets import VNet as OracleVNet
+    g = np.load(os.path.join(golden_dir, "vnet_prelu_32.npz"))
+    masks = _masks(g)
+    x = make_input((2, 1, 32, 32, 32))
+    gt2 = two_channel_gt(make_labels((2, 1, 32, 32, 32)))
+    o = fill_module_(OracleVNet(elu=False, in_channels=1, classes=2)).double().train()
+    queue = [mk.double() / 0.5 for mk in masks]
+    for mod in o.modules():
+        if isinstance(mod, torch.nn.Dropout3d):
+            mod.forward = lambda t: t * queue.pop(0).reshape(t.shape[0], t.shape[1], 1, 1, 1)
+    torch.nn.functional.binary_cross_entropy_with_logits(o(x.double()), gt2.double()).backward()
+    truth = {k: p.grad for k, p in o.named_parameters()}
+
+    m = fill_module_(VNet(elu=False, in_channels=1, classes=2)).cuda().train()
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in o.state_dict().items()}
+    for layer, mk in zip(m.dropout_layers(), masks):
+        layer.forced_masks = [mk]
+    pred = m(x.cuda())
+    loss = seg.functional.bce_with_logits(pred, gt2.cuda())
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    assert np.abs(pred.detach().cpu().numpy() - g["pred"]).max() < TOL
+    params = dict(m.named_parameters())
+    nslope = 0
+    for k in g.files:
+        if k.startswith("grad/"):
+            t = _sample(truth[k[5:]]).astype(np.float64)
+            scale = max(1e-3, np.abs(t).max())
+            ref_err = np.abs(g[k] - t).max() / scale
+            err = np.abs(_sample(params[k[5:]].grad) - t).max() / scale
+            nslope += "relu" in k
+            assert err <= 3e-4 and err <= 2 * max(ref_err, 2e-5), (k, err, ref_err)
+    assert nslope >= 6
+
+
 def _sample_np(t, k=65536):
     f = t.detach().reshape(-1)
     step = max(1, f.numel() // k)

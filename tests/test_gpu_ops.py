@@ -653,3 +653,26 @@ def test_norm_statistics_are_accurate_and_shift_invariant(seg, shape, offset, sc
     assert ((rstd.cpu().double() * (v64 + 1e-5).sqrt()) - 1).abs().max() < 2e-6
     ref_rv = 0.9 + 0.1 * xd.var(0, unbiased=True)
     assert ((rv.cpu().double() - ref_rv).abs() / ref_rv).max() < 1e-6
+
+
+@pytest.mark.parametrize("C,res", [(32, True), (16, False), (6, True)])
+def test_prelu_against_aten(seg, C, res):
+    """nn.PReLU(C)(x [+ res]) (vnet3d.py:14-18, elu=False): values, dx, d(res) and the slope gradient."""
+    F = seg.functional
+    N, D, H, W = 2, 5, 6, 7
+    x, r = rnd(N, C, D, H, W, seed=1), (rnd(N, C, D, H, W, seed=2) if res else None)
+    a = 0.25 + 0.2 * rnd(C, seed=3)
+    g = rnd(N, C, D, H, W, seed=4)
+    xr, ar = x.clone().requires_grad_(True), a.clone().requires_grad_(True)
+    rr = None if r is None else r.clone().requires_grad_(True)
+    yr = TF.prelu(xr + rr if res else xr, ar)
+    yr.backward(g)
+    xg, ag = cl(x).requires_grad_(True), a.cuda().requires_grad_(True)
+    rg = None if r is None else cl(r).requires_grad_(True)
+    yg = F.prelu(xg, ag, residual=rg)
+    yg.backward(cl(g))
+    assert (cf(yg) - yr.detach()).abs().max() < 1e-6
+    assert (cf(xg.grad) - xr.grad).abs().max() < 1e-6
+    if res:
+        assert (cf(rg.grad) - rr.grad).abs().max() < 1e-6
+    assert rel_err(ag.grad.cpu(), ar.grad) < 1e-5

@@ -62,6 +62,23 @@ def test_vnet_bit_identical():
         assert torch.equal(ga[k], gb[k]), k
 
 
+def test_vnet_prelu_branch_bit_identical():
+    """elu=False: nn.PReLU(nchan) in place of every ELU (vnet3d.py:14-18), incl. the state_dict keys of the slopes."""
+    R = _ref("models.three_d.vnet3d", "VNet")
+    a = fill_module_(R(elu=False, in_channels=1, classes=2)).train()
+    b = fill_module_(nets.VNet(elu=False, in_channels=1, classes=2)).train()
+    _same_keys(a, b)
+    assert "down_tr64.relu2.weight" in b.state_dict() and b.state_dict()["up_tr128.relu1.weight"].shape == (64,)
+    x = make_input((2, 1, 16, 16, 16))
+    torch.manual_seed(3)
+    ya, ga = _fwd_bwd(a, x)
+    torch.manual_seed(3)
+    yb, gb = _fwd_bwd(b, x)
+    assert torch.equal(ya, yb)
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
+
+
 def test_resunet_bit_identical():
     R = _ref("models.three_d.residual_unet3d", "UNet")
     a = fill_module_(R(in_channels=4, n_classes=4, base_n_filter=4)).train()
