@@ -7,6 +7,7 @@
 #include "common.h"
 #include "internal.h"
 #include <string.h>
+#include <stdlib.h>
 
 namespace seg {
 
@@ -257,7 +258,7 @@ void wgrad_reduce(const float* part, float* dw, int splits, int T, int Cin, int 
     CIT = CIT < 1 ? 1 : (CIT > 32 ? 32 : CIT);
     if (CIT > Cin) CIT = Cin;
     auto blocks = [&](int cit) { return (long long)((Cout + 31) / 32) * ((Cin + cit - 1) / cit) * ((T + TT - 1) / TT); };
-    if (splits >= 8) {
+    if (splits >= 8) {               // (measured: no gain below 8 strips, the transposing kernel's coalesced writes win there)
         const long long total = (long long)T * Cin * Cout;
         hipLaunchKernelGGL(wgrad_reduce_cols_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, part, dw, splits, T, Cin, Cout, accumulate);
         return;
