@@ -13,7 +13,7 @@ Adam step, Dice counters.  Workload = BASELINE.json configs[1]: UNet3D(1,2,32), 
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel family = the implicit-GEMM conv kernel, timed live
 with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle == the reference's PyTorch-CPU arithmetic,
-timed in a child process on this box's host cores, started before the first GPU call and overlapped with the GPU run).
+timed in a child process on this box's host cores, started before the first GPU call and released after the last GPU leg).
 """
 import argparse
 import json
@@ -253,10 +253,11 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(sample_shape, steps=3, reserve=2):
+def cpu_baseline(sample_shape, steps=3, reserve=0, gate=None):
     """Oracle (== reference arithmetic on ATen CPU) train step timed on the host cores.  Runs in a child process
-    of its own (``--cpu-baseline-child``) that never touches the GPU; ``reserve`` cores are left to the GPU
-    process's launch thread, which runs at the same time."""
+    of its own (``--cpu-baseline-child``) that never touches the GPU.  The child is started before the parent's first GPU call
+    (a GPU-initialised process must not fork + exec), builds its model, then blocks on ``gate`` (stdin) until the parent has
+    finished every GPU leg: neither side's timing sees the other's load."""
     import torch
     from oracle.nets import UNet3D as OracleUNet
     from oracle.step import train_step as oracle_step, weights_init_normal
@@ -270,6 +271,8 @@ def cpu_baseline(sample_shape, steps=3, reserve=2):
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(sample_shape, generator=g)
     gt = (torch.rand(sample_shape, generator=g) > 0.9).float()
+    if gate is not None and not gate.readline():          # parent: "go" after its last GPU leg; EOF = the parent is gone
+        sys.exit(0)
     # warm-up at the TIMED shape (oneDNN primitive creation and the first touch of ~20 GB of activations stay out of the timed steps)
     oracle_step(m, opt, x, gt)
     times = []
@@ -283,8 +286,7 @@ def cpu_baseline(sample_shape, steps=3, reserve=2):
             "best_step_value": vox / min(times), "step_seconds": [round(t, 3) for t in times],
             "sample": f"1 warm-up + {steps} timed train steps (mean) of the CPU oracle (reference arithmetic on ATen-CPU, anomaly mode off), all "
                       f"on x={list(sample_shape)} fp32 (cfg 2's full batch), {dt:.2f} s/step (best {min(times):.2f}), {cores} threads; the child "
-                      f"process runs BESIDE the GPU legs ({reserve} cores of the box's share are left to the GPU process's launch thread), so "
-                      f"this is a lower bound of what the idle host would do"}
+                      f"process is started before the first GPU call and runs AFTER the last GPU leg (host otherwise idle)"}
 
 
 def parse_args():
@@ -348,7 +350,7 @@ def main():
     args = parse_args()
     if args.cpu_baseline_child:
         shape = tuple(int(v) for v in args.cpu_sample.split(","))
-        print(json.dumps(cpu_baseline(shape, steps=args.cpu_steps)))
+        print(json.dumps(cpu_baseline(shape, steps=args.cpu_steps, gate=sys.stdin)))
         return 0
 
     # ---- start the ranks ourselves when nobody else did (no GPU call has happened in this process)
@@ -362,9 +364,9 @@ def main():
     rank_env, world_env = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     cpu_child = None
     if rank_env == 0 and world_env == 1 and not args.no_cpu_baseline and not args.rehearse_cpu:
-        # CPU baseline in its own process, started BEFORE the first GPU call and running beside the GPU work
+        # CPU baseline in its own process, started BEFORE the first GPU call; it waits at a gate until the GPU legs are done
         cpu_child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--cpu-sample", args.cpu_sample, "--cpu-steps", str(args.cpu_steps)],
-                                     stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                                     stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
 
     import torch
     import torch.distributed as dist
@@ -597,7 +599,7 @@ def main():
 
     if cpu_child is not None:
         try:
-            txt, _ = cpu_child.communicate(timeout=600)
+            txt, _ = cpu_child.communicate("go\n", timeout=600)
             res["cpu_baseline"] = json.loads(txt.strip().splitlines()[-1])
             res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
         except Exception as e:          # the GPU numbers stand on their own; say why the CPU leg is missing
