@@ -379,7 +379,7 @@ size_t conv_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, 
             IgemmPlan p;
             if (!igemm_plan(math, k, N, D, H, W, ci, co, 1, &p)) continue;
             const int ks = pick_ksplit(p.nM * p.nN, ci / p.CK);
-            size_t need = align_up(wq_bytes(math, T * Cin * Cout), 256) + align_up((size_t)p.nM * co * 3 * sizeof(float), 256) +
+            size_t need = align_up(wq_bytes(math, T * Cin * Cout), 256) + align_up((size_t)p.nM * co * 3 * sizeof(float), 256) + part_reduce_ws_bytes(co) +
                           (ks > 1 ? align_up((size_t)ks * N * D * H * W * co * sizeof(float), 256) + colsum_ws_bytes(co) : 0) + 1024;
             if (need > best) best = need;
         }
@@ -465,6 +465,7 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
     // the BatchNorm-backward sums of the layer in front ride in that kernel's epilogue (whole-K launches only)
     const bool bn_epi = bne && x3s && ksplit == 1 && !ssum && !bias && !act && (bne->ldx % 4) == 0 && ((uintptr_t)bne->x % 16) == 0 && Cout % 4 == 0;
     float* bnpart = bn_epi ? cv.take<float>((size_t)p.nM * Cout * 2) : nullptr;
+    double* rtmp = (bn_epi || spart) ? reinterpret_cast<double*>(cv.take<char>(part_reduce_ws_bytes(Cout))) : nullptr;
     size_t tail = cv.used();
     SEG_CHECK_WS(tail + ((ssum && ksplit > 1) ? colsum_ws_bytes(Cout) : 0), ws_bytes);
     const bool w16 = ((uintptr_t)w % 16) == 0;                     // the tiled packings read W in 16-byte pieces
@@ -498,7 +499,7 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
         }
     }
     if (bn_epi) {
-        norm_bwd_finalize(bnpart, p.nM, Cout, bne->s1, bne->s2, bne->dgamma, bne->dbeta, st);
+        norm_bwd_finalize(bnpart, p.nM, Cout, bne->s1, bne->s2, bne->dgamma, bne->dbeta, rtmp, st);
         SEG_CHECK_LAUNCH();
         bne->done = 1;
     }
@@ -507,7 +508,8 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
             if (math == MATH_B16) return channel_sums((const bf16*)y, ldy, nvox, Cout, ssum, ssq, nullptr, 0, (char*)ws + tail, ws_bytes - tail, st);
             return channel_sums((const float*)y, ldy, nvox, Cout, ssum, ssq, nullptr, 0, (char*)ws + tail, ws_bytes - tail, st);
         }
-        hipLaunchKernelGGL(igemm_stats_finalize_kernel, dim3(Cout), dim3(256), 0, st, spart, p.nM, Cout, ssum, ssq);
+        if (!tile_stats_finalize2(spart, p.nM, Cout, ssum, ssq, rtmp, st))
+            hipLaunchKernelGGL(igemm_stats_finalize_kernel, dim3(Cout), dim3(256), 0, st, spart, p.nM, Cout, ssum, ssq);
         SEG_CHECK_LAUNCH();
     }
     return MI355SEG_OK;

@@ -109,7 +109,10 @@ struct BnBwdEpi {
     const float* x; int ldx; const float* mean; const float* rstd; const float* gamma; const float* beta; int act; float slope;
     float* s1; float* s2; float* dgamma; float* dbeta; int done;
 };
-void norm_bwd_finalize(const float* part, int nblk, int C, float* s1, float* s2, float* dgamma, float* dbeta, hipStream_t st);   // norm.hip
+// norm.hip: per-tile epilogue partials -> per-channel totals (two-stage when there are many tiles; tmp = part_reduce_ws_bytes(C) of scratch)
+size_t part_reduce_ws_bytes(int C);
+void norm_bwd_finalize(const float* part, int nblk, int C, float* s1, float* s2, float* dgamma, float* dbeta, double* tmp, hipStream_t st);
+bool tile_stats_finalize2(const float* spart, int nM, int C, double* sum, double* sq, double* tmp, hipStream_t st);
 int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int N, int D, int H, int W,
                   int Cin, int Cout, int k, int dgrad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st,
                   const float* oscale = nullptr, int act = 0, float slope = 0.f, BnBwdEpi* bne = nullptr);
