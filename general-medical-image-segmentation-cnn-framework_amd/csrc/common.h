@@ -93,16 +93,18 @@ __device__ __forceinline__ void st4(bf16* p, f32x4_t v) {
     q[0] = (bf16)v[0]; q[1] = (bf16)v[1]; q[2] = (bf16)v[2]; q[3] = (bf16)v[3];
     *reinterpret_cast<bf16x4_t*>(p) = q;
 }
-// the same for HIP's float4 struct (.x .y .z .w), which the streaming kernels are written in
-__device__ __forceinline__ float4 ldf4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// the same for HIP's float4 struct (.x .y .z .w), which the streaming kernels are written in.  fp32 tensors: non-temporal loads and
+// stores (every elementwise / reduction pass touches each byte once and the tensors are far larger than L2 + Infinity Cache;
+// measured on cfg 2: norm / pool / stem-head families -3 %; the bf16 tensors of cfg 3 lost 1 % under the same policy and keep the default)
+__device__ __forceinline__ float4 ldf4(const float* p) { const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p)); return make_float4(v[0], v[1], v[2], v[3]); }
 __device__ __forceinline__ float4 ldf4(const bf16* p) {
     const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(p);
     return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
 // ld8 / st8: eight consecutive elements as floats (32 bytes of fp32, 16 of bf16; the pointer must be aligned to that)
 __device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
-    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    const f32x4_t a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p)), b = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p + 4));
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
 }
 __device__ __forceinline__ void ld8(const bf16* p, float (&v)[8]) {
     const bf16x8_t q = *reinterpret_cast<const bf16x8_t*>(p);
@@ -110,8 +112,8 @@ __device__ __forceinline__ void ld8(const bf16* p, float (&v)[8]) {
     for (int j = 0; j < 8; ++j) v[j] = (float)q[j];
 }
 __device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
-    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    __builtin_nontemporal_store(f32x4_t{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4_t*>(p));
+    __builtin_nontemporal_store(f32x4_t{v[4], v[5], v[6], v[7]}, reinterpret_cast<f32x4_t*>(p + 4));
 }
 __device__ __forceinline__ void st8(bf16* p, const float (&v)[8]) {
     bf16x8_t q;
@@ -119,7 +121,7 @@ __device__ __forceinline__ void st8(bf16* p, const float (&v)[8]) {
     for (int j = 0; j < 8; ++j) q[j] = (bf16)v[j];
     *reinterpret_cast<bf16x8_t*>(p) = q;
 }
-__device__ __forceinline__ void stf4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void stf4(float* p, float4 v) { __builtin_nontemporal_store(f32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4_t*>(p)); }
 __device__ __forceinline__ void stf4(bf16* p, float4 v) {
     bf16x4_t q;
     q[0] = (bf16)v.x; q[1] = (bf16)v.y; q[2] = (bf16)v.z; q[3] = (bf16)v.w;
