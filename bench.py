@@ -217,6 +217,31 @@ def run_leg(L, dev, name, net, shape, classes, loss_kind, flop_per_vox, steps, w
                            "note": "same weights and batch, random-init network on random labels; fp32 = bf16x6 / fp32 MFMA convolutions. "
                                    "bf16 does not meet north_star's 1e-4 Dice bar (an fp32 bar): argmax flips where the logit margin is below the bf16 "
                                    "deviation, as for the reference under torch.autocast(bfloat16) (tests/golden/bf16_reference_deviation.json)"}
+    if classes == 2:
+        # the same iteration captured once into a HIP graph and replayed (engine.GraphedTrainStep = `config.hip_graph=true` of train.py):
+        # what a launch-bound step gains when the host no longer enqueues every kernel (UNETR's token path: ~1300 launches per step)
+        try:
+            import gc
+            from mi355seg.engine import GraphedTrainStep
+            out = {"loss": out["loss"].detach().clone()}    # drop the eager iterations' autograd graphs (see GraphedTrainStep)
+            for p_ in model.parameters():
+                p_.grad = None
+            gc.collect()
+            opt_g = make_adam(model.parameters(), lr=1e-3, capturable=True)
+            gs = GraphedTrainStep(model, opt_g, x, gt, warmup=2, dtype=torch.bfloat16)
+            for _ in range(2):
+                gs(x, gt, sync_metric=False)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(steps):
+                gs(x, gt, sync_metric=False)
+            torch.cuda.synchronize()
+            msg = (time.perf_counter() - t2) / steps * 1e3
+            leg["hip_graph"] = {"ms_per_step": msg, "voxels_per_s": vox / (msg * 1e-3), "speedup_over_eager": ms / msg,
+                                "note": "one hipGraphLaunch per iteration, same kernels and arithmetic; `ms_per_step` above is the eager loop"}
+            del gs, opt_g
+        except Exception as e:
+            leg["hip_graph"] = {"error": repr(e)}
     del model, opt, x, out
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats()

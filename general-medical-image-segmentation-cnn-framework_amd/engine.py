@@ -92,10 +92,14 @@ class GraphedTrainStep:
     constructed with ``capturable=True`` (its step counter lives on the device), the in-library kernel profiler
     off, and a single process (the data-parallel gradient hooks are not captured).  Three eager warm-up steps run
     on a side stream first -- they size the workspace and set the kernels' LDS attributes -- and, like the captured
-    step, they DO update the model, so a freshly built instance has already taken ``warmup`` optimiser steps.
+    step, they DO update the model, so a freshly built instance has already taken ``warmup`` optimiser steps (``first`` holds
+    the loss and the Dice counters of the last of them).  Build it BEFORE any eager iteration of the same model, or after every
+    reference to an earlier iteration's outputs is gone: a parameter's AccumulateGrad node survives as long as an old autograd
+    graph does, stays bound to the stream it was created on (the default stream), and a default-stream node inside the capture
+    takes the process down in hipStreamEndCapture.
     Returned tensors are static buffers overwritten by the next call."""
 
-    def __init__(self, model, optimizer, x, gt, criterion=None, warmup=3):
+    def __init__(self, model, optimizer, x, gt, criterion=None, warmup=3, dtype=None):
         from ._lib import lib
         if not all(g.get("capturable", False) for g in optimizer.param_groups):
             raise ValueError("GraphedTrainStep: build the optimizer with capturable=True (e.g. torch.optim.Adam(..., capturable=True))")
@@ -106,13 +110,16 @@ class GraphedTrainStep:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            self.first = None
             for _ in range(warmup):
-                train_step(model, optimizer, self.x, self.gt, criterion, sync_metric=False)
+                o = train_step(model, optimizer, self.x, self.gt, criterion, sync_metric=False, dtype=dtype)
+                self.first = {"loss": o["loss"].detach().clone(), "counts": o["counts"].clone()}
+                del o
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.out = train_step(model, optimizer, self.x, self.gt, criterion, sync_metric=False)
+            self.out = train_step(model, optimizer, self.x, self.gt, criterion, sync_metric=False, dtype=dtype)
 
     def __call__(self, x, gt, sync_metric=True):
         self.x.copy_(x, non_blocking=True)

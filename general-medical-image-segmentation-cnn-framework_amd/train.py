@@ -16,7 +16,8 @@ from torch.optim.lr_scheduler import StepLR
 from . import distributed as D
 from .config import compose, parse_patch_size
 from .data import make_loader
-from .engine import make_adam, mixed_precision_dtype, train_step, weights_init_normal
+from .utils.metric import metric_from_counts
+from .engine import GraphedTrainStep, make_adam, mixed_precision_dtype, train_step, weights_init_normal
 from .registry import build_model
 
 
@@ -47,7 +48,12 @@ def train(config, model, logger):
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     model = model.to(device)
-    optimizer = make_adam(model.parameters(), lr=config.init_lr)                 # train.py:109 (torch's fused single-kernel Adam on the GPU)
+    # config.hip_graph=true (single process): the whole iteration is captured once and replayed -- for launch-bound shapes (64^3
+    # patches, UNETR's token path); the learning rate then lives in a device tensor so that StepLR still reaches the captured step
+    hg = config.get("hip_graph") if hasattr(config, "get") else getattr(config, "hip_graph", False)
+    hip_graph = str(hg).lower() in ("1", "true", "yes") and world == 1
+    optimizer = make_adam(model.parameters(), lr=torch.tensor(float(config.init_lr), device=device), capturable=True) if hip_graph \
+        else make_adam(model.parameters(), lr=config.init_lr)                   # train.py:109 (torch's fused single-kernel Adam on the GPU)
     scheduler = StepLR(optimizer, step_size=config.scheduler_step_size, gamma=config.scheduler_gamma) \
         if config.use_scheduler else None                                       # train.py:119-120
     elapsed_epochs = 0
@@ -70,6 +76,7 @@ def train(config, model, logger):
     if act_dtype != torch.float32:
         logger.info(f"mixed precision: activations in {act_dtype} (fp32 parameters, gradients, statistics, loss)")
     epochs = config.epochs - elapsed_epochs
+    graphed = None
     iteration = elapsed_epochs * len(loader)
     loss_meter, dice_meter = AverageMeter(), AverageMeter()
     for epoch in range(elapsed_epochs + 1, elapsed_epochs + epochs + 1):
@@ -79,7 +86,16 @@ def train(config, model, logger):
             x, gt = batch["source"]["data"], batch["gt"]["data"]
             if world > 1:
                 D.broadcast_buffers(model)
-            out = train_step(model, optimizer, x, gt, grad_hook=reducer, dtype=act_dtype)        # train.py:187-221
+            if hip_graph and graphed is None:
+                # the first iteration runs inside the constructor (eager, on the capture stream: workspaces sized, kernel attributes
+                # set, the parameters' gradient accumulators created there), then the iteration is captured for the following ones
+                graphed = GraphedTrainStep(model, optimizer, x, gt, warmup=1, dtype=act_dtype)
+                out = dict(graphed.first)
+                out["jaccard"], out["dice"] = metric_from_counts(out["counts"].cpu().tolist())
+            elif hip_graph:
+                out = graphed(x, gt)
+            else:
+                out = train_step(model, optimizer, x, gt, grad_hook=reducer, dtype=act_dtype)    # train.py:187-221
             iteration += 1
             loss_meter.update(out["loss"].item(), x.size(0))
             dice_meter.update(out["dice"], x.size(0))

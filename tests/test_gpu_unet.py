@@ -140,6 +140,32 @@ def test_train_cli_checkpoints_and_resume(seg, tmp_path):
     assert len(lines) == 2 and "Training/dice" in lines[0]
 
 
+def test_train_cli_hip_graph_matches_eager(seg, tmp_path):
+    """config.hip_graph=true: the iteration is captured after the first (eager) one and replayed; with StepLR stepping every epoch
+    (the learning rate lives in a device tensor) the run must land on the eager run's checkpoint (same seeds, same data)."""
+    from mi355seg.train import main
+    common = ["config=unet", "config.patch_size=32,32,32", "config.batch_size=1", "config.iters_per_epoch=3", "config.epochs=2",
+              "config.scheduler_step_size=1"]
+    torch.manual_seed(5)                   # train.py draws the initial weights from the global RNG (weights_init_normal, no seed of its own)
+    cfg_a, res_a = main(common + [f"config.output_dir={tmp_path / 'eager'}"])
+    torch.manual_seed(5)
+    cfg_b, res_b = main(common + [f"config.output_dir={tmp_path / 'graph'}", "config.hip_graph=true"])
+    a = torch.load(os.path.join(cfg_a.hydra_path, "latest_checkpoint.pt"), map_location="cpu")
+    b = torch.load(os.path.join(cfg_b.hydra_path, "latest_checkpoint.pt"), map_location="cpu")
+    # same kernels and order; the capturable Adam keeps lr / step / bias corrections in fp32 on the device (host doubles otherwise),
+    # so the two runs agree to rounding, not to the bit
+    assert abs(res_a["loss_avg"] - res_b["loss_avg"]) < 1e-4
+    for k in a["model"]:
+        if a["model"][k].is_floating_point():
+            # an Adam step moves an element by at most ~lr whatever the gradient's size, so rounding-level gradient differences on
+            # near-zero-gradient elements show up at the scale of lr: bound = the six steps' total reach (the loss agrees to 1e-5)
+            if "running" not in k:
+                assert (a["model"][k] - b["model"][k]).abs().max() <= 6 * 1e-3, k
+        else:
+            assert torch.equal(a["model"][k], b["model"][k]), k
+    assert abs(float(b["optim"]["param_groups"][0]["lr"]) - 0.001 * 0.8 ** 2) < 1e-9
+
+
 def test_predict_cli_sliding_window(seg, tmp_path):
     """predict.py: checkpoint load, eval-mode BN (running stats), grid patches + crop aggregation, metrics.csv."""
     from mi355seg.predict import main as predict_main, sliding_window_predict
