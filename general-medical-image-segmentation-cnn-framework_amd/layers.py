@@ -98,7 +98,7 @@ class Dropout3d(nn.Dropout3d):
         if self.forced_masks:
             keep = self.forced_masks.pop(0).to(device=x.device, dtype=torch.float32).reshape(N, C)
         else:
-            keep = torch.bernoulli(torch.full((N, C), 1.0 - self.p, device=x.device))
+            keep = torch.empty((N, C), device=x.device).bernoulli_(1.0 - self.p)     # one launch (no probability tensor to fill)
         return F.scale_channels(x, keep / (1.0 - self.p))
 
 
@@ -162,7 +162,7 @@ class Dropout(nn.Dropout):
     def draw(self, shape, device):
         if self.forced_masks:
             return self.forced_masks.pop(0).to(device=device, dtype=torch.float32).reshape(shape) / (1.0 - self.p)
-        return torch.bernoulli(torch.full(shape, 1.0 - self.p, device=device)) / (1.0 - self.p)
+        return torch.empty(shape, device=device).bernoulli_(1.0 - self.p).div_(1.0 - self.p)
 
     def forward(self, x):
         if not self.training or self.p == 0.0:
