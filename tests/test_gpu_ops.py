@@ -164,7 +164,8 @@ def test_conv3d_channel_slices_and_no_bias(seg):
 @pytest.mark.parametrize("case", [(2, 4, 4, 4, 16, 8), (1, 8, 8, 8, 64, 32), (1, 3, 5, 4, 6, 10), (2, 2, 2, 2, 512, 256),
                                   (2, 8, 8, 8, 512, 256), (1, 16, 16, 16, 128, 64), (1, 16, 32, 32, 64, 32),
                                   (1, 6, 6, 6, 64, 32), (1, 3, 5, 6, 32, 32), (2, 12, 12, 12, 128, 64),
-                                  (1, 8, 8, 16, 64, 16), (2, 5, 6, 7, 32, 16), (1, 4, 4, 8, 32, 4)])   # narrow Cout: flat (child, cout) tiles
+                                  (1, 8, 8, 16, 64, 16), (2, 5, 6, 7, 32, 16), (1, 4, 4, 8, 32, 4),     # narrow Cout: flat (child, cout) tiles
+                                  (1, 8, 8, 8, 256, 64), (1, 8, 8, 8, 128, 16)])         # direct GEMM, streaming form at K = 256 / 128 (convt_direct.hip)
 def test_conv_transpose3d_k2s2(seg, case):
     N, D, H, W, Cin, Cout = case
     F = seg.functional
