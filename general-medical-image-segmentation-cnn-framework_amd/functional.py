@@ -528,8 +528,8 @@ class _ConvBnAct(Function):
         ws = workspace(max(_conv_ws(L, x, N, D, H, W, Cin, Cout, k, stride, pad),
                            L.query("mi355seg_norm_ws_bytes", rows, 1, Cout)), dev)
         dy = torch.empty_like(y)
-        dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(Cout, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(Cout, dtype=torch.float32, device=dev) if gamma is not None else None      # no affine: instance norm
+        dbeta = torch.empty(Cout, dtype=torch.float32, device=dev) if gamma is not None else None
         db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
         L.call("mi355seg_norm_act_bwd_colsum_" + _sfx(x), _p(da), ldda, _p(y), Cout, _p(mean), _p(rstd), _p(gamma), _p(beta), None, 0,
                _p(dy), Cout, _p(dgamma), _p(dbeta), None, 0, _p(db), rows, 1, Cout, act, slope, _p(ws), ws.numel(), _stream())
@@ -543,6 +543,20 @@ class _ConvBnAct(Function):
             L.call("mi355seg_conv3d_wgrad_" + _sfx(x), _p(dy), Cout, _p(x), ldx, _p(dw), None, N, D, H, W, Cin, Cout, k, stride, pad,
                    0, _p(ws), ws.numel(), _stream())
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
+
+
+def conv_in_act(x, conv, norm, act=ACT_NONE, slope=0.01):
+    """act(InstanceNorm3d(conv(x))) (residual_unet3d.py:82-107: conv_norm_lrelu and the tail of norm_lrelu_upscale_conv_norm_lrelu;
+    affine=False, no running statistics).  With ONE sample per batch -- cfg 4 -- the per-(sample, channel) statistics are per-channel
+    statistics over the whole tensor, i.e. exactly what the convolution's epilogue already reduces for BatchNorm: the node of
+    conv_bn_act without affine parameters and buffers (no separate statistics pass over y).  N > 1: convolution, then the
+    instance-norm node."""
+    if x.shape[0] != 1 or norm.affine or norm.track_running_stats or not torch.is_grad_enabled():
+        return norm.forward_act(conv(x), act, slope)
+    stride = conv.stride[0] if isinstance(conv.stride, (tuple, list)) else conv.stride
+    pad = conv.padding[0] if isinstance(conv.padding, (tuple, list)) else conv.padding
+    return _ConvBnAct.apply(x, conv.weight, conv.bias, None, None, None, None, int(stride), int(pad), True, 0.0, float(norm.eps),
+                            int(act), float(slope), 0, False)
 
 
 def conv_bn_act(x, conv, bn, act=ACT_NONE, slope=0.01, left_pad=0):

@@ -29,7 +29,7 @@ class _ConvNormLrelu(nn.Sequential):
 
     def forward(self, x):
         conv, norm, _act = self.children()
-        return norm.forward_act(conv(x), *_LRELU)
+        return F.conv_in_act(x, conv, norm, *_LRELU)       # batch of one: the statistics come out of the convolution's epilogue
 
 
 class _NormLreluUpConvNormLrelu(nn.Sequential):
@@ -37,7 +37,7 @@ class _NormLreluUpConvNormLrelu(nn.Sequential):
 
     def forward(self, x):
         n0, _a0, up, conv, n1, _a1 = self.children()
-        return n1.forward_act(conv(up(n0.forward_act(x, *_LRELU))), *_LRELU)
+        return F.conv_in_act(up(n0.forward_act(x, *_LRELU)), conv, n1, *_LRELU)
 
 
 def _conv3(cin, cout, stride=1):
@@ -126,7 +126,7 @@ class UNet(nn.Module):
                 h = getattr(self, f"inorm3d_c{lvl}").forward_act(h, *_LRELU)
                 ctx.append(h)
         h = self.norm_lrelu_upscale_conv_norm_lrelu_l0(h)
-        h = self.inorm3d_l0.forward_act(self.conv3d_l0(h), *_LRELU)
+        h = F.conv_in_act(h, self.conv3d_l0, self.inorm3d_l0, *_LRELU)
         ds = {}
         for lvl in (1, 2, 3):                                  # localisation (:174-194)
             h = F.cat_channels(h, ctx[4 - lvl])
