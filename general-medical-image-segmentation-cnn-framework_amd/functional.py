@@ -1276,6 +1276,80 @@ def cat_channels(a, b):
     return _CatChannels.apply(a, b)
 
 
+class _BnActCatScaled(Function):
+    """cat((act(BatchNorm3d(y)), skip * scale), channels) -- V-Net's up-transition head (vnet3d.py:97-101: relu1(bn1(up_conv(x))),
+    do2(skipx), torch.cat) -- as one node: the normalise pass writes the left channel slice of the concat buffer and the dropout
+    scaling the right one (no separate Dropout3d tensor, no concat copies); the backward reads the two slices of the incoming
+    gradient in place.  ``scale`` None: the skip is copied (eval mode / p = 0)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, rmean, rvar, skip, scale, training, momentum, eps, act, slope):
+        y, ldy = cl_view(y, "norm input")
+        skip, lds = cl_view(skip, "concat skip input")
+        if y.shape[:4] != skip.shape[:4] or y.dtype != skip.dtype:
+            raise Mi355SegError(f"up-transition concat: {tuple(y.shape)} {y.dtype} vs {tuple(skip.shape)} {skip.dtype}")
+        N, D, H, W, Cu = y.shape
+        Cs = skip.shape[4]
+        rows = N * D * H * W
+        L = lib()
+        dev = y.device
+        ws = workspace(L.query("mi355seg_norm_ws_bytes", rows, 1, Cu), dev)
+        if training:
+            mean = torch.empty(Cu, dtype=torch.float32, device=dev)
+            rstd = torch.empty(Cu, dtype=torch.float32, device=dev)
+            L.call("mi355seg_norm_stats_" + _sfx(y), _p(y), ldy, rows, 1, Cu, eps, _p(mean), _p(rstd), _p(rmean), _p(rvar), momentum,
+                   _p(ws), ws.numel(), _stream())
+        else:
+            mean = rmean
+            rstd = torch.empty(Cu, dtype=torch.float32, device=dev)
+            L.call("mi355seg_rstd_from_var_f32", _p(rvar), eps, _p(rstd), Cu, _stream())
+        both = torch.empty((N, D, H, W, Cu + Cs), dtype=y.dtype, device=dev)
+        right = both.data_ptr() + both.element_size() * Cu
+        L.call("mi355seg_norm_act_fwd_" + _sfx(y), _p(y), ldy, _p(mean), _p(rstd), _p(gamma), _p(beta), None, 0,
+               both.data_ptr(), Cu + Cs, rows, 1, Cu, act, slope, _stream())
+        if scale is not None:
+            scale = scale.contiguous().to(torch.float32)
+            L.call("mi355seg_scale_channels_" + _sfx(y), _p(skip), lds, _p(scale), right, Cu + Cs, D * H * W, N, Cs, _stream())
+        else:
+            L.call("mi355seg_copy_rows_" + _sfx(y), _p(skip), lds, right, Cu + Cs, rows, Cs, _stream())
+        ctx.save_for_backward(y, mean, rstd, gamma, beta, scale)
+        ctx.cfg = (ldy, rows, Cu, Cs, act, slope, bool(training), (N, D, H, W))
+        return both
+
+    @staticmethod
+    def backward(ctx, dboth):
+        y, mean, rstd, gamma, beta, scale = ctx.saved_tensors
+        ldy, rows, Cu, Cs, act, slope, training, (N, D, H, W) = ctx.cfg
+        if not training:
+            raise Mi355SegError("backward through eval-mode BatchNorm (running statistics) is not supported")
+        dboth, ldd = cl_view(_like(dboth, y), "up-transition concat grad")
+        L = lib()
+        dev = y.device
+        ws = workspace(L.query("mi355seg_norm_ws_bytes", rows, 1, Cu), dev)
+        dy = torch.empty(y.shape, dtype=y.dtype, device=dev)
+        dgamma = torch.empty(Cu, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(Cu, dtype=torch.float32, device=dev)
+        L.call("mi355seg_norm_act_bwd_" + _sfx(y), _p(dboth), ldd, _p(y), ldy, _p(mean), _p(rstd), _p(gamma), _p(beta), None, 0,
+               _p(dy), Cu, _p(dgamma), _p(dbeta), None, 0, rows, 1, Cu, act, slope, _p(ws), ws.numel(), _stream())
+        right = dboth.data_ptr() + dboth.element_size() * Cu
+        if scale is not None:
+            dskip = torch.empty((N, D, H, W, Cs), dtype=y.dtype, device=dev)
+            L.call("mi355seg_scale_channels_" + _sfx(y), right, ldd, _p(scale), _p(dskip), Cs, D * H * W, N, Cs, _stream())
+        else:
+            dskip = dboth[..., Cu:]
+        return dy, dgamma, dbeta, None, None, dskip, None, None, None, None, None, None
+
+
+def bn_act_cat_scaled(y, bn, skip, scale, act=ACT_NONE, slope=0.01):
+    """cat((act(bn(y)), skip * scale), channel axis) for a layers.BatchNorm3d; ``scale`` = Dropout3d.draw_scale(...) or None."""
+    if bn.momentum is None or not bn.affine or not bn.track_running_stats:
+        raise NotImplementedError("bn_act_cat_scaled: BatchNorm3d must be affine with running statistics and a momentum")
+    if bn.training:
+        bn.num_batches_tracked.add_(1)
+    return _BnActCatScaled.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, skip, scale, bool(bn.training),
+                                 float(bn.momentum), float(bn.eps), int(act), float(slope))
+
+
 class _RepeatChannels(Function):
     """x.repeat(1, rep, 1, 1, 1) (vnet3d.py:55-56) in channel-last form."""
 

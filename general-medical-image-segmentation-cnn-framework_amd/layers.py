@@ -91,15 +91,19 @@ class Dropout3d(nn.Dropout3d):
         super().__init__(p, inplace)
         self.forced_masks = []
 
-    def forward(self, x):
+    def draw_scale(self, N, C, device):
+        """The per-(sample, channel) factor of this call -- keep / (1 - p) -- or None when the layer is the identity (eval, p = 0)."""
         if not self.training or self.p == 0.0:
-            return x
-        N, C = x.shape[0], x.shape[-1]
+            return None
         if self.forced_masks:
-            keep = self.forced_masks.pop(0).to(device=x.device, dtype=torch.float32).reshape(N, C)
+            keep = self.forced_masks.pop(0).to(device=device, dtype=torch.float32).reshape(N, C)
         else:
-            keep = torch.empty((N, C), device=x.device).bernoulli_(1.0 - self.p)     # one launch (no probability tensor to fill)
-        return F.scale_channels(x, keep / (1.0 - self.p))
+            keep = torch.empty((N, C), device=device).bernoulli_(1.0 - self.p)     # one launch (no probability tensor to fill)
+        return keep / (1.0 - self.p)
+
+    def forward(self, x):
+        scale = self.draw_scale(x.shape[0], x.shape[-1], x.device)
+        return x if scale is None else F.scale_channels(x, scale)
 
 
 class ReLU(nn.ReLU):

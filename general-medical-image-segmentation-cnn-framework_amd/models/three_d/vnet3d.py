@@ -106,9 +106,15 @@ class UpTransition(nn.Module):
         self.ops = _make_nConv(cout, units, elu)
 
     def forward(self, x, skipx):
-        kept_skip = self.do2(skipx)                      # the reference draws the skip mask first (vnet3d.py:99)
-        up = _bn_act(self.bn1, self.up_conv(self.do1(x)), self.relu1)
-        both = F.cat_channels(up, kept_skip)
+        if isinstance(self.relu1, ELU):
+            # one node: the skip's dropout mask first (as the reference draws it, vnet3d.py:99), then BN + ELU of the up-convolution
+            # into the left channel slice of the concat buffer and the scaled skip into the right one
+            scale = self.do2.draw_scale(skipx.shape[0], skipx.shape[-1], skipx.device)
+            both = F.bn_act_cat_scaled(self.up_conv(self.do1(x)), self.bn1, skipx, scale, F.ACT_ELU)
+        else:
+            kept_skip = self.do2(skipx)                  # the reference draws the skip mask first (vnet3d.py:99)
+            up = _bn_act(self.bn1, self.up_conv(self.do1(x)), self.relu1)
+            both = F.cat_channels(up, kept_skip)
         return _add_act(self.ops(both), both, self.relu2)
 
 
