@@ -173,16 +173,30 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * CIT, t0 = blockIdx.z * TT;
     const int tn = min(TT, T - t0);
     const int run = CIT * TT, pitch = run + 1;
-    for (int e = threadIdx.x; e < 32 * run; e += 256) {
-        const int col = e & 31, r = e >> 5;
-        const int cil = r % CIT, tl = r / CIT;
-        const int co = co0 + col, ci = ci0 + cil;
-        double s = 0.0;
-        if (co < Cout && ci < Cin && tl < tn) {
-            const long long i = ((long long)(t0 + tl) * Cin + ci) * Cout + co;
-            for (int k = 0; k < splits; ++k) s += (double)part[(long long)k * total + i];
+    // four elements per thread and trip: their strip loads are independent, so four (x the compiler's unroll of k) are in flight --
+    // with one workgroup per CU and one load at a time this kernel took 30-35 us whatever the layer
+    for (int e0 = threadIdx.x; e0 < 32 * run; e0 += 1024) {
+        long long idx[4]; int dst[4]; bool ok[4];
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 256 * u;
+            const int col = e & 31, r = e >> 5;
+            const int cil = r % CIT, tl = r / CIT;
+            const int co = co0 + col, ci = ci0 + cil;
+            ok[u] = e < 32 * run && co < Cout && ci < Cin && tl < tn;
+            idx[u] = ok[u] ? ((long long)(t0 + tl) * Cin + ci) * Cout + co : 0;
+            dst[u] = e < 32 * run ? col * pitch + cil * TT + tl : -1;
         }
-        tr[col * pitch + cil * TT + tl] = (float)s;
+        for (int k = 0; k < splits; ++k) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = part[(long long)k * total + idx[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (ok[u]) s[u] += (double)v[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (dst[u] >= 0) tr[dst[u]] = (float)s[u];
     }
     __syncthreads();
     const int cin_here = min(CIT, Cin - ci0);
@@ -263,7 +277,7 @@ void wgrad_reduce(const float* part, float* dw, int splits, int T, int Cin, int 
         hipLaunchKernelGGL(wgrad_reduce_cols_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, part, dw, splits, T, Cin, Cout, accumulate);
         return;
     }
-    while (CIT > 1 && blocks(CIT) < 256) CIT = (CIT + 1) / 2;       // wide layers: enough blocks for every CU
+    while (CIT > 1 && blocks(CIT) < 1024) CIT = (CIT + 1) / 2;      // four workgroups per CU: each thread then walks a short run (the kernel is latency-bound)
     if (blocks(CIT) < 256) {
         long long total = (long long)T * Cin * Cout;
         int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
