@@ -56,7 +56,12 @@ def train_step(model, optimizer, x, gt, criterion=None, sync_metric=True, grad_h
     optimizer.zero_grad(set_to_none=True)
     gt2 = two_channel_gt(gt)
     x = x.to(torch.float32)
-    with F.autocast(dtype or F.compute_dtype()):
+    # every training-mode BatchNorm counter advanced by one multi-tensor launch (the modules tally their calls meanwhile)
+    bns = [m for m in model.modules()
+           if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training and m.num_batches_tracked is not None]
+    if bns:
+        torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
+    with F.autocast(dtype or F.compute_dtype()), F.counters_batched(bns):
         if getattr(model, "takes_frequency_bands", False):      # the IS network, train.py:198-201: second output discarded
             from .models.three_d.IS import frequency_bands
             low_x, high_x = frequency_bands(x)

@@ -51,6 +51,48 @@ class autocast:
         return False
 
 
+class _CounterBatch(threading.local):
+    active = False
+    seen = None
+
+
+_COUNTERS = _CounterBatch()
+
+
+class counters_batched:
+    """While active, the fused BatchNorm entry points leave ``num_batches_tracked`` alone: engine.train_step has advanced the
+    counters of ``modules`` (every training-mode BatchNorm of the model) with ONE multi-tensor launch (18-24 one-element torch
+    kernels per step otherwise).  Calls are tallied, so a module used twice in one forward, or not at all, still ends with exactly
+    the count nn.BatchNorm3d would hold."""
+
+    def __init__(self, modules=()):
+        self.modules = list(modules)
+
+    def __enter__(self):
+        self.prev = (_COUNTERS.active, _COUNTERS.seen)
+        _COUNTERS.active, _COUNTERS.seen = True, {}
+
+    def __exit__(self, *exc):
+        seen = _COUNTERS.seen
+        _COUNTERS.active, _COUNTERS.seen = self.prev
+        for m in self.modules:
+            k = seen.pop(id(m), (m, 0))[1]
+            if k != 1:
+                m.num_batches_tracked.add_(k - 1)
+        for m, k in seen.values():                      # a BatchNorm outside the advanced set
+            m.num_batches_tracked.add_(k)
+
+
+def bump_counter(bn):
+    """nn.BatchNorm3d's per-forward ``num_batches_tracked += 1`` (training mode)."""
+    if bn.num_batches_tracked is None:
+        return
+    if _COUNTERS.active:
+        _COUNTERS.seen[id(bn)] = (bn, _COUNTERS.seen.get(id(bn), (bn, 0))[1] + 1)
+    else:
+        bn.num_batches_tracked.add_(1)
+
+
 def compute_dtype():
     return _AUTOCAST.stack[-1]
 
@@ -566,7 +608,7 @@ def conv_bn_act(x, conv, bn, act=ACT_NONE, slope=0.01, left_pad=0):
     stride = conv.stride[0] if isinstance(conv.stride, (tuple, list)) else conv.stride
     pad = conv.padding[0] if isinstance(conv.padding, (tuple, list)) else conv.padding
     if bn.training:
-        bn.num_batches_tracked.add_(1)
+        bump_counter(bn)
     # eval mode under torch.no_grad() (predict.py:79-81,133) takes the folded one-pass form where the layer has one
     return _ConvBnAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, int(stride), int(pad),
                             bool(bn.training), float(bn.momentum), float(bn.eps), int(act), float(slope), int(left_pad),
@@ -676,8 +718,8 @@ def double_conv_bn_act(x, conv1, bn1, conv2, bn2, act=ACT_NONE, slope=0.01, left
         st = conv.stride[0] if isinstance(conv.stride, (tuple, list)) else conv.stride
         pd = conv.padding[0] if isinstance(conv.padding, (tuple, list)) else conv.padding
         return int(st), int(pd)
-    bn1.num_batches_tracked.add_(1)
-    bn2.num_batches_tracked.add_(1)
+    bump_counter(bn1)
+    bump_counter(bn2)
     return _DoubleConvBnAct.apply(x, conv1.weight, conv1.bias, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
                                   conv2.weight, conv2.bias, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var,
                                   geo(conv1), geo(conv2), float(bn1.momentum), float(bn1.eps), float(bn2.momentum), float(bn2.eps),
@@ -1345,7 +1387,7 @@ def bn_act_cat_scaled(y, bn, skip, scale, act=ACT_NONE, slope=0.01):
     if bn.momentum is None or not bn.affine or not bn.track_running_stats:
         raise NotImplementedError("bn_act_cat_scaled: BatchNorm3d must be affine with running statistics and a momentum")
     if bn.training:
-        bn.num_batches_tracked.add_(1)
+        bump_counter(bn)
     return _BnActCatScaled.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, skip, scale, bool(bn.training),
                                  float(bn.momentum), float(bn.eps), int(act), float(slope))
 

@@ -50,7 +50,7 @@ class BatchNorm3d(nn.BatchNorm3d):
             raise NotImplementedError("BatchNorm3d: cumulative moving average (momentum=None) is not implemented")
         training = self.training or (self.running_mean is None)
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
+            F.bump_counter(self)
         return F.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, training,
                                 self.momentum, self.eps, act, slope, residual)
 
