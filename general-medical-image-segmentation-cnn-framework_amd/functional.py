@@ -1556,5 +1556,57 @@ class _Attention(Function):
         return dq, dk, dv, None, None
 
 
+class _AttentionQKV(Function):
+    """_Attention on a FUSED projection output qkv[B, P, 3E] = (Q | K | V) (one GEMM for the three projections of unetr.py:60-75):
+    the batched GEMMs read the three channel slices in place (row pitch 3E) and the backward writes dQ | dK | dV into the slices of
+    one [B, P, 3E] gradient, so the projection's backward is one input-gradient GEMM, one weight-gradient GEMM and one bias sum."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, keep):
+        _require_cuda(qkv, "attention input")
+        qkv = qkv.contiguous()
+        B, P, E3 = qkv.shape
+        E = E3 // 3
+        d = E // heads
+        alpha = 1.0 / (d ** 0.5)
+        q, k, v = _p(qkv), _p(qkv) + 4 * E, _p(qkv) + 8 * E
+        scores = torch.empty((B, heads, P, P), dtype=qkv.dtype, device=qkv.device)
+        _gemm(q, E3, 1, P * E3, d, k, 1, E3, P * E3, d, _p(scores), P, heads * P * P, P * P, None, P, P, d, B, heads, alpha)
+        probs = torch.empty_like(scores)
+        lib().call("mi355seg_softmax_rows_f32", _p(scores), _p(probs), B * heads * P, P, _stream())
+        pd = probs if keep is None else _mul(probs, keep)
+        ctxl = torch.empty((B, P, E), dtype=qkv.dtype, device=qkv.device)
+        _gemm(_p(pd), P, 1, heads * P * P, P * P, v, E3, 1, P * E3, d, _p(ctxl), E, P * E, d, None, P, d, P, B, heads)
+        ctx.save_for_backward(qkv, probs, keep)
+        ctx.cfg = (B, P, E, heads, d, alpha)
+        return ctxl
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, probs, keep = ctx.saved_tensors
+        B, P, E, heads, d, alpha = ctx.cfg
+        E3 = 3 * E
+        q, k, v = _p(qkv), _p(qkv) + 4 * E, _p(qkv) + 8 * E
+        do = do.contiguous()
+        pd = probs if keep is None else _mul(probs, keep)
+        HPP, PP = heads * P * P, P * P
+        dqkv = torch.empty_like(qkv)
+        dq, dk, dv = _p(dqkv), _p(dqkv) + 4 * E, _p(dqkv) + 8 * E
+        dpd = torch.empty_like(probs)                                   # dP = dO V^T
+        _gemm(_p(do), E, 1, P * E, d, v, 1, E3, P * E3, d, _p(dpd), P, HPP, PP, None, P, P, d, B, heads)
+        _gemm(_p(pd), 1, P, HPP, PP, _p(do), E, 1, P * E, d, dv, E3, P * E3, d, None, P, d, P, B, heads)             # dV = Pd^T dO
+        dp = dpd if keep is None else _mul(dpd, keep, out=dpd)
+        ds = torch.empty_like(probs)
+        lib().call("mi355seg_softmax_rows_bwd_f32", _p(probs), _p(dp), _p(ds), B * heads * P, P, _stream())
+        _gemm(_p(ds), P, 1, HPP, PP, k, E3, 1, P * E3, d, dq, E3, P * E3, d, None, P, d, P, B, heads, alpha)          # dQ = alpha dS K
+        _gemm(_p(ds), 1, P, HPP, PP, q, E3, 1, P * E3, d, dk, E3, P * E3, d, None, P, d, P, B, heads, alpha)          # dK = alpha dS^T Q
+        return dqkv, None, None
+
+
+def attention_qkv(qkv, heads, keep=None):
+    """Multi-head attention on the fused projection output [B, P, 3E] (fp32)."""
+    return _AttentionQKV.apply(qkv, int(heads), keep)
+
+
 def attention(q, k, v, heads, keep=None):
     return _Attention.apply(q, k, v, int(heads), keep)

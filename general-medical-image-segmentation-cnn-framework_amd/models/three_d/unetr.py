@@ -121,11 +121,16 @@ class SelfAttention(nn.Module):
         self.vis = False
 
     def forward(self, hidden_states):
-        q, k, v = (proj(hidden_states) for proj in (self.query, self.key, self.value))
+        # the three projections as ONE GEMM on the concatenated weights (the parameters stay separate: state_dict keys query / key /
+        # value of unetr.py:66-68; the concat's backward hands each its rows of the fused weight gradient)
+        w = torch.cat((self.query.weight, self.key.weight, self.value.weight), dim=0)
+        b = torch.cat((self.query.bias, self.key.bias, self.value.bias), dim=0)
+        qkv = F.linear(hidden_states, w, b)
         mask = None
         if self.training and self.attn_dropout.p > 0.0:
-            mask = self.attn_dropout.draw((q.shape[0], self.num_attention_heads, q.shape[1], q.shape[1]), q.device)
-        mixed = F.attention(q, k, v, self.num_attention_heads, mask)
+            n, p = qkv.shape[0], qkv.shape[1]
+            mask = self.attn_dropout.draw((n, self.num_attention_heads, p, p), qkv.device)
+        mixed = F.attention_qkv(qkv, self.num_attention_heads, mask)
         return self.proj_dropout(self.out(mixed)), None
 
 
