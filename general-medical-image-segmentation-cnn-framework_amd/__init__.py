@@ -6,7 +6,7 @@ from .functional import autocast
 from . import custom_ops          # registers torch.ops.mi355seg.* (dispatcher view of the same C-ABI entry points)
 from ._lib import LIB_PATH, Mi355SegError, lib
 
-_MATH = {"fp32": 0, "bf16x6": 2}
+_MATH = {"fp32": 0, "bf16x6": 2, "f16x3": 3}
 DEFAULT_CONV_MATH = "bf16x6"
 
 

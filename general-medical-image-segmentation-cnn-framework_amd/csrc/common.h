@@ -139,6 +139,25 @@ __device__ __forceinline__ void split3(float v, bf16& h, bf16& m, bf16& l) {
     l = (bf16)(r1 - (float)m);
 }
 
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+// v = h + l with two fp16 parts (v already scaled into the fp16 range): the operand split of the f16x3 convolutions
+__device__ __forceinline__ void split2h(float v, _Float16& h, _Float16& l) {
+    h = (_Float16)v;
+    l = (_Float16)(v - (float)h);
+}
+// f16x3 split (conv_x3s.hip, conv_wgrad_lowp.hip): the exponent s of the power of two that places a tensor's largest magnitude
+// in [2^14, 2^15) -- below the fp16 maximum with room for the rounding, as high as possible above the fp16 underflow.  2^s stays a
+// normal float (s <= 126: tensors whose maximum is below 2^-112 simply sit lower in the fp16 range); a zero / subnormal maximum
+// scales by one; an infinite or NaN maximum gives s = -114 and the non-finite values propagate as they would in fp32.
+__host__ __device__ __forceinline__ int f16x_scale_exp(float amax) {
+    const int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu);
+    const int s = e ? 141 - e : 0;
+    return s > 126 ? 126 : s;
+}
+__host__ __device__ __forceinline__ float pow2f(int s) { return __builtin_bit_cast(float, (unsigned)(s + 127) << 23); }   // -126 <= s <= 127
+
 // ---- optional per-family kernel timing (api.hip) ----
 enum ProfFamily { PF_IGEMM = 0, PF_WGRAD = 1, PF_GENERIC = 2, PF_CONVT = 3, PF_NORM = 4, PF_POOL = 5, PF_LOSS = 6, PF_DIRECT = 7 };
 extern unsigned g_prof_mask;     // bit f set: launches of ProfFamily f are bracketed by HIP events

@@ -397,7 +397,8 @@ static int conv_math_from_env() {
     if (!e || !e[0]) return MI355SEG_MATH_DEFAULT;
     if (!strcmp(e, "fp32") || !strcmp(e, "f32")) return MI355SEG_MATH_FP32;
     if (!strcmp(e, "bf16x6")) return MI355SEG_MATH_BF16X6;
-    fprintf(stderr, "libmi355seg: MI355SEG_CONV_MATH=%s is not one of fp32 / bf16x6; using the default\n", e);
+    if (!strcmp(e, "f16x3")) return MI355SEG_MATH_F16X3;
+    fprintf(stderr, "libmi355seg: MI355SEG_CONV_MATH=%s is not one of fp32 / bf16x6 / f16x3; using the default\n", e);
     return MI355SEG_MATH_DEFAULT;
 }
 static int g_conv_math = conv_math_from_env();
@@ -406,7 +407,9 @@ static int g_x3_shape = x3_shape_from_env();
 namespace seg {
 int x3_shape() { return g_x3_shape; }
 // policy for a convolution on fp32 tensors: the split-precision kernels where the selected math asks for them
-int f32_conv_policy() { return g_conv_math == MI355SEG_MATH_BF16X6 ? MATH_X3 : MATH_F32; }
+// (f16x3 shares the plans, tiles and launch paths of the bf16x6 policy; the kernels that have a two-piece form ask x3_f16())
+int f32_conv_policy() { return g_conv_math == MI355SEG_MATH_FP32 ? MATH_F32 : MATH_X3; }
+bool x3_f16() { return g_conv_math == MI355SEG_MATH_F16X3 && g_x3_shape == 16; }
 }
 
 // ---- patch embedding (kernel = stride, no padding; UNETR's k16 s16 conv, unetr.py:141-156) as a plain GEMM:
@@ -455,7 +458,7 @@ using namespace seg;
 extern "C" {
 
 int mi355seg_set_conv_math(int mode) {
-    SEG_CHECK_ARG(mode == MI355SEG_MATH_FP32 || mode == MI355SEG_MATH_BF16X6, "set_conv_math: unknown mode %d", mode);
+    SEG_CHECK_ARG(mode == MI355SEG_MATH_FP32 || mode == MI355SEG_MATH_BF16X6 || mode == MI355SEG_MATH_F16X3, "set_conv_math: unknown mode %d", mode);
     g_conv_math = mode;
     return MI355SEG_OK;
 }

@@ -114,6 +114,70 @@ __global__ void pack_wq_x3s_kernel(const float* __restrict__ w, bf16* __restrict
     }
 }
 
+// the same for the f16x3 form: two fp16 planes of w * 2^sw
+__global__ void pack_wq_x3s_f16_kernel(const float* __restrict__ w, _Float16* __restrict__ wq, int K, int Nn, int NBW, int mode, const float* __restrict__ oscale,
+                                       const float* __restrict__ amax_w) {
+    const int NT = 32 * NBW, NU = X3S_NPAIR * NBW, nch = K / 16;
+    const long long total = (long long)(Nn / NT) * nch * NU * 1024;
+    const float sc = pow2f(f16x_scale_exp(*amax_w));
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        long long q = idx;
+        const int e = (int)(q % 8); q /= 8;
+        const int lane = (int)(q % 64); q /= 64;
+        const int t2 = (int)(q % 2); q /= 2;
+        const int u = (int)(q % NU); q /= NU;
+        const int chunk = (int)(q % nch); q /= nch;
+        const int nt = (int)q;
+        const int s = u / NBW, nh = u % NBW, g = lane >> 4, c = lane & 15;
+        const int tap = x3s_pair_tap(s, g >> 1);
+        const int co = nt * NT + nh * 32 + t2 * 16 + c;
+        const float v = tap < 27 ? pack_src(w, mode, co, chunk * 16 + 8 * (g & 1) + e, tap, K, Nn, 27, 0, 27, TapList{}) * (oscale ? oscale[co] : 1.f) * sc : 0.f;
+        _Float16 bh, bl;
+        split2h(v, bh, bl);
+        const long long base = (((long long)nt * nch + chunk) * NU + u) * 2048 + t2 * 512 + lane * 8 + e;
+        wq[base] = bh; wq[base + 1024] = bl;
+    }
+}
+
+// max |x| over rows x C elements at pitch ld (C, ld multiples of 4, x 16-byte aligned; else the scalar loop), times rowscale[row / rows_per_scale]
+// when given (the folded inference weights w * oscale[co]), max-combined into *slot (an ordered compare of the bit patterns of
+// non-negative floats: order-independent, so the result is reproducible).  The caller zeroes the slot.
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int ld, long long rows, int C, const float* __restrict__ rowscale, unsigned* __restrict__ slot) {
+    float m = 0.f;
+    if ((C % 4) == 0 && (ld % 4) == 0 && ((uintptr_t)x % 16) == 0) {
+        const int cw = C / 4;
+        const long long total = rows * cw;
+        for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+            const long long r = idx / cw;
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(x + r * ld + (idx - r * cw) * 4);
+            const float sc = rowscale ? fabsf(rowscale[r]) : 1.f;
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) * sc);
+        }
+    } else {
+        const long long total = rows * C;
+        for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+            const long long r = idx / C;
+            m = fmaxf(m, fabsf(x[r * ld + (idx - r * C)]) * (rowscale ? fabsf(rowscale[r]) : 1.f));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+        // fmaxf drops NaNs: a tensor that holds one must still produce a non-finite result downstream, which the kernels that
+        // consume the slot get from the NaN operand itself (h = NaN), whatever the scale
+        atomicMax(slot, __builtin_bit_cast(unsigned, m));
+    }
+}
+void tensor_amax(const float* x, int ld, long long rows, int C, const float* rowscale, float* slot, hipStream_t st) {
+    const long long work = rows * (long long)C / 4;
+    const int grid = (int)(work / 1024 < 1 ? 1 : (work / 1024 > 2048 ? 2048 : work / 1024));
+    hipLaunchKernelGGL(amax_kernel, dim3(grid), dim3(256), 0, st, x, ld, rows, C, rowscale, reinterpret_cast<unsigned*>(slot));
+}
+
 // conv_b16s.hip layout: wq[nt][chunk][K-step s][16-channel tile tt][lane][8]; lane = (c, g), c = 4 g' + e':
 // element e = bf16 of W[co = nt*NT + 32 (tt / 2) + 8 g' + 4 (tt % 2) + e'][ci = chunk*16 + 8 (g & 1) + e][tap = 2 s + (g >> 1)]  (tap >= T: zero)
 __global__ void pack_wq_b16s_kernel(const float* __restrict__ w, bf16* __restrict__ wq, int K, int Nn, int T, int NT, int mode, const float* __restrict__ oscale) {
@@ -137,10 +201,11 @@ __global__ void pack_wq_b16s_kernel(const float* __restrict__ w, bf16* __restric
 // The two hot packings above, tiled: a workgroup owns NB (8; 4 for k5 and for narrow layers) GEMM columns x one 16-channel K chunk x all taps, reads that block of W
 // with full-width coalesced loads (the per-element kernels read W at a stride of T floats -- one 64-byte sector per 4 bytes used;
 // 10-16 us per layer, 0.4-0.8 ms of a V-Net / Res-U-Net step) into LDS and emits whole 16-byte fragment slots.
-// LAYOUT 0: conv_b16s.hip (P = NT), 1: conv_x3s.hip (P = NBW).  mode 0 / 1 as pack_src.
+// LAYOUT 0: conv_b16s.hip (P = NT), 1: conv_x3s.hip (P = NBW), 2: conv_x3s.hip f16x3 (two fp16 planes of w * 2^sw, sw from *amax_w).
+// mode 0 / 1 as pack_src.
 template <int LAYOUT, int NB>
 __global__ __launch_bounds__(256) void pack_tiled_kernel(const float* __restrict__ w, bf16* __restrict__ wq, int K, int Nn, int T, int P, int mode,
-                                                         const float* __restrict__ oscale) {
+                                                         const float* __restrict__ oscale, const float* __restrict__ amax_w) {
     extern __shared__ float tile[];
     const int nnb = Nn / NB;
     const int n0 = (blockIdx.x % nnb) * NB, chunk = blockIdx.x / nnb, k0 = chunk * 16;
@@ -161,7 +226,8 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const float* __restrict
         const int n = n0 + nl, g = 2 * gh + half;
         float v[8];
         if (tap < T) {
-            const float sc = (oscale && mode == 0) ? oscale[n] : 1.f;
+            float sc = (oscale && mode == 0) ? oscale[n] : 1.f;
+            if (LAYOUT == 2) sc *= pow2f(f16x_scale_exp(*amax_w));
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int kl = 8 * half + e;
@@ -178,6 +244,15 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const float* __restrict
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
             reinterpret_cast<bf16x8_t*>(wq)[((((long long)nt * nch + chunk) * nstep + s) * ntt + tt) * 64 + c + 16 * g] = o;
+        } else if (LAYOUT == 2) {
+            const int NBW = P, NT = 32 * NBW, nt = n / NT, nin = n - nt * NT;
+            const int nh = nin / 32, t2 = (nin & 31) >> 4, c = nin & 15;
+            f16x8_t oh, ol;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { _Float16 a, b; split2h(v[e], a, b); oh[e] = a; ol[e] = b; }
+            _Float16* dst = reinterpret_cast<_Float16*>(wq) + (((long long)nt * nch + chunk) * (X3S_NPAIR * NBW) + s * NBW + nh) * 2048 + t2 * 512 + (c + 16 * g) * 8;
+            *reinterpret_cast<f16x8_t*>(dst) = oh;
+            *reinterpret_cast<f16x8_t*>(dst + 1024) = ol;
         } else {
             const int NBW = P, NT = 32 * NBW, nt = n / NT, nin = n - nt * NT;
             const int nh = nin / 32, t2 = (nin & 31) >> 4, c = nin & 15;
@@ -193,16 +268,16 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const float* __restrict
 }
 
 template <int LAYOUT, int NB>
-static void launch_pack_tiled_nb(const float* w, bf16* wq, int K, int Nn, int T, int P, int mode, const float* oscale, hipStream_t st) {
+static void launch_pack_tiled_nb(const float* w, bf16* wq, int K, int Nn, int T, int P, int mode, const float* oscale, const float* amax_w, hipStream_t st) {
     const size_t lds = (size_t)16 * NB * T * sizeof(float);
     SEG_SET_LDS((pack_tiled_kernel<LAYOUT, NB>), lds);
-    hipLaunchKernelGGL((pack_tiled_kernel<LAYOUT, NB>), dim3((unsigned)((Nn / NB) * (K / 16))), dim3(256), lds, st, w, wq, K, Nn, T, P, mode, oscale);
+    hipLaunchKernelGGL((pack_tiled_kernel<LAYOUT, NB>), dim3((unsigned)((Nn / NB) * (K / 16))), dim3(256), lds, st, w, wq, K, Nn, T, P, mode, oscale, amax_w);
 }
 template <int LAYOUT>
-static void launch_pack_tiled(const float* w, bf16* wq, int K, int Nn, int T, int P, int mode, const float* oscale, hipStream_t st) {
+static void launch_pack_tiled(const float* w, bf16* wq, int K, int Nn, int T, int P, int mode, const float* oscale, hipStream_t st, const float* amax_w = nullptr) {
     // enough workgroups for the narrow layers, short serial work per workgroup for the 125-tap ones
-    if (T > 27 || (long long)(Nn / 8) * (K / 16) < 256) launch_pack_tiled_nb<LAYOUT, 4>(w, wq, K, Nn, T, P, mode, oscale, st);   // (runs of 4 T floats keep the 16-byte alignment)
-    else launch_pack_tiled_nb<LAYOUT, 8>(w, wq, K, Nn, T, P, mode, oscale, st);
+    if (T > 27 || (long long)(Nn / 8) * (K / 16) < 256) launch_pack_tiled_nb<LAYOUT, 4>(w, wq, K, Nn, T, P, mode, oscale, amax_w, st);   // (runs of 4 T floats keep the 16-byte alignment)
+    else launch_pack_tiled_nb<LAYOUT, 8>(w, wq, K, Nn, T, P, mode, oscale, amax_w, st);
 }
 
 static int pack_grid(long long total) { return (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256); }
@@ -444,7 +519,7 @@ static double matrix_bytes(int math, double act_elems, double w_elems) { return 
 // and the bias vector, the activation applied in the epilogue (or in the split-K reduce), no normalise pass
 int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int N, int D, int H, int W,
                   int Cin, int Cout, int k, int dgrad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st,
-                  const float* oscale, int act, float slope, BnBwdEpi* bne) {
+                  const float* oscale, int act, float slope, BnBwdEpi* bne, const float* x_amax, const float* w_amax) {
     IgemmPlan p;
     SEG_CHECK_ARG(igemm_plan(math, k, N, D, H, W, Cin, Cout, 1, &p), "conv_fwd_mfma: unsupported shape");
     SEG_CHECK_ARG(((uintptr_t)x % 16) == 0, "conv_fwd_mfma: input pointer must be 16-byte aligned");
@@ -466,10 +541,27 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
     const bool bn_epi = bne && x3s && ksplit == 1 && !ssum && !bias && !act && (bne->ldx % 4) == 0 && ((uintptr_t)bne->x % 16) == 0 && Cout % 4 == 0;
     float* bnpart = bn_epi ? cv.take<float>((size_t)p.nM * Cout * 2) : nullptr;
     double* rtmp = (bn_epi || spart) ? reinterpret_cast<double*>(cv.take<char>(part_reduce_ws_bytes(Cout))) : nullptr;
+    // f16x3: the two-piece fp16 split needs max |x| and max |w| (device scalars; measured here unless the caller hands them over)
+    const bool f16 = x3s && x3_f16();
+    float* amax = f16 ? cv.take<float>(2) : nullptr;
     size_t tail = cv.used();
     SEG_CHECK_WS(tail + ((ssum && ksplit > 1) ? colsum_ws_bytes(Cout) : 0), ws_bytes);
     const bool w16 = ((uintptr_t)w % 16) == 0;                     // the tiled packings read W in 16-byte pieces
-    if (b16s && w16) launch_pack_tiled<0>(w, (bf16*)wq, Cin, Cout, T, bp.NT, dgrad ? 1 : 0, oscale, st);
+    if (f16) {
+        if (!x_amax || !w_amax) {
+            if (hipMemsetAsync(amax, 0, 2 * sizeof(float), st) != hipSuccess) { set_error("conv_fwd_mfma: hipMemsetAsync failed"); return MI355SEG_EHIP; }
+            if (!x_amax) { tensor_amax((const float*)x, ldx, nvox, Cin, nullptr, amax, st); x_amax = amax; }
+            // oscale (forward only: W is (Cout, Cin, T)) goes by the rows of W
+            if (!w_amax) {
+                if (oscale && !dgrad) tensor_amax(w, Cin * T, Cout, Cin * T, oscale, amax + 1, st);
+                else tensor_amax(w, T * Cin * Cout, 1, T * Cin * Cout, nullptr, amax + 1, st);
+                w_amax = amax + 1;
+            }
+        }
+        if (w16) launch_pack_tiled<2>(w, (bf16*)wq, Cin, Cout, 27, p.NBW, dgrad ? 1 : 0, oscale, st, w_amax);
+        else hipLaunchKernelGGL(pack_wq_x3s_f16_kernel, dim3(pack_grid((long long)28 * Cin * Cout)), dim3(256), 0, st, w, (_Float16*)wq, Cin, Cout, p.NBW, dgrad ? 1 : 0, oscale, w_amax);
+    }
+    else if (b16s && w16) launch_pack_tiled<0>(w, (bf16*)wq, Cin, Cout, T, bp.NT, dgrad ? 1 : 0, oscale, st);
     else if (b16s) hipLaunchKernelGGL(pack_wq_b16s_kernel, dim3(pack_grid((long long)(T + 1) * Cin * Cout)), dim3(256), 0, st, w, (bf16*)wq, Cin, Cout, T, bp.NT, dgrad ? 1 : 0, oscale);
     else if (x3s && w16) launch_pack_tiled<1>(w, (bf16*)wq, Cin, Cout, 27, p.NBW, dgrad ? 1 : 0, oscale, st);
     else if (x3s) hipLaunchKernelGGL(pack_wq_x3s_kernel, dim3(pack_grid((long long)28 * Cin * Cout)), dim3(256), 0, st, w, (bf16*)wq, Cin, Cout, p.NBW, dgrad ? 1 : 0, oscale);
@@ -479,6 +571,7 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
                 p.ntx, p.nty, p.ntz, p.nN, nchunks, nchunks, p.nN, 1, 1, p.nM, ksplit, nchunks / ksplit, nvox * Cout, dbg_flags()};
     a.Di = a.Do = D; a.Hi = a.Ho = H; a.Wi = a.Wo = W;
     a.act = ksplit > 1 ? 0 : act; a.slope = slope;
+    if (f16) { a.amax_x = x_amax; a.amax_w = w_amax; }
     if (bn_epi) {
         a.bnx = bne->x; a.ldbnx = bne->ldx; a.bn_mean = bne->mean; a.bn_rstd = bne->rstd; a.bn_gamma = bne->gamma; a.bn_beta = bne->beta;
         a.bn_act = bne->act; a.bn_slope = bne->slope; a.bnpart = bnpart;

@@ -17,6 +17,15 @@
 //   slots r, and a tap shift only rotates them.
 //   Tile = the generic kernel's BX = 16 tile (4 x 4 x 16 or 2 x 4 x 16 voxels, 32 or 64 channels, same walk, same split-K,
 //   same BatchNorm-statistics epilogue), so the host-side plan is shared (conv_mfma.hip).
+//
+// F16 = true ("f16x3", round 4): the same kernel with a TWO-piece split on v_mfma_f32_16x16x32_f16.  v * 2^s = h + l with fp16 h, l
+// (11 + 11 mantissa bits and the sign of l: |v 2^s - h - l| <= 2^-23 |v 2^s|), the per-tensor power of two 2^s placing the
+// tensor's largest magnitude in [2^14, 2^15) so that h never overflows and l (>= 2^-11 of its value) stays above the fp16
+// underflow for every value within 2^-18 of the maximum (smaller values keep an absolute error of 2^-40 of the maximum: the fp16
+// subnormals are exact on the matrix cores).  Three MFMAs per product (l h, h l, h h; the dropped l l term is <= 2^-22 of the
+// product, 2^-24.6 rms) instead of six, 8 conversion VALU per four values instead of 22, four LDS pieces instead of six.  The two
+// maxima are read from device memory (a.amax_x, a.amax_w: upper bounds of max |x|, max |w|); the accumulators are scaled back
+// by 2^-(sx + sw) before anything in the epilogue looks at them.
 #include "common.h"
 #include "internal.h"
 #include "igemm_kernel.h"
@@ -27,12 +36,13 @@ namespace {
 
 constexpr int XBX = 16, XTY = 4, XHX = XBX + 2, XHY = XTY + 2;
 
-template <int LW>
+template <int LW, bool F16 = false>
 struct Geo {
+    static constexpr int NPL = F16 ? 2 : 3;                     // planes of the split
     static constexpr int LINES = 4 * LW, TZ = LINES / XTY, HZ = TZ + 2;
     static constexpr int NVOX = XHX * XHY * HZ;
     static constexpr int PS = (NVOX + 15) / 16 * 16;            // 16-byte slots per piece; a multiple of 16 slots (256 B)
-    static constexpr int LDS_BYTES = 6 * PS * 16;
+    static constexpr int LDS_BYTES = 2 * NPL * PS * 16;
     static constexpr int NPIECE = NVOX * 4;                     // staged 16-byte pieces (4 fp32 channels) per chunk
     static constexpr int NITER = (NPIECE + 255) / 256;
 };
@@ -52,13 +62,14 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 // LW = x-lines (16 voxels each) per wave: 4 -> tile 4 (z) x 4 (y) x 16, wave w owns z-slab w; 2 -> tile 2 x 4 x 16.
 // NBW = 32-channel blocks of the tile (NT = 32 * NBW output channels).
-template <int LW, int NBW>
+template <int LW, int NBW, bool F16>
 __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
-    using G = Geo<LW>;
+    using G = Geo<LW, F16>;
+    constexpr int NPL = G::NPL;
     constexpr int NT = 32 * NBW;
     constexpr int NTW = 2 * NBW;                                 // 16-channel MFMA tiles per wave
     constexpr int NU = X3S_NPAIR * NBW;                          // (K-step, 32-channel half) units per chunk
-    constexpr int UNIT = 6 * 512;                                // bf16 elements of one unit of packed weights: [plane][t2][lane][8]
+    constexpr int UNIT = 2 * NPL * 512;                          // 16-bit elements of one unit of packed weights: [plane][t2][lane][8]
     constexpr int PS = G::PS;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
@@ -95,6 +106,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
     const int n0 = ntile * NT;
     const int c0 = ks * a.cps, c1 = c0 + a.cps;
     const float* __restrict__ xin = reinterpret_cast<const float*>(a.x);
+    // f16x3: power-of-two scales of the two operands (the weights were scaled while they were packed)
+    int sx = 0, sw = 0;
+    if constexpr (F16) { sx = f16x_scale_exp(*a.amax_x); sw = f16x_scale_exp(*a.amax_w); }
+    const float xscale = pow2f(sx);
 
     // ---- halo staging: global -> registers (issue early) -> split3 -> LDS (write late).
     // Piece p = it * 256 + tid is (halo voxel p / 4, four channels p % 4) of the chunk.  Its byte offset inside sample n is the
@@ -129,12 +144,20 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
     };
     // x = h + m + l for a pair of values: three packed conversions, the remainders formed from the packed words
     auto split_pair = [](float x0_, float x1_, unsigned& h2, unsigned& m2, unsigned& l2) {
-        using f32x2 = __attribute__((ext_vector_type(2))) float;
+        using f32x2 = f32x2_t;
         h2 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0_, x1_}, bf16x2_t));
         const float r0 = x0_ - __builtin_bit_cast(float, h2 << 16), r1 = x1_ - __builtin_bit_cast(float, h2 & 0xFFFF0000u);
         m2 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2_t));
         const float q0 = r0 - __builtin_bit_cast(float, m2 << 16), q1 = r1 - __builtin_bit_cast(float, m2 & 0xFFFF0000u);
         l2 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{q0, q1}, bf16x2_t));
+    };
+    // f16x3: v 2^s = h + l, two packed conversions; the remainder is one v_fma_mix per value (f16 operand read in place)
+    auto split_pair_h = [&](float x0_, float x1_, unsigned& h2, unsigned& l2) {
+        const float s0 = x0_ * xscale, s1 = x1_ * xscale;
+        const f16x2_t hh = __builtin_convertvector(f32x2_t{s0, s1}, f16x2_t);
+        h2 = __builtin_bit_cast(unsigned, hh);
+        const float r0 = __builtin_fmaf((float)hh[0], -1.f, s0), r1 = __builtin_fmaf((float)hh[1], -1.f, s1);
+        l2 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r0, r1}, f16x2_t));
     };
     // piece p = it * 256 + tid sits at LDS byte  ((part >> 1) * PS + tid / 4) * 16 + (part & 1) * 8  +  it * 1024
     unsigned char* const wdst = lds_raw + (((tid & 3) >> 1) * PS + (tid >> 2)) * 16 + (tid & 1) * 8;
@@ -143,14 +166,23 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
         for (int it = 0; it < G::NITER; ++it) {
             if (it * 256 + tid < G::NPIECE) {
                 using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
-                unsigned h0, m0, l0, h1, m1, l1;
-                split_pair(stage[it][0], stage[it][1], h0, m0, l0);
-                split_pair(stage[it][2], stage[it][3], h1, m1, l1);
-                const u32x2 qh = {h0, h1}, qm = {m0, m1}, ql = {l0, l1};
                 unsigned char* dst = wdst + it * 1024;
-                *reinterpret_cast<u32x2*>(dst) = qh;
-                *reinterpret_cast<u32x2*>(dst + 2 * PS * 16) = qm;
-                *reinterpret_cast<u32x2*>(dst + 4 * PS * 16) = ql;
+                if constexpr (F16) {
+                    unsigned h0, l0, h1, l1;
+                    split_pair_h(stage[it][0], stage[it][1], h0, l0);
+                    split_pair_h(stage[it][2], stage[it][3], h1, l1);
+                    const u32x2 qh = {h0, h1}, ql = {l0, l1};
+                    *reinterpret_cast<u32x2*>(dst) = qh;
+                    *reinterpret_cast<u32x2*>(dst + 2 * PS * 16) = ql;
+                } else {
+                    unsigned h0, m0, l0, h1, m1, l1;
+                    split_pair(stage[it][0], stage[it][1], h0, m0, l0);
+                    split_pair(stage[it][2], stage[it][3], h1, m1, l1);
+                    const u32x2 qh = {h0, h1}, qm = {m0, m1}, ql = {l0, l1};
+                    *reinterpret_cast<u32x2*>(dst) = qh;
+                    *reinterpret_cast<u32x2*>(dst + 2 * PS * 16) = qm;
+                    *reinterpret_cast<u32x2*>(dst + 4 * PS * 16) = ql;
+                }
             }
         }
     };
@@ -176,12 +208,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
     for (int chunk = c0; chunk < c1; ++chunk) {
         const bf16* wp = wlane + (long long)chunk * (NU * UNIT);
         constexpr int WD = NBW == 2 && LW == 4 ? 1 : 2;          // weight units in flight ahead of the MFMAs (the 64-channel 4-line tile is register-bound)
-        bf16x8_t wf[WD + 1][2][3], xf[2][3];
+        bf16x8_t wf[WD + 1][2][NPL], xf[2][NPL];
         auto load_w = [&](int u) {
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) wf[u % (WD + 1)][t2][pl] = *reinterpret_cast<const bf16x8_t*>(wp + u * UNIT + (pl * 2 + t2) * 512);
+                for (int pl = 0; pl < NPL; ++pl) wf[u % (WD + 1)][t2][pl] = *reinterpret_cast<const bf16x8_t*>(wp + u * UNIT + (pl * 2 + t2) * 512);
         };
         // the first weight units are requested BEFORE the next chunk's halo: vmcnt retires in order
 #pragma unroll
@@ -191,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
         __syncthreads();
         const bool more = chunk + 1 < c1;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) xf[0][pl] = *reinterpret_cast<const bf16x8_t*>(lds_raw + xaddr(0, 0, pl));
+        for (int pl = 0; pl < NPL; ++pl) xf[0][pl] = *reinterpret_cast<const bf16x8_t*>(lds_raw + xaddr(0, 0, pl));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
@@ -204,24 +236,35 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
                 if (q + 1 < NU * LW) {
                     const int u2 = (q + 1) / LW, j2 = (q + 1) % LW;
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) xf[nxt][pl] = *reinterpret_cast<const bf16x8_t*>(lds_raw + xaddr(u2 / NBW, j2, pl));
+                    for (int pl = 0; pl < NPL; ++pl) xf[nxt][pl] = *reinterpret_cast<const bf16x8_t*>(lds_raw + xaddr(u2 / NBW, j2, pl));
                 }
-                // planes 0 / 1 / 2 = h / m / l; the small cross terms go in first; the two channel tiles alternate
-                constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
+                if constexpr (F16) {
+                    // planes 0 / 1 = h / l; the two cross terms go in first; the two channel tiles alternate
+                    constexpr int PW[3] = {1, 0, 0}, PX[3] = {0, 1, 0};
 #pragma unroll
-                for (int pr = 0; pr < 6; ++pr)
+                    for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
-                    for (int t2 = 0; t2 < 2; ++t2)
-                        acc[j][nh * 2 + t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u % (WD + 1)][t2][PW[pr]], xf[cur][PX[pr]], acc[j][nh * 2 + t2], 0, 0, 0);
+                        for (int t2 = 0; t2 < 2; ++t2)
+                            acc[j][nh * 2 + t2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, wf[u % (WD + 1)][t2][PW[pr]]),
+                                                                                      __builtin_bit_cast(f16x8_t, xf[cur][PX[pr]]), acc[j][nh * 2 + t2], 0, 0, 0);
+                } else {
+                    // planes 0 / 1 / 2 = h / m / l; the small cross terms go in first; the two channel tiles alternate
+                    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                    for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                        for (int t2 = 0; t2 < 2; ++t2)
+                            acc[j][nh * 2 + t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u % (WD + 1)][t2][PW[pr]], xf[cur][PX[pr]], acc[j][nh * 2 + t2], 0, 0, 0);
+                }
                 // interleave: the next line's voxels (DS, needed first) behind the first MFMAs, then the weights two units ahead
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
+                for (int k = 0; k < NPL; ++k) {
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 }
                 if (j == 0 || q < G::NITER) {
 #pragma unroll
-                    for (int k = 0; k < 7; ++k) {
+                    for (int k = 0; k < 2 * NPL + 1; ++k) {
                         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     }
@@ -234,6 +277,14 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
 
     // ---- epilogue: bias, 16-byte stores, optional BatchNorm partial statistics
     // acc[j][t][e] = y[voxel (line j, x = r)][channel n0 + 16 t + 4 g + e]
+    if constexpr (F16) {
+#pragma unroll
+        for (int j = 0; j < LW; ++j)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j][t][e] = __builtin_ldexpf(acc[j][t][e], -(sx + sw));
+    }
     float* yslab = reinterpret_cast<float*>(a.y) + (long long)ks * a.split_stride;     // ksplit > 1: raw partial sums of this split (split_stride 0 otherwise)
     const int gx = x0 + r;
     float ssum[NTW][4];
@@ -363,12 +414,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
     }
 }
 
-template <int LW, int NBW>
+template <int LW, int NBW, bool F16>
 void launch_x3s(const IgemmArgs& a, int nwg, hipStream_t st) {
-    constexpr int LDSB = Geo<LW>::LDS_BYTES;
+    constexpr int LDSB = Geo<LW, F16>::LDS_BYTES;
     static_assert(LDSB >= 8 * 64 * 4, "the statistics epilogue needs 8 x NT floats");
-    SEG_SET_LDS((conv_x3s_kernel<LW, NBW>), LDSB);
-    hipLaunchKernelGGL((conv_x3s_kernel<LW, NBW>), dim3(nwg), dim3(256), LDSB, st, a);
+    SEG_SET_LDS((conv_x3s_kernel<LW, NBW, F16>), LDSB);
+    hipLaunchKernelGGL((conv_x3s_kernel<LW, NBW, F16>), dim3(nwg), dim3(256), LDSB, st, a);
 }
 
 }  // namespace
@@ -380,9 +431,15 @@ bool x3s_plan_ok(const IgemmPlan& p, const void* x, int ldx, const void* y, int 
            (ldx % 4) == 0 && (ldy % 4) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0;
 }
 
+// a.amax_x != nullptr selects the f16x3 form (the weights at a.wq are then its two-plane fp16 packing)
 void dispatch_x3s(const IgemmPlan& p, const IgemmArgs& a, int nwg, hipStream_t st) {
-    if (p.MB == 2) { if (p.NBW == 2) launch_x3s<4, 2>(a, nwg, st); else launch_x3s<4, 1>(a, nwg, st); }
-    else { if (p.NBW == 2) launch_x3s<2, 2>(a, nwg, st); else launch_x3s<2, 1>(a, nwg, st); }
+    if (a.amax_x) {
+        if (p.MB == 2) { if (p.NBW == 2) launch_x3s<4, 2, true>(a, nwg, st); else launch_x3s<4, 1, true>(a, nwg, st); }
+        else { if (p.NBW == 2) launch_x3s<2, 2, true>(a, nwg, st); else launch_x3s<2, 1, true>(a, nwg, st); }
+        return;
+    }
+    if (p.MB == 2) { if (p.NBW == 2) launch_x3s<4, 2, false>(a, nwg, st); else launch_x3s<4, 1, false>(a, nwg, st); }
+    else { if (p.NBW == 2) launch_x3s<2, 2, false>(a, nwg, st); else launch_x3s<2, 1, false>(a, nwg, st); }
 }
 
 }  // namespace seg

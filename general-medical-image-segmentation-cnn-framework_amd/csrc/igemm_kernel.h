@@ -115,6 +115,8 @@ struct IgemmArgs {
     const float* bn_mean; const float* bn_rstd; const float* bn_gamma; const float* bn_beta;
     int bn_act; float bn_slope;
     float* bnpart;
+    // ---- f16x3 (conv_x3s.hip): device pointers to upper bounds of max |x| and max |w|; amax_x != nullptr selects that form
+    const float* amax_x; const float* amax_w;
 };
 
 

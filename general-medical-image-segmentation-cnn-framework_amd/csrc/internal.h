@@ -84,6 +84,7 @@ template <typename T> int head_wgrad(const T* dy, int lddy, const T* x, int ldx,
 // conv_generic.hip
 int f32_conv_policy();     // MATH_X3 when the bf16x6 conv math is selected, else MATH_F32
 int x3_shape();            // 16 | 32: MFMA shape of the bf16x6 forward / dgrad kernels (mi355seg_set_x3_shape)
+bool x3_f16();             // the split-precision kernels run the two-piece fp16 split (MI355SEG_MATH_F16X3) where they have that form
 void pack_w_fwd(const float* w, float* wp, int Cout, int Cin, int T, hipStream_t st);
 void pack_w_dgrad(const float* w, float* wd, int Cout, int Cin, int T, int flip, hipStream_t st);
 void wgrad_reduce(const float* part, float* dw, int splits, int T, int Cin, int Cout, int accumulate, hipStream_t st);
@@ -115,7 +116,10 @@ void norm_bwd_finalize(const float* part, int nblk, int C, float* s1, float* s2,
 bool tile_stats_finalize2(const float* spart, int nM, int C, double* sum, double* sq, double* tmp, hipStream_t st);
 int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int N, int D, int H, int W,
                   int Cin, int Cout, int k, int dgrad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st,
-                  const float* oscale = nullptr, int act = 0, float slope = 0.f, BnBwdEpi* bne = nullptr);
+                  const float* oscale = nullptr, int act = 0, float slope = 0.f, BnBwdEpi* bne = nullptr,
+                  const float* x_amax = nullptr, const float* w_amax = nullptr);
+// max |x| of a rows x C tensor at pitch ld (times |rowscale[row]| when given), max-combined into the zeroed device scalar *slot
+void tensor_amax(const float* x, int ld, long long rows, int C, const float* rowscale, float* slot, hipStream_t st);
 bool convt_mfma_supported(int math, int N, int D, int H, int W, int Cin, int Cout, int ldx, int ldy);
 int convt_fwd_mfma(int math, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int N, int D, int H, int W,
                    int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t st);

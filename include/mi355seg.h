@@ -62,6 +62,7 @@ int mi355seg_version(void);
  * Process-wide, read at each launch.  Initial value: environment MI355SEG_CONV_MATH = fp32 | bf16x6, else the default. */
 #define MI355SEG_MATH_FP32 0
 #define MI355SEG_MATH_BF16X6 2
+#define MI355SEG_MATH_F16X3 3
 #define MI355SEG_MATH_DEFAULT MI355SEG_MATH_BF16X6
 int mi355seg_set_conv_math(int mode);
 int mi355seg_get_conv_math(void);

@@ -483,7 +483,7 @@ def test_split_precision_conv_is_fp32_accurate(seg, case):
     errs = {}
     try:
         # bf16x6 on both MFMA shapes: 16 = conv_x3s.hip (v_mfma_f32_16x16x32_bf16, where its 16-wide tiles apply), 32 = the generic kernel
-        for math, shape in (("fp32", 16), ("bf16x6", 32), ("bf16x6", 16)):
+        for math, shape in (("fp32", 16), ("bf16x6", 32), ("bf16x6", 16), ("f16x3", 16)):
             seg.set_conv_math(math)
             seg.set_x3_shape(shape)
             assert seg.get_conv_math() == math and seg.get_x3_shape() == shape
@@ -497,10 +497,11 @@ def test_split_precision_conv_is_fp32_accurate(seg, case):
         seg.set_conv_math(DEFAULT_MATH)
         seg.set_x3_shape(16)
     scales = (float(want.abs().max()), float(xd.grad.abs().max()), float(wd.grad.abs().max()))
-    for shape in (32, 16):
-        for what, e6, e32, sc in zip(("fwd", "dgrad", "wgrad"), errs[("bf16x6", shape)], errs[("fp32", 16)], scales):
-            assert e6 < 3e-6 * max(1.0, sc), (shape, what, e6, e32, sc)
-            assert e6 < 4.0 * e32 + 2e-7 * max(1.0, sc), (shape, what, e6, e32, sc)
+    # f16x3 (two fp16 parts per operand under a per-tensor power-of-two scale, three fp16 MFMAs per product): the same criteria, unchanged
+    for key in (("bf16x6", 32), ("bf16x6", 16), ("f16x3", 16)):
+        for what, e6, e32, sc in zip(("fwd", "dgrad", "wgrad"), errs[key], errs[("fp32", 16)], scales):
+            assert e6 < 3e-6 * max(1.0, sc), (key, what, e6, e32, sc)
+            assert e6 < 4.0 * e32 + 2e-7 * max(1.0, sc), (key, what, e6, e32, sc)
 
 
 @pytest.mark.parametrize("case", [(1, 32, 32, 32, 32, 32, 0), (1, 16, 16, 16, 32, 64, 0), (1, 16, 16, 16, 64, 64, 0), (2, 16, 16, 16, 128, 128, 0),
@@ -526,7 +527,7 @@ def test_bf16x6_16x16x32_kernel_against_fp64_and_the_32x32x16_kernel(seg, case):
     st = torch.cuda.current_stream().cuda_stream
     res = {}
     try:
-        for math, shape in (("fp32", 16), ("bf16x6", 32), ("bf16x6", 16)):
+        for math, shape in (("fp32", 16), ("bf16x6", 32), ("bf16x6", 16), ("f16x3", 16)):
             seg.set_conv_math(math)
             seg.set_x3_shape(shape)
             y = torch.full((N, D, H, W, ldy), 7.0, device="cuda")
@@ -547,14 +548,61 @@ def test_bf16x6_16x16x32_kernel_against_fp64_and_the_32x32x16_kernel(seg, case):
         seg.set_x3_shape(16)
     sy, sd = float(want.abs().max()), float(want_dx.abs().max())
     rms = lambda e: float(e.pow(2).mean().sqrt())
-    e16, e32, ef = res[("bf16x6", 16)], res[("bf16x6", 32)], res[("fp32", 16)]
-    for i, sc in ((0, sy), (1, sd)):
-        assert float(e16[i].abs().max()) < 3e-6 * sc
-        assert rms(e16[i]) <= 1.25 * max(rms(e32[i]), rms(ef[i])) + 1e-9 * sc          # same error level as the other two maths
-        assert abs(float(e16[i].mean())) <= 2e-7 * sc                                  # no systematic offset
+    e32, ef = res[("bf16x6", 32)], res[("fp32", 16)]
     nvox = N * D * H * W
-    assert torch.allclose(e16[2], want.sum(dim=(0, 1, 2, 3)), rtol=0, atol=2e-6 * sy * nvox)
-    assert torch.allclose(e16[3], want.pow(2).sum(dim=(0, 1, 2, 3)), rtol=2e-6, atol=1e-9)
+    for key in (("bf16x6", 16), ("f16x3", 16)):                                        # the two forms of conv_x3s.hip
+        e16 = res[key]
+        for i, sc in ((0, sy), (1, sd)):
+            assert float(e16[i].abs().max()) < 3e-6 * sc, key
+            assert rms(e16[i]) <= 1.25 * max(rms(e32[i]), rms(ef[i])) + 1e-9 * sc, (key, rms(e16[i]), rms(e32[i]), rms(ef[i]))   # same error level as the other two maths
+            assert abs(float(e16[i].mean())) <= 2e-7 * sc, key                          # no systematic offset
+        assert torch.allclose(e16[2], want.sum(dim=(0, 1, 2, 3)), rtol=0, atol=2e-6 * sy * nvox)
+        assert torch.allclose(e16[3], want.pow(2).sum(dim=(0, 1, 2, 3)), rtol=2e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("xs,ws,tail", [(1.0, 1.0, 0.0), (1e-8, 1.0, 0.0), (3e-30, 0.02, 0.0), (1e6, 1e-3, 0.0), (1e18, 1e12, 0.0), (1.0, 1.0, 1e3), (1e-9, 1.0, 3e4),
+                                        (0.0, 1.0, 0.0)])
+def test_f16x3_is_scale_free(seg, xs, ws, tail):
+    """The two-piece fp16 split runs under per-tensor power-of-two scales taken from the tensors' own maxima, so its accuracy must
+    not depend on where the values sit in the fp32 range: gradients of ~1e-8 (mean-BCE), tensors near either end of the fp32
+    exponent range, a tensor whose largest value is 1e3 - 3e4 times its typical one (everything else then sits that far down in
+    the fp16 range: the low parts go subnormal and must still count), an all-zero tensor.  Forward and input gradient of
+    conv_x3s.hip against fp64, graded against the exact-fp32 path's own error on the same inputs."""
+    N, D, H, W, Cin, Cout = 1, 8, 8, 32, 64, 64
+    F, L = seg.functional, seg.lib()
+    x = rnd(N, D, H, W, Cin, seed=1) * xs
+    if tail:
+        x.view(-1)[12345] = tail * xs
+        x.view(-1)[777] = -0.7 * tail * xs
+    w = rnd(Cout, Cin, 3, 3, 3, seed=2, scale=(2.0 / (27 * Cin)) ** 0.5) * ws
+    want = TF.conv3d(x.permute(0, 4, 1, 2, 3).double(), w.double(), None, padding=1).permute(0, 2, 3, 4, 1)
+    xg, wg = x.cuda(), w.cuda()
+    ws_ = F.workspace(L.query("mi355seg_conv3d_ws_bytes", N, D, H, W, Cin, Cout, 3, 1, 1), xg.device)
+    st = torch.cuda.current_stream().cuda_stream
+    res = {}
+    try:
+        for math in ("fp32", "f16x3"):
+            seg.set_conv_math(math)
+            y = torch.empty((N, D, H, W, Cout), device="cuda")
+            dx = torch.empty((N, D, H, W, Cin), device="cuda")
+            L.call("mi355seg_conv3d_fwd_f32", xg.data_ptr(), Cin, wg.data_ptr(), None, y.data_ptr(), Cout, N, D, H, W, Cin, Cout, 3, 1, 1,
+                   None, None, ws_.data_ptr(), ws_.numel(), st)
+            # the same tensor as an incoming gradient of the transposed-role convolution (Cin == Cout here)
+            L.call("mi355seg_conv3d_dgrad_f32", xg.data_ptr(), Cout, wg.data_ptr(), dx.data_ptr(), Cin, N, D, H, W, Cin, Cout, 3, 1, 1,
+                   ws_.data_ptr(), ws_.numel(), st)
+            torch.cuda.synchronize()
+            res[math] = (y.cpu().double() - want, dx.cpu().double() - torch.nn.grad.conv3d_input((N, Cin, D, H, W), w.double(), x.permute(0, 4, 1, 2, 3).double(), padding=1).permute(0, 2, 3, 4, 1))
+    finally:
+        seg.set_conv_math(DEFAULT_MATH)
+    rms = lambda e: float(e.pow(2).mean().sqrt())
+    for i in (0, 1):
+        eh, ef = res["f16x3"][i], res["fp32"][i]
+        assert bool(torch.isfinite(eh).all())
+        if xs == 0.0:
+            assert float(eh.abs().max()) == 0.0
+            continue
+        assert rms(eh) <= 1.5 * rms(ef), (i, rms(eh), rms(ef))
+        assert float(eh.abs().max()) <= 2.0 * float(ef.abs().max()), (i, float(eh.abs().max()), float(ef.abs().max()))
 
 
 @pytest.mark.parametrize("shape", [(2, 5, 4, 6, 7), (2, 2, 4, 6, 8), (1, 3, 4, 6, 8), (3, 4, 2, 6, 10), (2, 2, 3, 5, 7), (1, 1, 4, 4, 4)])
