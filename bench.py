@@ -29,6 +29,7 @@ if ROOT not in sys.path:
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 matrix peak (spec, no sparsity)
 PEAK_BF16X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0   # fp32-equivalent peak of the split-precision path: six bf16 MFMAs per product
+PEAK_F16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0    # two-piece fp16 split: three fp16 MFMAs per product (F16 MFMA = the BF16 rate)
 PEAK_HBM_TBS = 8.0               # HBM3E spec peak
 
 WORKLOADS = {
@@ -40,7 +41,10 @@ WORKLOADS = {
 MATH_DTYPE = {
     "fp32": "f32",
     "bf16x6": "f32 (bf16x6 split MFMA: every fp32 conv operand = three bf16 parts, six bf16 products per fp32 product, fp32 accumulate)",
+    "f16x3": "f32 (f16x3 split MFMA: every fp32 conv operand = two fp16 parts under a per-tensor power-of-two scale, three fp16 products per "
+             "fp32 product, fp32 accumulate; graded against fp64 by the same tests as bf16x6 and the exact-fp32 MFMA path)",
 }
+MATH_PEAK = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16x6": PEAK_BF16X6_TFLOPS, "f16x3": PEAK_F16X3_TFLOPS}
 
 
 FAMILY_NAMES = ["conv_igemm_mfma", "conv_wgrad_mfma", "conv_generic", "convT_k2s2", "norm_act", "pool_upsample_layout", "loss_metric", "conv_direct_stem_head"]
@@ -320,9 +324,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="unet3d_f32_2x128", choices=sorted(WORKLOADS))
-    ap.add_argument("--conv-math", default=os.environ.get("MI355SEG_CONV_MATH") or "bf16x6", choices=["fp32", "bf16x6"],
-                    help="arithmetic of the k3/k5 MFMA convolutions: bf16x6 (default; fp32-accurate split on the bf16 matrix cores) "
-                         "or fp32 (exact fp32 MFMA)")
+    ap.add_argument("--conv-math", default=os.environ.get("MI355SEG_CONV_MATH") or "f16x3", choices=["fp32", "bf16x6", "f16x3"],
+                    help="arithmetic of the k3 MFMA convolutions on fp32 tensors: f16x3 (default; fp32-accurate two-piece split on the fp16 matrix "
+                         "cores), bf16x6 (three-piece split on the bf16 matrix cores) or fp32 (exact fp32 MFMA)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="2,1,128,128,128")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-oracle steps after one full-shape warm-up")
@@ -562,7 +566,7 @@ def main():
         n, tms, fl, by = buf[0], buf[1], buf[2], buf[3]
         if n > 0 and tms > 0:
             ach = fl / (tms * 1e-3) / 1e12
-            peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16x6": PEAK_BF16X6_TFLOPS}[args.conv_math]
+            peak = MATH_PEAK[args.conv_math]
             rec, note = pmc_traffic()
             traffic = None
             if rec is not None and rec.get("conv_math", "fp32") == args.conv_math:
@@ -571,15 +575,18 @@ def main():
                 note = f"PMC passes were taken with conv math {rec.get('conv_math', 'fp32')}, this run uses {args.conv_math}"
             kern = {"fp32": "conv_igemm_kernel<MATH_F32> (Conv3d k3 fwd+dgrad, v_mfma_f32_32x32x2_f32)",
                     "bf16x6": "conv_x3s_kernel (Conv3d k3 fwd+dgrad on fp32 tensors, six v_mfma_f32_16x16x32_bf16 per fp32 product; the W = 8 "
-                              "bottleneck layers on conv_igemm_kernel<MATH_X3>, 32x32x16)"}[args.conv_math]
+                              "bottleneck layers on conv_igemm_kernel<MATH_X3>, 32x32x16)",
+                    "f16x3": "conv_x3s_kernel<..., F16> (Conv3d k3 fwd+dgrad on fp32 tensors, three v_mfma_f32_16x16x32_f16 per fp32 product; the W = 8 "
+                             "bottleneck layers on conv_igemm_kernel<MATH_X3>, bf16x6 on 32x32x16)"}[args.conv_math]
             res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                                "frac": ach / peak, "traffic": traffic, "traffic_source": note,
                                "kernel": kern, "launches": int(n), "avg_launch_ms": tms / n,
                                "peak_basis": {"fp32": "fp32 MFMA 157.3 TFLOP/s",
-                                              "bf16x6": "bf16 MFMA 2500 TFLOP/s / 6 products = 416.7 fp32-equivalent TFLOP/s"}[args.conv_math],
+                                              "bf16x6": "bf16 MFMA 2500 TFLOP/s / 6 products = 416.7 fp32-equivalent TFLOP/s",
+                                              "f16x3": "fp16 MFMA 2500 TFLOP/s / 3 products = 833.3 fp32-equivalent TFLOP/s"}[args.conv_math],
                                "achieved_counts": "algorithmic fp32 FLOPs (2 x voxels x 27 x Cin x Cout per launch), not MFMA issue slots",
                                "algorithmic_gflop_per_launch": fl / n / 1e9, "hbm_algorithmic_gbs": by / (tms * 1e-3) / 1e9}
-    peak_step = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16x6": PEAK_BF16X6_TFLOPS}[args.conv_math]
+    peak_step = MATH_PEAK[args.conv_math]
     t_mfma = flop_per_vox * B * Dd * Hh * Ww / (peak_step * 1e12) * 1e3
     t_hbm = bytes_per_vox * B * Dd * Hh * Ww / (PEAK_HBM_TBS * 1e12) * 1e3
     res["step_roofline"] = {"conv_t_mfma_ms": t_mfma, "conv_t_hbm_ms": t_hbm, "frac_of_mfma_bound": t_mfma / ms, "frac_of_hbm_bound": t_hbm / ms}

@@ -7,12 +7,13 @@ from . import custom_ops          # registers torch.ops.mi355seg.* (dispatcher v
 from ._lib import LIB_PATH, Mi355SegError, lib
 
 _MATH = {"fp32": 0, "bf16x6": 2, "f16x3": 3}
-DEFAULT_CONV_MATH = "bf16x6"
+DEFAULT_CONV_MATH = "f16x3"
 
 
 def set_conv_math(mode):
-    """Arithmetic of the MFMA convolutions on fp32 tensors: "fp32" (exact fp32 MFMA), or "bf16x6" (the default: fp32-accurate
-    split on the bf16 matrix cores).  See include/mi355seg.h."""
+    """Arithmetic of the MFMA convolutions on fp32 tensors: "fp32" (exact fp32 MFMA), "bf16x6" (fp32-accurate three-piece
+    split on the bf16 matrix cores) or "f16x3" (the default: fp32-accurate two-piece split on the fp16 matrix cores under
+    per-tensor power-of-two scales).  See include/mi355seg.h."""
     if mode not in _MATH:
         raise ValueError(f"conv math must be one of {sorted(_MATH)}, got {mode!r}")
     lib().call("mi355seg_set_conv_math", _MATH[mode])

@@ -8,6 +8,8 @@
 //   MATH_X3  fp32 tensors ("bf16x6"): x and dy are split once, while they are staged, into three bf16 planes each
 //            (v = h + m + l, 24 mantissa bits) and six MFMAs (lh, hl, mm, mh, hm, hh) form each product -- fp32-level
 //            accuracy at 2.7x the fp32 matrix rate;
+//            NP = 2 ("f16x3", x3_f16()): the two-piece fp16 split of conv_x3s.hip -- v 2^s = h + l under per-tensor power-of-two
+//            scales from the tensors' maxima, three v_mfma_f32_16x16x32_f16 (lh, hl, hh) per product, slab scaled back on the way out;
 //   MATH_B16 bf16 tensors: one plane, one MFMA per k-step.
 //
 // K runs over voxels, but NDHWC keeps the CHANNELS of a voxel contiguous, so both MFMA operands are k-strided in memory.
@@ -46,7 +48,7 @@ struct LTile {
     static constexpr int HALO = KS / 2;
     static constexpr int NTAPS = KS == 3 ? 27 : KS * KS;          // taps per workgroup (k5: one dz plane)
     static constexpr int PLANES = KS == 3 ? 1 : KS;
-    static constexpr int VOX = (NP == 3 || S == 2) ? 128 : 256;   // output voxels per tile (three planes per operand / strided halo: half the tile)
+    static constexpr int VOX = (NP >= 2 || S == 2) ? 128 : 256;   // output voxels per tile (split planes per operand / strided halo: half the tile)
     static constexpr int TY = BX == 8 ? 8 : 4;
     static constexpr int LINES = VOX / BX;
     static constexpr int TZ = LINES / TY;
@@ -69,6 +71,7 @@ struct LWgradArgs {
     int ldx, lddy, N, D, H, W, Cin, Cout;      // D, H, W: input (x) extents
     int Do, Ho, Wo;                            // output (dy) extents
     int ntx, nty, ntz, ntiles, nstrips, npairs, ncob, ntaps_total;
+    const float* amax_x; const float* amax_dy;     // NP = 2: device scalars >= max |x|, max |dy|
 };
 
 __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* lds, int off0, int off1) {
@@ -102,6 +105,9 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
     const int ci0 = cib * 32, co0 = cob * 32;
     const IN_T* __restrict__ xin = reinterpret_cast<const IN_T*>(a.x);
     const IN_T* __restrict__ din = reinterpret_cast<const IN_T*>(a.dy);
+    int sx = 0, sd = 0;
+    if constexpr (NP == 2) { sx = f16x_scale_exp(*a.amax_x); sd = f16x_scale_exp(*a.amax_dy); }
+    const float xscale = pow2f(sx), dscale = pow2f(sd);
 
     // transposing-read lane geometry: lane 4q+p of a 16-lane group addresses voxel row q, channels 4p..4p+3 of the fragment's
     // 16 channels and receives the four voxels of channel 4q+p.  Group g = lane / 16 holds k = {4g .. 4g+3} (first read) and
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
         for (int ab = 0; ab < 4; ++ab) acc[tt][ab >> 1][ab & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     using stage_t = typename std::conditional<EPP == 4, f32x4, bf16x8_t>::type;
-    stage_t sx[XITER], sd[DITER];
+    stage_t stx[XITER], std_[DITER];
     auto load_stage = [&](int tile) {
         int mt = tile;
         const int txi = mt % a.ntx; mt /= a.ntx;
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
             const bool ok = (pc < XPIECES) && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
             stage_t v = {};
             if (ok) v = *reinterpret_cast<const stage_t*>(xin + ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.ldx + ci0 + part * EPP);
-            sx[it] = v;
+            stx[it] = v;
         }
 #pragma unroll
         for (int it = 0; it < DITER; ++it) {
@@ -161,13 +167,19 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
             stage_t dv = {};                          // partial tiles: voxels outside the volume contribute nothing
             if (gz < a.Do && gy < a.Ho && gx < a.Wo)
                 dv = *reinterpret_cast<const stage_t*>(din + ((((long long)n * a.Do + gz) * a.Ho + gy) * a.Wo + gx) * a.lddy + co0 + part * EPP);
-            sd[it] = dv;
+            std_[it] = dv;
         }
     };
-    auto put = [&](unsigned char* base, int pc, const stage_t& v) {
+    auto put = [&](unsigned char* base, int pc, const stage_t& v, float scale) {
         unsigned char* dst = base + (pc / PPV) * T::ROW + (pc % PPV) * (EPP * 2);
         if constexpr (EPP == 4) {
-            if constexpr (NP == 3) {                  // split once per staged value: planes h | m | l of the voxel row
+            if constexpr (NP == 2) {                  // two fp16 planes h | l of the scaled voxel row
+                f16x4_t qh, ql;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { _Float16 bh, bl; split2h(v[e] * scale, bh, bl); qh[e] = bh; ql[e] = bl; }
+                *reinterpret_cast<f16x4_t*>(dst) = qh;
+                *reinterpret_cast<f16x4_t*>(dst + 64) = ql;
+            } else if constexpr (NP == 3) {                  // split once per staged value: planes h | m | l of the voxel row
                 bf16x4_t qh, qm, ql;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { bf16 bh, bm, bl; split3(v[e], bh, bm, bl); qh[e] = bh; qm[e] = bm; ql[e] = bl; }
@@ -188,10 +200,10 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
 #pragma unroll
         for (int it = 0; it < XITER; ++it) {
             const int pc = it * LW_THREADS + tid;
-            if (pc < XPIECES) put(xs, pc, sx[it]);
+            if (pc < XPIECES) put(xs, pc, stx[it], xscale);
         }
 #pragma unroll
-        for (int it = 0; it < DITER; ++it) put(ds, it * LW_THREADS + tid, sd[it]);
+        for (int it = 0; it < DITER; ++it) put(ds, it * LW_THREADS + tid, std_[it], dscale);
     };
 
     // byte offset of 32-voxel k-step ks, read t inside the x halo / the dy tile (lane part excluded)
@@ -221,7 +233,15 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
                 for (int pl = 0; pl < NP; ++pl) ac[buf][a2][pl] = tr_frag(xs, abase[tt] + xoff(ks, 0) + a2 * 32 + pl * 64, abase[tt] + xoff(ks, 1) + a2 * 32 + pl * 64);
         };
         auto mfma_half = [&](int cur, int tt, int b) {
-            if constexpr (NP == 3) {                // planes 0 / 1 / 2 = h / m / l; the small cross terms go in first; the two ci tiles alternate
+            if constexpr (NP == 2) {                // planes 0 / 1 = h / l of the fp16 split; the two cross terms go in first
+                constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+                for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                    for (int a2 = 0; a2 < 2; ++a2)
+                        acc[tt][a2][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ac[cur][a2][PA[pr]]), __builtin_bit_cast(f16x8_t, bc[b][PB[pr]]),
+                                                                               acc[tt][a2][b], 0, 0, 0);
+            } else if constexpr (NP == 3) {                // planes 0 / 1 / 2 = h / m / l; the small cross terms go in first; the two ci tiles alternate
                 constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
                 for (int pr = 0; pr < 6; ++pr)
@@ -234,7 +254,7 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
                     acc[tt][a2][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[cur][a2][0], bc[b][0], acc[tt][a2][b], 0, 0, 0);
             }
         };
-        if constexpr (NP == 3 || S == 2) {
+        if constexpr (NP >= 2 || S == 2) {
             // (the strided tiles are register-bound too.)  bf16x6: 24 MFMAs per tap-tile hide the reads of the next one by themselves (two waves per SIMD); pinning the order by
             // hand costs registers the three-plane fragments do not leave (measured: 42 spilled VGPRs, 0.68x) -- compiler order
 #pragma unroll
@@ -291,7 +311,11 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
 #pragma unroll
         for (int ab = 0; ab < 4; ++ab)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dst[(long long)(16 * (ab >> 1) + e) * a.Cout + 16 * (ab & 1)] = acc[tt][ab >> 1][ab & 1][e];
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[tt][ab >> 1][ab & 1][e];
+                if constexpr (NP == 2) v = __builtin_ldexpf(v, -(sx + sd));
+                dst[(long long)(16 * (ab >> 1) + e) * a.Cout + 16 * (ab & 1)] = v;
+            }
     }
 }
 
@@ -366,7 +390,10 @@ static void launch_lwgrad(const LWgradArgs& a, int nwg, hipStream_t st) {
 
 template <int KS>
 static void dispatch_lwgrad(int math, const LWgradPlan& p, const LWgradArgs& a, int nwg, hipStream_t st) {
-    if (math == MATH_X3) {
+    if (math == MATH_X3 && a.amax_x) {
+        if (p.BX == 16) launch_lwgrad<16, KS, 2, float>(a, nwg, st);
+        else launch_lwgrad<8, KS, 2, float>(a, nwg, st);
+    } else if (math == MATH_X3) {
         if (p.BX == 16) launch_lwgrad<16, KS, 3, float>(a, nwg, st);
         else launch_lwgrad<8, KS, 3, float>(a, nwg, st);
     } else {
@@ -377,15 +404,26 @@ static void dispatch_lwgrad(int math, const LWgradPlan& p, const LWgradArgs& a, 
 }
 
 int conv_wgrad_lowp(int math, const void* dy, int lddy, const void* x, int ldx, float* dw, int N, int D, int H, int W, int Cin,
-                    int Cout, int k, int stride, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+                    int Cout, int k, int stride, int accumulate, void* ws, size_t ws_bytes, hipStream_t st, const float* x_amax, const float* dy_amax) {
     LWgradPlan p;
     const int pad = k / 2, Do = lw_out(D, k, stride, pad), Ho = lw_out(H, k, stride, pad), Wo = lw_out(W, k, stride, pad);
     SEG_CHECK_ARG(lwgrad_plan(math, k, stride, N, Do, Ho, Wo, Cin, Cout, &p), "conv_wgrad_lowp: unsupported shape");
     SEG_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, "conv_wgrad_lowp: pointers must be 16-byte aligned");
     Carver cv(ws);
     float* part = cv.take<float>((size_t)p.nstrips * p.taps * Cin * Cout);
+    const bool f16 = math == MATH_X3 && x3_f16();
+    float* amax = f16 ? cv.take<float>(2) : nullptr;
     SEG_CHECK_WS(cv.used(), ws_bytes);
-    LWgradArgs a{x, dy, part, ldx, lddy, N, D, H, W, Cin, Cout, Do, Ho, Wo, p.ntx, p.nty, p.ntz, p.ntiles, p.nstrips, p.npairs, Cout / 32, p.taps};
+    LWgradArgs a{x, dy, part, ldx, lddy, N, D, H, W, Cin, Cout, Do, Ho, Wo, p.ntx, p.nty, p.ntz, p.ntiles, p.nstrips, p.npairs, Cout / 32, p.taps, nullptr, nullptr};
+    if (f16) {
+        if (!x_amax || !dy_amax) {
+            if (hipMemsetAsync(amax, 0, 2 * sizeof(float), st) != hipSuccess) { set_error("conv_wgrad_lowp: hipMemsetAsync failed"); return MI355SEG_EHIP; }
+            if (!x_amax) { tensor_amax((const float*)x, ldx, (long long)N * D * H * W, Cin, nullptr, amax, st); x_amax = amax; }
+            if (!dy_amax) { tensor_amax((const float*)dy, lddy, (long long)N * Do * Ho * Wo, Cout, nullptr, amax + 1, st); dy_amax = amax + 1; }
+            SEG_CHECK_LAUNCH();
+        }
+        a.amax_x = x_amax; a.amax_dy = dy_amax;
+    }
     const int nwg = p.nstrips * p.npairs * p.planes;
     const double vox = (double)N * Do * Ho * Wo;
     {

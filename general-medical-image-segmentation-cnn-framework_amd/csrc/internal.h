@@ -156,7 +156,8 @@ bool wgrad_lowp_supported(int math, int N, int D, int H, int W, int Cin, int Cou
 size_t wgrad_lowp_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k);
 size_t wgrad_lowp_ws_bytes_geom(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad);
 int conv_wgrad_lowp(int math, const void* dy, int lddy, const void* x, int ldx, float* dw, int N, int D, int H, int W, int Cin,
-                    int Cout, int k, int stride, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+                    int Cout, int k, int stride, int accumulate, void* ws, size_t ws_bytes, hipStream_t st,
+                    const float* x_amax = nullptr, const float* dy_amax = nullptr);
 size_t wgrad_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k);
 bool wgrad_mfma_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int lddy);
 int conv_wgrad_mfma(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin,

@@ -58,12 +58,19 @@ int mi355seg_version(void);
  *   BF16X6 -- every fp32 operand is split into three bf16 parts (x = h + m + l, 24 mantissa bits) and six
  *             v_mfma_f32_32x32x16_bf16 (hh, hm, mh, mm, hl, lh) form each product: fp32-level accuracy (the dropped
  *             terms are below 2^-23 of a product) at 2.7x the fp32 matrix rate;
+ *   F16X3  -- every fp32 operand, scaled by a per-tensor power of two 2^s that places the tensor's largest magnitude in
+ *             [2^14, 2^15), is split into two fp16 parts (v 2^s = h + l: 11 + 11 mantissa bits and the sign of l) and three
+ *             v_mfma_f32_16x16x32_f16 (hh, hl, lh) form each product; the result is scaled back by 2^-(sx + sw).  The dropped
+ *             l*l term is <= 2^-22 of a product (2^-24.6 rms); values more than 2^18 below their tensor's maximum keep an
+ *             absolute error of 2^-40 of that maximum.  Same fp64-graded accuracy tests as BF16X6 at half its MFMA count.
+ *             The maxima are measured on the device (one pass per tensor) unless the caller hands them over (*_amax entry
+ *             points).  Covers the k3 s1 forward / input gradient / weight gradient; layers without that form run BF16X6;
  * (bf16 TENSORS have their own entry points, *_bf16: there the products are plain bf16 MFMAs.)
- * Process-wide, read at each launch.  Initial value: environment MI355SEG_CONV_MATH = fp32 | bf16x6, else the default. */
+ * Process-wide, read at each launch.  Initial value: environment MI355SEG_CONV_MATH = fp32 | bf16x6 | f16x3, else the default. */
 #define MI355SEG_MATH_FP32 0
 #define MI355SEG_MATH_BF16X6 2
 #define MI355SEG_MATH_F16X3 3
-#define MI355SEG_MATH_DEFAULT MI355SEG_MATH_BF16X6
+#define MI355SEG_MATH_DEFAULT MI355SEG_MATH_F16X3
 int mi355seg_set_conv_math(int mode);
 int mi355seg_get_conv_math(void);
 /* MFMA shape of the BF16X6 forward / input-gradient kernels: 16 = v_mfma_f32_16x16x32_bf16 (conv_x3s.hip; the default: the

@@ -20,9 +20,9 @@ def _sample(t, k=4096):
     return f[::step][:k].cpu().numpy()
 
 
-@pytest.fixture(autouse=True, params=["bf16x6", "fp32"])
+@pytest.fixture(autouse=True, params=["f16x3", "bf16x6", "fp32"])
 def conv_math(request):
-    """Every model-level parity test runs under both arithmetics of the MFMA convolutions: the default split-precision
+    """Every model-level parity test runs under all three arithmetics of the MFMA convolutions: the split-precision "f16x3",
     "bf16x6" and the exact fp32 MFMA (include/mi355seg.h, mi355seg_set_conv_math)."""
     import mi355seg
     mi355seg.set_conv_math(request.param)

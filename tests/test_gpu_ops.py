@@ -10,7 +10,7 @@ import torch.nn.functional as TF
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
-DEFAULT_MATH = "bf16x6"        # the library default (include/mi355seg.h, MI355SEG_MATH_DEFAULT)
+DEFAULT_MATH = "f16x3"         # the library default (include/mi355seg.h, MI355SEG_MATH_DEFAULT)
 
 
 @pytest.fixture(scope="module")
