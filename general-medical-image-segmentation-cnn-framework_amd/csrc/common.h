@@ -186,6 +186,20 @@ __device__ __forceinline__ long long wave_sum(long long v) {
     return v;
 }
 
+// max-combine a workgroup's non-negative value into a device scalar (compare of the bit patterns: order-independent, so the result
+// is reproducible).  Every thread of the workgroup must call it (block size a multiple of 64, at most 1024).
+__device__ __forceinline__ void block_amax_commit(float m, unsigned* slot) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float sh_amax__[16];
+    if ((threadIdx.x & 63) == 0) sh_amax__[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, sh_amax__[i]);
+        atomicMax(slot, __builtin_bit_cast(unsigned, m));
+    }
+}
+
 // activation value / derivative in terms of the pre-activation z
 __device__ __forceinline__ float act_apply(float z, int act, float slope) {
     switch (act) {

@@ -516,6 +516,33 @@ int mi355seg_conv3d_fwd_f32(const float* x, int ldx, const float* w, const float
                             float* y, int ldy, int N, int D, int H, int W, int Cin, int Cout,
                             int k, int stride, int pad, double* stats_sum, double* stats_sq,
                             void* ws, size_t ws_bytes, void* stream) {
+    return mi355seg_conv3d_fwd_ax_f32(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, stride, pad, stats_sum, stats_sq, nullptr, nullptr, ws, ws_bytes, stream);
+}
+
+// max |x| of a rows x C tensor at pitch ld, max-combined into the device scalar *amax (which the caller has zeroed, or which
+// already holds the maximum of other parts of the same tensor): what the *_ax entry points take as x_amax / w_amax / dy_amax
+int mi355seg_amax_f32(const float* x, int ld, long long rows, int C, float* amax, void* stream) {
+    SEG_CHECK_ARG(x && amax && rows > 0 && C > 0 && ld >= C, "amax: bad arguments");
+    tensor_amax(x, ld, rows, C, nullptr, amax, (hipStream_t)stream);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_conv_math_takes_amax(void) { return x3_f16() ? 1 : 0; }
+// bit 0: the forward of this layer reads x_amax / w_amax, bit 1: its input gradient reads dy_amax / w_amax, bit 2: its weight
+// gradient reads dy_amax / x_amax (0 under the other maths and for layers without an f16x3 form: nothing worth handing over)
+int mi355seg_conv3d_amax_use_f32(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
+    if (!x3_f16()) return 0;
+    int m = 0;
+    if (conv_fwd_takes_amax(N, D, H, W, Cin, Cout, k, stride, pad)) m |= 1;
+    if (conv_fwd_takes_amax(N, D, H, W, Cout, Cin, k, stride, pad)) m |= 2;
+    if (wgrad_lowp_supported(MATH_X3, N, D, H, W, Cin, Cout, k, stride, pad, Cin, Cout)) m |= 4;
+    return m;
+}
+
+int mi355seg_conv3d_fwd_ax_f32(const float* x, int ldx, const float* w, const float* bias,
+                            float* y, int ldy, int N, int D, int H, int W, int Cin, int Cout,
+                            int k, int stride, int pad, double* stats_sum, double* stats_sq, const float* x_amax, const float* w_amax,
+                            void* ws, size_t ws_bytes, void* stream) {
     ConvGeom g{N, D, H, W, Cin, Cout, k, stride, pad, 0, 0, 0};
     int rc = check_geom(&g, "conv3d_fwd");
     if (rc) return rc;
@@ -524,7 +551,8 @@ int mi355seg_conv3d_fwd_f32(const float* x, int ldx, const float* w, const float
     hipStream_t st = (hipStream_t)stream;
     const int pol = f32_conv_policy();
     if (pol != MATH_F32 && conv_mfma_supported(pol, N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy))
-        return conv_fwd_mfma(pol, x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, /*dgrad=*/0, stats_sum, stats_sq, ws, ws_bytes, st);
+        return conv_fwd_mfma(pol, x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, /*dgrad=*/0, stats_sum, stats_sq, ws, ws_bytes, st,
+                             nullptr, 0, 0.f, nullptr, x_amax, w_amax);
     if (conv_mfma_supported(MATH_F32, N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy))
         return conv_fwd_mfma(MATH_F32, x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, /*dgrad=*/0, stats_sum, stats_sq, ws, ws_bytes, st);
     if (patch_embed_supported(D, H, W, Cin, k, stride, pad)) {
@@ -566,6 +594,11 @@ int mi355seg_conv3d_fwd_f32(const float* x, int ldx, const float* w, const float
 int mi355seg_conv3d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
                               int N, int D, int H, int W, int Cin, int Cout,
                               int k, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
+    return mi355seg_conv3d_dgrad_ax_f32(dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, k, stride, pad, nullptr, nullptr, ws, ws_bytes, stream);
+}
+int mi355seg_conv3d_dgrad_ax_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
+                              int N, int D, int H, int W, int Cin, int Cout,
+                              int k, int stride, int pad, const float* dy_amax, const float* w_amax, void* ws, size_t ws_bytes, void* stream) {
     ConvGeom g{N, D, H, W, Cin, Cout, k, stride, pad, 0, 0, 0};
     int rc = check_geom(&g, "conv3d_dgrad");
     if (rc) return rc;
@@ -574,7 +607,8 @@ int mi355seg_conv3d_dgrad_f32(const float* dy, int lddy, const float* w, float* 
     // k3 s1 p1: dgrad is the same convolution with flipped taps and Cin<->Cout swapped
     const int pol = f32_conv_policy();
     if (pol != MATH_F32 && conv_mfma_supported(pol, N, D, H, W, Cout, Cin, k, stride, pad, lddy, lddx))
-        return conv_fwd_mfma(pol, dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cout, Cin, k, /*dgrad=*/1, nullptr, nullptr, ws, ws_bytes, st);
+        return conv_fwd_mfma(pol, dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cout, Cin, k, /*dgrad=*/1, nullptr, nullptr, ws, ws_bytes, st,
+                             nullptr, 0, 0.f, nullptr, dy_amax, w_amax);
     if (conv_mfma_supported(MATH_F32, N, D, H, W, Cout, Cin, k, stride, pad, lddy, lddx))
         return conv_fwd_mfma(MATH_F32, dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cout, Cin, k, /*dgrad=*/1, nullptr, nullptr, ws, ws_bytes, st);
     if (conv_gather_dgrad_supported(MATH_F32, N, D, H, W, Cin, Cout, k, stride, pad, lddy, lddx) && ((uintptr_t)dy % 16) == 0)
@@ -603,6 +637,14 @@ int mi355seg_conv3d_dgrad_bnsums_f32(const float* dy, int lddy, const float* w, 
                                      const float* bn_x, int ld_bnx, const float* mean, const float* rstd, const float* gamma, const float* beta,
                                      int act, float slope, float* s1, float* s2, float* dgamma, float* dbeta,
                                      void* ws, size_t ws_bytes, void* stream) {
+    return mi355seg_conv3d_dgrad_bnsums_ax_f32(dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, k, stride, pad, bn_x, ld_bnx, mean, rstd, gamma, beta,
+                                               act, slope, s1, s2, dgamma, dbeta, nullptr, nullptr, ws, ws_bytes, stream);
+}
+int mi355seg_conv3d_dgrad_bnsums_ax_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
+                                     int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                                     const float* bn_x, int ld_bnx, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                     int act, float slope, float* s1, float* s2, float* dgamma, float* dbeta, const float* dy_amax, const float* w_amax,
+                                     void* ws, size_t ws_bytes, void* stream) {
     ConvGeom g{N, D, H, W, Cin, Cout, k, stride, pad, 0, 0, 0};
     int rc = check_geom(&g, "conv3d_dgrad_bnsums");
     if (rc) return rc;
@@ -613,10 +655,11 @@ int mi355seg_conv3d_dgrad_bnsums_f32(const float* dy, int lddy, const float* w, 
     const int pol = f32_conv_policy();
     if (pol == MATH_X3 && conv_mfma_supported(pol, N, D, H, W, Cout, Cin, k, stride, pad, lddy, lddx)) {
         BnBwdEpi e{bn_x, ld_bnx, mean, rstd, gamma, beta, act, slope, s1, s2, dgamma, dbeta, 0};
-        rc = conv_fwd_mfma(pol, dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cout, Cin, k, /*dgrad=*/1, nullptr, nullptr, ws, ws_bytes, st, nullptr, 0, 0.f, &e);
+        rc = conv_fwd_mfma(pol, dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cout, Cin, k, /*dgrad=*/1, nullptr, nullptr, ws, ws_bytes, st, nullptr, 0, 0.f, &e,
+                           dy_amax, w_amax);
         if (rc || e.done) return rc;
     } else {
-        rc = mi355seg_conv3d_dgrad_f32(dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, k, stride, pad, ws, ws_bytes, stream);
+        rc = mi355seg_conv3d_dgrad_ax_f32(dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, k, stride, pad, dy_amax, w_amax, ws, ws_bytes, stream);
         if (rc) return rc;
     }
     return mi355seg_norm_act_bwd_sums_f32(dx, lddx, bn_x, ld_bnx, mean, rstd, gamma, beta, nullptr, 0, s1, s2, dgamma, dbeta,
@@ -626,6 +669,12 @@ int mi355seg_conv3d_dgrad_bnsums_f32(const float* dy, int lddy, const float* w, 
 int mi355seg_conv3d_wgrad_f32(const float* dy, int lddy, const float* x, int ldx,
                               float* dw, float* db, int N, int D, int H, int W, int Cin, int Cout,
                               int k, int stride, int pad, int accumulate,
+                              void* ws, size_t ws_bytes, void* stream) {
+    return mi355seg_conv3d_wgrad_ax_f32(dy, lddy, x, ldx, dw, db, N, D, H, W, Cin, Cout, k, stride, pad, accumulate, nullptr, nullptr, ws, ws_bytes, stream);
+}
+int mi355seg_conv3d_wgrad_ax_f32(const float* dy, int lddy, const float* x, int ldx,
+                              float* dw, float* db, int N, int D, int H, int W, int Cin, int Cout,
+                              int k, int stride, int pad, int accumulate, const float* dy_amax, const float* x_amax,
                               void* ws, size_t ws_bytes, void* stream) {
     ConvGeom g{N, D, H, W, Cin, Cout, k, stride, pad, 0, 0, 0};
     int rc = check_geom(&g, "conv3d_wgrad");
@@ -645,7 +694,7 @@ int mi355seg_conv3d_wgrad_f32(const float* dy, int lddy, const float* x, int ldx
     }
     if (f32_conv_policy() == MATH_X3 && wgrad_lowp_supported(MATH_X3, N, D, H, W, Cin, Cout, k, stride, pad, ldx, lddy) &&
         ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0)
-        return conv_wgrad_lowp(MATH_X3, dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, stride, accumulate, ws, ws_bytes, st);
+        return conv_wgrad_lowp(MATH_X3, dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, stride, accumulate, ws, ws_bytes, st, x_amax, dy_amax);
     if (wgrad_mfma_supported(N, D, H, W, Cin, Cout, k, stride, pad, ldx, lddy) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0)
         return conv_wgrad_mfma(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, accumulate, ws, ws_bytes, st);
     if (k == 1 && stride == 1 && pad == 0 && f32_conv_policy() == MATH_X3 && pw_wgrad_lowp_supported((long long)N * D * H * W, Cin, Cout, ldx, lddy, 4) &&

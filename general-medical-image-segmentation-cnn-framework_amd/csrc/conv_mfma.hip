@@ -443,6 +443,14 @@ bool conv_mfma_supported(int math, int N, int D, int H, int W, int Cin, int Cout
     return igemm_plan(math, k, N, D, H, W, Cin, Cout, 1, &p);
 }
 
+// would conv_fwd_mfma(MATH_X3, ...) run the f16x3 form of conv_x3s.hip on this geometry (16-byte aligned pointers, pitches = channels)?
+bool conv_fwd_takes_amax(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
+    if (!x3_f16() || !igemm_shape_ok(k, stride, pad) || k != 3 || (Cin % 4) || (Cout % 4)) return false;
+    IgemmPlan p;
+    if (!igemm_plan(MATH_X3, k, N, D, H, W, Cin, Cout, 1, &p)) return false;
+    return x3s_plan_ok(p, nullptr, Cin, nullptr, Cout, (long long)D * H * W);
+}
+
 size_t conv_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
     if (!igemm_shape_ok(k, stride, pad)) return 0;
     size_t best = 0;

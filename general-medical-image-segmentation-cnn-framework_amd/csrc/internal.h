@@ -120,6 +120,7 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
                   const float* x_amax = nullptr, const float* w_amax = nullptr);
 // max |x| of a rows x C tensor at pitch ld (times |rowscale[row]| when given), max-combined into the zeroed device scalar *slot
 void tensor_amax(const float* x, int ld, long long rows, int C, const float* rowscale, float* slot, hipStream_t st);
+bool conv_fwd_takes_amax(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad);
 bool convt_mfma_supported(int math, int N, int D, int H, int W, int Cin, int Cout, int ldx, int ldy);
 int convt_fwd_mfma(int math, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int N, int D, int H, int W,
                    int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t st);

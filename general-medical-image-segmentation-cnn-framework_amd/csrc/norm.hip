@@ -295,14 +295,16 @@ template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const T* __restrict__ x, int ldx,
         const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
         const float* __restrict__ beta, const T* __restrict__ res, int ldres, T* __restrict__ y, int ldy,
-        long long rows, int C, int lanes, int rpi, int act, float slope) {
+        long long rows, int C, int lanes, int rpi, int act, float slope, unsigned* __restrict__ amax_out) {
     constexpr int NJ = VEC ? 4 : 1;
     const int g = blockIdx.y;
     const int cw = VEC ? C / 4 : C;
     const int rsub = threadIdx.x / lanes;
-    if (rsub >= rpi) return;
+    const bool active = rsub < rpi;
+    if (!active && !amax_out) return;
     const long long rbase = (long long)g * rows;
-    for (int cc = threadIdx.x % lanes; cc < cw; cc += lanes) {
+    float amax = 0.f;                   // max |y| of this thread's outputs (amax_out: the f16x3 scale of the convolution that reads y)
+    for (int cc = threadIdx.x % lanes; active && cc < cw; cc += lanes) {
         const int c = cc * NJ;
         float al[NJ], be[NJ];
 #pragma unroll
@@ -329,6 +331,7 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const T* __restrict__
                         o.z = act_apply(fmaf(v[u].z, al[NJ > 1 ? 2 : 0], be[NJ > 1 ? 2 : 0]) + rr[u].z, act, slope);
                         o.w = act_apply(fmaf(v[u].w, al[NJ > 1 ? 3 : 0], be[NJ > 1 ? 3 : 0]) + rr[u].w, act, slope);
                         stf4(y + (rbase + r + u) * ldy + c, o);
+                        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
                     }
             }
             continue;
@@ -337,10 +340,13 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const T* __restrict__
             const long long row = rbase + r;
             {
                 const float rv = res ? ld1(res + row * ldres + c) : 0.f;
-                st1(y + row * ldy + c, act_apply(fmaf(ld1(x + row * ldx + c), al[0], be[0]) + rv, act, slope));
+                const float o = act_apply(fmaf(ld1(x + row * ldx + c), al[0], be[0]) + rv, act, slope);
+                st1(y + row * ldy + c, o);
+                amax = fmaxf(amax, fabsf(o));
             }
         }
     }
+    if (amax_out) block_amax_commit(amax, amax_out);
 }
 
 // eight channels per thread: 16-byte accesses on bf16 tensors (launched for bf16 only, see norm_api.inc)
@@ -380,14 +386,15 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(const T* __rest
         const float* __restrict__ gamma, const float* __restrict__ beta, const T* __restrict__ res, int ldres,
         const float* __restrict__ s1, const float* __restrict__ s2, T* __restrict__ dx, int lddx,
         T* __restrict__ dres, int lddres, long long rows, int C, int lanes, int rpi, int act, float slope,
-        float* __restrict__ dxpart) {
+        float* __restrict__ dxpart, unsigned* __restrict__ amax_out) {
     constexpr int NJ = VEC ? 4 : 1;
     __shared__ float shs[256 * 4];
     const int g = blockIdx.y;
     const int cw = VEC ? C / 4 : C;
     const int rsub = threadIdx.x / lanes;
     const bool active = rsub < rpi;
-    if (!active && !dxpart) return;
+    if (!active && !dxpart && !amax_out) return;
+    float amax = 0.f;                   // max |dx| of this thread's outputs
     const long long rbase = (long long)g * rows;
     const float invM = 1.f / (float)rows;
     float colsum[NJ];
@@ -425,6 +432,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(const T* __rest
                 oz[j] = dz;
                 od[j] = ga[j] * rs[j] * (dz - k1[j] - xh * k2[j]);
                 colsum[j] += od[j];
+                amax = fmaxf(amax, fabsf(od[j]));
             }
             if (VEC) {
                 stf4(dx + row * lddx + c, make_float4(od[0], od[NJ > 1 ? 1 : 0], od[NJ > 1 ? 2 : 0], od[NJ > 1 ? 3 : 0]));
@@ -452,6 +460,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(const T* __rest
             for (int j = 0; j < NJ; ++j) { dst[j * 2] = acc[j]; dst[j * 2 + 1] = 0.f; }
         }
     }
+    if (amax_out) block_amax_commit(amax, amax_out);
 }
 
 template <typename T, bool VEC, bool BWD>

@@ -123,8 +123,10 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
+        F.amax_pool_reset()              # the captured step zero-fills the chunk of operand-maximum slots it draws from INSIDE the capture
         with torch.cuda.graph(self.graph):
             self.out = train_step(model, optimizer, self.x, self.gt, criterion, sync_metric=False, dtype=dtype)
+        F.amax_pool_reset()
 
     def __call__(self, x, gt, sync_metric=True):
         self.x.copy_(x, non_blocking=True)

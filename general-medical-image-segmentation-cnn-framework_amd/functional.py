@@ -245,10 +245,81 @@ def cast(x, dtype=None):
     return _Cast.apply(x, dtype or compute_dtype())
 
 
+# ----------------------------------------------------------------------------- f16x3 operand maxima
+# The default conv math on fp32 tensors ("f16x3", include/mi355seg.h) splits every operand into two fp16 parts under a per-tensor
+# power-of-two scale and needs max |.| of both operands as device scalars.  The plain entry points measure them with a pass of
+# their own; here they ride along instead: the norm + activation kernels emit the maximum of what they write, a max-pool keeps
+# its input's maximum, and a tensor carries its scalar as the attribute ``_seg_amax`` = (1-element fp32 tensor, tensor version)
+# to whatever convolution reads it (a missing / stale attribute only means that the library measures).  Weight maxima are taken
+# in the forward (one small launch per layer) and reused by that layer's backward.
+_AMAX_POOL = {}
+
+
+def _amax_slot(device):
+    """A zeroed 1-element fp32 device tensor (the kernels max-combine into it), cut from a chunk that is zero-filled once."""
+    st = _AMAX_POOL.get(device)
+    if st is None or st[1] >= st[0].numel():
+        st = [torch.zeros(2048, dtype=torch.float32, device=device), 0]
+        _AMAX_POOL[device] = st
+    slot = st[0][st[1]:st[1] + 1]
+    st[1] += 1
+    return slot
+
+
+def amax_pool_reset():
+    """Forget the current slot chunks (engine.GraphedTrainStep: a captured step must zero-fill the chunk it draws from inside the capture)."""
+    _AMAX_POOL.clear()
+
+
+def _takes_amax(x):
+    return x.dtype == torch.float32 and lib().query("mi355seg_conv_math_takes_amax") != 0
+
+
+_AMAX_USE = {}
+
+
+def _amax_use(x, N, D, H, W, Cin, Cout, k, stride, pad):
+    """Which passes of this layer read operand maxima under the selected conv math (bit 0 forward, 1 input gradient, 2 weight gradient)."""
+    if x.dtype != torch.float32:
+        return 0
+    L = lib()
+    key = (L.query("mi355seg_get_conv_math"), L.query("mi355seg_get_x3_shape"), N, D, H, W, Cin, Cout, k, stride, pad)
+    use = _AMAX_USE.get(key)
+    if use is None:
+        use = _AMAX_USE[key] = L.query("mi355seg_conv3d_amax_use_f32", N, D, H, W, Cin, Cout, k, stride, pad)
+    return use
+
+
+def _get_amax(t):
+    rec = getattr(t, "_seg_amax", None)
+    if rec is None or rec[1] != t._version or rec[0].device != t.device:
+        return None
+    return rec[0]
+
+
+def _set_amax(t, slot):
+    if slot is not None:
+        t._seg_amax = (slot, t._version)
+    return t
+
+
+def _measure_amax(t, ld, rows, C, slot=None):
+    """max |t| over rows x C at pitch ld into a fresh slot (or max-combined into ``slot``)."""
+    if slot is None:
+        slot = _amax_slot(t.device)
+    lib().call("mi355seg_amax_f32", _p(t), ld, rows, C, _p(slot), _stream())
+    return slot
+
+
+def _weight_amax(w):
+    return _measure_amax(w, w.numel(), 1, w.numel())
+
+
 # ----------------------------------------------------------------------------- conv
 class _Conv3d(Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, pad):
+        xa_in = _get_amax(x)
         x, ldx = cl_view(x, "conv3d input")
         N, D, H, W, Cin = x.shape
         Cout, Cin_w, k = w.shape[0], w.shape[1], w.shape[2]
@@ -259,8 +330,18 @@ class _Conv3d(Function):
         y = torch.empty((N, Do, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
         L = lib()
         ws = workspace(_conv_ws(L, x, N, D, H, W, Cin, Cout, k, stride, pad), x.device)
-        L.call("mi355seg_conv3d_fwd_" + _sfx(x), _p(x), ldx, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
-               None, None, _p(ws), ws.numel(), _stream())
+        ctx.amax = None
+        use = _amax_use(x, N, D, H, W, Cin, Cout, k, stride, pad)
+        if use:
+            xa, wa = xa_in, (_weight_amax(w) if use & 3 else None)
+            if xa is None and (use & 1) and (use & 4) and ctx.needs_input_grad[1]:    # forward and weight gradient both read x: measure once
+                xa = _measure_amax(x, ldx, N * D * H * W, Cin)
+            L.call("mi355seg_conv3d_fwd_ax_f32", _p(x), ldx, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
+                   None, None, _p(xa), _p(wa), _p(ws), ws.numel(), _stream())
+            ctx.amax = (xa, wa)
+        else:
+            L.call("mi355seg_conv3d_fwd_" + _sfx(x), _p(x), ldx, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
+                   None, None, _p(ws), ws.numel(), _stream())
         ctx.save_for_backward(x, w)
         ctx.geom = (N, D, H, W, Cin, Cout, k, stride, pad, ldx, b is not None)
         return y
@@ -273,11 +354,27 @@ class _Conv3d(Function):
         L = lib()
         ws = workspace(_conv_ws(L, x, N, D, H, W, Cin, Cout, k, stride, pad), x.device)
         dx = dw = db = None
+        want_dw = ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2])
+        if ctx.amax is not None:
+            xa, wa = ctx.amax
+            da = _get_amax(dy)
+            if da is None and ctx.needs_input_grad[0] and want_dw:      # both gradients read dy: measure it once
+                da = _measure_amax(dy, lddy, N * D * H * W, Cout)
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty((N, D, H, W, Cin), dtype=x.dtype, device=x.device)
+                L.call("mi355seg_conv3d_dgrad_ax_f32", _p(dy), lddy, _p(w), _p(dx), Cin, N, D, H, W, Cin, Cout, k, stride, pad,
+                       _p(da), _p(wa), _p(ws), ws.numel(), _stream())
+            if want_dw:
+                dw = torch.empty_like(w)
+                db = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_b else None
+                L.call("mi355seg_conv3d_wgrad_ax_f32", _p(dy), lddy, _p(x), ldx, _p(dw), _p(db), N, D, H, W, Cin, Cout, k, stride, pad,
+                       0, _p(da), _p(xa), _p(ws), ws.numel(), _stream())
+            return dx, dw, db, None, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((N, D, H, W, Cin), dtype=x.dtype, device=x.device)
             L.call("mi355seg_conv3d_dgrad_" + _sfx(x), _p(dy), lddy, _p(w), _p(dx), Cin, N, D, H, W, Cin, Cout, k, stride, pad,
                    _p(ws), ws.numel(), _stream())
-        if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
+        if want_dw:
             dw = torch.empty_like(w)
             db = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_b else None
             L.call("mi355seg_conv3d_wgrad_" + _sfx(x), _p(dy), lddy, _p(x), ldx, _p(dw), _p(db), N, D, H, W, Cin, Cout, k, stride, pad,
@@ -348,8 +445,14 @@ class _ConvT3dK2S2Cat(Function):
         w = w.contiguous()
         L = lib()
         ws = workspace(L.query("mi355seg_convt3d_k2s2_ws_bytes", N, D, H, W, Cin, Cout), x.device)
+        sa = _get_amax(skip) if _takes_amax(x) else None
         L.call("mi355seg_convt3d_k2s2_fwd_" + _sfx(x), _p(x), ldx, _p(w), _p(b), _p(base), Cout + Cs, N, D, H, W, Cin, Cout,
                _p(ws), ws.numel(), _stream())
+        if sa is not None:
+            # max |cat| = max(max |up-convolution| (one pass over the left slice), max |skip| (its own scalar, max-combined))
+            ca = _measure_amax(base, Cout + Cs, N * 8 * D * H * W, Cout)
+            _measure_amax(sa, 1, 1, 1, ca)
+            _set_amax(base, ca)
         ctx.save_for_backward(x, w)
         ctx.geom = (N, D, H, W, Cin, Cout, Cs, ldx, b is not None)
         return base
@@ -506,6 +609,7 @@ class _ConvBnAct(Function):
 
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, rmean, rvar, stride, pad, training, momentum, eps, act, slope, left_pad, inference=False):
+        xa_in = _get_amax(x)
         x, ldx = cl_view(x, "conv3d input")
         N, D, H, W, Cin = x.shape
         Cout, k = w.shape[0], w.shape[2]
@@ -521,7 +625,24 @@ class _ConvBnAct(Function):
         fused = (not training) and inference and x.data_ptr() % 16 == 0 and \
             L.query("mi355seg_conv3d_fused_supported_" + _sfx(x), N, D, H, W, Cin, Cout, k, stride, pad, ldx, left_pad + Cout)
         y = None if fused else torch.empty((N, Do, Ho, Wo, Cout), dtype=x.dtype, device=dev)
-        if training:
+        ax = training and _takes_amax(x)          # f16x3: operand maxima ride along (this layer's input, weights, and its output for the next layer)
+        ctx.amax = None
+        if ax:
+            sums = torch.empty(2 * Cout, dtype=torch.float64, device=dev)
+            use = _amax_use(x, N, D, H, W, Cin, Cout, k, stride, pad)
+            xa, wa = (xa_in if use else None), None
+            if use & 3:
+                wa = _weight_amax(w)
+            if xa is None and (use & 1) and (use & 4):
+                xa = _measure_amax(x, ldx, N * D * H * W, Cin)
+            L.call("mi355seg_conv3d_fwd_ax_f32", _p(x), ldx, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
+                   sums.data_ptr(), sums.data_ptr() + 8 * Cout, _p(xa), _p(wa), _p(ws), ws.numel(), _stream())
+            ctx.amax = (xa, wa)
+            mean = torch.empty(Cout, dtype=torch.float32, device=dev)
+            rstd = torch.empty(Cout, dtype=torch.float32, device=dev)
+            L.call("mi355seg_norm_stats_from_sums_f32", sums.data_ptr(), sums.data_ptr() + 8 * Cout, rows, Cout, eps,
+                   _p(mean), _p(rstd), _p(rmean), _p(rvar), momentum, _stream())
+        elif training:
             sums = torch.empty(2 * Cout, dtype=torch.float64, device=dev)
             L.call("mi355seg_conv3d_fwd_" + _sfx(x), _p(x), ldx, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
                    sums.data_ptr(), sums.data_ptr() + 8 * Cout, _p(ws), ws.numel(), _stream())
@@ -552,8 +673,14 @@ class _ConvBnAct(Function):
             a = full[..., left_pad:]
         else:
             a = torch.empty_like(y)
-        L.call("mi355seg_norm_act_fwd_" + _sfx(x), _p(y), Cout, _p(mean), _p(rstd), _p(gamma), _p(beta), None, 0,
-               a.data_ptr(), left_pad + Cout, rows, 1, Cout, act, slope, _stream())
+        if ax:
+            aa = _amax_slot(dev)
+            L.call("mi355seg_norm_act_fwd_ax_f32", _p(y), Cout, _p(mean), _p(rstd), _p(gamma), _p(beta), None, 0,
+                   a.data_ptr(), left_pad + Cout, rows, 1, Cout, act, slope, _p(aa), _stream())
+            _set_amax(a, aa)
+        else:
+            L.call("mi355seg_norm_act_fwd_" + _sfx(x), _p(y), Cout, _p(mean), _p(rstd), _p(gamma), _p(beta), None, 0,
+                   a.data_ptr(), left_pad + Cout, rows, 1, Cout, act, slope, _stream())
         ctx.save_for_backward(x, w, y, mean, rstd, gamma, beta)
         ctx.cfg = (N, D, H, W, Cin, Cout, k, stride, pad, ldx, b is not None, rows, act, slope, bool(training))
         return a
@@ -573,6 +700,21 @@ class _ConvBnAct(Function):
         dgamma = torch.empty(Cout, dtype=torch.float32, device=dev) if gamma is not None else None      # no affine: instance norm
         dbeta = torch.empty(Cout, dtype=torch.float32, device=dev) if gamma is not None else None
         db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
+        if ctx.amax is not None and (ctx.amax[0] is not None or ctx.amax[1] is not None):
+            xa, wa = ctx.amax
+            dya = _amax_slot(dev)
+            L.call("mi355seg_norm_act_bwd_colsum_ax_f32", _p(da), ldda, _p(y), Cout, _p(mean), _p(rstd), _p(gamma), _p(beta), None, 0,
+                   _p(dy), Cout, _p(dgamma), _p(dbeta), None, 0, _p(db), _p(dya), rows, 1, Cout, act, slope, _p(ws), ws.numel(), _stream())
+            dx = dw = None
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty((N, D, H, W, Cin), dtype=x.dtype, device=dev)
+                L.call("mi355seg_conv3d_dgrad_ax_f32", _p(dy), Cout, _p(w), _p(dx), Cin, N, D, H, W, Cin, Cout, k, stride, pad,
+                       _p(dya), _p(wa), _p(ws), ws.numel(), _stream())
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty_like(w)
+                L.call("mi355seg_conv3d_wgrad_ax_f32", _p(dy), Cout, _p(x), ldx, _p(dw), None, N, D, H, W, Cin, Cout, k, stride, pad,
+                       0, _p(dya), _p(xa), _p(ws), ws.numel(), _stream())
+            return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
         L.call("mi355seg_norm_act_bwd_colsum_" + _sfx(x), _p(da), ldda, _p(y), Cout, _p(mean), _p(rstd), _p(gamma), _p(beta), None, 0,
                _p(dy), Cout, _p(dgamma), _p(dbeta), None, 0, _p(db), rows, 1, Cout, act, slope, _p(ws), ws.numel(), _stream())
         dx = dw = None
@@ -623,12 +765,14 @@ class _DoubleConvBnAct(Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, g1, be1, rm1, rv1, w2, b2, g2, be2, rm2, rv2, geo1, geo2, mom1, eps1, mom2, eps2, act, slope, left_pad):
+        xa_in = _get_amax(x)
         x, ldx = cl_view(x, "conv3d input")
         L = lib()
         dev = x.device
         N = x.shape[0]
+        ax = _takes_amax(x)           # f16x3: operand maxima ride along
 
-        def layer(inp, ldin, w, b, g, be, rm, rv, geo, mom, eps, lp):
+        def layer(inp, ldin, w, b, g, be, rm, rv, geo, mom, eps, lp, xa):
             D, H, W, Cin = inp.shape[1:]
             Cout, k = w.shape[0], w.shape[2]
             stride, pad = geo
@@ -639,24 +783,35 @@ class _DoubleConvBnAct(Function):
             ws = workspace(max(_conv_ws(L, inp, N, D, H, W, Cin, Cout, k, stride, pad), L.query("mi355seg_norm_ws_bytes", rows, 1, Cout)), dev)
             y = torch.empty((N, Do, Ho, Wo, Cout), dtype=inp.dtype, device=dev)
             sums = torch.empty(2 * Cout, dtype=torch.float64, device=dev)
-            L.call("mi355seg_conv3d_fwd_f32", _p(inp), ldin, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
-                   sums.data_ptr(), sums.data_ptr() + 8 * Cout, _p(ws), ws.numel(), _stream())
+            wa = aa = None
+            use = _amax_use(inp, N, D, H, W, Cin, Cout, k, stride, pad) if ax else 0
+            if use & 3:
+                wa = _weight_amax(w)
+            if not use:
+                xa = None
+            elif xa is None and (use & 1) and (use & 4):
+                xa = _measure_amax(inp, ldin, N * D * H * W, Cin)
+            L.call("mi355seg_conv3d_fwd_ax_f32", _p(inp), ldin, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
+                   sums.data_ptr(), sums.data_ptr() + 8 * Cout, _p(xa), _p(wa), _p(ws), ws.numel(), _stream())
             mean = torch.empty(Cout, dtype=torch.float32, device=dev)
             rstd = torch.empty(Cout, dtype=torch.float32, device=dev)
             L.call("mi355seg_norm_stats_from_sums_f32", sums.data_ptr(), sums.data_ptr() + 8 * Cout, rows, Cout, eps,
                    _p(mean), _p(rstd), _p(rm), _p(rv), mom, _stream())
             full = torch.empty((N, Do, Ho, Wo, lp + Cout), dtype=inp.dtype, device=dev)
             a = full[..., lp:] if lp else full
-            L.call("mi355seg_norm_act_fwd_f32", _p(y), Cout, _p(mean), _p(rstd), _p(g), _p(be), None, 0,
-                   a.data_ptr(), lp + Cout, rows, 1, Cout, act, slope, _stream())
-            return y, mean, rstd, a, (N, D, H, W, Cin, Cout, k, stride, pad, ldin, b is not None, rows)
+            if ax:
+                aa = _amax_slot(dev)
+            L.call("mi355seg_norm_act_fwd_ax_f32", _p(y), Cout, _p(mean), _p(rstd), _p(g), _p(be), None, 0,
+                   a.data_ptr(), lp + Cout, rows, 1, Cout, act, slope, _p(aa), _stream())
+            return y, mean, rstd, a, (N, D, H, W, Cin, Cout, k, stride, pad, ldin, b is not None, rows), (xa, wa, aa)
 
         w1, w2 = w1.contiguous(), w2.contiguous()
-        y1, mean1, rstd1, a1, cfg1 = layer(x, ldx, w1, b1, g1, be1, rm1, rv1, geo1, mom1, eps1, 0)
-        y2, mean2, rstd2, a2, cfg2 = layer(a1, a1.shape[-1], w2, b2, g2, be2, rm2, rv2, geo2, mom2, eps2, left_pad)
+        y1, mean1, rstd1, a1, cfg1, am1 = layer(x, ldx, w1, b1, g1, be1, rm1, rv1, geo1, mom1, eps1, 0, xa_in)
+        y2, mean2, rstd2, a2, cfg2, am2 = layer(a1, a1.shape[-1], w2, b2, g2, be2, rm2, rv2, geo2, mom2, eps2, left_pad, am1[2])
         ctx.save_for_backward(x, w1, y1, mean1, rstd1, g1, be1, a1, w2, y2, mean2, rstd2, g2, be2)
         ctx.cfg = (cfg1, cfg2, act, slope)
-        return a2
+        ctx.amax = (am1, am2)
+        return _set_amax(a2, am2[2])
 
     @staticmethod
     def backward(ctx, da2):
@@ -674,34 +829,38 @@ class _DoubleConvBnAct(Function):
         dy2 = torch.empty_like(y2)
         dg2, dbe2 = torch.empty(C2, **f32), torch.empty(C2, **f32)
         db2 = torch.empty(C2, **f32) if has_b2 else None
-        L.call("mi355seg_norm_act_bwd_colsum_f32", _p(da2), ldda2, _p(y2), C2, _p(mean2), _p(rstd2), _p(g2), _p(be2), None, 0,
-               _p(dy2), C2, _p(dg2), _p(dbe2), None, 0, _p(db2), rows2, 1, C2, act, slope, _p(ws), ws.numel(), _stream())
+        (xa1, wa1, _), (xa2, wa2, _) = ctx.amax
+        # f16x3: the two gradients d(conv output) take their maxima from the norm-backward kernels that write them
+        dya2 = _amax_slot(dev) if (wa2 is not None or xa2 is not None) else None
+        dya1 = _amax_slot(dev) if (wa1 is not None or xa1 is not None) else None
+        L.call("mi355seg_norm_act_bwd_colsum_ax_f32", _p(da2), ldda2, _p(y2), C2, _p(mean2), _p(rstd2), _p(g2), _p(be2), None, 0,
+               _p(dy2), C2, _p(dg2), _p(dbe2), None, 0, _p(db2), _p(dya2), rows2, 1, C2, act, slope, _p(ws), ws.numel(), _stream())
         # conv2 input gradient = d(act1); BN1's two column sums come out of the same kernel
         da1 = torch.empty((N, D2, H2, W2, C1), dtype=x.dtype, device=dev)
         s12 = torch.empty(2 * C1, **f32)
         dg1, dbe1 = torch.empty(C1, **f32), torch.empty(C1, **f32)
-        L.call("mi355seg_conv3d_dgrad_bnsums_f32", _p(dy2), C2, _p(w2), _p(da1), C1, N, D2, H2, W2, C1, C2, k2, st2, pd2,
+        L.call("mi355seg_conv3d_dgrad_bnsums_ax_f32", _p(dy2), C2, _p(w2), _p(da1), C1, N, D2, H2, W2, C1, C2, k2, st2, pd2,
                _p(y1), C1, _p(mean1), _p(rstd1), _p(g1), _p(be1), act, slope, s12.data_ptr(), s12.data_ptr() + 4 * C1, _p(dg1), _p(dbe1),
-               _p(ws), ws.numel(), _stream())
+               _p(dya2), _p(wa2), _p(ws), ws.numel(), _stream())
         dw2 = torch.empty_like(w2)
-        L.call("mi355seg_conv3d_wgrad_f32", _p(dy2), C2, _p(a1), lda1, _p(dw2), None, N, D2, H2, W2, C1, C2, k2, st2, pd2,
-               0, _p(ws), ws.numel(), _stream())
+        L.call("mi355seg_conv3d_wgrad_ax_f32", _p(dy2), C2, _p(a1), lda1, _p(dw2), None, N, D2, H2, W2, C1, C2, k2, st2, pd2,
+               0, _p(dya2), _p(xa2), _p(ws), ws.numel(), _stream())
         del dy2
         # layer 1: the apply half of the norm backward (+ conv1's bias gradient), then conv1's gradients
         dy1 = torch.empty_like(y1)
         db1 = torch.empty(C1, **f32) if has_b1 else None
-        L.call("mi355seg_norm_act_bwd_apply_f32", _p(da1), C1, _p(y1), C1, _p(mean1), _p(rstd1), _p(g1), _p(be1), None, 0,
-               s12.data_ptr(), s12.data_ptr() + 4 * C1, _p(dy1), C1, None, 0, _p(db1), rows1, 1, C1, act, slope, _p(ws), ws.numel(), _stream())
+        L.call("mi355seg_norm_act_bwd_apply_ax_f32", _p(da1), C1, _p(y1), C1, _p(mean1), _p(rstd1), _p(g1), _p(be1), None, 0,
+               s12.data_ptr(), s12.data_ptr() + 4 * C1, _p(dy1), C1, None, 0, _p(db1), _p(dya1), rows1, 1, C1, act, slope, _p(ws), ws.numel(), _stream())
         del da1
         dx = dw1 = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((N, D1, H1, W1, Cin1), dtype=x.dtype, device=dev)
-            L.call("mi355seg_conv3d_dgrad_f32", _p(dy1), C1, _p(w1), _p(dx), Cin1, N, D1, H1, W1, Cin1, C1, k1, st1, pd1,
-                   _p(ws), ws.numel(), _stream())
+            L.call("mi355seg_conv3d_dgrad_ax_f32", _p(dy1), C1, _p(w1), _p(dx), Cin1, N, D1, H1, W1, Cin1, C1, k1, st1, pd1,
+                   _p(dya1), _p(wa1), _p(ws), ws.numel(), _stream())
         if ctx.needs_input_grad[1]:
             dw1 = torch.empty_like(w1)
-            L.call("mi355seg_conv3d_wgrad_f32", _p(dy1), C1, _p(x), ldx, _p(dw1), None, N, D1, H1, W1, Cin1, C1, k1, st1, pd1,
-                   0, _p(ws), ws.numel(), _stream())
+            L.call("mi355seg_conv3d_wgrad_ax_f32", _p(dy1), C1, _p(x), ldx, _p(dw1), None, N, D1, H1, W1, Cin1, C1, k1, st1, pd1,
+                   0, _p(dya1), _p(xa1), _p(ws), ws.numel(), _stream())
         return (dx, dw1, db1, dg1, dbe1, None, None, dw2, db2, dg2, dbe2, None, None) + (None,) * 9
 
 
@@ -827,6 +986,7 @@ def scale_channels(x, scale):
 class _MaxPool2(Function):
     @staticmethod
     def forward(ctx, x):
+        xa = _get_amax(x)
         x, ldx = cl_view(x, "max_pool3d input")
         N, D, H, W, C = x.shape
         y = torch.empty((N, D // 2, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
@@ -834,7 +994,7 @@ class _MaxPool2(Function):
         lib().call("mi355seg_maxpool2_fwd_" + _sfx(x), _p(x), ldx, _p(y), C, _p(idx), N, D, H, W, C, _stream())
         ctx.save_for_backward(idx)
         ctx.geom = (N, D, H, W, C)
-        return y
+        return _set_amax(y, xa)             # max |max_pool(x)| <= max |x|
 
     @staticmethod
     def backward(ctx, dy):
@@ -859,7 +1019,12 @@ class _PoolAndSkip(Function):
         lib().call("mi355seg_maxpool2_fwd_" + _sfx(xv), _p(xv), ldx, _p(y), C, _p(idx), N, D, H, W, C, _stream())
         ctx.save_for_backward(idx)
         ctx.geom = (N, D, H, W, C)
-        return y, x.view_as(x)
+        skip = x.view_as(x)
+        xa = _get_amax(x)
+        if xa is not None:              # max |max_pool(x)| <= max |x| (equal for the non-negative outputs of a ReLU)
+            _set_amax(y, xa)
+            _set_amax(skip, xa)
+        return y, skip
 
     @staticmethod
     def backward(ctx, dy, dskip):

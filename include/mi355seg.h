@@ -102,6 +102,35 @@ int mi355seg_conv3d_fwd_f32(const float* x, int ldx, const float* w, const float
                             int k, int stride, int pad, double* stats_sum, double* stats_sq,
                             void* ws, size_t ws_bytes, void* stream);
 
+/* F16X3 operand maxima.  The two-piece fp16 split needs an upper bound of max |.| of both operands of a convolution (a device
+ * scalar each).  The plain entry points measure them (one pass over each operand per call); the *_ax forms take them from the
+ * caller, who usually has them for free: mi355seg_norm_act_fwd_ax_f32 / mi355seg_norm_act_bwd_*_ax_f32 emit the maximum of the
+ * tensor they write, a max-pool keeps its input's maximum, a parameter's maximum changes once per optimiser step
+ * (mi355seg_amax_f32).  A bound above the true maximum by a factor 2^j costs j bits of headroom above the fp16 underflow; a
+ * bound BELOW the true maximum by more than 2x overflows fp16 (non-finite results).  NULL = measure.  Ignored by the other maths.
+ * mi355seg_conv_math_takes_amax() != 0 while the selected math uses them. */
+int mi355seg_conv_math_takes_amax(void);
+/* which passes of this layer read operand maxima under the selected math: bit 0 forward (x, w), bit 1 input gradient (dy, w),
+ * bit 2 weight gradient (dy, x); 0 = none (hand nothing over, nothing is measured either) */
+int mi355seg_conv3d_amax_use_f32(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad);
+int mi355seg_amax_f32(const float* x, int ld, long long rows, int C, float* amax /* max-combined into; zero it first */, void* stream);
+int mi355seg_conv3d_fwd_ax_f32(const float* x, int ldx, const float* w, const float* bias,
+                               float* y, int ldy, int N, int D, int H, int W, int Cin, int Cout,
+                               int k, int stride, int pad, double* stats_sum, double* stats_sq, const float* x_amax, const float* w_amax,
+                               void* ws, size_t ws_bytes, void* stream);
+int mi355seg_conv3d_dgrad_ax_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
+                                 int N, int D, int H, int W, int Cin, int Cout,
+                                 int k, int stride, int pad, const float* dy_amax, const float* w_amax, void* ws, size_t ws_bytes, void* stream);
+int mi355seg_conv3d_dgrad_bnsums_ax_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
+                                        int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                                        const float* bn_x, int ld_bnx, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                        int act, float slope, float* s1, float* s2, float* dgamma, float* dbeta, const float* dy_amax, const float* w_amax,
+                                        void* ws, size_t ws_bytes, void* stream);
+int mi355seg_conv3d_wgrad_ax_f32(const float* dy, int lddy, const float* x, int ldx,
+                                 float* dw, float* db, int N, int D, int H, int W, int Cin, int Cout,
+                                 int k, int stride, int pad, int accumulate, const float* dy_amax, const float* x_amax,
+                                 void* ws, size_t ws_bytes, void* stream);
+
 /* Inference forward (predict.py:79-81,133: model.eval()): eval-mode BatchNorm and the activation that follows it folded into the
  * convolution -- y = act(conv(x, w) * oscale[co] + oshift[co]).  oscale is multiplied into the packed weights, oshift takes the
  * bias slot and the activation runs in the MFMA kernel's epilogue: no normalise pass over y.  mi355seg_bn_fold_f32 builds the two
@@ -219,6 +248,26 @@ int mi355seg_norm_act_bwd_apply_f32(const float* dy, int lddy, const float* x, i
                                     float* dx, int lddx, float* dres, int lddres, float* dx_colsum,
                                     long long rows, int groups, int C, int act, float slope,
                                     void* ws, size_t ws_bytes, void* stream);
+
+/* The same three with the maximum magnitude of the tensor they WRITE as a by-product (F16X3 operand maxima, see
+ * mi355seg_conv3d_fwd_ax_f32): max |y| resp. max |dx| is max-combined into the device scalar the last pointer names (zeroed by the
+ * caller; NULL = not wanted).  One compare per element in kernels that are HBM-bound, one atomic max per workgroup. */
+int mi355seg_norm_act_fwd_ax_f32(const float* x, int ldx, const float* mean, const float* rstd,
+                                 const float* gamma, const float* beta, const float* res, int ldres,
+                                 float* y, int ldy, long long rows, int groups, int C,
+                                 int act, float slope, float* y_amax, void* stream);
+int mi355seg_norm_act_bwd_colsum_ax_f32(const float* dy, int lddy, const float* x, int ldx,
+                                        const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                        const float* res, int ldres,
+                                        float* dx, int lddx, float* dgamma, float* dbeta, float* dres, int lddres, float* dx_colsum, float* dx_amax,
+                                        long long rows, int groups, int C, int act, float slope,
+                                        void* ws, size_t ws_bytes, void* stream);
+int mi355seg_norm_act_bwd_apply_ax_f32(const float* dy, int lddy, const float* x, int ldx,
+                                       const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                       const float* res, int ldres, const float* s1, const float* s2,
+                                       float* dx, int lddx, float* dres, int lddres, float* dx_colsum, float* dx_amax,
+                                       long long rows, int groups, int C, int act, float slope,
+                                       void* ws, size_t ws_bytes, void* stream);
 
 /* Eval-mode BatchNorm (running stats) is norm_act_fwd with mean=running_mean and
  * rstd = 1/sqrt(running_var+eps) computed by: */
@@ -425,6 +474,9 @@ int mi355seg_mul_f32(const float* a, const float* b, float* out, long long n, vo
  * (ld*) count ELEMENTS.  Conv3d shapes without a native bf16 kernel run through the fp32 entry point on fp32 copies
  * made in the workspace (mi355seg_conv3d_ws_bytes_bf16 sizes for that). */
 int mi355seg_norm_stats_bf16(const mi355seg_bf16* x, int ldx, long long rows, int groups, int C, float eps, float* mean, float* rstd, float* running_mean, float* running_var, float momentum, void* ws, size_t ws_bytes, void* stream);
+int mi355seg_norm_act_fwd_ax_bf16(const mi355seg_bf16* x, int ldx, const float* mean, const float* rstd, const float* gamma, const float* beta, const mi355seg_bf16* res, int ldres, mi355seg_bf16* y, int ldy, long long rows, int groups, int C, int act, float slope, float* y_amax, void* stream);
+int mi355seg_norm_act_bwd_colsum_ax_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, const float* mean, const float* rstd, const float* gamma, const float* beta, const mi355seg_bf16* res, int ldres, mi355seg_bf16* dx, int lddx, float* dgamma, float* dbeta, mi355seg_bf16* dres, int lddres, float* dx_colsum, float* dx_amax, long long rows, int groups, int C, int act, float slope, void* ws, size_t ws_bytes, void* stream);
+int mi355seg_norm_act_bwd_apply_ax_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, const float* mean, const float* rstd, const float* gamma, const float* beta, const mi355seg_bf16* res, int ldres, const float* s1, const float* s2, mi355seg_bf16* dx, int lddx, mi355seg_bf16* dres, int lddres, float* dx_colsum, float* dx_amax, long long rows, int groups, int C, int act, float slope, void* ws, size_t ws_bytes, void* stream);
 int mi355seg_norm_act_fwd_bf16(const mi355seg_bf16* x, int ldx, const float* mean, const float* rstd, const float* gamma, const float* beta, const mi355seg_bf16* res, int ldres, mi355seg_bf16* y, int ldy, long long rows, int groups, int C, int act, float slope, void* stream);
 int mi355seg_norm_act_bwd_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, const float* mean, const float* rstd, const float* gamma, const float* beta, const mi355seg_bf16* res, int ldres, mi355seg_bf16* dx, int lddx, float* dgamma, float* dbeta, mi355seg_bf16* dres, int lddres, long long rows, int groups, int C, int act, float slope, void* ws, size_t ws_bytes, void* stream);
 int mi355seg_norm_act_bwd_colsum_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, const float* mean, const float* rstd, const float* gamma, const float* beta, const mi355seg_bf16* res, int ldres, mi355seg_bf16* dx, int lddx, float* dgamma, float* dbeta, mi355seg_bf16* dres, int lddres, float* dx_colsum, long long rows, int groups, int C, int act, float slope, void* ws, size_t ws_bytes, void* stream);
