@@ -539,12 +539,14 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
     const int nchunks = Cin / p.CK;
     const long long nvox = (long long)N * D * H * W;
     const int ksplit = b16s ? bp.ksplit : ((ldy % 4 == 0) ? pick_ksplit(p.nM * p.nN, nchunks) : 1);
+    // fp32 tensors under f16x3: the large layers run conv_x3w's 8 x 4 x 16 tiles (fewer, larger M-tiles: decided before anything is sized by nM)
+    const bool x3w = math == MATH_X3 && x3s_enabled() && x3_f16() && x3s_plan_ok(p, x, ldx, y, ldy, (long long)D * H * W) && x3w_plan(p, N, D, H, W, Cin, Cout, ksplit);
     Carver cv(ws);
     void* wq = cv.take<char>(wq_bytes(math, (size_t)T * Cin * Cout));
     float* spart = (ssum && ksplit == 1) ? cv.take<float>((size_t)p.nM * Cout * 3) : nullptr;
     float* slabs = ksplit > 1 ? cv.take<float>((size_t)ksplit * nvox * Cout) : nullptr;
     // fp32 tensors, bf16x6, 16-wide tiles: the 16x16x32-MFMA kernel (conv_x3s.hip) with its own weight packing
-    const bool x3s = math == MATH_X3 && x3s_enabled() && x3s_plan_ok(p, x, ldx, ksplit > 1 ? (void*)slabs : y, ksplit > 1 ? Cout : ldy, (long long)D * H * W);
+    const bool x3s = x3w || (math == MATH_X3 && x3s_enabled() && x3s_plan_ok(p, x, ldx, ksplit > 1 ? (void*)slabs : y, ksplit > 1 ? Cout : ldy, (long long)D * H * W));
     // the BatchNorm-backward sums of the layer in front ride in that kernel's epilogue (whole-K launches only)
     const bool bn_epi = bne && x3s && ksplit == 1 && !ssum && !bias && !act && (bne->ldx % 4) == 0 && ((uintptr_t)bne->x % 16) == 0 && Cout % 4 == 0;
     float* bnpart = bn_epi ? cv.take<float>((size_t)p.nM * Cout * 2) : nullptr;

@@ -27,6 +27,7 @@
 #include "internal.h"
 #include <initializer_list>
 #include <type_traits>
+#include <stdlib.h>
 
 namespace seg {
 
@@ -72,7 +73,14 @@ struct LWgradArgs {
     int Do, Ho, Wo;                            // output (dy) extents
     int ntx, nty, ntz, ntiles, nstrips, npairs, ncob, ntaps_total;
     const float* amax_x; const float* amax_dy;     // NP = 2: device scalars >= max |x|, max |dy|
+    int dbg;                                       // -DMI355SEG_TUNE timing probes (MI355SEG_DBG): 8 no tile loads after the first, 16 no split / LDS writes after the
+                                                   // first, 64 every tile loads the strip's FIRST tile again (same instructions, cache-resident data)
 };
+#ifdef MI355SEG_TUNE
+#define LW_DBG(a, bit) ((a).dbg & (bit))
+#else
+#define LW_DBG(a, bit) 0
+#endif
 
 __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* lds, int off0, int off1) {
     // two transposing reads = the 8 consecutive k (voxels) of this lane's channel
@@ -293,9 +301,9 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
     if (tile < a.ntiles) load_stage(tile);
     for (; tile < a.ntiles; tile += a.nstrips) {
         __syncthreads();
-        write_stage();
+        if (!LW_DBG(a, 16) || tile == strip) write_stage();
         __syncthreads();
-        if (tile + a.nstrips < a.ntiles) load_stage(tile + a.nstrips);
+        if (tile + a.nstrips < a.ntiles && !LW_DBG(a, 8)) load_stage(LW_DBG(a, 64) ? strip : tile + a.nstrips);
         // every lane of every wave runs the transposing reads (they need EXEC all ones); a wave without a fourth tap
         // simply issues one tap-tile fewer
         if (has_last) tile_mfma(std::integral_constant<int, LW_TPW>{});
@@ -414,7 +422,7 @@ int conv_wgrad_lowp(int math, const void* dy, int lddy, const void* x, int ldx, 
     const bool f16 = math == MATH_X3 && x3_f16();
     float* amax = f16 ? cv.take<float>(2) : nullptr;
     SEG_CHECK_WS(cv.used(), ws_bytes);
-    LWgradArgs a{x, dy, part, ldx, lddy, N, D, H, W, Cin, Cout, Do, Ho, Wo, p.ntx, p.nty, p.ntz, p.ntiles, p.nstrips, p.npairs, Cout / 32, p.taps, nullptr, nullptr};
+    LWgradArgs a{x, dy, part, ldx, lddy, N, D, H, W, Cin, Cout, Do, Ho, Wo, p.ntx, p.nty, p.ntz, p.ntiles, p.nstrips, p.npairs, Cout / 32, p.taps, nullptr, nullptr, 0};
     if (f16) {
         if (!x_amax || !dy_amax) {
             if (hipMemsetAsync(amax, 0, 2 * sizeof(float), st) != hipSuccess) { set_error("conv_wgrad_lowp: hipMemsetAsync failed"); return MI355SEG_EHIP; }
@@ -424,6 +432,9 @@ int conv_wgrad_lowp(int math, const void* dy, int lddy, const void* x, int ldx, 
         }
         a.amax_x = x_amax; a.amax_dy = dy_amax;
     }
+#ifdef MI355SEG_TUNE
+    { static const char* e = getenv("MI355SEG_DBG"); a.dbg = e ? atoi(e) : 0; }
+#endif
     const int nwg = p.nstrips * p.npairs * p.planes;
     const double vox = (double)N * Do * Ho * Wo;
     {

@@ -34,6 +34,12 @@ namespace seg {
 
 namespace {
 
+#ifndef X3S_WD
+#define X3S_WD 3
+#endif
+#ifndef X3S_XD
+#define X3S_XD 2
+#endif
 constexpr int XBX = 16, XTY = 4, XHX = XBX + 2, XHY = XTY + 2;
 
 template <int LW, bool F16 = false>
@@ -58,6 +64,151 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
     return v;
+}
+
+// ---- epilogue shared by the kernels of this file: a wave holds LW x-lines (line0 .. line0 + LW - 1 of a TZ x 4 x 16 tile) x all
+// NT = 32 NBW channels of the tile; scale_exp != 0: the accumulators are first multiplied by 2^scale_exp (f16x3)
+template <int LW, int NBW, int TZ>
+__device__ __forceinline__ void x3_epilogue(const IgemmArgs& a, f32x4 (&acc)[LW][2 * NBW], int scale_exp, int ks, int mtile, int n, int x0, int y0, int z0,
+                                            int n0, int line0, int r, int g, int wave, int tid, unsigned char* lds_raw) {
+    constexpr int NT = 32 * NBW, NTW = 2 * NBW;
+    // ---- epilogue: bias, 16-byte stores, optional BatchNorm partial statistics
+    // acc[j][t][e] = y[voxel (line j, x = r)][channel n0 + 16 t + 4 g + e]
+    if (scale_exp != 0) {
+#pragma unroll
+        for (int j = 0; j < LW; ++j)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j][t][e] = __builtin_ldexpf(acc[j][t][e], scale_exp);
+    }
+    float* yslab = reinterpret_cast<float*>(a.y) + (long long)ks * a.split_stride;     // ksplit > 1: raw partial sums of this split (split_stride 0 otherwise)
+    const int gx = x0 + r;
+    float ssum[NTW][4];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ssum[t][e] = 0.f;
+    f32x4 bv[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) bv[t] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n0 + 16 * t + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < LW; ++j) {
+        const int line = line0 + j;
+        const int gz = z0 + line / XTY, gy = y0 + line % XTY;
+        const bool inside = gz < a.D && gy < a.H && gx < a.W;
+        float* dst = yslab + ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.ldy + n0 + 4 * g;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            f32x4 v = acc[j][t] + bv[t];
+            if (a.act) { v[0] = act_apply(v[0], a.act, a.slope); v[1] = act_apply(v[1], a.act, a.slope); v[2] = act_apply(v[2], a.act, a.slope); v[3] = act_apply(v[3], a.act, a.slope); }
+            if (inside) {
+                *reinterpret_cast<f32x4*>(dst + 16 * t) = v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ssum[t][e] += v[e];
+            }
+        }
+    }
+    if (a.bnpart) {
+        // BatchNorm-backward column sums of the layer in front (input-gradient launch, no bias / activation / split): the tile just
+        // stored is d(activation); read that layer's pre-norm tensor at the same voxels and reduce dz and dz * xhat per channel
+        float sa[NTW][4], sb[NTW][4];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int c = n0 + 16 * t + 4 * g;
+            const f32x4 mu = *reinterpret_cast<const f32x4*>(a.bn_mean + c), rs = *reinterpret_cast<const f32x4*>(a.bn_rstd + c);
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(a.bn_gamma + c), be = *reinterpret_cast<const f32x4*>(a.bn_beta + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sa[t][e] = 0.f; sb[t][e] = 0.f; }
+#pragma unroll
+            for (int j = 0; j < LW; ++j) {
+                const int line = line0 + j;
+                const int gz = z0 + line / XTY, gy = y0 + line % XTY;
+                if (gz < a.D && gy < a.H && gx < a.W) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(a.bnx + ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.ldbnx + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xh = (xv[e] - mu[e]) * rs[e];
+                        const float dz = acc[j][t][e] * act_grad(fmaf(xh, ga[e], be[e]), a.bn_act, a.bn_slope);
+                        sa[t][e] += dz; sb[t][e] = fmaf(dz, xh, sb[t][e]);
+                    }
+                }
+            }
+        }
+        float* lds = reinterpret_cast<float*>(lds_raw);
+        __syncthreads();                 // LDS halo no longer needed
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v1 = row16_sum(sa[t][e]), v2 = row16_sum(sb[t][e]);
+                if (r == 0) { lds[wave * NT + 16 * t + 4 * g + e] = v1; lds[(4 + wave) * NT + 16 * t + 4 * g + e] = v2; }
+            }
+        __syncthreads();
+        if (tid < NT) {
+            float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { v1 += lds[w * NT + tid]; v2 += lds[(4 + w) * NT + tid]; }
+            float* dst = a.bnpart + ((long long)mtile * a.Cout + n0 + tid) * 2;
+            dst[0] = v1; dst[1] = v2;
+        }
+    }
+    if (a.spart) {
+        // per channel (sum, M2 about the tile mean, n) of this tile, as conv_igemm_kernel: spart[mtile][c] = {sum, M2, n}
+        float* lds = reinterpret_cast<float*>(lds_raw);
+        __syncthreads();                 // LDS halo no longer needed
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float s1 = row16_sum(ssum[t][e]);
+                if (r == 0) lds[wave * NT + 16 * t + 4 * g + e] = s1;
+            }
+        const int vz = min(TZ, a.D - z0), vy = min(XTY, a.H - y0), vx = min(XBX, a.W - x0);
+        const float cnt = (float)(vz * vy * vx);
+        __syncthreads();
+        float tmean[NTW][4];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 16 * t + 4 * g + e;
+                tmean[t][e] = (lds[c] + lds[NT + c] + lds[2 * NT + c] + lds[3 * NT + c]) / cnt;
+            }
+        __syncthreads();
+        float m2[NTW][4];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m2[t][e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < LW; ++j) {
+            const int line = line0 + j;
+            const bool inside = (z0 + line / XTY) < a.D && (y0 + line % XTY) < a.H && gx < a.W;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = acc[j][t][e] + bv[t][e] - tmean[t][e];
+                    if (inside) m2[t][e] += d * d;
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = row16_sum(m2[t][e]);
+                if (r == 0) lds[(4 + wave) * NT + 16 * t + 4 * g + e] = v;
+            }
+        __syncthreads();
+        if (tid < NT) {
+            float s1 = 0.f, mm = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s1 += lds[w * NT + tid]; mm += lds[(4 + w) * NT + tid]; }
+            float* dst = a.spart + ((long long)mtile * a.Cout + n0 + tid) * 3;
+            dst[0] = s1; dst[1] = mm; dst[2] = cnt;
+        }
+    }
 }
 
 // LW = x-lines (16 voxels each) per wave: 4 -> tile 4 (z) x 4 (y) x 16, wave w owns z-slab w; 2 -> tile 2 x 4 x 16.
@@ -194,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
     const int xb0 = (lane_slot + hi) * 16, xb1 = (lane_slot + hi * XHX) * 16, xb2 = (lane_slot + hi * XHY * XHX) * 16, xb3 = lane_slot * 16;
     auto xaddr = [&](int s, int j, int pl) {                     // s, j, pl are compile-time after unrolling: the rest folds into the offset field
         const int base = pair_kind(s) == 0 ? xb0 : (pair_kind(s) == 1 ? xb1 : (pair_kind(s) == 2 ? xb2 : xb3));
-        return base + (j * XHX + tap_slot(x3s_pair_tap(s, 0)) + 2 * pl * PS) * 16;
+        return base + (((j >> 2) * XHY + (j & 3)) * XHX + tap_slot(x3s_pair_tap(s, 0)) + 2 * pl * PS) * 16;      // (LW = 8: lines 4 .. 7 are the next z-slab)
     };
 
     f32x4 acc[LW][NTW];
@@ -207,8 +358,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
     load_stage(c0);
     for (int chunk = c0; chunk < c1; ++chunk) {
         const bf16* wp = wlane + (long long)chunk * (NU * UNIT);
-        constexpr int WD = NBW == 2 && LW == 4 ? 1 : 2;          // weight units in flight ahead of the MFMAs (the 64-channel 4-line tile is register-bound)
-        bf16x8_t wf[WD + 1][2][NPL], xf[2][NPL];
+        // weight units in flight ahead of the MFMAs (bf16x6: the 64-channel 4-line tile is register-bound) and voxel fragments
+        // requested XD regions ahead.  f16x3 (r4 ablation: weights loaded once per chunk +28-41 % on <4, 2> at one unit = 384 cycles of
+        // lead, +13 % on <4, 1> at two; voxel fragments read once +14-17 % at one region = 96 cycles of lead): the two-plane fragments
+        // leave the registers for three units and two regions
+        constexpr int WD = F16 ? X3S_WD : (NBW == 2 && LW == 4 ? 1 : 2);
+        constexpr int XD = F16 ? X3S_XD : 1;
+        bf16x8_t wf[WD + 1][2][NPL], xf[XD + 1][NPL];
         auto load_w = [&](int u) {
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
@@ -218,23 +374,29 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
         // the first weight units are requested BEFORE the next chunk's halo: vmcnt retires in order
 #pragma unroll
         for (int u = 0; u < WD; ++u) load_w(u);
+        // (-DMI355SEG_TUNE timing probes, MI355SEG_DBG: 1 = stage the halo for the first chunk only, 2 = weight fragments loaded for the first
+        //  unit of a chunk only, 8 = voxel fragments read for the first (unit, line) only; same MFMAs, garbage results)
+        if (!SEG_DBG(a, 1) || chunk == c0) {
         __syncthreads();                                         // every wave is done reading the previous chunk
-        write_stage();
+        if (!SEG_DBG(a, 4) || chunk == c0) write_stage();
         __syncthreads();
+        }
         const bool more = chunk + 1 < c1;
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) xf[0][pl] = *reinterpret_cast<const bf16x8_t*>(lds_raw + xaddr(0, 0, pl));
+        for (int q0 = 0; q0 < XD; ++q0)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) xf[q0][pl] = *reinterpret_cast<const bf16x8_t*>(lds_raw + xaddr((q0 / LW) / NBW, q0 % LW, pl));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int s = u / NBW, nh = u % NBW;
 #pragma unroll
             for (int j = 0; j < LW; ++j) {
-                const int q = u * LW + j, cur = q & 1, nxt = cur ^ 1;
-                if (j == 0 && u + WD < NU) load_w(u + WD);
-                if (q < G::NITER && more) load_piece(chunk + 1, q);
-                if (q + 1 < NU * LW) {
-                    const int u2 = (q + 1) / LW, j2 = (q + 1) % LW;
+                const int q = u * LW + j, cur = q % (XD + 1), nxt = (q + XD) % (XD + 1);
+                if (j == 0 && u + WD < NU && !SEG_DBG(a, 2)) load_w(u + WD);
+                if (q < G::NITER && more && !SEG_DBG(a, 1) && !SEG_DBG(a, 16)) load_piece(chunk + 1, q);
+                if (q + XD < NU * LW && !SEG_DBG(a, 8)) {
+                    const int u2 = (q + XD) / LW, j2 = (q + XD) % LW;
 #pragma unroll
                     for (int pl = 0; pl < NPL; ++pl) xf[nxt][pl] = *reinterpret_cast<const bf16x8_t*>(lds_raw + xaddr(u2 / NBW, j2, pl));
                 }
@@ -275,143 +437,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    // ---- epilogue: bias, 16-byte stores, optional BatchNorm partial statistics
-    // acc[j][t][e] = y[voxel (line j, x = r)][channel n0 + 16 t + 4 g + e]
-    if constexpr (F16) {
-#pragma unroll
-        for (int j = 0; j < LW; ++j)
-#pragma unroll
-            for (int t = 0; t < NTW; ++t)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[j][t][e] = __builtin_ldexpf(acc[j][t][e], -(sx + sw));
-    }
-    float* yslab = reinterpret_cast<float*>(a.y) + (long long)ks * a.split_stride;     // ksplit > 1: raw partial sums of this split (split_stride 0 otherwise)
-    const int gx = x0 + r;
-    float ssum[NTW][4];
-#pragma unroll
-    for (int t = 0; t < NTW; ++t)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ssum[t][e] = 0.f;
-    f32x4 bv[NTW];
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) bv[t] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n0 + 16 * t + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < LW; ++j) {
-        const int line = line0 + j;
-        const int gz = z0 + line / XTY, gy = y0 + line % XTY;
-        const bool inside = gz < a.D && gy < a.H && gx < a.W;
-        float* dst = yslab + ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.ldy + n0 + 4 * g;
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            f32x4 v = acc[j][t] + bv[t];
-            if (a.act) { v[0] = act_apply(v[0], a.act, a.slope); v[1] = act_apply(v[1], a.act, a.slope); v[2] = act_apply(v[2], a.act, a.slope); v[3] = act_apply(v[3], a.act, a.slope); }
-            if (inside) {
-                *reinterpret_cast<f32x4*>(dst + 16 * t) = v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) ssum[t][e] += v[e];
-            }
-        }
-    }
-    if (a.bnpart) {
-        // BatchNorm-backward column sums of the layer in front (input-gradient launch, no bias / activation / split): the tile just
-        // stored is d(activation); read that layer's pre-norm tensor at the same voxels and reduce dz and dz * xhat per channel
-        float sa[NTW][4], sb[NTW][4];
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            const int c = n0 + 16 * t + 4 * g;
-            const f32x4 mu = *reinterpret_cast<const f32x4*>(a.bn_mean + c), rs = *reinterpret_cast<const f32x4*>(a.bn_rstd + c);
-            const f32x4 ga = *reinterpret_cast<const f32x4*>(a.bn_gamma + c), be = *reinterpret_cast<const f32x4*>(a.bn_beta + c);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { sa[t][e] = 0.f; sb[t][e] = 0.f; }
-#pragma unroll
-            for (int j = 0; j < LW; ++j) {
-                const int line = line0 + j;
-                const int gz = z0 + line / XTY, gy = y0 + line % XTY;
-                if (gz < a.D && gy < a.H && gx < a.W) {
-                    const f32x4 xv = *reinterpret_cast<const f32x4*>(a.bnx + ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.ldbnx + c);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float xh = (xv[e] - mu[e]) * rs[e];
-                        const float dz = acc[j][t][e] * act_grad(fmaf(xh, ga[e], be[e]), a.bn_act, a.bn_slope);
-                        sa[t][e] += dz; sb[t][e] = fmaf(dz, xh, sb[t][e]);
-                    }
-                }
-            }
-        }
-        float* lds = reinterpret_cast<float*>(lds_raw);
-        __syncthreads();                 // LDS halo no longer needed
-#pragma unroll
-        for (int t = 0; t < NTW; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v1 = row16_sum(sa[t][e]), v2 = row16_sum(sb[t][e]);
-                if (r == 0) { lds[wave * NT + 16 * t + 4 * g + e] = v1; lds[(4 + wave) * NT + 16 * t + 4 * g + e] = v2; }
-            }
-        __syncthreads();
-        if (tid < NT) {
-            float v1 = 0.f, v2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) { v1 += lds[w * NT + tid]; v2 += lds[(4 + w) * NT + tid]; }
-            float* dst = a.bnpart + ((long long)mtile * a.Cout + n0 + tid) * 2;
-            dst[0] = v1; dst[1] = v2;
-        }
-    }
-    if (a.spart) {
-        // per channel (sum, M2 about the tile mean, n) of this tile, as conv_igemm_kernel: spart[mtile][c] = {sum, M2, n}
-        float* lds = reinterpret_cast<float*>(lds_raw);
-        __syncthreads();                 // LDS halo no longer needed
-#pragma unroll
-        for (int t = 0; t < NTW; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float s1 = row16_sum(ssum[t][e]);
-                if (r == 0) lds[wave * NT + 16 * t + 4 * g + e] = s1;
-            }
-        const int vz = min(G::TZ, a.D - z0), vy = min(XTY, a.H - y0), vx = min(XBX, a.W - x0);
-        const float cnt = (float)(vz * vy * vx);
-        __syncthreads();
-        float tmean[NTW][4];
-#pragma unroll
-        for (int t = 0; t < NTW; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = 16 * t + 4 * g + e;
-                tmean[t][e] = (lds[c] + lds[NT + c] + lds[2 * NT + c] + lds[3 * NT + c]) / cnt;
-            }
-        __syncthreads();
-        float m2[NTW][4];
-#pragma unroll
-        for (int t = 0; t < NTW; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) m2[t][e] = 0.f;
-#pragma unroll
-        for (int j = 0; j < LW; ++j) {
-            const int line = line0 + j;
-            const bool inside = (z0 + line / XTY) < a.D && (y0 + line % XTY) < a.H && gx < a.W;
-#pragma unroll
-            for (int t = 0; t < NTW; ++t)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float d = acc[j][t][e] + bv[t][e] - tmean[t][e];
-                    if (inside) m2[t][e] += d * d;
-                }
-        }
-#pragma unroll
-        for (int t = 0; t < NTW; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = row16_sum(m2[t][e]);
-                if (r == 0) lds[(4 + wave) * NT + 16 * t + 4 * g + e] = v;
-            }
-        __syncthreads();
-        if (tid < NT) {
-            float s1 = 0.f, mm = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) { s1 += lds[w * NT + tid]; mm += lds[(4 + w) * NT + tid]; }
-            float* dst = a.spart + ((long long)mtile * a.Cout + n0 + tid) * 3;
-            dst[0] = s1; dst[1] = mm; dst[2] = cnt;
-        }
-    }
+    x3_epilogue<LW, NBW, G::TZ>(a, acc, F16 ? -(sx + sw) : 0, ks, mtile, n, x0, y0, z0, n0, line0, r, g, wave, tid, lds_raw);
 }
 
 template <int LW, int NBW, bool F16>
@@ -420,6 +446,227 @@ void launch_x3s(const IgemmArgs& a, int nwg, hipStream_t st) {
     static_assert(LDSB >= 8 * 64 * 4, "the statistics epilogue needs 8 x NT floats");
     SEG_SET_LDS((conv_x3s_kernel<LW, NBW, F16>), LDSB);
     hipLaunchKernelGGL((conv_x3s_kernel<LW, NBW, F16>), dim3(nwg), dim3(256), LDSB, st, a);
+}
+
+
+// ---------------------------------------------------------------- conv_x3w: the f16x3 form for the layers that fill the chip
+// r4 ablation of conv_x3s<.., F16> (profiles/r04_x3s_f16_ablation_probe.log: same MFMAs, one input stream removed at a time): weight
+// fragments loaded once per chunk +21-45 %, no re-staging +8-13 %, voxel fragments read once +10-18 %, all three 1.55-1.65x.  With
+// three MFMAs per product instead of six the loop is bound by the four waves' re-loads of the same weight fragments through the
+// L1 (a fragment fed 6 MFMAs: 43 B/clk/CU of the 64) and by the staging phase between two barriers.  This kernel trades occupancy
+// for registers: ONE workgroup per CU, one wave per SIMD (up to 512 registers), tile = 8 (z) x 4 (y) x 16 (x) voxels x 32 NBW channels,
+// a wave owns EIGHT x-lines and all channels of the tile -- a weight fragment feeds 12 MFMAs (21 B/clk/CU), NBW = 2: a voxel fragment
+// feeds 6 -- and the halo tile is double-buffered in LDS (2 x 68 KB): the next chunk's pieces are requested, split and written
+// into the other buffer a few at a time between the MFMAs of the current chunk (a ring of RING pieces instead of the whole
+// chunk in registers), one barrier per chunk.  Weight fragments run WL K-steps ahead in a register ring of WR slots; NCH chunks
+// per loop iteration make the ring's phase static (NCH * 14 steps = 0 mod WR).  ksplit == 1 only; same weight packing (LAYOUT 2),
+// same tile walk, same epilogue as conv_x3s.
+template <int NBW>
+struct GeoW {
+    static constexpr int LW = 8, TZ = 8, HZ = TZ + 2;
+    static constexpr int NVOX = XHX * XHY * HZ;                  // 1080
+    static constexpr int PS = (NVOX + 15) / 16 * 16;            // 1088
+    static constexpr int BUF = 4 * PS * 16;                     // one buffer: planes h / l x channel half
+    static constexpr int LDS_BYTES = 2 * BUF;
+    static constexpr int NPIECE = NVOX * 4;
+    static constexpr int NITER = (NPIECE + 255) / 256;          // 17
+    static constexpr int NCH = NBW == 2 ? 1 : 2;                // chunks per loop iteration
+    static constexpr int WR = NBW == 2 ? 2 : 4, WL = NBW == 2 ? 1 : 2;      // weight ring slots / K-steps of lead
+    static constexpr int RING = 8;                              // halo pieces in flight
+    static_assert((NCH * X3S_NPAIR) % WR == 0 && WL < WR, "the weight ring's phase must be static");
+};
+
+template <int NBW>
+__global__ __launch_bounds__(256, 1) void conv_x3w_kernel(IgemmArgs a) {
+    using G = GeoW<NBW>;
+    constexpr int LW = G::LW, NT = 32 * NBW, NTW = 2 * NBW, PS = G::PS, NITER = G::NITER, RING = G::RING;
+    constexpr int NS = X3S_NPAIR;                                // K-steps per chunk
+    constexpr int STEP = NBW * 2048;                             // fp16 elements of one K-step of packed weights: [nh][plane][t2][lane][8]
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    int ntile, mtile, n, x0, y0, z0;
+    {
+        const int total = (int)gridDim.x, bid = blockIdx.x;
+        const int q8 = total >> 3, r8 = total & 7, xcd = bid & 7;
+        const int xstart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, xcnt = q8 + (xcd < r8 ? 1 : 0);
+        const int local = bid >> 3;
+        if (local >= xcnt) return;
+        int t = xstart + local;
+        ntile = t % a.nN;
+        mtile = t / a.nN;
+        int mt = mtile;
+        const int per_n = a.ntx * a.nty * a.ntz;
+        n = mt / per_n; mt -= n * per_n;
+        const int zfull = a.ntz / a.bz;
+        const int rowtiles = a.ntx * a.nty * a.bz;
+        int zrow = mt / rowtiles, bzz = a.bz;
+        if (zrow >= zfull) { zrow = zfull; bzz = a.ntz - zfull * a.bz; }
+        mt -= zrow * rowtiles;
+        const int blk = a.ntx * a.by * bzz;
+        const int b = mt / blk; mt -= b * blk;
+        const int txi = mt % a.ntx; mt /= a.ntx;
+        const int tyi = b * a.by + mt % a.by;
+        const int tzi = zrow * a.bz + mt / a.by;
+        x0 = txi * XBX; y0 = tyi * XTY; z0 = tzi * G::TZ;
+    }
+    const int n0 = ntile * NT;
+    const int c1 = a.cps;                                        // ksplit == 1: all chunks
+    const float* __restrict__ xin = reinterpret_cast<const float*>(a.x);
+    const int sx = f16x_scale_exp(*a.amax_x), sw = f16x_scale_exp(*a.amax_w);
+    const float xscale = pow2f(sx);
+
+    // ---- halo pieces: piece p = it * 256 + tid = (halo voxel p / 4, four channels p % 4); per-tile byte offsets, buffer loads with
+    // a range check that zero-fills the pieces outside the volume (as conv_x3s)
+    int voff[NITER];
+#pragma unroll
+    for (int it = 0; it < NITER; ++it) {
+        const int p = it * 256 + tid;
+        const int vox = p >> 2, part = p & 3;
+        const int hz = vox / (XHY * XHX), rem = vox % (XHY * XHX);
+        const int hy = rem / XHX, hx = rem % XHX;
+        const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool ok = (p < G::NPIECE) && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        voff[it] = ok ? (((gz * a.H + gy) * a.W + gx) * a.ldx + part * 4) * 4 : 0x7FFFFFF0;
+    }
+    const float* xsample = xin + (long long)n * a.D * a.H * a.W * a.ldx;
+    const int sample_bytes = a.D * a.H * a.W * a.ldx * 4;
+    f32x4 ring[RING];
+    auto load_piece = [&](int chunk, int it) {
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xsample + chunk * 16), 0, sample_bytes, 0x00020000);
+        ring[it % RING] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[it], 0, 0));
+    };
+    auto split_pair_h = [&](float x0_, float x1_, unsigned& h2, unsigned& l2) {
+        const float s0 = x0_ * xscale, s1 = x1_ * xscale;
+        const f16x2_t hh = __builtin_convertvector(f32x2_t{s0, s1}, f16x2_t);
+        h2 = __builtin_bit_cast(unsigned, hh);
+        const float r0 = __builtin_fmaf((float)hh[0], -1.f, s0), r1 = __builtin_fmaf((float)hh[1], -1.f, s1);
+        l2 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r0, r1}, f16x2_t));
+    };
+    unsigned char* const wdst = lds_raw + (((tid & 3) >> 1) * PS + (tid >> 2)) * 16 + (tid & 1) * 8;
+    auto write_piece = [&](int buf, int it) {
+        if (it * 256 + tid < G::NPIECE) {
+            using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+            const f32x4 v = ring[it % RING];
+            unsigned h0, l0, h1, l1;
+            split_pair_h(v[0], v[1], h0, l0);
+            split_pair_h(v[2], v[3], h1, l1);
+            unsigned char* dst = wdst + buf * G::BUF + it * 1024;
+            *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(dst + 2 * PS * 16) = u32x2{l0, l1};
+        }
+    };
+
+    // per-lane LDS byte bases of the voxel fragments (line 0 of this wave, plane h, buffer 0), one per pair kind
+    const int line0 = wave * LW;
+    const int lane_slot = ((line0 / XTY) * XHY + (line0 % XTY)) * XHX + r + (g & 1) * PS;
+    const int hi = g >> 1;
+    const int xb0 = (lane_slot + hi) * 16, xb1 = (lane_slot + hi * XHX) * 16, xb2 = (lane_slot + hi * XHY * XHX) * 16, xb3 = lane_slot * 16;
+    auto xoffs = [](int buf, int s, int j, int pl) {             // compile-time part of a fragment address: folds into the offset field
+        return buf * G::BUF + ((((j >> 2) * XHY + (j & 3)) * XHX + tap_slot(x3s_pair_tap(s, 0))) + 2 * pl * PS) * 16;
+    };
+
+    f32x4 acc[LW][NTW];
+#pragma unroll
+    for (int j = 0; j < LW; ++j)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // weight fragments of linear K-step `lin` (= chunk * 14 + s): fragment (tile t = 2 nh + t2, plane pl) at nh * 2048 + pl * 1024 + t2 * 512
+    const _Float16* wlane = reinterpret_cast<const _Float16*>(a.wq) + (long long)ntile * a.nchunks * (NS * STEP) + lane * 8;
+    const int nlin = c1 * NS;
+    bf16x8_t wf[G::WR][NTW][2];
+    auto load_w_frag = [&](int slot, int lin, int f) {         // f = 0 .. 2 NTW - 1: (tile, plane)
+        const int t = f >> 1, pl = f & 1;
+        wf[slot][t][pl] = *reinterpret_cast<const bf16x8_t*>(wlane + (long long)lin * STEP + (t >> 1) * 2048 + pl * 1024 + (t & 1) * 512);
+    };
+
+    // ---- prologue: the first chunk's halo (through the ring, RING pieces at a time), the first WL steps of weights
+#pragma unroll
+    for (int sl = 0; sl < G::WL; ++sl)
+#pragma unroll
+        for (int f = 0; f < 2 * NTW; ++f) load_w_frag(sl, sl < nlin ? sl : 0, f);
+#pragma unroll
+    for (int it0 = 0; it0 < NITER; it0 += RING) {
+#pragma unroll
+        for (int it = it0; it < it0 + RING && it < NITER; ++it) load_piece(0, it);
+#pragma unroll
+        for (int it = it0; it < it0 + RING && it < NITER; ++it) write_piece(0, it);
+    }
+    __syncthreads();
+
+    bf16x8_t xf[2][2];
+    for (int chunk = 0; chunk < c1; chunk += G::NCH) {
+#pragma unroll
+        for (int h = 0; h < G::NCH; ++h) {
+            const int cur = G::NCH == 2 ? h : (chunk & 1);      // NCH == 1: the buffer alternates with the (runtime) chunk parity
+            const int cbuf = G::NCH == 2 ? h : 0;               // compile-time part of the buffer choice (NCH == 1: added at run time below)
+            const int rt = G::NCH == 2 ? 0 : cur * G::BUF;      // run-time buffer offset (bytes)
+            const int nbuf = 1 - cur;                            // where the next chunk's halo goes
+            const bool more = chunk + h + 1 < c1;
+            const int b0 = xb0 + rt, b1 = xb1 + rt, b2 = xb2 + rt, b3 = xb3 + rt;
+            const unsigned char* xl = lds_raw;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) xf[0][pl] = *reinterpret_cast<const bf16x8_t*>(xl + b0 + xoffs(cbuf, 0, 0, pl));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int hs = h * NS + s;                       // step index inside the loop iteration: the ring phase
+                const int lin = (chunk + h) * NS + s;
+#pragma unroll
+                for (int j = 0; j < LW; ++j) {
+                    const int q = s * LW + j, cb = q & 1, nb = cb ^ 1;
+                    // weights WL steps ahead, spread over the lines of the step
+                    {
+                        constexpr int FPL = (2 * NTW + LW - 1) / LW;               // fragments requested per line
+#pragma unroll
+                        for (int f = j * FPL; f < (j + 1) * FPL && f < 2 * NTW; ++f) {
+                            const int l2 = lin + G::WL;
+                            load_w_frag((hs + G::WL) % G::WR, l2 < nlin ? l2 : nlin - 1, f);
+                        }
+                    }
+                    // the next chunk's halo: piece q requested in region q, split and written RING regions later
+                    if (q >= RING && q - RING < NITER && more) write_piece(nbuf, q - RING);
+                    if (q < NITER && more) load_piece(chunk + h + 1, q);
+                    if (q + 1 < NS * LW) {
+                        const int s2 = (q + 1) / LW, j2 = (q + 1) % LW;
+#pragma unroll
+                        for (int pl = 0; pl < 2; ++pl)
+                            xf[nb][pl] = *reinterpret_cast<const bf16x8_t*>(xl + (pair_kind(s2) == 0 ? b0 : (pair_kind(s2) == 1 ? b1 : (pair_kind(s2) == 2 ? b2 : b3))) + xoffs(cbuf, s2, j2, pl));
+                    }
+                    constexpr int PW[3] = {1, 0, 0}, PX[3] = {0, 1, 0};            // planes 0 / 1 = h / l; the cross terms first
+#pragma unroll
+                    for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                        for (int t = 0; t < NTW; ++t)
+                            acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, wf[hs % G::WR][t][PW[pr]]),
+                                                                            __builtin_bit_cast(f16x8_t, xf[cb][PX[pr]]), acc[j][t], 0, 0, 0);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);           // one scheduling region per (K-step, line)
+                }
+            }
+            __syncthreads();                                     // the other buffer is complete, this one is free
+        }
+    }
+
+    x3_epilogue<LW, NBW, G::TZ>(a, acc, -(sx + sw), 0, mtile, n, x0, y0, z0, n0, line0, r, g, wave, tid, lds_raw);
+}
+
+template <int NBW>
+void launch_x3w(const IgemmArgs& a, int nwg, hipStream_t st) {
+    constexpr int LDSB = GeoW<NBW>::LDS_BYTES;
+    SEG_SET_LDS((conv_x3w_kernel<NBW>), LDSB);
+    hipLaunchKernelGGL((conv_x3w_kernel<NBW>), dim3(nwg), dim3(256), LDSB, st, a);
 }
 
 }  // namespace
@@ -431,8 +678,31 @@ bool x3s_plan_ok(const IgemmPlan& p, const void* x, int ldx, const void* y, int 
            (ldx % 4) == 0 && (ldy % 4) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0;
 }
 
+// conv_x3w (f16x3, one 8 x 4 x 16-voxel tile per CU at a time): for layers that cut enough of its tiles to fill the chip a few times
+// over with little z padding; NBW = 1 runs two chunks per loop iteration.  Rewrites the M-tile geometry of the plan.
+bool x3w_plan(IgemmPlan& p, int N, int D, int H, int W, int Cin, int Cout, int ksplit) {
+#ifdef MI355SEG_TUNE
+    static const char* off = getenv("MI355SEG_NO_X3W");
+    if (off && off[0] == '1') return false;
+#endif
+    if (ksplit != 1 || p.WN != 1 || p.NBW != 1) return false;      // (NBW = 2: conv_x3w<2> measured at parity with conv_x3s<4, 2>: kept off)
+    const int ntz = (D + 7) / 8, nty = (H + 3) / 4, ntx = (W + 15) / 16;
+    const long long tiles = (long long)N * ntz * nty * ntx * p.nN;
+    if (tiles < 512 || (double)(ntz * 8) / D > 1.15) return false;
+    p.MB = 4; p.TZ = 8; p.ntx = ntx; p.nty = nty; p.ntz = ntz; p.nM = N * ntz * nty * ntx;
+    return true;
+}
+
 // a.amax_x != nullptr selects the f16x3 form (the weights at a.wq are then its two-plane fp16 packing)
 void dispatch_x3s(const IgemmPlan& p, const IgemmArgs& a, int nwg, hipStream_t st) {
+    if (a.amax_x && p.MB == 4) {
+#ifdef X3W_NBW1
+        if (p.NBW == 2) launch_x3w<2>(a, nwg, st); else launch_x3w<1>(a, nwg, st);
+#else
+        if (p.NBW == 2) launch_x3w<2>(a, nwg, st); else launch_x3s<8, 1, true>(a, nwg, st);
+#endif
+        return;
+    }
     if (a.amax_x) {
         if (p.MB == 2) { if (p.NBW == 2) launch_x3s<4, 2, true>(a, nwg, st); else launch_x3s<4, 1, true>(a, nwg, st); }
         else { if (p.NBW == 2) launch_x3s<2, 2, true>(a, nwg, st); else launch_x3s<2, 1, true>(a, nwg, st); }

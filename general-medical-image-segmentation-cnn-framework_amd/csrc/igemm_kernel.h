@@ -657,6 +657,7 @@ __host__ __device__ constexpr int x3s_pair_tap(int s, int which) {
 }
 bool x3s_plan_ok(const IgemmPlan& p, const void* x, int ldx, const void* y, int ldy, long long sample_voxels);
 void dispatch_x3s(const IgemmPlan& p, const IgemmArgs& a, int nwg, hipStream_t st);
+bool x3w_plan(IgemmPlan& p, int N, int D, int H, int W, int Cin, int Cout, int ksplit);
 
 // conv_b16s.hip: bf16 tensors, k3 / k5 stride 1, on v_mfma_f32_16x16x32_bf16 (eight x-lines of 16 voxels x 32 channels per wave).
 // K-step s of a 16-channel chunk contracts taps 2s and 2s + 1 (the odd last tap pairs with zero weights).

@@ -43,6 +43,18 @@ def run(name, fn):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     print(f"{name:6s} {ms:8.3f} ms  {flops / ms / 1e9:7.1f} TFLOP/s   [{dtype}, conv math {mi355seg.get_conv_math() if dtype == 'f32' else 'bf16'}] N={N} {D}x{H}x{W} {Cin}->{Cout} k{k} s{stride}")
+if dtype == "f32" and L.query("mi355seg_conv_math_takes_amax") and "--measure-amax" not in sys.argv:
+    # f16x3: the operand maxima are handed over (as the training path does), so the lines time the convolution kernels alone
+    am = torch.zeros(3, device="cuda")
+    L.call("mi355seg_amax_f32", x.data_ptr(), Cin, N * D * H * W, Cin, am.data_ptr(), st)
+    L.call("mi355seg_amax_f32", w.data_ptr(), w.numel(), 1, w.numel(), am.data_ptr() + 4, st)
+    L.call("mi355seg_amax_f32", y.data_ptr(), Cout, N * Do * Ho * Wo, Cout, am.data_ptr() + 8, st)
+    ax, aw, ay = am.data_ptr(), am.data_ptr() + 4, am.data_ptr() + 8
+    run("fwd", lambda: L.call("mi355seg_conv3d_fwd_ax_f32", x.data_ptr(), Cin, w.data_ptr(), b.data_ptr(), y.data_ptr(), Cout, N, D, H, W, Cin, Cout, k, stride, pad, None, None, ax, aw, ws.data_ptr(), ws.numel(), st))
+    L.call("mi355seg_amax_f32", y.data_ptr(), Cout, N * Do * Ho * Wo, Cout, am.data_ptr() + 8, st)
+    run("dgrad", lambda: L.call("mi355seg_conv3d_dgrad_ax_f32", y.data_ptr(), Cout, w.data_ptr(), dx.data_ptr(), Cin, N, D, H, W, Cin, Cout, k, stride, pad, ay, aw, ws.data_ptr(), ws.numel(), st))
+    run("wgrad", lambda: L.call("mi355seg_conv3d_wgrad_ax_f32", y.data_ptr(), Cout, x.data_ptr(), Cin, dw.data_ptr(), None, N, D, H, W, Cin, Cout, k, stride, pad, 0, ay, ax, ws.data_ptr(), ws.numel(), st))
+    sys.exit(0)
 run("fwd", lambda: L.call("mi355seg_conv3d_fwd" + sfx, x.data_ptr(), Cin, w.data_ptr(), b.data_ptr(), y.data_ptr(), Cout, N, D, H, W, Cin, Cout, k, stride, pad, None, None, ws.data_ptr(), ws.numel(), st))
 run("dgrad", lambda: L.call("mi355seg_conv3d_dgrad" + sfx, y.data_ptr(), Cout, w.data_ptr(), dx.data_ptr(), Cin, N, D, H, W, Cin, Cout, k, stride, pad, ws.data_ptr(), ws.numel(), st))
 run("wgrad", lambda: L.call("mi355seg_conv3d_wgrad" + sfx, y.data_ptr(), Cout, x.data_ptr(), Cin, dw.data_ptr(), None, N, D, H, W, Cin, Cout, k, stride, pad, 0, ws.data_ptr(), ws.numel(), st))
