@@ -221,35 +221,80 @@ def run_leg(L, dev, name, net, shape, classes, loss_kind, flop_per_vox, steps, w
                            "note": "same weights and batch, random-init network on random labels; fp32 = bf16x6 / fp32 MFMA convolutions. "
                                    "bf16 does not meet north_star's 1e-4 Dice bar (an fp32 bar): argmax flips where the logit margin is below the bf16 "
                                    "deviation, as for the reference under torch.autocast(bfloat16) (tests/golden/bf16_reference_deviation.json)"}
-    if classes == 2:
-        # the same iteration captured once into a HIP graph and replayed (engine.GraphedTrainStep = `config.hip_graph=true` of train.py):
-        # what a launch-bound step gains when the host no longer enqueues every kernel (UNETR's token path: ~1300 launches per step)
-        try:
-            import gc
-            from mi355seg.engine import GraphedTrainStep
-            out = {"loss": out["loss"].detach().clone()}    # drop the eager iterations' autograd graphs (see GraphedTrainStep)
-            for p_ in model.parameters():
-                p_.grad = None
-            gc.collect()
-            opt_g = make_adam(model.parameters(), lr=1e-3, capturable=True)
-            gs = GraphedTrainStep(model, opt_g, x, gt, warmup=2, dtype=torch.bfloat16)
-            for _ in range(2):
-                gs(x, gt, sync_metric=False)
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            for _ in range(steps):
-                gs(x, gt, sync_metric=False)
-            torch.cuda.synchronize()
-            msg = (time.perf_counter() - t2) / steps * 1e3
-            leg["hip_graph"] = {"ms_per_step": msg, "voxels_per_s": vox / (msg * 1e-3), "speedup_over_eager": ms / msg,
-                                "note": "one hipGraphLaunch per iteration, same kernels and arithmetic; `ms_per_step` above is the eager loop"}
-            del gs, opt_g
-        except Exception as e:
-            leg["hip_graph"] = {"error": repr(e)}
     del model, opt, x, out
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats()
     return leg
+
+
+def run_cfg1_leg(dev, conv_math, steps):
+    """BASELINE configs[0] on the GPU: UNet3D(1, 2, 32), x = [1, 1, 64, 64, 64] fp32, the train.py:187-221 iteration, eager loop
+    (launch-bound at this size: the HIP-graph replay of the same step is reported beside it from a process of its own)."""
+    import torch
+    from mi355seg.engine import make_adam, train_step, weights_init_normal
+    from mi355seg.models.three_d.unet3d import UNet3D
+    torch.manual_seed(0)
+    model = UNet3D(in_channels=1, out_channels=2, init_features=32)
+    model.apply(weights_init_normal("kaiming"))
+    model = model.to(dev).train()
+    opt = make_adam(model.parameters(), lr=1e-3)
+    g = torch.Generator(device="cpu").manual_seed(4321)
+    x = torch.randn((1, 1, 64, 64, 64), generator=g).to(dev)
+    gt = (torch.rand((1, 1, 64, 64, 64), generator=g) > 0.9).float().to(dev)
+    for _ in range(3):
+        out = train_step(model, opt, x, gt, sync_metric=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = train_step(model, opt, x, gt, sync_metric=False)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"workload": "unet3d_f32_1x64: UNet3D(1,2,32) fwd+BCE+bwd+Adam+Dice, x=[1,1,64,64,64] fp32 (BASELINE configs[0], the reference's "
+                        f"train.py config=unet defaults at batch 1), conv math {conv_math}", "ms_per_step": ms, "voxels_per_s": 64 ** 3 / (ms * 1e-3),
+            "dtype": MATH_DTYPE[conv_math], "steps": steps, "warmup": 3, "loss": float(out["loss"].item())}
+
+
+def graph_leg_child(name, steps, gate):
+    """The HIP-graph replay of one bf16 leg in a process of its own: started before the parent's first GPU call, it blocks on
+    ``gate`` until the parent has finished its eager legs and freed its memory, then builds a FRESH model / optimizer, captures the
+    iteration before any eager step (engine.GraphedTrainStep) and times ``steps`` replays.  A capture failure that aborts the
+    process (hipStreamEndCapture cannot be caught) then costs this number, not the parent's line."""
+    if not gate.readline():
+        return None
+    import torch
+    from mi355seg.engine import GraphedTrainStep, make_adam, weights_init_normal
+    dt = torch.bfloat16
+    if name == "unet3d_f32_1x64":
+        net, shape, classes, dt = "unet3d", (1, 1, 64, 64, 64), 2, torch.float32
+    else:
+        _, net, shape, classes, _, _ = next(l for l in LEGS if l[0] == name)
+    N, C, D, H, W = shape
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(0)
+    if net == "unet3d":
+        from mi355seg.models.three_d.unet3d import UNet3D
+        model = UNet3D(in_channels=1, out_channels=2, init_features=32)
+    else:
+        model = build_leg_model(net, C, classes, D, H, W)
+    model.apply(weights_init_normal("kaiming"))
+    model = model.to(dev).train()
+    opt = make_adam(model.parameters(), lr=1e-3, capturable=True)
+    g = torch.Generator(device="cpu").manual_seed(4321)
+    x = torch.randn((N, C, D, H, W), generator=g).to(dev)
+    gt = (torch.rand((N, 1, D, H, W), generator=g) > 0.9).float().to(dev)
+    gs = GraphedTrainStep(model, opt, x, gt, warmup=3, dtype=dt)
+    for _ in range(2):
+        gs(x, gt, sync_metric=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = gs(x, gt, sync_metric=False)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"ms_per_step": ms, "voxels_per_s": N * D * H * W / (ms * 1e-3), "loss": float(out["loss"].item()), "steps": steps,
+            "note": "one hipGraphLaunch per iteration, same kernels and arithmetic, fresh model captured before any eager step, in a "
+                    "process of its own; `ms_per_step` of the leg is the eager loop"}
 
 
 def usable_cores():
@@ -311,7 +356,28 @@ def cpu_baseline(sample_shape, steps=3, reserve=0, gate=None):
         times.append(time.perf_counter() - t0)
     dt = sum(times) / len(times)
     vox = x.numel()
-    return {"value": vox / dt, "unit": "voxels/s", "cores": cores, "cpu": cpu_model_name(), "kind": "port",
+    # BASELINE configs[0] (the reference's own CPU-runnable case: batch 1, 64^3, train.py config=unet defaults) on the same cores, and
+    # the same steps under torch.autograd.set_detect_anomaly(True), which the reference's loop switches on (train.py:183)
+    x1 = torch.randn((1, 1, 64, 64, 64), generator=g)
+    gt1 = (torch.rand((1, 1, 64, 64, 64), generator=g) > 0.9).float()
+    oracle_step(m, opt, x1, gt1)
+    t1 = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        oracle_step(m, opt, x1, gt1)
+        t1.append(time.perf_counter() - t0)
+    t1a = []
+    with torch.autograd.set_detect_anomaly(True):
+        oracle_step(m, opt, x1, gt1)
+        for _ in range(3):
+            t0 = time.perf_counter()
+            oracle_step(m, opt, x1, gt1)
+            t1a.append(time.perf_counter() - t0)
+    cfg1 = {"value": x1.numel() / (sum(t1) / len(t1)), "unit": "voxels/s", "cores": cores, "kind": "port", "step_seconds": [round(t, 3) for t in t1],
+            "anomaly_mode_on_value": x1.numel() / (sum(t1a) / len(t1a)), "anomaly_mode_on_step_seconds": [round(t, 3) for t in t1a],
+            "sample": "x=[1,1,64,64,64] fp32 (BASELINE configs[0]): 1 warm-up + 5 timed oracle train steps; then 1 + 3 steps under "
+                      "torch.autograd.set_detect_anomaly(True) as the reference's train loop runs them (train.py:183)"}
+    return {"value": vox / dt, "unit": "voxels/s", "cores": cores, "cpu": cpu_model_name(), "kind": "port", "cfg1": cfg1,
             "best_step_value": vox / min(times), "step_seconds": [round(t, 3) for t in times],
             "sample": f"1 warm-up + {steps} timed train steps (mean) of the CPU oracle (reference arithmetic on ATen-CPU, anomaly mode off), all "
                       f"on x={list(sample_shape)} fp32 (cfg 2's full batch), {dt:.2f} s/step (best {min(times):.2f}), {cores} threads; the child "
@@ -331,12 +397,13 @@ def parse_args():
     ap.add_argument("--cpu-sample", default="2,1,128,128,128")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-oracle steps after one full-shape warm-up")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--graph-leg-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-workloads", action="store_true", help="skip the bf16 legs of BASELINE configs 3-5 reported under `workloads`")
     ap.add_argument("--leg-steps", type=int, default=10, help="timed steps per `workloads` leg (3 warm-up steps before them)")
     ap.add_argument("--no-exact-leg", action="store_true", help="skip the untimed exact-fp32 steps reported beside the headline")
     ap.add_argument("--no-prof", action="store_true", help="skip the in-library HIP-event kernel timing")
     ap.add_argument("--prof-all", action="store_true", help="HIP-event timing of every kernel family (adds ~1 %% to the step)")
-    ap.add_argument("--hip-graph", action="store_true", help="experiment: replay the whole train step as one captured HIP graph (N=1, implies --no-prof)")
+    ap.add_argument("--hip-graph", action="store_true", help="experiment: replay the train step as captured HIP graphs (implies --no-prof)")
     ap.add_argument("--dump-launches", default=None, help="write per-launch (family, ms, GFLOP, TFLOP/s) of the LAST timed step to this file")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="plumbing rehearsal without a GPU (tests only): the launch / rendezvous / reducer / barrier / JSON path on a "
@@ -381,6 +448,9 @@ def main():
         shape = tuple(int(v) for v in args.cpu_sample.split(","))
         print(json.dumps(cpu_baseline(shape, steps=args.cpu_steps, gate=sys.stdin)))
         return 0
+    if args.graph_leg_child:
+        print(json.dumps(graph_leg_child(args.graph_leg_child, args.leg_steps, sys.stdin)))
+        return 0
 
     # ---- start the ranks ourselves when nobody else did (no GPU call has happened in this process)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -396,6 +466,14 @@ def main():
         # CPU baseline in its own process, started BEFORE the first GPU call; it waits at a gate until the GPU legs are done
         cpu_child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--cpu-sample", args.cpu_sample, "--cpu-steps", str(args.cpu_steps)],
                                      stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+
+    graph_children = {}
+    if rank_env == 0 and world_env == 1 and not args.no_workloads and not args.rehearse_cpu and not args.hip_graph and args.workload == "unet3d_f32_2x128":
+        # the HIP-graph replays of the two-class legs, each in a gated process of its own (see graph_leg_child)
+        for name in ["unet3d_f32_1x64"] + [l[0] for l in LEGS if l[3] == 2]:
+            if True:
+                graph_children[name] = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--graph-leg-child", name, "--leg-steps", str(args.leg_steps)],
+                                                        stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
 
     import torch
     import torch.distributed as dist
@@ -446,11 +524,10 @@ def main():
         rank_devices = gathered
 
     graphed = None
-    if args.hip_graph:                  # experiment: the whole step as one hipGraphLaunch (single process, no kernel timing)
-        assert world == 1, "--hip-graph is a single-process experiment"
+    if args.hip_graph:                  # experiment: the step as captured HIP graphs (world > 1: two graphs with the eager reducer between them)
         from mi355seg.engine import GraphedTrainStep
         args.no_prof = True
-        graphed = GraphedTrainStep(model, opt, x, gt, warmup=3)
+        graphed = GraphedTrainStep(model, opt, x, gt, warmup=3, grad_hook=reducer)
 
     def rehearsal_step():
         D.broadcast_buffers(model)
@@ -468,10 +545,10 @@ def main():
     def step():
         if args.rehearse_cpu:
             return rehearsal_step()
+        if world > 1:
+            D.broadcast_buffers(model, async_op=graphed is None)       # launched here, waited for at the forward's first norm layer
         if graphed is not None:
             return graphed(x, gt, sync_metric=False)
-        if world > 1:
-            D.broadcast_buffers(model)
         return train_step(model, opt, x, gt, sync_metric=False, grad_hook=reducer)
 
     def sync():
@@ -483,9 +560,11 @@ def main():
     sync()
     if world > 1:
         dist.barrier()
-    if reducer is not None:                 # the `comm` block counts the timed steps only
+    if reducer is not None:                 # the `comm` block counts the timed steps only (the wait timers are off outside a bench)
         reducer.timer.reset()
+        reducer.timer.enable()
     D.BUFFER_BROADCAST_TIMER.reset()
+    D.BUFFER_BROADCAST_TIMER.enable(world > 1)
     if not args.no_prof:
         L.call("mi355seg_prof_reset")
         # default: bracket only the two MFMA conv families (51 launches per step); --prof-all brackets all ~400
@@ -622,6 +701,10 @@ def main():
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
         res["workloads"] = {}
+        try:                                 # BASELINE configs[0] at its own shape on the HIP path (the reference's train.py config=unet defaults, batch 1)
+            res["workloads"]["unet3d_f32_1x64"] = run_cfg1_leg(dev, args.conv_math, args.leg_steps)
+        except Exception as e:
+            res["workloads"]["unet3d_f32_1x64"] = {"error": repr(e)}
         for name, net, shape, classes, loss_kind, fpv in LEGS:
             try:
                 res["workloads"][name] = run_leg(L, dev, name, net, shape, classes, loss_kind, fpv, args.leg_steps)
@@ -629,11 +712,28 @@ def main():
                 res["workloads"][name] = {"error": repr(e)}
                 L.call("mi355seg_prof_enable", 0)
 
+    for name, child in graph_children.items():          # one at a time, after the eager legs, with the parent's cached memory released
+        leg = res.get("workloads", {}).get(name)
+        try:
+            torch.cuda.empty_cache()
+            txt, _ = child.communicate("go\n", timeout=300)
+            hg = json.loads(txt.strip().splitlines()[-1])
+            if leg is not None and hg:
+                hg["speedup_over_eager"] = leg["ms_per_step"] / hg["ms_per_step"] if "ms_per_step" in leg else None
+                leg["hip_graph"] = hg
+        except Exception as e:
+            child.kill()
+            if leg is not None:
+                leg["hip_graph"] = {"error": repr(e), "child_returncode": child.returncode}
     if cpu_child is not None:
         try:
             txt, _ = cpu_child.communicate("go\n", timeout=600)
             res["cpu_baseline"] = json.loads(txt.strip().splitlines()[-1])
             res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+            leg1 = res.get("workloads", {}).get("unet3d_f32_1x64")
+            if leg1 is not None and "error" not in leg1 and res["cpu_baseline"].get("cfg1"):
+                leg1["cpu_baseline"] = res["cpu_baseline"].pop("cfg1")
+                leg1["gpu_over_cpu"] = leg1["voxels_per_s"] / leg1["cpu_baseline"]["value"]
         except Exception as e:          # the GPU numbers stand on their own; say why the CPU leg is missing
             cpu_child.kill()
             res["cpu_baseline"] = None

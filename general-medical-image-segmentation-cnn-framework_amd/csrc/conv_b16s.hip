@@ -310,7 +310,11 @@ bool b16s_plan(int KS, int N, int D, int H, int W, int Cin, int Cout, const void
 size_t b16s_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k) {
     B16sPlan p;
     if (!b16s_geom(k, N, D, H, W, Cin, Cout, &p)) return 0;
-    return align_up((size_t)2 * p.nsteps * 16 * (Cin / 16) * Cout * 2, 256) + align_up((size_t)p.nM * Cout * 3 * sizeof(float), 256) +
+    // what conv_fwd_mfma carves on this path, in its own expressions: the packed weights as wq_bytes(MATH_B16, T Cin Cout) sizes them
+    // (the 28-tap-style padding + 64 elements, larger than the 2 * nsteps taps for k5), the per-tile statistics triples with their
+    // two-stage reduce scratch, the split-K slabs with the column-sum scratch of the statistics that then follow the reduce
+    const size_t T = (size_t)k * k * k, nelem = T * Cin * Cout;
+    return align_up((nelem + nelem / 27 + 64) * 2, 256) + align_up((size_t)p.nM * Cout * 3 * sizeof(float), 256) + align_up(part_reduce_ws_bytes(Cout), 256) +
            (p.ksplit > 1 ? align_up((size_t)p.ksplit * N * D * H * W * Cout * sizeof(float), 256) + colsum_ws_bytes(Cout) : 0) + 1024;
 }
 

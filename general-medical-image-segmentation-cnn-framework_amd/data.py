@@ -33,7 +33,9 @@ class SyntheticPatches:
 
 
 class DevicePatchQueue:
-    """The reference's patch pipeline (dataloader.py:52-67: ``tio.Queue(training_set, queue_length=10,
+    """UNPINNED restatement of tio.Queue / tio.UniformSampler / tio.ZNormalization semantics (torchio is absent from the build image
+    and the reference holds no fixtures for its data pipeline; tests/test_data_queue.py checks the properties stated here).
+    The reference's patch pipeline (dataloader.py:52-67: ``tio.Queue(training_set, queue_length=10,
     samples_per_volume=10, UniformSampler(patch_size))`` over ``ZNormalization()``-transformed subjects), kept on the
     device.  Volumes ``<data_path>/*.npy`` (labels ``<gt_path>/<same name>.npy``; [C,D,H,W] or [D,H,W]) are uploaded
     once, z-normalised per volume over all their voxels (mean / unbiased std, tio's ZNormalization without a mask)

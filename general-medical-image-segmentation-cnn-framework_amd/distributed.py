@@ -82,14 +82,27 @@ class CommTimer:
     """Accumulates how long the step spent WAITING on communication, measured where the step waits: HIP events on the compute
     stream (the collectives run on the communicator's stream; ``work.wait()`` only makes the compute stream wait for them, so
     the time between the two events is the exposed part -- what backward did not hide -- plus the scatter-back copy), or the
-    host clock for the CPU (gloo) rehearsal.  ``total_ms()`` synchronises once, at the end of the timed region."""
+    host clock for the CPU (gloo) rehearsal.  ``total_ms()`` synchronises once, at the end of the timed region.
 
-    def __init__(self):
-        self.pairs, self.host_ms, self.calls = [], 0.0, 0
+    OFF by default: a training run pays nothing for it (no events recorded on the compute stream, nothing kept per step); only
+    the call tally runs.  ``enable()`` -- bench.py, the tests -- turns the measurement on; finished event pairs are folded into a
+    scalar every ``FOLD`` calls, so even an enabled timer holds a bounded number of live events."""
+
+    FOLD = 64
+
+    def __init__(self, enabled=False):
+        self.enabled = enabled
+        self.pairs, self.host_ms, self.calls, self.folded_ms = [], 0.0, 0, 0.0
+
+    def enable(self, on=True):
+        self.enabled = bool(on)
+        return self
 
     def start(self, device):
         import time
         self.calls += 1
+        if not self.enabled:
+            return None
         if device.type == "cuda":
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -98,19 +111,39 @@ class CommTimer:
 
     def stop(self, token):
         import time
+        if token is None:
+            return
         if isinstance(token, tuple):
             token[1].record()
             self.pairs.append(token)
+            if len(self.pairs) >= self.FOLD:
+                self._fold()
         else:
             self.host_ms += (time.perf_counter() - token) * 1e3
 
+    def _fold(self, wait=False):
+        """Move the pairs whose end event has completed (all of them when ``wait``) into the scalar and drop their events."""
+        keep = []
+        for a, b in self.pairs:
+            if wait:
+                b.synchronize()
+            if wait or b.query():
+                self.folded_ms += a.elapsed_time(b)
+            else:
+                keep.append((a, b))
+        if len(keep) >= self.FOLD:               # nothing has completed for FOLD calls: wait for the oldest half rather than grow
+            for a, b in keep[:self.FOLD // 2]:
+                b.synchronize()
+                self.folded_ms += a.elapsed_time(b)
+            keep = keep[self.FOLD // 2:]
+        self.pairs = keep
+
     def reset(self):
-        self.pairs, self.host_ms, self.calls = [], 0.0, 0
+        self.pairs, self.host_ms, self.calls, self.folded_ms = [], 0.0, 0, 0.0
 
     def total_ms(self):
-        if self.pairs:
-            self.pairs[-1][1].synchronize()
-        return self.host_ms + sum(a.elapsed_time(b) for a, b in self.pairs)
+        self._fold(wait=True)
+        return self.host_ms + self.folded_ms
 
 
 BUFFER_BROADCAST_TIMER = CommTimer()
@@ -171,9 +204,16 @@ class GradAllReducer:
     def _active(self):
         return self.always or world_size() > 1
 
+    def suspend_hooks(self, on=True):
+        """Hooks off: nothing is launched from backward, every bucket goes out at the reducer's call (engine.GraphedTrainStep: a
+        captured backward runs no Python, and a collective must not be issued inside a capture)."""
+        self._suspended = bool(on)
+        if on:
+            self._pending = [len(b) for b in self.buckets]
+
     def _make_hook(self, bi):
         def hook(_param):
-            if not self._active():
+            if not self._active() or getattr(self, "_suspended", False):
                 return
             self._pending[bi] -= 1
             if self._pending[bi] == 0:
@@ -288,9 +328,12 @@ def flatten_buffers(model):
     return flat
 
 
-def broadcast_buffers(model, src=0):
+def broadcast_buffers(model, src=0, async_op=False):
     """DDP(broadcast_buffers=True): rank ``src``'s BatchNorm running statistics (and
-    num_batches_tracked) overwrite every rank's before the forward -- one collective on the flattened buffers."""
+    num_batches_tracked) overwrite every rank's before the forward -- one collective on the flattened buffers.
+    ``async_op``: the collective is only LAUNCHED here (on the communicator's stream); the compute stream waits for it where the
+    first norm layer of the forward touches a buffer (functional.bump_counter), so zero_grad, the label kernel, the layout change
+    and the first convolution run beside it instead of behind it."""
     if world_size() == 1:
         return
     bufs = [b for b in model.buffers()]
@@ -299,7 +342,11 @@ def broadcast_buffers(model, src=0):
     token = BUFFER_BROADCAST_TIMER.start(bufs[0].device)
     flat = getattr(model, "_mi355seg_flat_buffers", None)
     if flat is not None and {b.untyped_storage().data_ptr() for b in bufs} == {flat.untyped_storage().data_ptr()}:
-        dist.broadcast(flat, src=src)
+        if async_op:
+            from . import functional as F
+            F.defer_wait(dist.broadcast(flat, src=src, async_op=True))
+        else:
+            dist.broadcast(flat, src=src)
         BUFFER_BROADCAST_TIMER.stop(token)
         return
     model._mi355seg_flat_buffers = None           # the module was moved / re-created since: gather + scatter, one collective per dtype class

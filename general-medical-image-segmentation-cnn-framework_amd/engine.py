@@ -46,7 +46,7 @@ def make_adam(params, lr, **kw):
     return torch.optim.Adam(params, lr=lr, **kw)
 
 
-def train_step(model, optimizer, x, gt, criterion=None, sync_metric=True, grad_hook=None, dtype=None):
+def train_step(model, optimizer, x, gt, criterion=None, sync_metric=True, grad_hook=None, dtype=None, step_optimizer=True):
     """One iteration.  ``gt`` is the single-channel label volume [N,1,D,H,W].  ``dtype`` = torch.bfloat16 runs the
     forward under mi355seg.autocast (bf16 activations; the loss and everything after it stay fp32).
     ``grad_hook`` (if given) runs between backward and optimizer.step -- the data-parallel
@@ -56,11 +56,11 @@ def train_step(model, optimizer, x, gt, criterion=None, sync_metric=True, grad_h
     optimizer.zero_grad(set_to_none=True)
     gt2 = two_channel_gt(gt)
     x = x.to(torch.float32)
-    # every training-mode BatchNorm counter advanced by one multi-tensor launch (the modules tally their calls meanwhile)
+    # every training-mode BatchNorm counter advanced by one multi-tensor launch AFTER the forward (the modules tally their calls
+    # meanwhile): the forward's first access to a module buffer is then its first norm layer, which is where a buffer broadcast
+    # launched ahead of the step (distributed.broadcast_buffers(async_op=True)) is waited for
     bns = [m for m in model.modules()
            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training and m.num_batches_tracked is not None]
-    if bns:
-        torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
     with F.autocast(dtype or F.compute_dtype()), F.counters_batched(bns):
         if getattr(model, "takes_frequency_bands", False):      # the IS network, train.py:198-201: second output discarded
             from .models.three_d.IS import frequency_bands
@@ -68,6 +68,9 @@ def train_step(model, optimizer, x, gt, criterion=None, sync_metric=True, grad_h
             pred, _ = model(x, low_x, high_x)
         else:
             pred = model(x)
+    F.flush_deferred_waits()                                     # (a model without norm layers)
+    if bns:
+        torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
     if criterion is None:
         # nn.BCEWithLogitsLoss + pred.argmax + gt.argmax + the Dice counters in one pass over the logits
         loss, mask, counts = F.bce_argmax_dice(pred, gt2)
@@ -80,7 +83,8 @@ def train_step(model, optimizer, x, gt, criterion=None, sync_metric=True, grad_h
     loss.backward()
     if grad_hook is not None:
         grad_hook(model)
-    optimizer.step()
+    if step_optimizer:                       # (GraphedTrainStep with a gradient hook captures the optimizer step as a graph of its own)
+        optimizer.step()
     out = {"pred": pred, "mask": mask, "loss": loss.detach(), "counts": counts}
     if sync_metric:
         out["jaccard"], out["dice"] = metric_from_counts(counts.cpu().tolist())
@@ -94,8 +98,11 @@ class GraphedTrainStep:
     removes that; at 128^3 the step is GPU-bound either way.
 
     Constraints of stream capture: fixed input shapes (the patch pipeline already guarantees them), an optimizer
-    constructed with ``capturable=True`` (its step counter lives on the device), the in-library kernel profiler
-    off, and a single process (the data-parallel gradient hooks are not captured).  Three eager warm-up steps run
+    constructed with ``capturable=True`` (its step counter lives on the device) and the in-library kernel profiler off.
+    Data parallel (``grad_hook`` = the gradient reducer): the collectives are host calls, so the iteration is captured as TWO
+    graphs -- zero_grad ... backward, and the optimizer step -- with the reducer run eagerly between their replays (its
+    post-accumulate-grad hooks, which only fire while Python runs a backward, are suspended: every bucket goes out at the call;
+    the launch-bound part of the step is still one ``hipGraphLaunch``).  Three eager warm-up steps run
     on a side stream first -- they size the workspace and set the kernels' LDS attributes -- and, like the captured
     step, they DO update the model, so a freshly built instance has already taken ``warmup`` optimiser steps (``first`` holds
     the loss and the Dice counters of the last of them).  Build it BEFORE any eager iteration of the same model, or after every
@@ -104,34 +111,55 @@ class GraphedTrainStep:
     takes the process down in hipStreamEndCapture.
     Returned tensors are static buffers overwritten by the next call."""
 
-    def __init__(self, model, optimizer, x, gt, criterion=None, warmup=3, dtype=None):
+    def __init__(self, model, optimizer, x, gt, criterion=None, warmup=3, dtype=None, grad_hook=None, after_eager_ok=False):
         from ._lib import lib
         if not all(g.get("capturable", False) for g in optimizer.param_groups):
             raise ValueError("GraphedTrainStep: build the optimizer with capturable=True (e.g. torch.optim.Adam(..., capturable=True))")
+        # an eager iteration leaves p.grad behind (train_step clears it at the START of the next one) and, as long as anything still
+        # refers to its outputs, gradient accumulators bound to the default stream -- inside a capture those abort the process in
+        # hipStreamEndCapture, which no try / except can catch.  Refuse here instead.
+        if not after_eager_ok and any(p.grad is not None for p in model.parameters()):
+            raise RuntimeError("GraphedTrainStep: this model has already run an eager backward (p.grad is set).  Build the graphed step "
+                               "BEFORE any eager iteration of the same model (or on a fresh model / optimizer with the same state); if every "
+                               "reference to earlier outputs is gone and the gradients were cleared on purpose, pass after_eager_ok=True")
         lib().call("mi355seg_prof_enable", 0)
-        self.model, self.optimizer, self.criterion = model, optimizer, criterion
+        self.model, self.optimizer, self.criterion, self.grad_hook = model, optimizer, criterion, grad_hook
         self.x = x.detach().to(torch.float32).clone()
         self.gt = gt.detach().clone()
+        if grad_hook is not None and hasattr(grad_hook, "suspend_hooks"):
+            grad_hook.suspend_hooks(True)            # from here on every bucket is launched at the reducer's call
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             self.first = None
             for _ in range(warmup):
-                o = train_step(model, optimizer, self.x, self.gt, criterion, sync_metric=False, dtype=dtype)
+                o = train_step(model, optimizer, self.x, self.gt, criterion, sync_metric=False, dtype=dtype, grad_hook=grad_hook)
                 self.first = {"loss": o["loss"].detach().clone(), "counts": o["counts"].clone()}
                 del o
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
+        self.opt_graph = None
         F.amax_pool_reset()              # the captured step zero-fills the chunk of operand-maximum slots it draws from INSIDE the capture
-        with torch.cuda.graph(self.graph):
-            self.out = train_step(model, optimizer, self.x, self.gt, criterion, sync_metric=False, dtype=dtype)
+        if grad_hook is None:
+            with torch.cuda.graph(self.graph):
+                self.out = train_step(model, optimizer, self.x, self.gt, criterion, sync_metric=False, dtype=dtype)
+        else:
+            with torch.cuda.graph(self.graph):
+                self.out = train_step(model, optimizer, self.x, self.gt, criterion, sync_metric=False, dtype=dtype, step_optimizer=False)
+            grad_hook(model)                         # the captured backward has not run: these are the last warm-up gradients, reduced once more
+            self.opt_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.opt_graph, pool=self.graph.pool()):
+                optimizer.step()
         F.amax_pool_reset()
 
     def __call__(self, x, gt, sync_metric=True):
         self.x.copy_(x, non_blocking=True)
         self.gt.copy_(gt, non_blocking=True)
         self.graph.replay()
+        if self.opt_graph is not None:
+            self.grad_hook(self.model)               # mean all-reduce of the static gradient tensors, in place
+            self.opt_graph.replay()
         out = dict(self.out)
         if sync_metric:
             out["jaccard"], out["dice"] = metric_from_counts(out["counts"].cpu().tolist())

@@ -83,8 +83,24 @@ class counters_batched:
             m.num_batches_tracked.add_(k)
 
 
+_DEFERRED_WAITS = []
+
+
+def defer_wait(work):
+    """A collective launched ahead of the forward (distributed.broadcast_buffers(async_op=True)): waited for by the first norm layer."""
+    _DEFERRED_WAITS.append(work)
+
+
+def flush_deferred_waits():
+    while _DEFERRED_WAITS:
+        _DEFERRED_WAITS.pop().wait()
+
+
 def bump_counter(bn):
-    """nn.BatchNorm3d's per-forward ``num_batches_tracked += 1`` (training mode)."""
+    """nn.BatchNorm3d's per-forward ``num_batches_tracked += 1`` (training mode).  Also the point where a forward first touches a
+    module buffer: a buffer broadcast launched ahead of the step is waited for here."""
+    if _DEFERRED_WAITS:
+        flush_deferred_waits()
     if bn.num_batches_tracked is None:
         return
     if _COUNTERS.active:
@@ -1252,8 +1268,12 @@ class _DiceRows(Function):
 
 
 def dice_rows_autograd(x, t, apply_sigmoid=False, p=2.0):
-    """Per-row Dice sums of a [R, L] pair as float64 [R, 5] (one reduction launch + one finalise for all rows)."""
-    return _DiceRows.apply(x, t, apply_sigmoid, p)
+    """Per-row Dice sums of a [R, L] pair as float64 [R, 5] (one reduction launch + one finalise for all rows; more rows than
+    a launch grid holds -- 65535 -- go in slices)."""
+    R = x.shape[0]
+    if R <= 65535:
+        return _DiceRows.apply(x, t, apply_sigmoid, p)
+    return torch.cat([_DiceRows.apply(x[i:i + 65535], t[i:i + 65535], apply_sigmoid, p) for i in range(0, R, 65535)], dim=0)
 
 
 class _SoftmaxCh(Function):

@@ -24,7 +24,10 @@ from .utils.metric import metric_from_counts
 
 
 def grid_locations(size, patch, overlap):
-    """All patch origins [(z, y, x)] covering a volume of ``size`` (torchio GridSampler._get_patches_locations)."""
+    """All patch origins [(z, y, x)] covering a volume of ``size`` (torchio GridSampler._get_patches_locations).
+    UNPINNED restatement (this function and the crop aggregation below): torchio's GridSampler / GridAggregator are third-party code
+    that is absent here and for which the reference holds no fixtures; restated from torchio 0.20.3 and property-tested
+    (tests/test_predict_grid.py).  What IS pinned on this row is the arithmetic of the patches (test_gpu_unet.py::test_inference_path_*)."""
     axes = []
     for s, p, o in zip(size, patch, overlap):
         if p > s:
@@ -109,8 +112,13 @@ def sliding_window_predict(model, volume, patch_size, overlap=(4, 4, 36), batch_
 
 
 def znorm(v):
-    """tio.ZNormalization (predict.py:94): zero mean / unit std over the whole volume."""
-    return (v - v.mean()) / (v.std() + 1e-8)
+    """tio.ZNormalization (predict.py:94): zero mean / unit (unbiased) std over the whole volume, no epsilon -- torchio refuses a
+    constant volume (``Standard deviation is 0``), so does this.  UNPINNED restatement: torchio is absent from the build image and
+    the reference holds no fixture for it; the formula is torchio 0.20's ``ZNormalization.znorm``."""
+    std = v.std()
+    if float(std) == 0.0:
+        raise RuntimeError("znorm: standard deviation is 0 for this volume (tio.ZNormalization raises here too)")
+    return (v - v.mean()) / std
 
 
 def predict(config, model, log=print):

@@ -48,11 +48,13 @@ def train(config, model, logger):
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     model = model.to(device)
-    # config.hip_graph=true (single process): the whole iteration is captured once and replayed -- for launch-bound shapes (64^3
-    # patches, UNETR's token path); the learning rate then lives in a device tensor so that StepLR still reaches the captured step
-    hg = config.get("hip_graph") if hasattr(config, "get") else getattr(config, "hip_graph", False)
-    hip_graph = str(hg).lower() in ("1", "true", "yes") and world == 1
-    optimizer = make_adam(model.parameters(), lr=torch.tensor(float(config.init_lr), device=device), capturable=True) if hip_graph \
+    # config.hip_graph=true: the iteration is captured once and replayed -- for launch-bound shapes (64^3 patches, UNETR's token
+    # path); the learning rate then lives in a device tensor so that StepLR still reaches the captured step.  Data parallel: two
+    # graphs (through backward, optimizer step) with the gradient reducer between their replays.
+    # config.capturable_adam=true: the same device-resident optimizer state without the graph (eager runs that must match a graphed one)
+    flag = lambda name: str(config.get(name) if hasattr(config, "get") else getattr(config, name, False)).lower() in ("1", "true", "yes")
+    hip_graph = flag("hip_graph")
+    optimizer = make_adam(model.parameters(), lr=torch.tensor(float(config.init_lr), device=device), capturable=True) if (hip_graph or flag("capturable_adam")) \
         else make_adam(model.parameters(), lr=config.init_lr)                   # train.py:109 (torch's fused single-kernel Adam on the GPU)
     scheduler = StepLR(optimizer, step_size=config.scheduler_step_size, gamma=config.scheduler_gamma) \
         if config.use_scheduler else None                                       # train.py:119-120
@@ -85,11 +87,11 @@ def train(config, model, logger):
             t0 = time.time()
             x, gt = batch["source"]["data"], batch["gt"]["data"]
             if world > 1:
-                D.broadcast_buffers(model)
+                D.broadcast_buffers(model, async_op=True)               # launched here, waited for at the forward's first norm layer
             if hip_graph and graphed is None:
                 # the first iteration runs inside the constructor (eager, on the capture stream: workspaces sized, kernel attributes
                 # set, the parameters' gradient accumulators created there), then the iteration is captured for the following ones
-                graphed = GraphedTrainStep(model, optimizer, x, gt, warmup=1, dtype=act_dtype)
+                graphed = GraphedTrainStep(model, optimizer, x, gt, warmup=1, dtype=act_dtype, grad_hook=reducer)
                 out = dict(graphed.first)
                 out["jaccard"], out["dice"] = metric_from_counts(out["counts"].cpu().tolist())
             elif hip_graph:

@@ -95,7 +95,7 @@ class DiceLossss(nn.Module):
         smooth = 1e-5
         n = inputs.shape[0]
         # rows = (sample, class): one reduction launch for all of them, then the per-class sums over the batch
-        s = F.dice_rows_autograd(inputs.contiguous().view(n * self.n_classes, -1), target.view(n * self.n_classes, -1), False, 2.0)
+        s = F.dice_rows_autograd(inputs.contiguous().view(n * self.n_classes, -1), target.contiguous().view(n * self.n_classes, -1), False, 2.0)
         s = s.view(n, self.n_classes, 5).sum(dim=0)
         dice = 1 - (2 * s[:, 0] + smooth) / (s[:, 3] + s[:, 4] + smooth)
         w = torch.as_tensor(weight, dtype=torch.float64, device=dice.device)

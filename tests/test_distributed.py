@@ -46,6 +46,7 @@ def _worker(rank, world, port, out):
     assert flat is not None and flat.dtype == torch.uint8 and D.flatten_buffers(model) is flat
     assert all(b.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() and b.data_ptr() % 16 == 0 for b in model.buffers())
     D.BUFFER_BROADCAST_TIMER.reset()
+    D.BUFFER_BROADCAST_TIMER.enable()                          # (the wait timers are opt-in: a training run records nothing)
     D.broadcast_buffers(model)                                 # one collective, no copies
     assert D.BUFFER_BROADCAST_TIMER.calls == 1 and D.BUFFER_BROADCAST_TIMER.total_ms() > 0.0
     for (k, a), b in zip(model.named_buffers(), ref.buffers()):
@@ -56,6 +57,8 @@ def _worker(rank, world, port, out):
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.randn(2, 1, 4, 4, 4, generator=g)
     hooked = D.GradAllReducer(model, bucket_mb=0.0001)         # tiny buckets -> several collectives, launched from hooks
+    assert not hooked.timer.enabled
+    hooked.timer.enable()
     results = []
     for step in range(2):                                      # twice: the per-bucket countdown must re-arm
         for p in model.parameters():
@@ -202,3 +205,34 @@ def test_replicas_start_from_rank0_parameters_and_stay_identical():
         assert torch.equal(x, y)                                        # and still one model after a step on different shards
     assert any(not torch.equal(x, y) for x, y in zip(s0, a0))          # the step did move the parameters
     # (running statistics are rank-local between two forwards, as under DDP: rank 0's are re-broadcast at the next one)
+
+
+def test_comm_timer_is_opt_in_and_bounded():
+    """A long world > 1 training run must not accumulate timing events: the wait timers record nothing unless enabled (bench.py
+    enables them for its timed steps), and an enabled timer folds finished measurements into a scalar."""
+    from mi355seg.distributed import CommTimer
+    t = CommTimer()
+    dev = torch.device("cpu")
+    for _ in range(1000):
+        t.stop(t.start(dev))
+    assert t.calls == 1000 and not t.pairs and t.host_ms == 0.0 and t.total_ms() == 0.0
+
+    class FakeEvent:                       # stands in for a HIP event (no GPU in this suite): completes after `lag` queries
+        def __init__(self, lag):
+            self.lag = lag
+        def record(self):
+            pass
+        def query(self):
+            self.lag -= 1
+            return self.lag < 0
+        def synchronize(self):
+            self.lag = -1
+        def elapsed_time(self, other):
+            return 0.5
+    t = CommTimer(enabled=True)
+    for i in range(10 * CommTimer.FOLD):
+        t.pairs.append((FakeEvent(0), FakeEvent(3 if i % 7 == 0 else 0)))      # what stop() does for a device token
+        if len(t.pairs) >= t.FOLD:
+            t._fold()
+        assert len(t.pairs) < 2 * CommTimer.FOLD
+    assert abs(t.total_ms() - 0.5 * 10 * CommTimer.FOLD) < 1e-9 and not t.pairs

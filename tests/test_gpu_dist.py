@@ -118,3 +118,62 @@ def test_two_rank_hip_path_gradients_equal_the_mean_of_per_shard_oracle_gradient
         assert torch.equal(out[0][0][k], out[1][0][k]), k                  # both replicas hold the same reduced gradient
     assert torch.equal(out[0][2], out[0][4] + out[1][4]) and torch.equal(out[0][2], out[1][2])      # global integer Dice counters
     assert abs(out[0][3] - (shard[0][1] + shard[1][1]) / 2) < 1e-5
+
+
+def _graph_ddp_worker(rank, world, port, out):
+    """Data-parallel steps of the HIP U-Net on two ranks sharing cuda:0, once eager (reducer from hooks) and once as captured graphs
+    with the reducer between the two replays (engine.GraphedTrainStep(grad_hook=...))."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import mi355seg
+    from mi355seg import distributed as D
+    from mi355seg.engine import GraphedTrainStep, train_step
+    from mi355seg.models.three_d.unet3d import UNet3D
+    from oracle.fill import fill_module_, make_input, make_labels
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = make_input((1, 1, 16, 16, 16), freq=0.05, phase=float(rank)).cuda()
+    gt = make_labels((1, 1, 16, 16, 16), thresh=0.8 - 0.3 * rank).cuda()
+    res = {}
+    for mode in ("eager", "graph"):
+        model = fill_module_(UNet3D(1, 2, 4)).cuda().train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+        reducer = D.setup_replica(model, bucket_mb=0.05)
+        losses = []
+        if mode == "eager":
+            for i in (0, 0, 2, 3):                                                         # the graphed object's two warm-up steps run on x
+                D.broadcast_buffers(model, async_op=True)
+                losses.append(float(train_step(model, opt, x + 0.1 * i, gt, sync_metric=False, grad_hook=reducer)["loss"]))
+        else:
+            g = GraphedTrainStep(model, opt, x, gt, warmup=2, grad_hook=reducer)          # two eager steps (x), then replays
+            losses = [None, float(g.first["loss"])]
+            for i in (2, 3):
+                D.broadcast_buffers(model)
+                losses.append(float(g(x + 0.1 * i, gt, sync_metric=False)["loss"]))
+        res[mode] = (losses, {k: v.detach().cpu() for k, v in model.state_dict().items()})
+        reducer.detach()
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_graphed_step_matches_the_eager_data_parallel_step():
+    """the HIP-graph step under data parallelism -- backward and optimizer step as two captured graphs, the bucketed
+    gradient all-reduce between their replays, buffers broadcast ahead of the step -- lands on the eager data-parallel run's
+    parameters (both ranks, which must also agree with each other)."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_graph_ddp_worker, args=(2, port, out), nprocs=2, join=True)
+    for rank in (0, 1):
+        le, lg = out[rank]["eager"][0], out[rank]["graph"][0]
+        assert le[1:] == lg[1:], (rank, le, lg)                                         # same losses step by step (the first warm-up loss is not kept)
+        for k, v in out[rank]["eager"][1].items():
+            assert torch.equal(v, out[rank]["graph"][1][k]), (rank, k)                  # and the same parameters / buffers after four steps
+    for mode in ("graph", "eager"):                                                     # the replicas' PARAMETERS stay identical (their BatchNorm
+        for k, v in out[0][mode][1].items():                                            # running statistics are rank-local until the next broadcast)
+            if "running_" not in k:
+                assert torch.equal(v, out[1][mode][1][k]), (mode, k)
