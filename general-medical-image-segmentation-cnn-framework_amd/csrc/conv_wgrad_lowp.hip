@@ -262,7 +262,7 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
                     acc[tt][a2][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[cur][a2][0], bc[b][0], acc[tt][a2][b], 0, 0, 0);
             }
         };
-        if constexpr (NP >= 2 || S == 2) {
+        if constexpr (NP == 3 || S == 2) {
             // (the strided tiles are register-bound too.)  bf16x6: 24 MFMAs per tap-tile hide the reads of the next one by themselves (two waves per SIMD); pinning the order by
             // hand costs registers the three-plane fragments do not leave (measured: 42 spilled VGPRs, 0.68x) -- compiler order
 #pragma unroll
@@ -288,10 +288,16 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
                 if (tt == NTT - 1 && ks + 1 < T::KSTEPS) load_b(ks + 1, 0);
                 mfma_half(cur, tt, 1);
                 // spread the region's reads over its MFMAs (groups that find no read left are no-ops)
+                if constexpr (NP == 1) {
 #pragma unroll
-                for (int k = 0; k < 2; ++k) { __builtin_amdgcn_sched_group_barrier(0x100, 3, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+                    for (int k = 0; k < 2; ++k) { __builtin_amdgcn_sched_group_barrier(0x100, 3, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
 #pragma unroll
-                for (int k = 0; k < 2; ++k) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+                    for (int k = 0; k < 2; ++k) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+                } else {
+                    // f16x3: 12 MFMAs per region, 8 transposing reads for the next region's x fragments (+ up to 8 for the next k-step's dy)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
