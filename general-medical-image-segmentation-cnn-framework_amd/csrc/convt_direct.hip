@@ -36,6 +36,7 @@ struct CtArgs {
     long long nvox;         // N * D * H * W coarse voxels
     int nchunk;             // K / 64
     int ntn;                // N-tiles
+    unsigned* amax_out;     // SCATTER, optional: max |y| of what this launch writes, max-combined (the f16x3 scale of the convolution that reads the concat buffer)
 };
 
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h2, unsigned& m2, unsigned& l2) {
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(256, 2) void convt_gemm_kernel(CtArgs a) {
 
     // ---- epilogue: lane holds rows n = 4g .. 4g+3 of column (voxel) r of every 16 x 16 tile
     TT* const yg = static_cast<TT*>(a.y);
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const long long v = vox0 + wm * WM + i * 16 + r;
@@ -195,6 +197,7 @@ __global__ __launch_bounds__(256, 2) void convt_gemm_kernel(CtArgs a) {
                 if (a.bias) o += *reinterpret_cast<const f32x4*>(a.bias + co);
                 p = yg + (fb + ((long long)(t >> 2) * fH + ((t >> 1) & 1)) * fW + (t & 1)) * a.ldy + co;
             }
+            if constexpr (F32 && !GATHER) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
             if constexpr (F32) {
                 *reinterpret_cast<f32x4*>(p) = o;
             } else {
@@ -203,6 +206,9 @@ __global__ __launch_bounds__(256, 2) void convt_gemm_kernel(CtArgs a) {
                 *reinterpret_cast<bf16x4_t*>(p) = q;
             }
         }
+    }
+    if constexpr (F32 && !GATHER) {
+        if (a.amax_out) block_amax_commit(amax, a.amax_out);       // (uniform: every thread of the workgroup gets here)
     }
 }
 
@@ -278,6 +284,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void convt_stream_kernel(CtArgs a) {
         }
     };
     const unsigned char* const wrd = lds_raw + (g * BN + r) * 16;
+    float amax = 0.f;
     auto compute_store = [&](unsigned t, stage_t (&xs)[TM][KS][SW]) {
         f32x4 acc[TM][TN];
 #pragma unroll
@@ -329,6 +336,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void convt_stream_kernel(CtArgs a) {
             for (int j = 0; j < TN; ++j) {
                 f32x4 o = acc[i][j];
                 if (!GATHER) o += *reinterpret_cast<const f32x4*>(bl + (j * 16 + 4 * g) * 4);      // LDS: its own counter, no vmcnt drain
+                if constexpr (F32 && !GATHER) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
                 if constexpr (F32) {
                     *reinterpret_cast<f32x4*>(base + noff[j]) = o;
                 } else {
@@ -363,6 +371,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void convt_stream_kernel(CtArgs a) {
         copy_x();
         load_x(tile_of(it + 1), xb);
         compute_store(tile_of(it), xa);
+    }
+    if constexpr (F32 && !GATHER) {
+        if (a.amax_out) block_amax_commit(amax, a.amax_out);
     }
 }
 
@@ -468,7 +479,7 @@ static void launch_any(const CtPlan& p, const CtArgs& a, hipStream_t st) {
 
 template <typename TT>
 int convt_direct(bool gather, const TT* x, int ldx, const float* w, const float* bias, TT* y, int ldy, int N, int D, int H, int W, int Cin, int Cout,
-                 void* ws, size_t ws_bytes, hipStream_t st) {
+                 void* ws, size_t ws_bytes, hipStream_t st, float* y_amax) {
     constexpr int NP = sizeof(TT) == 4 ? 3 : 1;
     CtPlan p;
     SEG_CHECK_ARG(ct_plan((int)sizeof(TT), gather, (long long)N * D * H * W, Cin, Cout, &p), "convt_direct: unsupported shape");
@@ -478,7 +489,7 @@ int convt_direct(bool gather, const TT* x, int ldx, const float* w, const float*
     const long long slots = (long long)p.K * p.Nc / 8;
     hipLaunchKernelGGL(convt_pack_planes_kernel<NP>, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, w, wq, Cin, Cout, gather ? 1 : 0, p.BN, p.K, p.Nc);
     SEG_CHECK_LAUNCH();
-    CtArgs a{x, wq, gather ? nullptr : bias, y, ldx, ldy, D, H, W, Cout, (long long)N * D * H * W, p.K / 64, p.Nc / p.BN};
+    CtArgs a{x, wq, gather ? nullptr : bias, y, ldx, ldy, D, H, W, Cout, (long long)N * D * H * W, p.K / 64, p.Nc / p.BN, gather ? nullptr : reinterpret_cast<unsigned*>(y_amax)};
     const double vox = (double)a.nvox;
     ProfScope ps(PF_CONVT, 2.0 * vox * 8 * Cin * Cout, sizeof(TT) * vox * (Cin + 8.0 * Cout) + 4.0 * 8 * Cin * Cout, st);
     if (gather) launch_any<TT, true>(p, a, st); else launch_any<TT, false>(p, a, st);
@@ -486,7 +497,7 @@ int convt_direct(bool gather, const TT* x, int ldx, const float* w, const float*
     return MI355SEG_OK;
 }
 
-template int convt_direct<float>(bool, const float*, int, const float*, const float*, float*, int, int, int, int, int, int, int, void*, size_t, hipStream_t);
-template int convt_direct<bf16>(bool, const bf16*, int, const float*, const float*, bf16*, int, int, int, int, int, int, int, void*, size_t, hipStream_t);
+template int convt_direct<float>(bool, const float*, int, const float*, const float*, float*, int, int, int, int, int, int, int, void*, size_t, hipStream_t, float*);
+template int convt_direct<bf16>(bool, const bf16*, int, const float*, const float*, bf16*, int, int, int, int, int, int, int, void*, size_t, hipStream_t, float*);
 
 }  // namespace seg

@@ -137,7 +137,7 @@ template <typename T> int conv_gwgrad(const T* dy, int lddy, const T* x, int ldx
 bool convt_direct_supported(int elem_bytes, bool gather, int N, int D, int H, int W, int Cin, int Cout, int ld_coarse, int ld_fine);
 size_t convt_direct_ws_bytes(int Cin, int Cout);
 template <typename TT> int convt_direct(bool gather, const TT* x, int ldx, const float* w, const float* bias, TT* y, int ldy, int N, int D, int H, int W,
-                                        int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t st);
+                                        int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t st, float* y_amax = nullptr);
 // convt_wgrad_lowp.hip: ConvTranspose3d k2 s2 weight gradient on the bf16 matrix cores (fp32 tensors: bf16x6 planes)
 void convt_wgrad_reduce(const float* part, float* dw, int splits, int Cin, int Cout, hipStream_t st);   // convt.hip: dw[ci][co][tap] = sum of the slabs
 size_t convt_wgrad_lowp_ws_bytes(long long nvox, int Cin, int Cout);

@@ -699,13 +699,21 @@ __global__ __launch_bounds__(256) void part_reduce_kernel(const float* __restric
     }
 }
 
-// stage 2; kind 0: BatchNorm backward (s1, s2, dgamma = s2, dbeta = s1 as floats), kind 1: statistics (sum, sq as doubles)
-__global__ __launch_bounds__(64) void part_finalize_kernel(const double* __restrict__ tmp, int R, int C, int kind, float* __restrict__ s1, float* __restrict__ s2,
+// stage 2; kind 0: BatchNorm backward (s1, s2, dgamma = s2, dbeta = s1 as floats), kind 1: statistics (sum, sq as doubles).
+// A workgroup owns 32 channels; its eight row lanes each walk every eighth slice (independent loads in flight instead of one
+// thread's serial walk over all slices: 18 us -> 3 us per layer at 64 slices), LDS combine in a fixed order.
+__global__ __launch_bounds__(256) void part_finalize_kernel(const double* __restrict__ tmp, int R, int C, int kind, float* __restrict__ s1, float* __restrict__ s2,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, double* __restrict__ sum, double* __restrict__ sq) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double sh[8][32][2];
+    const int cl = threadIdx.x & 31, q = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
     double a = 0.0, b = 0.0;
-    for (int r = 0; r < R; ++r) { a += tmp[((long long)r * C + c) * 2]; b += tmp[((long long)r * C + c) * 2 + 1]; }
+    if (c < C)
+        for (int r = q; r < R; r += 8) { a += tmp[((long long)r * C + c) * 2]; b += tmp[((long long)r * C + c) * 2 + 1]; }
+    sh[q][cl][0] = a; sh[q][cl][1] = b;
+    __syncthreads();
+    if (q != 0 || c >= C) return;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) { a += sh[j][cl][0]; b += sh[j][cl][1]; }
     if (kind == 0) {
         s1[c] = (float)a; s2[c] = (float)b;
         if (dgamma) { dgamma[c] = (float)b; dbeta[c] = (float)a; }
@@ -714,13 +722,14 @@ __global__ __launch_bounds__(64) void part_finalize_kernel(const double* __restr
     }
 }
 
+constexpr int kPartSlices = 256;
 static int part_slices(int nblk, int C) {
-    int R = 512 / ((C + 31) / 32);                      // about two workgroups per CU in stage 1
-    if (R > 64) R = 64;
+    int R = 2048 / ((C + 31) / 32);                     // about eight workgroups per CU in stage 1 (64 slices: 11 us per layer at 16384 tiles x 32 channels)
+    if (R > kPartSlices) R = kPartSlices;
     if (R > nblk / 16) R = nblk / 16;
     return R < 1 ? 1 : R;
 }
-size_t part_reduce_ws_bytes(int C) { return align_up((size_t)64 * C * 2 * sizeof(double), 256); }
+size_t part_reduce_ws_bytes(int C) { return align_up((size_t)kPartSlices * C * 2 * sizeof(double), 256); }
 
 // s1 / s2 (+ dgamma / dbeta) from per-tile {sum dz, sum dz * xhat} pairs produced by a convolution's epilogue (conv_x3s.hip);
 // tmp: part_reduce_ws_bytes(C) of scratch (null: the one-stage kernel)
@@ -728,7 +737,7 @@ void norm_bwd_finalize(const float* part, int nblk, int C, float* s1, float* s2,
     if (tmp && nblk > 512) {
         const int R = part_slices(nblk, C);
         hipLaunchKernelGGL((part_reduce_kernel<2, 0>), dim3((C + 31) / 32, R), dim3(256), 0, st, part, nblk, C, R, tmp);
-        hipLaunchKernelGGL(part_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, tmp, R, C, 0, s1, s2, dgamma, dbeta, (double*)nullptr, (double*)nullptr);
+        hipLaunchKernelGGL(part_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, tmp, R, C, 0, s1, s2, dgamma, dbeta, (double*)nullptr, (double*)nullptr);
         return;
     }
     hipLaunchKernelGGL(bwd_finalize_kernel, dim3(C), dim3(64), 0, st, part, nblk, C, 1, s1, s2, dgamma, dbeta);
@@ -740,7 +749,7 @@ bool tile_stats_finalize2(const float* spart, int nM, int C, double* sum, double
     if (!tmp || nM <= 512) return false;
     const int R = part_slices(nM, C);
     hipLaunchKernelGGL((part_reduce_kernel<3, 1>), dim3((C + 31) / 32, R), dim3(256), 0, st, spart, nM, C, R, tmp);
-    hipLaunchKernelGGL(part_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, tmp, R, C, 1, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, sum, sq);
+    hipLaunchKernelGGL(part_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, tmp, R, C, 1, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, sum, sq);
     return true;
 }
 

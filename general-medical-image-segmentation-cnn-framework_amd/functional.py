@@ -462,13 +462,16 @@ class _ConvT3dK2S2Cat(Function):
         L = lib()
         ws = workspace(L.query("mi355seg_convt3d_k2s2_ws_bytes", N, D, H, W, Cin, Cout), x.device)
         sa = _get_amax(skip) if _takes_amax(x) else None
-        L.call("mi355seg_convt3d_k2s2_fwd_" + _sfx(x), _p(x), ldx, _p(w), _p(b), _p(base), Cout + Cs, N, D, H, W, Cin, Cout,
-               _p(ws), ws.numel(), _stream())
         if sa is not None:
-            # max |cat| = max(max |up-convolution| (one pass over the left slice), max |skip| (its own scalar, max-combined))
-            ca = _measure_amax(base, Cout + Cs, N * 8 * D * H * W, Cout)
+            # max |cat| = max(max |up-convolution| (from that kernel's epilogue), max |skip| (its own scalar, max-combined))
+            ca = _amax_slot(x.device)
+            L.call("mi355seg_convt3d_k2s2_fwd_ax_f32", _p(x), ldx, _p(w), _p(b), _p(base), Cout + Cs, N, D, H, W, Cin, Cout, _p(ca),
+                   _p(ws), ws.numel(), _stream())
             _measure_amax(sa, 1, 1, 1, ca)
             _set_amax(base, ca)
+        else:
+            L.call("mi355seg_convt3d_k2s2_fwd_" + _sfx(x), _p(x), ldx, _p(w), _p(b), _p(base), Cout + Cs, N, D, H, W, Cin, Cout,
+                   _p(ws), ws.numel(), _stream())
         ctx.save_for_backward(x, w)
         ctx.geom = (N, D, H, W, Cin, Cout, Cs, ldx, b is not None)
         return base

@@ -179,6 +179,11 @@ size_t mi355seg_convt3d_k2s2_ws_bytes(int N, int D, int H, int W, int Cin, int C
 int mi355seg_convt3d_k2s2_fwd_f32(const float* x, int ldx, const float* w, const float* bias,
                                   float* y, int ldy, int N, int D, int H, int W, int Cin, int Cout,
                                   void* ws, size_t ws_bytes, void* stream);
+/* the same with max |y| as a by-product (F16X3 operand maxima: the up-convolution half of a decoder's concat buffer) */
+int mi355seg_convt3d_k2s2_fwd_ax_f32(const float* x, int ldx, const float* w, const float* bias,
+                                  float* y, int ldy, int N, int D, int H, int W, int Cin, int Cout,
+                                  float* y_amax,
+                                     void* ws, size_t ws_bytes, void* stream);
 int mi355seg_convt3d_k2s2_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
                                     int N, int D, int H, int W, int Cin, int Cout,
                                     void* ws, size_t ws_bytes, void* stream);
@@ -492,6 +497,7 @@ int mi355seg_maxpool2_bwd_bf16(const mi355seg_bf16* dy, int lddy, const uint8_t*
 int mi355seg_maxpool2_bwd_add_bf16(const mi355seg_bf16* dy, int lddy, const uint8_t* idx, const mi355seg_bf16* add, int ldadd, mi355seg_bf16* dx, int lddx, int N, int D, int H, int W, int C, void* stream);
 int mi355seg_upsample2_fwd_bf16(const mi355seg_bf16* x, int ldx, mi355seg_bf16* y, int ldy, int N, int D, int H, int W, int C, void* stream);
 int mi355seg_upsample2_bwd_bf16(const mi355seg_bf16* dy, int lddy, mi355seg_bf16* dx, int lddx, int N, int D, int H, int W, int C, void* stream);
+int mi355seg_convt3d_k2s2_fwd_ax_bf16(const mi355seg_bf16* x, int ldx, const float* w, const float* bias, mi355seg_bf16* y, int ldy, int N, int D, int H, int W, int Cin, int Cout, float* y_amax, void* ws, size_t ws_bytes, void* stream);
 int mi355seg_convt3d_k2s2_fwd_bf16(const mi355seg_bf16* x, int ldx, const float* w, const float* bias, mi355seg_bf16* y, int ldy, int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 int mi355seg_convt3d_k2s2_dgrad_bf16(const mi355seg_bf16* dy, int lddy, const float* w, mi355seg_bf16* dx, int lddx, int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 int mi355seg_convt3d_k2s2_wgrad_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, float* dw, float* db, int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
