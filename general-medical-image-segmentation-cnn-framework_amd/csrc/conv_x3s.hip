@@ -34,6 +34,9 @@ namespace seg {
 
 namespace {
 
+#ifndef X3S_WN2
+#define X3S_WN2 1
+#endif
 #ifndef X3S_WD
 #define X3S_WD 3
 #endif
@@ -42,10 +45,10 @@ namespace {
 #endif
 constexpr int XBX = 16, XTY = 4, XHX = XBX + 2, XHY = XTY + 2;
 
-template <int LW, bool F16 = false>
+template <int LW, bool F16 = false, int WN = 1>
 struct Geo {
     static constexpr int NPL = F16 ? 2 : 3;                     // planes of the split
-    static constexpr int LINES = 4 * LW, TZ = LINES / XTY, HZ = TZ + 2;
+    static constexpr int LINES = (4 / WN) * LW, TZ = LINES / XTY, HZ = TZ + 2;
     static constexpr int NVOX = XHX * XHY * HZ;
     static constexpr int PS = (NVOX + 15) / 16 * 16;            // 16-byte slots per piece; a multiple of 16 slots (256 B)
     static constexpr int LDS_BYTES = 2 * NPL * PS * 16;
@@ -68,10 +71,15 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 // ---- epilogue shared by the kernels of this file: a wave holds LW x-lines (line0 .. line0 + LW - 1 of a TZ x 4 x 16 tile) x all
 // NT = 32 NBW channels of the tile; scale_exp != 0: the accumulators are first multiplied by 2^scale_exp (f16x3)
-template <int LW, int NBW, int TZ>
+// WN = 2: the four waves form a 2 (lines) x 2 (channels) grid -- wave (wm, wn) = (wave / 2, wave % 2) holds its LW lines x the 32 NBW
+// channels n0 + 32 NBW wn .. of a tile of 64 NBW channels; the per-tile statistics then sum the two waves that share a channel block.
+template <int LW, int NBW, int TZ, int WN = 1>
 __device__ __forceinline__ void x3_epilogue(const IgemmArgs& a, f32x4 (&acc)[LW][2 * NBW], int scale_exp, int ks, int mtile, int n, int x0, int y0, int z0,
-                                            int n0, int line0, int r, int g, int wave, int tid, unsigned char* lds_raw) {
-    constexpr int NT = 32 * NBW, NTW = 2 * NBW;
+                                            int n0_tile, int line0, int r, int g, int wave, int tid, unsigned char* lds_raw) {
+    constexpr int NT = 32 * NBW, NTW = 2 * NBW;              // channels / 16-channel MFMA tiles of ONE wave
+    constexpr int NTT = NT * WN, WM = 4 / WN;                // channels of the tile, waves along the lines
+    const int wn = WN == 1 ? 0 : wave % WN;
+    const int n0 = n0_tile + wn * NT;
     // ---- epilogue: bias, 16-byte stores, optional BatchNorm partial statistics
     // acc[j][t][e] = y[voxel (line j, x = r)][channel n0 + 16 t + 4 g + e]
     if (scale_exp != 0) {
@@ -145,11 +153,12 @@ __device__ __forceinline__ void x3_epilogue(const IgemmArgs& a, f32x4 (&acc)[LW]
                 if (r == 0) { lds[wave * NT + 16 * t + 4 * g + e] = v1; lds[(4 + wave) * NT + 16 * t + 4 * g + e] = v2; }
             }
         __syncthreads();
-        if (tid < NT) {
+        if (tid < NTT) {
+            const int cw = tid / NT, cl = tid % NT;          // which channel block of the tile, channel inside it
             float v1 = 0.f, v2 = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) { v1 += lds[w * NT + tid]; v2 += lds[(4 + w) * NT + tid]; }
-            float* dst = a.bnpart + ((long long)mtile * a.Cout + n0 + tid) * 2;
+            for (int w = 0; w < WM; ++w) { v1 += lds[(w * WN + cw) * NT + cl]; v2 += lds[(4 + w * WN + cw) * NT + cl]; }
+            float* dst = a.bnpart + ((long long)mtile * a.Cout + n0_tile + tid) * 2;
             dst[0] = v1; dst[1] = v2;
         }
     }
@@ -173,7 +182,10 @@ __device__ __forceinline__ void x3_epilogue(const IgemmArgs& a, f32x4 (&acc)[LW]
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int c = 16 * t + 4 * g + e;
-                tmean[t][e] = (lds[c] + lds[NT + c] + lds[2 * NT + c] + lds[3 * NT + c]) / cnt;
+                float sm = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) sm += lds[(w * WN + wn) * NT + c];
+                tmean[t][e] = sm / cnt;
             }
         __syncthreads();
         float m2[NTW][4];
@@ -201,11 +213,12 @@ __device__ __forceinline__ void x3_epilogue(const IgemmArgs& a, f32x4 (&acc)[LW]
                 if (r == 0) lds[(4 + wave) * NT + 16 * t + 4 * g + e] = v;
             }
         __syncthreads();
-        if (tid < NT) {
+        if (tid < NTT) {
+            const int cw = tid / NT, cl = tid % NT;
             float s1 = 0.f, mm = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) { s1 += lds[w * NT + tid]; mm += lds[(4 + w) * NT + tid]; }
-            float* dst = a.spart + ((long long)mtile * a.Cout + n0 + tid) * 3;
+            for (int w = 0; w < WM; ++w) { s1 += lds[(w * WN + cw) * NT + cl]; mm += lds[(4 + w * WN + cw) * NT + cl]; }
+            float* dst = a.spart + ((long long)mtile * a.Cout + n0_tile + tid) * 3;
             dst[0] = s1; dst[1] = mm; dst[2] = cnt;
         }
     }
@@ -213,13 +226,17 @@ __device__ __forceinline__ void x3_epilogue(const IgemmArgs& a, f32x4 (&acc)[LW]
 
 // LW = x-lines (16 voxels each) per wave: 4 -> tile 4 (z) x 4 (y) x 16, wave w owns z-slab w; 2 -> tile 2 x 4 x 16.
 // NBW = 32-channel blocks of the tile (NT = 32 * NBW output channels).
-template <int LW, int NBW, bool F16>
+// WN = 2 (r4, f16x3): 2 x 2 wave grid on the 64 NBW-channel tile -- a wave owns LW lines and ONE of the two channel blocks, so it loads
+// half of the tile's weight fragments and each feeds twice the MFMAs (the r4 probes: weight-fragment loads are the first bound of
+// the three-MFMA loop: 43 B/clk/CU of L1 traffic on the <4, 2> tile)
+template <int LW, int NBW, bool F16, int WN = 1>
 __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
-    using G = Geo<LW, F16>;
+    using G = Geo<LW, F16, WN>;
     constexpr int NPL = G::NPL;
-    constexpr int NT = 32 * NBW;
+    constexpr int NT = 32 * NBW * WN;                            // channels of the tile
     constexpr int NTW = 2 * NBW;                                 // 16-channel MFMA tiles per wave
-    constexpr int NU = X3S_NPAIR * NBW;                          // (K-step, 32-channel half) units per chunk
+    constexpr int NU = X3S_NPAIR * NBW;                          // (K-step, 32-channel half) units per chunk that THIS wave runs
+    constexpr int NUP = X3S_NPAIR * NBW * WN;                    // ... that the packed weights of the tile hold per chunk
     constexpr int UNIT = 2 * NPL * 512;                          // 16-bit elements of one unit of packed weights: [plane][t2][lane][8]
     constexpr int PS = G::PS;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -339,7 +356,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
     };
 
     // per-lane LDS byte bases of the voxel fragments: line 0 of this wave, tap (0, 0, 0), plane h; one per pair kind
-    const int line0 = wave * LW;
+    const int wm = WN == 1 ? wave : wave / WN, wn = WN == 1 ? 0 : wave % WN;     // position in the wave grid
+    const int line0 = wm * LW;
     const int lane_slot = ((line0 / XTY) * XHY + (line0 % XTY)) * XHX + r + (g & 1) * PS;
     const int hi = g >> 1;
     const int xb0 = (lane_slot + hi) * 16, xb1 = (lane_slot + hi * XHX) * 16, xb2 = (lane_slot + hi * XHY * XHX) * 16, xb3 = lane_slot * 16;
@@ -354,10 +372,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
 #pragma unroll
         for (int t = 0; t < NTW; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const bf16* wlane = reinterpret_cast<const bf16*>(a.wq) + (long long)ntile * a.nchunks * (NU * UNIT) + lane * 8;
+    const bf16* wlane = reinterpret_cast<const bf16*>(a.wq) + (long long)ntile * a.nchunks * (NUP * UNIT) + lane * 8;
     load_stage(c0);
     for (int chunk = c0; chunk < c1; ++chunk) {
-        const bf16* wp = wlane + (long long)chunk * (NU * UNIT);
+        const bf16* wp = wlane + (long long)chunk * (NUP * UNIT) + wn * (NBW * UNIT);       // unit u of this wave = packed unit (u / NBW) * NBW * WN + wn * NBW + u % NBW
         // weight units in flight ahead of the MFMAs (bf16x6: the 64-channel 4-line tile is register-bound) and voxel fragments
         // requested XD regions ahead.  f16x3 (r4 ablation: weights loaded once per chunk +28-41 % on <4, 2> at one unit = 384 cycles of
         // lead, +13 % on <4, 1> at two; voxel fragments read once +14-17 % at one region = 96 cycles of lead): the two-plane fragments
@@ -369,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) wf[u % (WD + 1)][t2][pl] = *reinterpret_cast<const bf16x8_t*>(wp + u * UNIT + (pl * 2 + t2) * 512);
+                for (int pl = 0; pl < NPL; ++pl) wf[u % (WD + 1)][t2][pl] = *reinterpret_cast<const bf16x8_t*>(wp + ((u / NBW) * (NBW * WN) + u % NBW) * UNIT + (pl * 2 + t2) * 512);
         };
         // the first weight units are requested BEFORE the next chunk's halo: vmcnt retires in order
 #pragma unroll
@@ -437,15 +455,15 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    x3_epilogue<LW, NBW, G::TZ>(a, acc, F16 ? -(sx + sw) : 0, ks, mtile, n, x0, y0, z0, n0, line0, r, g, wave, tid, lds_raw);
+    x3_epilogue<LW, NBW, G::TZ, WN>(a, acc, F16 ? -(sx + sw) : 0, ks, mtile, n, x0, y0, z0, n0, line0, r, g, wave, tid, lds_raw);
 }
 
-template <int LW, int NBW, bool F16>
+template <int LW, int NBW, bool F16, int WN = 1>
 void launch_x3s(const IgemmArgs& a, int nwg, hipStream_t st) {
-    constexpr int LDSB = Geo<LW, F16>::LDS_BYTES;
+    constexpr int LDSB = Geo<LW, F16, WN>::LDS_BYTES;
     static_assert(LDSB >= 8 * 64 * 4, "the statistics epilogue needs 8 x NT floats");
-    SEG_SET_LDS((conv_x3s_kernel<LW, NBW, F16>), LDSB);
-    hipLaunchKernelGGL((conv_x3s_kernel<LW, NBW, F16>), dim3(nwg), dim3(256), LDSB, st, a);
+    SEG_SET_LDS((conv_x3s_kernel<LW, NBW, F16, WN>), LDSB);
+    hipLaunchKernelGGL((conv_x3s_kernel<LW, NBW, F16, WN>), dim3(nwg), dim3(256), LDSB, st, a);
 }
 
 
@@ -704,7 +722,8 @@ void dispatch_x3s(const IgemmPlan& p, const IgemmArgs& a, int nwg, hipStream_t s
         return;
     }
     if (a.amax_x) {
-        if (p.MB == 2) { if (p.NBW == 2) launch_x3s<4, 2, true>(a, nwg, st); else launch_x3s<4, 1, true>(a, nwg, st); }
+        // 64-channel tile of four lines per wave-row: the 2 x 2 wave grid (eight lines x 32 channels per wave)
+        if (p.MB == 2) { if (p.NBW == 2) launch_x3s<X3S_WN2 ? 8 : 4, X3S_WN2 ? 1 : 2, true, X3S_WN2 ? 2 : 1>(a, nwg, st); else launch_x3s<4, 1, true>(a, nwg, st); }
         else { if (p.NBW == 2) launch_x3s<2, 2, true>(a, nwg, st); else launch_x3s<2, 1, true>(a, nwg, st); }
         return;
     }
