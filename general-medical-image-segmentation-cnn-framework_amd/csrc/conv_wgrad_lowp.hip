@@ -147,36 +147,70 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
 
     using stage_t = typename std::conditional<EPP == 4, f32x4, bf16x8_t>::type;
     stage_t stx[XITER], std_[DITER];
-    auto load_stage = [&](int tile) {
+    // ---- tile loads.  A piece's place inside the tile never changes: its three halo coordinates (one byte each, packed) and its
+    // byte offset from the tile's first halo voxel are computed once; per tile only wave-uniform values change -- the descriptor
+    // base (the tile's first halo voxel: scalar arithmetic) and the packed bounds the coordinates are tested against, all three
+    // axes in two packed additions (field + (128 - lo) sets bit 7 iff h >= lo; (127 + hi) - field sets it iff h < hi; fields stay
+    // below 256, so nothing carries).  Pieces outside the volume are requested past the descriptor's range and read as zeros.
+    // Six full-rate VALU instructions per piece instead of the ~10 quarter-rate multiplies of the 64-bit address of each piece,
+    // and the pipelined kernels request ONE piece per scheduling region, inside the MFMA stream (r4: a burst of address arithmetic
+    // in all eight waves ahead of the MFMAs left the MFMA pipes idle for a third of the tile, profiles/r04_wgrad_f16_ablation_probe.log)
+    constexpr int ESZ = (int)sizeof(IN_T);
+    constexpr unsigned OOB = 0x7FFFFFF0u;
+    int crd[XITER], rel[XITER], dcrd[DITER], drel[DITER];
+#pragma unroll
+    for (int it = 0; it < XITER; ++it) {
+        const int pc = it * LW_THREADS + tid;
+        const int vox = pc / PPV, part = pc % PPV;
+        const int hz = vox / (T::HY * T::HX), rem = vox % (T::HY * T::HX);
+        const int hy = rem / T::HX, hx = rem % T::HX;
+        crd[it] = pc < XPIECES ? (hx | (hy << 8) | (hz << 16)) : 0x7f7f7f;
+        rel[it] = (((hz * a.H + hy) * a.W + hx) * a.ldx + part * EPP) * ESZ;
+    }
+#pragma unroll
+    for (int it = 0; it < DITER; ++it) {
+        const int pc = it * LW_THREADS + tid;
+        const int vox = pc / PPV, part = pc % PPV;
+        const int line = vox / BX, xx = vox % BX;
+        dcrd[it] = xx | ((line % T::TY) << 8) | ((line / T::TY) << 16);
+        drel[it] = ((((line / T::TY) * a.Ho + line % T::TY) * a.Wo + xx) * a.lddy + part * EPP) * ESZ;
+    }
+    __amdgpu_buffer_rsrc_t rx, rd;
+    int xA = 0, xB = 0, dA = 0;
+    auto clamp7 = [](int v) { return v < 0 ? 0 : (v > 127 ? 127 : v); };
+    auto tile_geom = [&](int tile, bool valid) {                 // wave-uniform
         int mt = tile;
         const int txi = mt % a.ntx; mt /= a.ntx;
         const int tyi = mt % a.nty; mt /= a.nty;
         const int tzi = mt % a.ntz;
         const int n = mt / a.ntz;
         const int x0 = txi * BX, y0 = tyi * T::TY, z0 = tzi * T::TZ;
-#pragma unroll
-        for (int it = 0; it < XITER; ++it) {
-            const int pc = it * LW_THREADS + tid;
-            const int vox = pc / PPV, part = pc % PPV;
-            const int hz = vox / (T::HY * T::HX), rem = vox % (T::HY * T::HX);
-            const int hy = rem / T::HX, hx = rem % T::HX;
-            const int gz = z0 * S + hz + (KS == 3 ? -1 : plane - T::HALO), gy = y0 * S - T::HALO + hy, gx = x0 * S - T::HALO + hx;
-            const bool ok = (pc < XPIECES) && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-            stage_t v = {};
-            if (ok) v = *reinterpret_cast<const stage_t*>(xin + ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.ldx + ci0 + part * EPP);
-            stx[it] = v;
+        const int ox = x0 * S - T::HALO, oy = y0 * S - T::HALO, oz = z0 * S + (KS == 3 ? -1 : plane - T::HALO);      // first halo voxel
+        const int lox = clamp7(-ox), loy = clamp7(-oy), loz = clamp7(-oz);
+        const int hix = valid ? clamp7(a.W - ox) : 0, hiy = clamp7(a.H - oy), hiz = clamp7(a.D - oz);
+        xB = (128 - lox) | ((128 - loy) << 8) | ((128 - loz) << 16);
+        xA = (127 + hix) | ((127 + hiy) << 8) | ((127 + hiz) << 16);
+        dA = (127 + (valid ? clamp7(a.Wo - x0) : 0)) | ((127 + clamp7(a.Ho - y0)) << 8) | ((127 + clamp7(a.Do - z0)) << 16);
+        const IN_T* xb = xin + ((((long long)n * a.D + oz) * a.H + oy) * a.W + ox) * a.ldx + ci0;
+        const IN_T* db = din + ((((long long)n * a.Do + z0) * a.Ho + y0) * a.Wo + x0) * a.lddy + co0;
+        rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<IN_T*>(xb), 0, (int)OOB, 0x00020000);
+        rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<IN_T*>(db), 0, (int)OOB, 0x00020000);
+    };
+    auto load_piece = [&](int j) {                               // j: compile-time after unrolling
+        if (j < XITER) {
+            const int u = xA - crd[j], v = crd[j] + xB;
+            const bool ok = ((u & v) & 0x808080) == 0x808080;
+            stx[j] = __builtin_bit_cast(stage_t, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)rel[j] : OOB, 0, 0));
+        } else {
+            const int k = j - XITER;
+            const bool ok = ((dA - dcrd[k]) & 0x808080) == 0x808080;
+            std_[k] = __builtin_bit_cast(stage_t, __builtin_amdgcn_raw_buffer_load_b128(rd, ok ? (unsigned)drel[k] : OOB, 0, 0));
         }
+    };
+    constexpr int NPC = XITER + DITER;
+    auto load_stage = [&]() {
 #pragma unroll
-        for (int it = 0; it < DITER; ++it) {
-            const int pc = it * LW_THREADS + tid;
-            const int vox = pc / PPV, part = pc % PPV;
-            const int line = vox / BX, xx = vox % BX;
-            const int gz = z0 + line / T::TY, gy = y0 + line % T::TY, gx = x0 + xx;
-            stage_t dv = {};                          // partial tiles: voxels outside the volume contribute nothing
-            if (gz < a.Do && gy < a.Ho && gx < a.Wo)
-                dv = *reinterpret_cast<const stage_t*>(din + ((((long long)n * a.Do + gz) * a.Ho + gy) * a.Wo + gx) * a.lddy + co0 + part * EPP);
-            std_[it] = dv;
-        }
+        for (int j = 0; j < NPC; ++j) load_piece(j);
     };
     auto put = [&](unsigned char* base, int pc, const stage_t& v, float scale) {
         unsigned char* dst = base + (pc / PPV) * T::ROW + (pc % PPV) * (EPP * 2);
@@ -274,6 +308,7 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
                     mfma_half(0, tt, 0);
                     mfma_half(0, tt, 1);
                 }
+                if (ks == 0) load_stage();                          // the next tile, behind the first k-step's reads
             }
         } else {
             load_b(0, 0); load_b(0, 1);
@@ -286,6 +321,11 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
                 if (u + 1 < NREG) load_a(cur ^ 1, (u + 1) / NTT, (u + 1) % NTT);
                 mfma_half(cur, tt, 0);
                 if (tt == NTT - 1 && ks + 1 < T::KSTEPS) load_b(ks + 1, 0);
+                {                                                   // the next tile's pieces, spread over the regions
+                    constexpr int PPR = (NPC + NREG - 1) / NREG;
+#pragma unroll
+                    for (int j = u * PPR; j < (u + 1) * PPR && j < NPC; ++j) load_piece(j);
+                }
                 mfma_half(cur, tt, 1);
                 // spread the region's reads over its MFMAs (groups that find no read left are no-ops)
                 if constexpr (NP == 1) {
@@ -304,12 +344,14 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
     };
 
     int tile = strip;
-    if (tile < a.ntiles) load_stage(tile);
+    tile_geom(tile, tile < a.ntiles);
+    load_stage();
     for (; tile < a.ntiles; tile += a.nstrips) {
         __syncthreads();
         if (!LW_DBG(a, 16) || tile == strip) write_stage();
         __syncthreads();
-        if (tile + a.nstrips < a.ntiles && !LW_DBG(a, 8)) load_stage(LW_DBG(a, 64) ? strip : tile + a.nstrips);
+        // the loads of the next tile are requested inside tile_mfma; past the strip's last tile (hi bound 0) they all read zeros
+        tile_geom(LW_DBG(a, 64) ? strip : tile + a.nstrips, tile + a.nstrips < a.ntiles && !LW_DBG(a, 8));
         // every lane of every wave runs the transposing reads (they need EXEC all ones); a wave without a fourth tap
         // simply issues one tap-tile fewer
         if (has_last) tile_mfma(std::integral_constant<int, LW_TPW>{});
