@@ -42,4 +42,13 @@ def get_b16_tiles():
     return lib().query("mi355seg_get_b16_tiles")
 
 
-__all__ = ["set_b16_tiles", "get_b16_tiles", "set_x3_shape", "get_x3_shape", "functional", "autocast", "lib", "LIB_PATH", "Mi355SegError", "set_conv_math", "get_conv_math"]
+def set_wgrad_wide(mode):
+    """0: never the wide f16x3 weight-gradient kernel, 1 (default): where it pays, 2: wherever the geometry allows (include/mi355seg.h)."""
+    lib().call("mi355seg_set_wgrad_wide", int(mode))
+
+
+def get_wgrad_wide():
+    return lib().query("mi355seg_get_wgrad_wide")
+
+
+__all__ = ["set_b16_tiles", "get_b16_tiles", "set_wgrad_wide", "get_wgrad_wide", "set_x3_shape", "get_x3_shape", "functional", "autocast", "lib", "LIB_PATH", "Mi355SegError", "set_conv_math", "get_conv_math"]

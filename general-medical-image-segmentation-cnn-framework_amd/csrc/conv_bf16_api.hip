@@ -98,6 +98,13 @@ int mi355seg_set_b16_tiles(int mode) {
 }
 int mi355seg_get_b16_tiles(void) { return get_b16_tiles(); }
 
+int mi355seg_set_wgrad_wide(int mode) {
+    SEG_CHECK_ARG(mode >= 0 && mode <= 2, "set_wgrad_wide: 0 (never), 1 (where it pays) or 2 (wherever the geometry allows), got %d", mode);
+    set_wgrad_wide(mode);
+    return MI355SEG_OK;
+}
+int mi355seg_get_wgrad_wide(void) { return get_wgrad_wide(); }
+
 // workspace of the three bf16 Conv3d entry points for one layer geometry (contiguous tensors assumed for the fallback test)
 size_t mi355seg_conv3d_ws_bytes_bf16(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
     size_t base = mi355seg_conv3d_ws_bytes(N, D, H, W, Cin, Cout, k, stride, pad);

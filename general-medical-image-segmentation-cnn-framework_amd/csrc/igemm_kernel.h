@@ -666,6 +666,8 @@ bool b16s_geom(int KS, int N, int D, int H, int W, int Cin, int Cout, B16sPlan* 
 bool b16s_plan(int KS, int N, int D, int H, int W, int Cin, int Cout, const void* x, int ldx, const void* y, int ldy, B16sPlan* p);
 size_t b16s_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k);
 void dispatch_b16s(const B16sPlan& p, const IgemmArgs& a, int nwg, hipStream_t st);
+void set_wgrad_wide(int mode);
+int get_wgrad_wide();
 void set_b16_tiles(int mode);
 int get_b16_tiles();
 

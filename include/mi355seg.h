@@ -86,6 +86,11 @@ int mi355seg_get_x3_shape(void);
  * by default).  Process-wide, read at each launch (A/B timing, tests of both kernels on one shape). */
 int mi355seg_set_b16_tiles(int mode);
 int mi355seg_get_b16_tiles(void);
+/* The f16x3 weight gradient of k3 s1 convolutions with Cout % 64 == 0 has a second kernel (conv_wgrad_f16w_kernel: four waves, one per
+ * SIMD, a 32 x 64 channel block per workgroup -- half the LDS fragment reads per MFMA).  0: never, 1 (default): where the strip of
+ * tiles per workgroup is long enough for it to pay, 2: wherever the geometry allows.  Same results contract either way. */
+int mi355seg_set_wgrad_wide(int mode);
+int mi355seg_get_wgrad_wide(void);
 
 /* ------------------------------------------------------------------ Conv3d
  * Replaces nn.Conv3d forward/backward (ATen convolution / convolution_backward):

@@ -560,6 +560,35 @@ def test_bf16x6_16x16x32_kernel_against_fp64_and_the_32x32x16_kernel(seg, case):
         assert torch.allclose(e16[3], want.pow(2).sum(dim=(0, 1, 2, 3)), rtol=2e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize("case", [(1, 8, 16, 32, 32, 64), (2, 5, 9, 40, 64, 128), (1, 3, 7, 21, 32, 64), (1, 16, 48, 64, 128, 128)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_f16x3_wide_weight_gradient(seg, case):
+    """conv_wgrad_f16w_kernel (f16x3, k3 s1, Cout % 64 == 0: four waves, a 32 x 64 channel block per workgroup; include/mi355seg.h,
+    mi355seg_set_wgrad_wide): forced on wherever the geometry allows (mode 2: full, ragged and BX = 8 tiles, D smaller than a tile,
+    and -- last case -- a shape the default mode 1 sends there), against the fp64 weight gradient by the criteria of
+    test_split_precision_conv_is_fp32_accurate, and against the 32 x 32 kernel (mode 0): both sum the same products."""
+    N, D, H, W, Cin, Cout = case
+    F = seg.functional
+    x, w = rnd(N, Cin, D, H, W, seed=11), rnd(Cout, Cin, 3, 3, 3, seed=12, scale=(2.0 / (27 * Cin)) ** 0.5)
+    g = rnd(N, Cout, D, H, W, seed=13) * 1e-6                   # gradients of a mean loss are small: the scale must not matter
+    wd = w.double().requires_grad_(True)
+    TF.conv3d(x.double(), wd, None, padding=1).backward(g.double())
+    got = {}
+    try:
+        for mode in (0, 2, 1):
+            seg.set_wgrad_wide(mode)
+            assert seg.get_wgrad_wide() == mode
+            xg, wg = cl(x).requires_grad_(True), w.cuda().requires_grad_(True)
+            F.conv3d(xg, wg, None, 1, 1).backward(cl(g))
+            got[mode] = wg.grad.cpu().double()
+    finally:
+        seg.set_wgrad_wide(1)
+    sc = float(wd.grad.abs().max())
+    for mode in (0, 2, 1):
+        assert float((got[mode] - wd.grad).abs().max()) < 3e-6 * sc, mode
+    assert float((got[2] - got[0]).abs().max()) < 1e-6 * sc
+
+
 @pytest.mark.parametrize("xs,ws,tail", [(1.0, 1.0, 0.0), (1e-8, 1.0, 0.0), (3e-30, 0.02, 0.0), (1e6, 1e-3, 0.0), (1e18, 1e12, 0.0), (1.0, 1.0, 1e3), (1e-9, 1.0, 3e4),
                                         (0.0, 1.0, 0.0)])
 def test_f16x3_is_scale_free(seg, xs, ws, tail):
