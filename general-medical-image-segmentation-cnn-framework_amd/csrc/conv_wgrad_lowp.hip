@@ -375,32 +375,37 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
     }
 }
 
-// ---- f16x3, k3 s1, Cout % 64 == 0: the WIDE kernel -- four waves (one per SIMD: 512 registers each), a 32 (ci) x 64 (co) block pair per
-// workgroup.  The kernel above is bound by the LDS: 0.83-0.89 transposing reads per MFMA with 8 waves sharing the LDS pipe keeps
-// it 89 % busy at the full MFMA rate (r4: 144 MFMAs + 128 ds_read_b64_tr_b16 per wave and tile), so any conflict or write starves
-// the MFMA pipes (busy 0.55-0.6).  Here a wave owns SEVEN tap-tiles of 2 x 4 accumulators (224 registers): an x fragment feeds
-// four co halves, a dy fragment seven taps -- 0.43 reads per MFMA.  Same tile, slab layout and reduction as above.
+// ---- the WIDE kernel (stride 1, Cout % 64 == 0; f16x3 on fp32 tensors, or bf16 tensors): four waves, one per SIMD with up to 512
+// registers, a 32 (ci) x 64 (co) block pair per workgroup.  The 8-wave kernel above issues 0.83-0.89 (f16x3) / 1.25 (bf16) transposing
+// reads per MFMA and runs its staging with the MFMA pipes idle; here a wave owns SEVEN tap-tiles of 2 x 4 accumulators (224 AGPRs):
+// an x fragment feeds four co quarters, a dy fragment seven taps -- 0.43 / 0.64 reads per MFMA.  Same tile, slab layout and reduction.
 #ifndef FW_SPLIT
 #define FW_SPLIT 1
 #endif
 constexpr int FW_WAVES = 4, FW_THREADS = FW_WAVES * 64, FW_TPW = 7;
 
-template <int BX>
+template <int BX, int KS, int NP>
 struct FTile {
-    using X = LTile<BX, 3, 2, 1>;
-    static constexpr int DROW = 2 * 128 + 32;                    // planes h | l of 64 fp16 channels + 32 bytes: pitch / 32 = 9, odd
+    using X = LTile<BX, KS, NP, 1>;
+    static constexpr int DROW = 128 * NP + 32;                   // NP planes of 64 16-bit channels + 32 bytes: pitch / 32 odd
     static constexpr int D_BYTES = X::VOX * DROW;
     static constexpr int LDS_BYTES = X::X_BYTES + D_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the LDS");
 };
 
-template <int BX>
-__global__ __launch_bounds__(FW_THREADS, 1) void conv_wgrad_f16w_kernel(LWgradArgs a) {
-    using T = LTile<BX, 3, 2, 1>;
-    using F = FTile<BX>;
-    constexpr int XPIECES = T::NVOX * 8, DPIECES = T::VOX * 16;                // 16-byte pieces: 32 ci / 64 co fp32 channels per voxel
+template <int BX, int KS, typename IN_T>
+__global__ __launch_bounds__(FW_THREADS, 1) void conv_wgrad_wide_kernel(LWgradArgs a) {
+    constexpr bool F32 = std::is_same<IN_T, float>::value;
+    constexpr int NP = F32 ? 2 : 1, NPR = F32 ? 3 : 1;           // operand planes, MFMA products per fragment pair
+    constexpr int EPP = F32 ? 4 : 8, ESZ = (int)sizeof(IN_T);
+    constexpr int PPX = 32 / EPP, PPD = 64 / EPP;                 // 16-byte pieces per voxel: 32 ci / 64 co
+    using T = LTile<BX, KS, NP, 1>;
+    using F = FTile<BX, KS, NP>;
+    constexpr int XPIECES = T::NVOX * PPX, DPIECES = T::VOX * PPD;
     constexpr int XITER = (XPIECES + FW_THREADS - 1) / FW_THREADS, DITER = DPIECES / FW_THREADS, NPC = XITER + DITER;
-    static_assert(DPIECES % FW_THREADS == 0 && (BX == 16 || BX == 8), "dy tile must split evenly over the workgroup");
+    constexpr int VPI = FW_THREADS / PPD, LPI = VPI / BX;         // dy voxels / tile lines per piece index
+    static_assert(DPIECES % FW_THREADS == 0 && VPI % BX == 0 && T::TY % LPI == 0, "dy pieces must cover whole lines");
+    constexpr int NTAPS = T::NTAPS;                               // 27, or the 25 of one dz plane (k5)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* xs = lds;
     unsigned char* ds = lds + T::X_BYTES;
@@ -410,12 +415,14 @@ __global__ __launch_bounds__(FW_THREADS, 1) void conv_wgrad_f16w_kernel(LWgradAr
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int pair = t % a.npairs, strip = t / a.npairs;
+    const int plane = t % T::PLANES, tp = t / T::PLANES;          // k5: which dz plane of taps this workgroup owns
+    const int pair = tp % a.npairs, strip = tp / a.npairs;
     const int cib = pair / a.ncob, cob = pair % a.ncob;
     const int ci0 = cib * 32, co0 = cob * 64;
-    const float* __restrict__ xin = reinterpret_cast<const float*>(a.x);
-    const float* __restrict__ din = reinterpret_cast<const float*>(a.dy);
-    const int sx = f16x_scale_exp(*a.amax_x), sd = f16x_scale_exp(*a.amax_dy);
+    const IN_T* __restrict__ xin = reinterpret_cast<const IN_T*>(a.x);
+    const IN_T* __restrict__ din = reinterpret_cast<const IN_T*>(a.dy);
+    int sx = 0, sd = 0;
+    if constexpr (F32) { sx = f16x_scale_exp(*a.amax_x); sd = f16x_scale_exp(*a.amax_dy); }
     const float xscale = pow2f(sx), dscale = pow2f(sd);
 
     // transposing-read lane geometry: as in conv_wgrad_lowp_kernel
@@ -425,12 +432,13 @@ __global__ __launch_bounds__(FW_THREADS, 1) void conv_wgrad_f16w_kernel(LWgradAr
     const int lane_x = kq_x * T::ROW + chan_off;
     const int lane_d = (4 * g + q) * F::DROW + chan_off;
 
-    int abase[FW_TPW];
+    int abase[FW_TPW];                                            // wave w owns taps w, w + 4, ...; a slot past the last tap repeats it (dropped at the end)
 #pragma unroll
     for (int tt = 0; tt < FW_TPW; ++tt) {
         int tap = wave + FW_WAVES * tt;
-        if (tap > 26) tap = 26;
-        abase[tt] = (((tap / 9) * T::HY + (tap / 3) % 3) * T::HX + tap % 3) * T::ROW + lane_x;
+        if (tap > NTAPS - 1) tap = NTAPS - 1;
+        const int dz = KS == 3 ? tap / 9 : 0, dy = KS == 3 ? (tap / 3) % 3 : tap / KS, dx = tap % KS;
+        abase[tt] = ((dz * T::HY + dy) * T::HX + dx) * T::ROW + lane_x;
     }
 
     f32x4 acc[FW_TPW][2][4];                                      // [tap-tile][ci half][co quarter]
@@ -440,25 +448,26 @@ __global__ __launch_bounds__(FW_THREADS, 1) void conv_wgrad_f16w_kernel(LWgradAr
         for (int ab = 0; ab < 8; ++ab) acc[tt][ab >> 2][ab & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- tile loads: x pieces as above (packed halo coordinates + byte offset per piece).  dy piece `it` of a lane is voxel
-    // it * 16 + tid / 16: the same x (and, BX = 8, the same line parity) for every `it`, so one packed coordinate and one offset
-    // per lane serve all eight; the line of piece `it` moves the bounds and the descriptor offset by wave-uniform amounts.
+    // it * VPI + tid / PPD: the same x (and the same line inside the LPI lines of a piece index) for every `it`, so one packed
+    // coordinate and one offset per lane serve all of them; the line of piece `it` moves the bounds and the descriptor offset by
+    // wave-uniform amounts.
     constexpr unsigned OOB = 0x7FFFFFF0u;
-    f32x4 stx[XITER], std_[DITER];
+    using stage_t = typename std::conditional<F32, f32x4, bf16x8_t>::type;
+    stage_t stx[XITER], std_[DITER];
     int crd[XITER], rel[XITER];
 #pragma unroll
     for (int it = 0; it < XITER; ++it) {
         const int pc = it * FW_THREADS + tid;
-        const int vox = pc >> 3, part = pc & 7;
+        const int vox = pc / PPX, part = pc % PPX;
         const int hz = vox / (T::HY * T::HX), rem = vox % (T::HY * T::HX);
         const int hy = rem / T::HX, hx = rem % T::HX;
         crd[it] = pc < XPIECES ? (hx | (hy << 8) | (hz << 16)) : 0x7f7f7f;
-        rel[it] = (((hz * a.H + hy) * a.W + hx) * a.ldx + part * 4) * 4;
+        rel[it] = (((hz * a.H + hy) * a.W + hx) * a.ldx + part * EPP) * ESZ;
     }
-    const int dvox0 = tid >> 4, dpart = tid & 15;
-    const int dxx = dvox0 % BX, dhb = dvox0 / BX;                 // BX = 16: dhb = 0
+    const int dvox0 = tid / PPD, dpart = tid % PPD;
+    const int dxx = dvox0 % BX, dhb = dvox0 / BX;                 // dhb < LPI
     const int dcrd = dxx | (dhb << 8);
-    const int drel = ((dhb * a.Wo + dxx) * a.lddy + dpart * 4) * 4;
-    auto dline = [](int it) { return BX == 16 ? it : 2 * it; };  // line of piece `it` (BX = 8: + dhb)
+    const int drel = ((dhb * a.Wo + dxx) * a.lddy + dpart * EPP) * ESZ;
     __amdgpu_buffer_rsrc_t rx, rd;
     int xA = 0, xB = 0, dA = 0;
     auto clamp7 = [](int v) { return v < 0 ? 0 : (v > 127 ? 127 : v); };
@@ -469,101 +478,102 @@ __global__ __launch_bounds__(FW_THREADS, 1) void conv_wgrad_f16w_kernel(LWgradAr
         const int tzi = mt % a.ntz;
         const int n = mt / a.ntz;
         const int x0 = txi * BX, y0 = tyi * T::TY, z0 = tzi * T::TZ;
-        const int ox = x0 - 1, oy = y0 - 1, oz = z0 - 1;         // first halo voxel
+        const int ox = x0 - T::HALO, oy = y0 - T::HALO, oz = z0 + (KS == 3 ? -1 : plane - T::HALO);      // first halo voxel
         const int lox = clamp7(-ox), loy = clamp7(-oy), loz = clamp7(-oz);
         const int hix = valid ? clamp7(a.W - ox) : 0, hiy = clamp7(a.H - oy), hiz = clamp7(a.D - oz);
         xB = (128 - lox) | ((128 - loy) << 8) | ((128 - loz) << 16);
         xA = (127 + hix) | ((127 + hiy) << 8) | ((127 + hiz) << 16);
         dA = (127 + (valid ? clamp7(a.Wo - x0) : 0)) | ((127 + clamp7(a.Ho - y0)) << 8) | ((127 + clamp7(a.Do - z0)) << 16);
-        const float* xb = xin + ((((long long)n * a.D + oz) * a.H + oy) * a.W + ox) * a.ldx + ci0;
-        const float* db = din + ((((long long)n * a.Do + z0) * a.Ho + y0) * a.Wo + x0) * a.lddy + co0;
-        rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)OOB, 0x00020000);
-        rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(db), 0, (int)OOB, 0x00020000);
+        const IN_T* xb = xin + ((((long long)n * a.D + oz) * a.H + oy) * a.W + ox) * a.ldx + ci0;
+        const IN_T* db = din + ((((long long)n * a.Do + z0) * a.Ho + y0) * a.Wo + x0) * a.lddy + co0;
+        rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<IN_T*>(xb), 0, (int)OOB, 0x00020000);
+        rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<IN_T*>(db), 0, (int)OOB, 0x00020000);
     };
     auto load_piece = [&](int j) {                               // j: compile-time after unrolling
         if (j < XITER) {
             const int u = xA - crd[j], v = crd[j] + xB;
             const bool ok = ((u & v) & 0x808080) == 0x808080;
-            stx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)rel[j] : OOB, 0, 0));
+            stx[j] = __builtin_bit_cast(stage_t, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)rel[j] : OOB, 0, 0));
         } else {
-            const int k = j - XITER, ln = dline(k);
+            const int k = j - XITER, ln = k * LPI;               // first line of the piece index (+ dhb in the lane)
             const int ly = ln % T::TY, lz = ln / T::TY;          // compile-time
             const bool ok = (((dA - ((ly << 8) | (lz << 16))) - dcrd) & 0x808080) == 0x808080;
-            const int soff = ((lz * a.Ho + ly) * a.Wo) * a.lddy * 4;      // wave-uniform
-            std_[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, ok ? (unsigned)drel : OOB, soff, 0));
+            const int soff = ((lz * a.Ho + ly) * a.Wo) * a.lddy * ESZ;      // wave-uniform
+            std_[k] = __builtin_bit_cast(stage_t, __builtin_amdgcn_raw_buffer_load_b128(rd, ok ? (unsigned)drel : OOB, soff, 0));
         }
     };
-    auto put = [&](unsigned char* dst, int lplane, const f32x4& v, float scale) {
-        f16x4_t qh, ql;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { _Float16 bh, bl; split2h(v[e] * scale, bh, bl); qh[e] = bh; ql[e] = bl; }
-        *reinterpret_cast<f16x4_t*>(dst) = qh;
-        *reinterpret_cast<f16x4_t*>(dst + lplane) = ql;
+    auto lds_dst = [&](int j) {
+        const int pc = j * FW_THREADS + tid;
+        return j < XITER ? xs + (pc / PPX) * T::ROW + (pc % PPX) * 16 / NP : ds + ((j - XITER) * VPI + dvox0) * F::DROW + dpart * 16 / NP;
     };
-#if FW_SPLIT
-    // the splits run inside the MFMA stream, in the registers the piece arrived in: between the barriers only the LDS writes remain
-    f16x4_t cvh[NPC], cvl[NPC];
+    // f16x3: the splits run inside the MFMA stream (FW_SPLIT), in the registers the piece arrived in: between the barriers only the LDS
+    // writes remain
+    f16x4_t cvh[F32 && FW_SPLIT ? NPC : 1], cvl[F32 && FW_SPLIT ? NPC : 1];
     auto split_piece = [&](int j) {
-        const float sc = j < XITER ? xscale : dscale;
-        f32x4 v;
-        if (j < XITER) v = stx[j]; else v = std_[j - XITER];
+        if constexpr (F32 && FW_SPLIT) {
+            const float sc = j < XITER ? xscale : dscale;
+            f32x4 v;
+            if (j < XITER) v = stx[j]; else v = std_[j - XITER];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { _Float16 bh, bl; split2h(v[e] * sc, bh, bl); cvh[j][e] = bh; cvl[j][e] = bl; }
+            for (int e = 0; e < 4; ++e) { _Float16 bh, bl; split2h(v[e] * sc, bh, bl); cvh[j][e] = bh; cvl[j][e] = bl; }
+        }
     };
     auto write_stage = [&]() {
 #pragma unroll
         for (int j = 0; j < NPC; ++j) {
-            const int pc = j * FW_THREADS + tid;
-            unsigned char* dst = j < XITER ? xs + (pc >> 3) * T::ROW + (pc & 7) * 8 : ds + ((j - XITER) * 16 + dvox0) * F::DROW + dpart * 8;
-            if (j >= XITER || pc < XPIECES) {
+            if (j < XITER && j * FW_THREADS + tid >= XPIECES) continue;
+            unsigned char* dst = lds_dst(j);
+            if constexpr (!F32) {
+                *reinterpret_cast<bf16x8_t*>(dst) = j < XITER ? stx[j] : std_[j < XITER ? 0 : j - XITER];
+            } else if constexpr (FW_SPLIT) {
                 *reinterpret_cast<f16x4_t*>(dst) = cvh[j];
                 *reinterpret_cast<f16x4_t*>(dst + (j < XITER ? 64 : 128)) = cvl[j];
+            } else {
+                const float sc = j < XITER ? xscale : dscale;
+                f32x4 v;
+                if (j < XITER) v = stx[j]; else v = std_[j < XITER ? 0 : j - XITER];
+                f16x4_t qh, ql;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { _Float16 bh, bl; split2h(v[e] * sc, bh, bl); qh[e] = bh; ql[e] = bl; }
+                *reinterpret_cast<f16x4_t*>(dst) = qh;
+                *reinterpret_cast<f16x4_t*>(dst + (j < XITER ? 64 : 128)) = ql;
             }
         }
     };
-#else
-    auto split_piece = [&](int) {};
-    auto write_stage = [&]() {
-#pragma unroll
-        for (int it = 0; it < XITER; ++it) {
-            const int pc = it * FW_THREADS + tid;
-            if (pc < XPIECES) put(xs + (pc >> 3) * T::ROW + (pc & 7) * 8, 64, stx[it], xscale);
-        }
-#pragma unroll
-        for (int it = 0; it < DITER; ++it) put(ds + (it * 16 + dvox0) * F::DROW + dpart * 8, 128, std_[it], dscale);
-    };
-#endif
 
     auto xoff = [](int ks, int t2) {
-        const int line = BX == 16 ? 2 * ks + t2 : 4 * ks + 2 * t2;
-        return (((line / T::TY) * T::HY + (line % T::TY)) * T::HX) * T::ROW;
+        const int line = BX == 32 ? ks : (BX == 16 ? 2 * ks + t2 : 4 * ks + 2 * t2);
+        return ((((line / T::TY) * T::HY + (line % T::TY)) * T::HX) + (BX == 32 ? 16 * t2 : 0)) * T::ROW;
     };
     auto doff = [](int ks, int t2) { return (ks * 32 + 16 * t2) * F::DROW; };
 
-    // one scheduling region per (k-step, tap-tile): 24 MFMAs; the x fragments of the next region are requested behind its first
-    // MFMAs, the dy fragments of the next k-step (double-buffered) during the k-step's last tap-tile, one tile piece per region
-    auto tile_mfma = [&](auto ntc) {
-        constexpr int NTT = decltype(ntc)::value;
-        constexpr int NREG = T::KSTEPS * NTT;
+    // one scheduling region per (k-step, tap-tile): 8 NPR MFMAs; the x fragments of the next region are requested behind its first
+    // MFMAs, the dy fragments of the next k-step during the k-step's last tap-tile, tile pieces in the first regions
+    auto tile_mfma = [&]() {
+        constexpr int NTT = FW_TPW, NREG = T::KSTEPS * NTT;
         constexpr int PPR = 2, NLR = (NPC + PPR - 1) / PPR;        // tile pieces requested per region, regions that request
         static_assert(NREG >= 2 * NLR, "the requests and the splits each need their regions");
-        bf16x8_t bc[4][2], ac[2][2][2];
+        bf16x8_t bc[4][NP], ac[2][2][NP];
         auto load_b1 = [&](int b, int ks) {
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
+            for (int pl = 0; pl < NP; ++pl)
                 bc[b][pl] = tr_frag(ds, lane_d + doff(ks, 0) + b * 32 + pl * 128, lane_d + doff(ks, 1) + b * 32 + pl * 128);
         };
         auto load_a = [&](int buf, int ks, int tt) {
 #pragma unroll
             for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl)
+                for (int pl = 0; pl < NP; ++pl)
                     ac[buf][a2][pl] = tr_frag(xs, abase[tt] + xoff(ks, 0) + a2 * 32 + pl * 64, abase[tt] + xoff(ks, 1) + a2 * 32 + pl * 64);
         };
-        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};      // planes 0 / 1 = h / l; the two cross terms go in first
         auto mfma = [&](int cur, int tt, int a2, int b, int pr) {
-            acc[tt][a2][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ac[cur][a2][PA[pr]]), __builtin_bit_cast(f16x8_t, bc[b][PB[pr]]),
-                                                                   acc[tt][a2][b], 0, 0, 0);
+            if constexpr (F32) {                                  // planes 0 / 1 = h / l; the two cross terms go in first
+                constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+                acc[tt][a2][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ac[cur][a2][PA[pr]]), __builtin_bit_cast(f16x8_t, bc[b][PB[pr]]),
+                                                                       acc[tt][a2][b], 0, 0, 0);
+            } else {
+                acc[tt][a2][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[cur][a2][0], bc[b][0], acc[tt][a2][b], 0, 0, 0);
+            }
         };
 #pragma unroll
         for (int b = 0; b < 4; ++b) load_b1(b, 0);
@@ -573,36 +583,36 @@ __global__ __launch_bounds__(FW_THREADS, 1) void conv_wgrad_f16w_kernel(LWgradAr
         for (int u = 0; u < NREG; ++u) {
             const int ks = u / NTT, tt = u % NTT, cur = u & 1;
             if (u + 1 < NREG) load_a(cur ^ 1, (u + 1) / NTT, (u + 1) % NTT);
-            // the next tile: two pieces requested per region in the first regions, split (FW_SPLIT) in the last ones -- 17 regions
-            // (~3 us) later, with one wave per SIMD a wait on memory stalls the SIMD
+            // the next tile: two pieces requested per region in the first regions, split (f16x3) in the last ones -- with one wave per
+            // SIMD a wait on memory stalls the SIMD, so the distance is as long as the tile allows
 #pragma unroll
             for (int k = 0; k < PPR; ++k) {
                 const int jl = u * PPR + k, js = (u - (NREG - NLR)) * PPR + k;
                 if (jl < NPC) load_piece(jl);
-                if (FW_SPLIT && js >= 0 && js < NPC) split_piece(js);
+                if (js >= 0 && js < NPC) split_piece(js);
             }
             if (tt == NTT - 1 && ks + 1 < T::KSTEPS) {
                 // the k-step's last tap-tile: one co quarter at a time, its dy fragments of the NEXT k-step requested right behind its
-                // six MFMAs (single-buffered: the fragments' registers are free by then)
+                // MFMAs (single-buffered: the fragments' registers are free by then)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
 #pragma unroll
-                    for (int pr = 0; pr < 3; ++pr)
+                    for (int pr = 0; pr < NPR; ++pr)
 #pragma unroll
                         for (int a2 = 0; a2 < 2; ++a2) mfma(cur, tt, a2, b, pr);
                     load_b1(b, ks + 1);
                 }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 6, 0); __builtin_amdgcn_sched_group_barrier(0x100, 6, 0); }
+                for (int k = 0; k < 4; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 2 * NPR, 0); __builtin_amdgcn_sched_group_barrier(0x100, 3 * NP, 0); }
             } else {
 #pragma unroll
-                for (int pr = 0; pr < 3; ++pr)
+                for (int pr = 0; pr < NPR; ++pr)
 #pragma unroll
                     for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
                         for (int b = 0; b < 4; ++b) mfma(cur, tt, a2, b, pr);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); }
+                for (int k = 0; k < 8; ++k) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, NPR, 0); }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -619,22 +629,26 @@ __global__ __launch_bounds__(FW_THREADS, 1) void conv_wgrad_f16w_kernel(LWgradAr
         if (!LW_DBG(a, 16) || tile == strip) write_stage();
         __syncthreads();
         tile_geom(LW_DBG(a, 64) ? strip : tile + a.nstrips, tile + a.nstrips < a.ntiles && !LW_DBG(a, 8));
-        // (wave 3 owns six taps: its seventh tap-tile repeats tap 26 and is dropped at the end -- the other waves run seven anyway,
-        // and one instantiation of the MFMA stream keeps the accumulators' register assignment the same on every path)
-        tile_mfma(std::integral_constant<int, FW_TPW>{});
+        // (ONE instantiation of the MFMA stream: with a shorter one for the waves that own a tap fewer in a branch, the register
+        // allocator moved accumulators between AGPRs and VGPRs at every merge -- 250-330 spills)
+        tile_mfma();
     }
 
     // slab store: part[strip][tap][ci][co]
 #pragma unroll
     for (int tt = 0; tt < FW_TPW; ++tt) {
         const int tap = wave + FW_WAVES * tt;
-        if (tap > 26) break;
-        float* dst = a.part + (((long long)strip * a.ntaps_total + tap) * a.Cin + ci0 + 4 * g) * a.Cout + co0 + li;
+        float* dst = a.part + (((long long)strip * a.ntaps_total + plane * NTAPS + tap) * a.Cin + ci0 + 4 * g) * a.Cout + co0 + li;
+        if (tap <= NTAPS - 1) {
 #pragma unroll
-        for (int ab = 0; ab < 8; ++ab)
+            for (int ab = 0; ab < 8; ++ab)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                dst[(long long)(16 * (ab >> 2) + e) * a.Cout + 16 * (ab & 3)] = __builtin_ldexpf(acc[tt][ab >> 2][ab & 3][e], -(sx + sd));
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[tt][ab >> 2][ab & 3][e];
+                    if constexpr (F32) v = __builtin_ldexpf(v, -(sx + sd));
+                    dst[(long long)(16 * (ab >> 2) + e) * a.Cout + 16 * (ab & 3)] = v;
+                }
+        }
     }
 }
 
@@ -648,7 +662,7 @@ struct LWgradPlan { int KS, BX, ntx, nty, ntz, ntiles, nstrips, npairs, taps, pl
 // D, H, W: OUTPUT extents (the space the tiles are cut in)
 static bool lwgrad_plan(int math, int KS, int stride, int N, int D, int H, int W, int Cin, int Cout, LWgradPlan* p, bool wide = false) {
     if ((KS != 3 && KS != 5) || Cin % 32 || Cout % 32 || W < 4) return false;
-    if (wide && (math != MATH_X3 || KS != 3 || stride != 1 || Cout % 64)) return false;
+    if (wide && (stride != 1 || Cout % 64 || (math == MATH_X3 && KS != 3))) return false;
     if (stride != 1 && !(stride == 2 && KS == 3 && math == MATH_B16)) return false;
     const int vox = (math == MATH_X3 || stride == 2) ? 128 : 256;
     int BX = 0; long long best = -1;
@@ -721,6 +735,13 @@ static void launch_lwgrad(const LWgradArgs& a, int nwg, hipStream_t st) {
     hipLaunchKernelGGL((conv_wgrad_lowp_kernel<BX, KS, NP, IN_T, S>), dim3(nwg), dim3(LW_THREADS), T::LDS_BYTES, st, a);
 }
 
+template <int BX, int KS, typename IN_T>
+static void launch_wide(const LWgradArgs& a, int nwg, hipStream_t st) {
+    using F = FTile<BX, KS, std::is_same<IN_T, float>::value ? 2 : 1>;
+    SEG_SET_LDS((conv_wgrad_wide_kernel<BX, KS, IN_T>), F::LDS_BYTES);
+    hipLaunchKernelGGL((conv_wgrad_wide_kernel<BX, KS, IN_T>), dim3(nwg), dim3(FW_THREADS), F::LDS_BYTES, st, a);
+}
+
 template <int KS>
 static void dispatch_lwgrad(int math, const LWgradPlan& p, const LWgradArgs& a, int nwg, hipStream_t st) {
     if (math == MATH_X3 && a.amax_x) {
@@ -741,7 +762,7 @@ int conv_wgrad_lowp(int math, const void* dy, int lddy, const void* x, int ldx, 
     LWgradPlan p;
     const int pad = k / 2, Do = lw_out(D, k, stride, pad), Ho = lw_out(H, k, stride, pad), Wo = lw_out(W, k, stride, pad);
     // f16x3, k3 s1, Cout % 64 == 0: the wide kernel (mi355seg_set_wgrad_wide)
-    const bool wide = g_wgrad_wide != 0 && math == MATH_X3 && x3_f16() && lwgrad_plan(math, k, stride, N, Do, Ho, Wo, Cin, Cout, &p, true);
+    const bool wide = g_wgrad_wide != 0 && (math == MATH_B16 || (math == MATH_X3 && x3_f16())) && lwgrad_plan(math, k, stride, N, Do, Ho, Wo, Cin, Cout, &p, true);
     SEG_CHECK_ARG(wide || lwgrad_plan(math, k, stride, N, Do, Ho, Wo, Cin, Cout, &p), "conv_wgrad_lowp: unsupported shape");
     SEG_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, "conv_wgrad_lowp: pointers must be 16-byte aligned");
     Carver cv(ws);
@@ -767,8 +788,9 @@ int conv_wgrad_lowp(int math, const void* dy, int lddy, const void* x, int ldx, 
     {
         ProfScope ps(PF_WGRAD, 2.0 * vox * p.taps * Cin * Cout, (math == MATH_B16 ? 2.0 : 4.0) * vox * (Cin + Cout) + 4.0 * p.taps * Cin * Cout, st);
         if (wide) {
-            if (p.BX == 16) { SEG_SET_LDS((conv_wgrad_f16w_kernel<16>), FTile<16>::LDS_BYTES); hipLaunchKernelGGL((conv_wgrad_f16w_kernel<16>), dim3(nwg), dim3(FW_THREADS), FTile<16>::LDS_BYTES, st, a); }
-            else { SEG_SET_LDS((conv_wgrad_f16w_kernel<8>), FTile<8>::LDS_BYTES); hipLaunchKernelGGL((conv_wgrad_f16w_kernel<8>), dim3(nwg), dim3(FW_THREADS), FTile<8>::LDS_BYTES, st, a); }
+            if (math == MATH_X3) { if (p.BX == 16) launch_wide<16, 3, float>(a, nwg, st); else launch_wide<8, 3, float>(a, nwg, st); }
+            else if (k == 3) { if (p.BX == 32) launch_wide<32, 3, bf16>(a, nwg, st); else if (p.BX == 16) launch_wide<16, 3, bf16>(a, nwg, st); else launch_wide<8, 3, bf16>(a, nwg, st); }
+            else { if (p.BX == 32) launch_wide<32, 5, bf16>(a, nwg, st); else if (p.BX == 16) launch_wide<16, 5, bf16>(a, nwg, st); else launch_wide<8, 5, bf16>(a, nwg, st); }
         }
         else if (k == 3 && stride == 2) {
             if (p.BX == 32) launch_lwgrad<32, 3, 1, bf16, 2>(a, nwg, st);
