@@ -693,9 +693,17 @@ static bool lwgrad_plan(int math, int KS, int stride, int N, int D, int H, int W
 
 static int lw_out(int n, int k, int s, int p) { return (n + 2 * p - k) / s + 1; }
 
+// the tile pieces are addressed by 32-bit byte offsets from the tile's first (halo) voxel on a buffer descriptor: the deepest halo (ten
+// planes of the input, eight of the output gradient) must stay below the descriptor's 2 GB range
+static bool lw_offsets_fit(int math, int H, int W, int ldx, int Ho, int Wo, int lddy) {
+    const long long esz = math == MATH_B16 ? 2 : 4;
+    return 10ll * (H + 8) * (W + 8) * ldx * esz < 0x7FFF0000ll && 8ll * (Ho + 8) * (Wo + 8) * lddy * esz < 0x7FFF0000ll;
+}
+
 bool wgrad_lowp_supported(int math, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int lddy) {
     const int al = math == MATH_B16 ? 8 : 4;
     if (!((k == 3 && pad == 1) || (k == 5 && pad == 2)) || (ldx % al) || (lddy % al)) return false;
+    if (!lw_offsets_fit(math, H, W, ldx, lw_out(H, k, stride, pad), lw_out(W, k, stride, pad), lddy)) return false;
     LWgradPlan p;
     return lwgrad_plan(math, k, stride, N, lw_out(D, k, stride, pad), lw_out(H, k, stride, pad), lw_out(W, k, stride, pad), Cin, Cout, &p);
 }
@@ -765,6 +773,7 @@ int conv_wgrad_lowp(int math, const void* dy, int lddy, const void* x, int ldx, 
     const bool wide = g_wgrad_wide != 0 && (math == MATH_B16 || (math == MATH_X3 && x3_f16())) && lwgrad_plan(math, k, stride, N, Do, Ho, Wo, Cin, Cout, &p, true);
     SEG_CHECK_ARG(wide || lwgrad_plan(math, k, stride, N, Do, Ho, Wo, Cin, Cout, &p), "conv_wgrad_lowp: unsupported shape");
     SEG_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, "conv_wgrad_lowp: pointers must be 16-byte aligned");
+    SEG_CHECK_ARG(lw_offsets_fit(math, H, W, ldx, Ho, Wo, lddy), "conv_wgrad_lowp: a tile's halo spans more than 2 GB (wgrad_lowp_supported says so)");
     Carver cv(ws);
     float* part = cv.take<float>((size_t)p.nstrips * p.taps * Cin * Cout);
     const bool f16 = math == MATH_X3 && x3_f16();
