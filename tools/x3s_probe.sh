@@ -4,9 +4,9 @@
 # 16 halo pieces not requested (stale registers are converted and written), 4 no conversion / LDS writes (barriers kept)
 export MI355SEG_LIB_PATH=$PWD/ab/tune.so
 export MI355SEG_NO_X3W=${NO_X3W:-1}
-for shp in "2 128 128 128 64 32" "2 64 64 64 128 64"; do
+for shp in "${SHAPE1:-2 128 128 128 64 32}" "${SHAPE2:-2 64 64 64 128 64}"; do
   for d in ${PROBES:-0 1 2 8 3 11}; do
     echo "== $shp  MI355SEG_DBG=$d"
-    MI355SEG_DBG=$d python tools/bench_layer.py $shp 3 20 --conv-math f16x3 2>&1 | grep "fwd\|dgrad"
+    MI355SEG_DBG=$d python tools/bench_layer.py $shp 3 20 --conv-math f16x3 2>&1 | grep "fwd\|dgrad\|rror"
   done
 done
