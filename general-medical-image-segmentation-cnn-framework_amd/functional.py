@@ -916,14 +916,20 @@ class _Act(Function):
         y = torch.empty((N, D, H, W, C), dtype=x.dtype, device=x.device)
         rows = N * D * H * W
         lib().call("mi355seg_act_fwd_" + _sfx(x), _p(x), ldx, _p(res), ldres, _p(y), C, rows, C, act, slope, _stream())
-        ctx.save_for_backward(x, res)
         ctx.cfg = (ldx, ldres, rows, C, act, slope)
+        ctx.has_res = res is not None
+        ctx.x_dtype = x.dtype
+        if act != ACT_NONE:                  # a plain sum needs nothing for its backward
+            ctx.save_for_backward(x, res)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, res = ctx.saved_tensors
         ldx, ldres, rows, C, act, slope = ctx.cfg
+        if act == ACT_NONE:                  # x + residual: the gradient of both is dy itself -- no kernel, no copy
+            g = dy if dy.dtype == ctx.x_dtype else dy.to(ctx.x_dtype)
+            return g, (g if ctx.has_res else None), None, None
+        x, res = ctx.saved_tensors
         dy, lddy = cl_view(_like(dy, x), "activation grad")
         dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
         lib().call("mi355seg_act_bwd_" + _sfx(x), _p(dy), lddy, _p(x), ldx, _p(res), ldres, _p(dx), C, rows, C, act, slope, _stream())
