@@ -212,11 +212,13 @@ __global__ __launch_bounds__(256, 2) void conv_b16s_kernel(IgemmArgs a) {
                 *reinterpret_cast<f32x4*>(yslab + off) = acc[j][0];
                 *reinterpret_cast<f32x4*>(yslab + off + 4) = acc[j][1];
             } else {
-                bf16x8_t o;
+                bf16x8_t o, rs = {};
+                if (a.res) rs = *reinterpret_cast<const bf16x8_t*>(reinterpret_cast<const bf16*>(a.res) + ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.ldres + cbase);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     float v = acc[j][c >> 2][c & 3] + bv[c];
                     if (a.act) v = act_apply(v, a.act, a.slope);
+                    if (a.res) v = (float)(bf16)v + (float)rs[c];       // the convolution's own bf16 rounding, then the sum's
                     o[c] = (bf16)v; ssum[c] += v;
                 }
                 *reinterpret_cast<bf16x8_t*>(yout + off) = o;

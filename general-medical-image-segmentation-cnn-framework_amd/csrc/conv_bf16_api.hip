@@ -140,6 +140,26 @@ int mi355seg_conv3d_fwd_fused_bf16(const mi355seg_bf16* x, int ldx, const float*
     return conv_fwd_mfma(MATH_B16, x, ldx, w, oshift, y, ldy, N, D, H, W, Cin, Cout, k, /*dgrad=*/0, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream, oscale, act, slope);
 }
 
+// y = conv(x) + res as the reference's two bf16 operations give it (each rounded to bf16): the sum rides in the convolution's epilogue
+// where the launch allows (conv_b16s tiles, whole-K), else the activation kernel adds it in place
+int mi355seg_conv3d_fwd_res_bf16(const mi355seg_bf16* x, int ldx, const float* w, const float* bias, const mi355seg_bf16* res, int ldres,
+                                 mi355seg_bf16* y, int ldy, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                                 void* ws, size_t ws_bytes, void* stream) {
+    SEG_CHECK_ARG(res && ldres >= Cout, "conv3d_fwd_res_bf16: null residual or pitch < channels");
+    hipStream_t st = (hipStream_t)stream;
+    const int Do = oext(D, k, stride, pad), Ho = oext(H, k, stride, pad), Wo = oext(W, k, stride, pad);
+    if (x && y && native_fwd(N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy) == NB_IGEMM && ((uintptr_t)x % 16) == 0) {
+        int fused = 0;
+        int rc = conv_fwd_mfma(MATH_B16, x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, /*dgrad=*/0, nullptr, nullptr, ws, ws_bytes, st,
+                               nullptr, 0, 0.f, nullptr, nullptr, nullptr, res, ldres, &fused);
+        if (rc || fused) return rc;
+    } else {
+        int rc = mi355seg_conv3d_fwd_bf16(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, stride, pad, nullptr, nullptr, ws, ws_bytes, stream);
+        if (rc) return rc;
+    }
+    return mi355seg_act_fwd_bf16(y, ldy, res, ldres, y, ldy, (long long)N * Do * Ho * Wo, Cout, 0, 0.f, stream);
+}
+
 int mi355seg_conv3d_fwd_bf16(const mi355seg_bf16* x, int ldx, const float* w, const float* bias, mi355seg_bf16* y, int ldy,
                              int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad,
                              double* stats_sum, double* stats_sq, void* ws, size_t ws_bytes, void* stream) {

@@ -527,8 +527,10 @@ static double matrix_bytes(int math, double act_elems, double w_elems) { return 
 // and the bias vector, the activation applied in the epilogue (or in the split-K reduce), no normalise pass
 int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int N, int D, int H, int W,
                   int Cin, int Cout, int k, int dgrad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st,
-                  const float* oscale, int act, float slope, BnBwdEpi* bne, const float* x_amax, const float* w_amax) {
+                  const float* oscale, int act, float slope, BnBwdEpi* bne, const float* x_amax, const float* w_amax, const void* res, int ldres,
+                  int* res_fused) {
     IgemmPlan p;
+    if (res_fused) *res_fused = 0;
     SEG_CHECK_ARG(igemm_plan(math, k, N, D, H, W, Cin, Cout, 1, &p), "conv_fwd_mfma: unsupported shape");
     SEG_CHECK_ARG(((uintptr_t)x % 16) == 0, "conv_fwd_mfma: input pointer must be 16-byte aligned");
     const int T = k * k * k;
@@ -582,6 +584,7 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
     a.Di = a.Do = D; a.Hi = a.Ho = H; a.Wi = a.Wo = W;
     a.act = ksplit > 1 ? 0 : act; a.slope = slope;
     if (f16) { a.amax_x = x_amax; a.amax_w = w_amax; }
+    if (res && res_fused && b16s && ksplit == 1 && !ssum && (ldres % 8) == 0 && ((uintptr_t)res % 16) == 0) { a.res = res; a.ldres = ldres; *res_fused = 1; }
     if (bn_epi) {
         a.bnx = bne->x; a.ldbnx = bne->ldx; a.bn_mean = bne->mean; a.bn_rstd = bne->rstd; a.bn_gamma = bne->gamma; a.bn_beta = bne->beta;
         a.bn_act = bne->act; a.bn_slope = bne->slope; a.bnpart = bnpart;

@@ -117,6 +117,9 @@ struct IgemmArgs {
     float* bnpart;
     // ---- f16x3 (conv_x3s.hip): device pointers to upper bounds of max |x| and max |w|; amax_x != nullptr selects that form
     const float* amax_x; const float* amax_w;
+    // ---- residual sum in the epilogue (conv_b16s.hip, whole-K launches): y = bf16(bf16(conv + bias) + res), the value of the reference's
+    // separate `conv(x) + res` on bf16 tensors (residual_unet3d.py:121,140-168); res has y's geometry at pitch ldres
+    const void* res; int ldres;
 };
 
 

@@ -117,7 +117,9 @@ bool tile_stats_finalize2(const float* spart, int nM, int C, double* sum, double
 int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int N, int D, int H, int W,
                   int Cin, int Cout, int k, int dgrad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st,
                   const float* oscale = nullptr, int act = 0, float slope = 0.f, BnBwdEpi* bne = nullptr,
-                  const float* x_amax = nullptr, const float* w_amax = nullptr);
+                  const float* x_amax = nullptr, const float* w_amax = nullptr, const void* res = nullptr, int ldres = 0, int* res_fused = nullptr);
+// (res: a tensor of y's geometry to add to the result; *res_fused = 1 when the launch took it into its epilogue -- bf16 16x16x32 tiles,
+// whole-K, no statistics --, else 0 and the caller adds it)
 // max |x| of a rows x C tensor at pitch ld (times |rowscale[row]| when given), max-combined into the zeroed device scalar *slot
 void tensor_amax(const float* x, int ld, long long rows, int C, const float* rowscale, float* slot, hipStream_t st);
 bool conv_fwd_takes_amax(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad);

@@ -8,6 +8,7 @@ Activations inside the package are channel-last: a 5-D fp32 tensor of logical sh
 [N, D, H, W, C] whose last stride is 1 and whose voxel pitch (stride of W) may exceed C
 (a channel slice of a wider concat buffer).
 """
+import os
 import threading
 
 import torch
@@ -334,7 +335,7 @@ def _weight_amax(w):
 # ----------------------------------------------------------------------------- conv
 class _Conv3d(Function):
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad):
+    def forward(ctx, x, w, b, stride, pad, res=None):
         xa_in = _get_amax(x)
         x, ldx = cl_view(x, "conv3d input")
         N, D, H, W, Cin = x.shape
@@ -355,11 +356,18 @@ class _Conv3d(Function):
             L.call("mi355seg_conv3d_fwd_ax_f32", _p(x), ldx, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
                    None, None, _p(xa), _p(wa), _p(ws), ws.numel(), _stream())
             ctx.amax = (xa, wa)
+        elif res is not None:                # bf16: conv(x) + res, the sum in the convolution's epilogue where the launch allows
+            res, ldres = cl_view(res, "conv3d residual")
+            if res.shape != y.shape or res.dtype != x.dtype:
+                raise Mi355SegError(f"conv3d: residual {tuple(res.shape)} {res.dtype} does not match the output {tuple(y.shape)} {x.dtype}")
+            L.call("mi355seg_conv3d_fwd_res_bf16", _p(x), ldx, _p(w), _p(b), _p(res), ldres, _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
+                   _p(ws), ws.numel(), _stream())
         else:
             L.call("mi355seg_conv3d_fwd_" + _sfx(x), _p(x), ldx, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
                    None, None, _p(ws), ws.numel(), _stream())
         ctx.save_for_backward(x, w)
         ctx.geom = (N, D, H, W, Cin, Cout, k, stride, pad, ldx, b is not None)
+        ctx.has_res = res is not None
         return y
 
     @staticmethod
@@ -385,7 +393,7 @@ class _Conv3d(Function):
                 db = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_b else None
                 L.call("mi355seg_conv3d_wgrad_ax_f32", _p(dy), lddy, _p(x), ldx, _p(dw), _p(db), N, D, H, W, Cin, Cout, k, stride, pad,
                        0, _p(da), _p(xa), _p(ws), ws.numel(), _stream())
-            return dx, dw, db, None, None
+            return dx, dw, db, None, None, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((N, D, H, W, Cin), dtype=x.dtype, device=x.device)
             L.call("mi355seg_conv3d_dgrad_" + _sfx(x), _p(dy), lddy, _p(w), _p(dx), Cin, N, D, H, W, Cin, Cout, k, stride, pad,
@@ -395,12 +403,17 @@ class _Conv3d(Function):
             db = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_b else None
             L.call("mi355seg_conv3d_wgrad_" + _sfx(x), _p(dy), lddy, _p(x), ldx, _p(dw), _p(db), N, D, H, W, Cin, Cout, k, stride, pad,
                    0, _p(ws), ws.numel(), _stream())
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, (dy if ctx.has_res else None)        # d(conv + res) / d res = dy itself
 
 
-def conv3d(x, weight, bias=None, stride=1, padding=0):
-    """nn.Conv3d on a channel-last tensor (cubic kernel, isotropic stride/padding)."""
-    return _Conv3d.apply(x, weight, bias, int(stride), int(padding))
+def conv3d(x, weight, bias=None, stride=1, padding=0, residual=None):
+    """nn.Conv3d on a channel-last tensor (cubic kernel, isotropic stride/padding); residual: conv(x) + residual (bf16 tensors: one
+    launch where the convolution's epilogue can take the sum, mi355seg_conv3d_fwd_res_bf16)."""
+    if residual is None:
+        return _Conv3d.apply(x, weight, bias, int(stride), int(padding))
+    if x.dtype == torch.bfloat16 and residual.dtype == torch.bfloat16 and not os.environ.get("MI355SEG_NO_RES_EPILOGUE"):
+        return _Conv3d.apply(x, weight, bias, int(stride), int(padding), residual)
+    return activation(_Conv3d.apply(x, weight, bias, int(stride), int(padding)), ACT_NONE, residual=residual)
 
 
 class _ConvT3dK2S2(Function):

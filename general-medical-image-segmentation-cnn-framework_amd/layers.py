@@ -21,10 +21,11 @@ def _iso(v, what):
 class Conv3d(nn.Conv3d):
     """nn.Conv3d (cubic kernel, isotropic stride/padding, dilation 1, groups 1)."""
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """residual: conv(x) + residual in one launch where the kernel allows (functional.conv3d)."""
         if self.groups != 1 or _iso(self.dilation, "dilation") != 1 or self.padding_mode != "zeros":
             raise NotImplementedError("Conv3d: only groups=1, dilation=1, zero padding are implemented")
-        return F.conv3d(x, self.weight, self.bias, _iso(self.stride, "stride"), _iso(self.padding, "padding"))
+        return F.conv3d(x, self.weight, self.bias, _iso(self.stride, "stride"), _iso(self.padding, "padding"), residual=residual)
 
 
 class ConvTranspose3d(nn.ConvTranspose3d):

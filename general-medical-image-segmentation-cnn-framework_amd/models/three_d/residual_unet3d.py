@@ -19,9 +19,9 @@ _LRELU = (F.ACT_LRELU, 0.01)
 class _NormLreluConv(nn.Sequential):
     """[InstanceNorm3d, LeakyReLU, Conv3d] with the norm and activation fused (keys '.2.weight')."""
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
         norm, _act, conv = self.children()
-        return conv(norm.forward_act(x, *_LRELU))
+        return conv(norm.forward_act(x, *_LRELU), residual=residual)       # residual: the block's sum rides in the convolution
 
 
 class _ConvNormLrelu(nn.Sequential):
@@ -112,16 +112,15 @@ class UNet(nn.Module):
         h = self.conv3d_c1_1(h)
         res = h
         h = self.conv3d_c1_2(self.lrelu(h))
-        h = self.lrelu_conv_c1(self.dropout3d(h))
-        h = F.activation(h, F.ACT_NONE, residual=res)
+        act1, conv1 = self.lrelu_conv_c1.children()
+        h = conv1(act1(self.dropout3d(h)), residual=res)       # (:121) conv + residual in one launch
         ctx = [self.lrelu(h)]
         h = self.inorm3d_c1.forward_act(h, *_LRELU)
         for lvl in (2, 3, 4, 5):                               # (:123-168)
             h = getattr(self, f"conv3d_c{lvl}")(h)
             res = h
             blk = getattr(self, f"norm_lrelu_conv_c{lvl}")     # shared weights, applied twice
-            h = blk(self.dropout3d(blk(h)))
-            h = F.activation(h, F.ACT_NONE, residual=res)
+            h = blk(self.dropout3d(blk(h)), residual=res)       # (:131,:141,...) the residual sum in the second convolution's epilogue
             if lvl < 5:
                 h = getattr(self, f"inorm3d_c{lvl}").forward_act(h, *_LRELU)
                 ctx.append(h)

@@ -516,6 +516,10 @@ int mi355seg_repeat_channels_bwd_bf16(const mi355seg_bf16* dy, int lddy, mi355se
 int mi355seg_add_bias_bf16(mi355seg_bf16* y, int ldy, const float* bias, long long rows, int C, void* stream);
 size_t mi355seg_conv3d_ws_bytes_bf16(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad);
 int mi355seg_conv3d_fwd_bf16(const mi355seg_bf16* x, int ldx, const float* w, const float* bias, mi355seg_bf16* y, int ldy, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, double* stats_sum, double* stats_sq, void* ws, size_t ws_bytes, void* stream);
+/* y = conv(x) + res on bf16 tensors, each of the two operations rounded to bf16 as the reference's `conv(...) + residual` under autocast
+ * (/root/reference/models/three_d/residual_unet3d.py:121,140-168): the sum rides in the convolution's epilogue where the launch allows
+ * (k3 / k5 s1 on the 16x16x32 tiles, whole-K), else the library adds it in place after the convolution.  res: y's geometry at pitch ldres. */
+int mi355seg_conv3d_fwd_res_bf16(const mi355seg_bf16* x, int ldx, const float* w, const float* bias, const mi355seg_bf16* res, int ldres, mi355seg_bf16* y, int ldy, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
 int mi355seg_conv3d_dgrad_bf16(const mi355seg_bf16* dy, int lddy, const float* w, mi355seg_bf16* dx, int lddx, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
 int mi355seg_conv3d_wgrad_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, float* dw, float* db, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, void* stream);
 int mi355seg_cast_f32_to_bf16(const float* src, int ldsrc, mi355seg_bf16* dst, int lddst, long long rows, int C, void* stream);
