@@ -589,6 +589,36 @@ def test_f16x3_wide_weight_gradient(seg, case):
     assert float((got[2] - got[0]).abs().max()) < 1e-6 * sc
 
 
+def test_f16x3_wide_weight_gradient_at_cfg2_size(seg):
+    """BASELINE cfg 2's largest layer the wide kernel takes (2 x 128^3, 32 -> 64) at full size, through two size-independent properties:
+    the wide and the 8-wave kernel sum the same 8.4 M products per element in different fp32 orders (each is within 3e-6 of the fp64 value
+    by the small-shape tests: 6e-6 of the scale between them), and the weight gradient is linear in the output gradient
+    (dW(g1 + 2 g2) = dW(g1) + 2 dW(g2) to the same bar)."""
+    F = seg.functional
+    N, D, Cin, Cout = 2, 128, 32, 64
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(N, D, D, D, Cin, device="cuda", generator=gen)
+    g1 = torch.randn(N, D, D, D, Cout, device="cuda", generator=gen) * 1e-6
+    g2 = torch.randn(N, D, D, D, Cout, device="cuda", generator=gen) * 1e-6
+    w = (torch.randn(Cout, Cin, 3, 3, 3, device="cuda", generator=gen) * 0.05).requires_grad_(True)
+
+    def dw(g, mode):
+        seg.set_wgrad_wide(mode)
+        try:
+            w.grad = None
+            F.conv3d(x, w, None, 1, 1).backward(g)
+            return w.grad.double()
+        finally:
+            seg.set_wgrad_wide(1)
+
+    a1, a0 = dw(g1, 1), dw(g1, 0)
+    sc = float(a0.abs().max())
+    assert float((a1 - a0).abs().max()) < 6e-6 * sc
+    b1 = dw(g2, 1)
+    c1 = dw(g1 + 2 * g2, 1)
+    assert float((c1 - (a1 + 2 * b1)).abs().max()) < 6e-6 * float(c1.abs().max())
+
+
 @pytest.mark.parametrize("xs,ws,tail", [(1.0, 1.0, 0.0), (1e-8, 1.0, 0.0), (3e-30, 0.02, 0.0), (1e6, 1e-3, 0.0), (1e18, 1e12, 0.0), (1.0, 1.0, 1e3), (1e-9, 1.0, 3e4),
                                         (0.0, 1.0, 0.0)])
 def test_f16x3_is_scale_free(seg, xs, ws, tail):
