@@ -229,6 +229,94 @@ __global__ __launch_bounds__(GD_WAVES * 64) void gemm_direct_kernel(GemmArgs g) 
     }
 }
 
+// ---- the same GEMMs on the bf16 matrix cores (mi355seg_gemm_lowp_f32: the token path under bf16 autocast, where the reference's own
+// nn.Linear / matmul run in bf16, unetr.py:59-138 under torch.autocast): fp32 operands in memory, rounded to bf16 (RNE) in registers,
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation, fp32 result.  A lane holds EIGHT consecutive k of its row / column per MFMA
+// (k = 16 j + 8 h + e): two float4 loads where the operand is contiguous along k, eight coalesced dword loads otherwise; one MFMA
+// does the work of eight fp32 ones.  K % 8 == 0 (host): a lane's group of eight is inside K or wholly past it (zeros).
+template <bool AK, bool BK>
+__global__ __launch_bounds__(GD_WAVES * 64) void gemm_direct_lowp_kernel(GemmArgs g) {
+    __shared__ float red[GD_WAVES * 1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, i = lane & 31;
+    const int b0 = blockIdx.z / g.nb1, b1 = blockIdx.z % g.nb1;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int arow = min(m0 + i, g.M - 1), bcol = min(n0 + i, g.N - 1);
+    const float* __restrict__ ap = g.A + b0 * g.a_b0 + b1 * g.a_b1 + (long long)arow * g.a_rs;
+    const float* __restrict__ bp = g.B + b0 * g.b_b0 + b1 * g.b_b1 + (long long)bcol * g.b_cs;
+    const int nblk = (g.K + 15) / 16;
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+    auto ld8 = [&](const float* __restrict__ base, long long kstride, bool contiguous, int j, float (&r)[8]) {
+        const int k = 16 * j + 8 * h;
+        if (k >= g.K) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = 0.f;
+            return;
+        }
+        if (contiguous) {
+            const float4 q0 = *reinterpret_cast<const float4*>(base + k), q1 = *reinterpret_cast<const float4*>(base + k + 4);
+            r[0] = q0.x; r[1] = q0.y; r[2] = q0.z; r[3] = q0.w; r[4] = q1.x; r[5] = q1.y; r[6] = q1.z; r[7] = q1.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = base[(long long)(k + e) * kstride];
+        }
+    };
+    constexpr int U = 2;
+    float ra[3][U][8], rb[3][U][8];
+    const int mine = nblk > wave ? (nblk - wave + GD_WAVES - 1) / GD_WAVES : 0;    // 16-deep k-blocks of this wave: wave, wave + 4, ...
+    const int trips = (mine + U - 1) / U;
+    auto fetch = [&](int jt, float (&xa)[U][8], float (&xb)[U][8]) {
+        if (jt >= trips) return;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = min(wave + GD_WAVES * (jt * U + u), nblk - 1);
+            ld8(ap, g.a_cs, AK, j, xa[u]); ld8(bp, g.b_rs, BK, j, xb[u]);
+        }
+    };
+    auto mm = [&](int jt, const float (&xa)[U][8], const float (&xb)[U][8]) {
+        if (jt >= trips) return;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (jt * U + u < mine) {
+                bf16x8_t va, vb;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { va[e] = (bf16)xa[u][e]; vb[e] = (bf16)xb[u][e]; }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, vb, acc, 0, 0, 0);
+            }
+    };
+    fetch(0, ra[0], rb[0]);
+    fetch(1, ra[1], rb[1]);
+    for (int jt = 0; jt < trips; jt += 3) {
+        fetch(jt + 2, ra[2], rb[2]);
+        mm(jt, ra[0], rb[0]);
+        fetch(jt + 3, ra[0], rb[0]);
+        mm(jt + 1, ra[1], rb[1]);
+        fetch(jt + 4, ra[1], rb[1]);
+        mm(jt + 2, ra[2], rb[2]);
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) red[wave * 1024 + ((v & 3) + 8 * (v >> 2) + 4 * h) * 32 + i] = acc[v];
+    __syncthreads();
+    float* C = g.C + b0 * g.c_b0 + b1 * g.c_b1;
+#pragma unroll
+    for (int q = 0; q < 1024 / (GD_WAVES * 64); ++q) {
+        const int e = q * GD_WAVES * 64 + tid, r = e >> 5, c = e & 31;
+        if (m0 + r < g.M && n0 + c < g.N) {
+            float sum = red[e];
+#pragma unroll
+            for (int w = 1; w < GD_WAVES; ++w) sum += red[w * 1024 + e];           // wave order: deterministic
+            float* dst = C + (long long)(m0 + r) * g.c_rs + n0 + c;
+            float val = g.alpha * sum + (g.bias ? g.bias[n0 + c] : 0.f);
+            if (g.accumulate) val += *dst;
+            if (g.relu) val = val > 0.f ? val : 0.f;
+            *dst = val;
+        }
+    }
+}
+
+
 __global__ __launch_bounds__(256) void gemm_splitk_epilogue(GemmArgs g) {
     const long long total = (long long)g.M * g.N;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
@@ -382,11 +470,11 @@ size_t mi355seg_gemm_ws_bytes(int M, int N, int K, int nb0, int nb1) {
     return S > 1 ? (size_t)S * M * N * sizeof(float) : 0;
 }
 
-int mi355seg_gemm_f32(const float* A, long long a_rs, long long a_cs, long long a_b0, long long a_b1,
-                      const float* B, long long b_rs, long long b_cs, long long b_b0, long long b_b1,
-                      float* C, long long c_rs, long long c_b0, long long c_b1, const float* bias,
-                      int M, int N, int K, int nb0, int nb1, float alpha, int relu, int accumulate,
-                      void* ws, size_t ws_bytes, void* stream) {
+static int gemm_impl(int lowp, const float* A, long long a_rs, long long a_cs, long long a_b0, long long a_b1,
+                     const float* B, long long b_rs, long long b_cs, long long b_b0, long long b_b1,
+                     float* C, long long c_rs, long long c_b0, long long c_b1, const float* bias,
+                     int M, int N, int K, int nb0, int nb1, float alpha, int relu, int accumulate,
+                     void* ws, size_t ws_bytes, void* stream) {
     SEG_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && nb0 > 0 && nb1 > 0 && (long long)nb0 * nb1 < 4096, "gemm: bad arguments");
     int S, kchunk;
     gemm_plan(M, N, K, nb0 * nb1, S, kchunk);
@@ -400,7 +488,13 @@ int mi355seg_gemm_f32(const float* A, long long a_rs, long long a_cs, long long 
             GemmArgs g{A, B, C, bias, a_rs, a_cs, a_b0, a_b1, b_rs, b_cs, b_b0, b_b1, c_rs, c_b0, c_b1, M, N, K, nb1, alpha, relu, accumulate,
                        1, K, 0, 0, nullptr};
             dim3 grid(cdiv(N, 32), cdiv(M, 32), nb0 * nb1);
-            if (ak && bk) hipLaunchKernelGGL((gemm_direct_kernel<true, true>), grid, dim3(GD_WAVES * 64), 0, (hipStream_t)stream, g);
+            if (lowp) {
+                if (ak && bk) hipLaunchKernelGGL((gemm_direct_lowp_kernel<true, true>), grid, dim3(GD_WAVES * 64), 0, (hipStream_t)stream, g);
+                else if (ak) hipLaunchKernelGGL((gemm_direct_lowp_kernel<true, false>), grid, dim3(GD_WAVES * 64), 0, (hipStream_t)stream, g);
+                else if (bk) hipLaunchKernelGGL((gemm_direct_lowp_kernel<false, true>), grid, dim3(GD_WAVES * 64), 0, (hipStream_t)stream, g);
+                else hipLaunchKernelGGL((gemm_direct_lowp_kernel<false, false>), grid, dim3(GD_WAVES * 64), 0, (hipStream_t)stream, g);
+            }
+            else if (ak && bk) hipLaunchKernelGGL((gemm_direct_kernel<true, true>), grid, dim3(GD_WAVES * 64), 0, (hipStream_t)stream, g);
             else if (ak) hipLaunchKernelGGL((gemm_direct_kernel<true, false>), grid, dim3(GD_WAVES * 64), 0, (hipStream_t)stream, g);
             else if (bk) hipLaunchKernelGGL((gemm_direct_kernel<false, true>), grid, dim3(GD_WAVES * 64), 0, (hipStream_t)stream, g);
             else hipLaunchKernelGGL((gemm_direct_kernel<false, false>), grid, dim3(GD_WAVES * 64), 0, (hipStream_t)stream, g);
@@ -425,6 +519,23 @@ int mi355seg_gemm_f32(const float* A, long long a_rs, long long a_cs, long long 
         SEG_CHECK_LAUNCH();
     }
     return MI355SEG_OK;
+}
+
+int mi355seg_gemm_f32(const float* A, long long a_rs, long long a_cs, long long a_b0, long long a_b1,
+                      const float* B, long long b_rs, long long b_cs, long long b_b0, long long b_b1,
+                      float* C, long long c_rs, long long c_b0, long long c_b1, const float* bias,
+                      int M, int N, int K, int nb0, int nb1, float alpha, int relu, int accumulate,
+                      void* ws, size_t ws_bytes, void* stream) {
+    return gemm_impl(0, A, a_rs, a_cs, a_b0, a_b1, B, b_rs, b_cs, b_b0, b_b1, C, c_rs, c_b0, c_b1, bias, M, N, K, nb0, nb1, alpha, relu, accumulate, ws, ws_bytes, stream);
+}
+// fp32 tensors, products on the bf16 matrix cores (operands rounded to bf16 in registers, fp32 accumulation and result): the small-GEMM
+// kernel only; shapes outside its range run the fp32 kernels
+int mi355seg_gemm_lowp_f32(const float* A, long long a_rs, long long a_cs, long long a_b0, long long a_b1,
+                           const float* B, long long b_rs, long long b_cs, long long b_b0, long long b_b1,
+                           float* C, long long c_rs, long long c_b0, long long c_b1, const float* bias,
+                           int M, int N, int K, int nb0, int nb1, float alpha, int relu, int accumulate,
+                           void* ws, size_t ws_bytes, void* stream) {
+    return gemm_impl(1, A, a_rs, a_cs, a_b0, a_b1, B, b_rs, b_cs, b_b0, b_b1, C, c_rs, c_b0, c_b1, bias, M, N, K, nb0, nb1, alpha, relu, accumulate, ws, ws_bytes, stream);
 }
 
 int mi355seg_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,

@@ -1637,12 +1637,18 @@ def _mul(a, b, out=None):
 
 
 # ----------------------------------------------------------------------------- UNETR encoder ops
+def _lowp_now():
+    """Inside autocast(torch.bfloat16) the token path's GEMMs take bf16 products (fp32 accumulate), as the reference's nn.Linear / matmul do
+    under torch.autocast; a Function records the mode at its forward and keeps it for its backward."""
+    return _AUTOCAST.stack[-1] == torch.bfloat16 and not os.environ.get("MI355SEG_TOKEN_GEMM_FP32")       # (the variable: fp32 products, for A/B timing)
+
+
 def _gemm(A, a_rs, a_cs, a_b0, a_b1, B, b_rs, b_cs, b_b0, b_b1, C, c_rs, c_b0, c_b1, bias, M, N, K, nb0=1, nb1=1,
-          alpha=1.0, relu=0, accumulate=0):
+          alpha=1.0, relu=0, accumulate=0, lowp=False):
     L = lib()
     need = L.query("mi355seg_gemm_ws_bytes", M, N, K, nb0, nb1)
     ws = workspace(need, torch.device("cuda", torch.cuda.current_device())) if need else None
-    L.call("mi355seg_gemm_f32", A, a_rs, a_cs, a_b0, a_b1, B, b_rs, b_cs, b_b0, b_b1, C, c_rs, c_b0, c_b1, bias,
+    L.call("mi355seg_gemm_lowp_f32" if lowp else "mi355seg_gemm_f32", A, a_rs, a_cs, a_b0, a_b1, B, b_rs, b_cs, b_b0, b_b1, C, c_rs, c_b0, c_b1, bias,
            M, N, K, nb0, nb1, alpha, relu, accumulate, _p(ws), ws.numel() if ws is not None else 0, _stream())
 
 
@@ -1651,19 +1657,21 @@ class _Linear(Function):
 
     @staticmethod
     def forward(ctx, x, w, b, relu):
+        lowp = ctx.lowp = _lowp_now()
         _require_cuda(x, "linear input")
         shp = x.shape
         x2 = x.contiguous().view(-1, shp[-1])
         w = w.contiguous()
         M, K, N = x2.shape[0], x2.shape[1], w.shape[0]
         y = torch.empty((M, N), dtype=x.dtype, device=x.device)
-        _gemm(_p(x2), K, 1, 0, 0, _p(w), 1, K, 0, 0, _p(y), N, 0, 0, _p(b), M, N, K, relu=int(relu))
+        _gemm(_p(x2), K, 1, 0, 0, _p(w), 1, K, 0, 0, _p(y), N, 0, 0, _p(b), M, N, K, relu=int(relu), lowp=lowp)
         ctx.save_for_backward(x2, w, y if relu else None)
         ctx.cfg = (shp, M, N, K, bool(relu), b is not None)
         return y.view(*shp[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
+        lowp = ctx.lowp
         x2, w, yrelu = ctx.saved_tensors
         shp, M, N, K, relu, has_b = ctx.cfg
         dy2 = dy.contiguous().view(M, N)
@@ -1672,9 +1680,9 @@ class _Linear(Function):
             lib().call("mi355seg_act_bwd_f32", _p(dy2), N, _p(yrelu), N, None, 0, _p(g), N, M, N, ACT_RELU, 0.0, _stream())
             dy2 = g
         dx = torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
-        _gemm(_p(dy2), N, 1, 0, 0, _p(w), K, 1, 0, 0, _p(dx), K, 0, 0, None, M, K, N)
+        _gemm(_p(dy2), N, 1, 0, 0, _p(w), K, 1, 0, 0, _p(dx), K, 0, 0, None, M, K, N, lowp=lowp)
         dw = torch.empty_like(w)
-        _gemm(_p(dy2), 1, N, 0, 0, _p(x2), K, 1, 0, 0, _p(dw), K, 0, 0, None, N, K, M)
+        _gemm(_p(dy2), 1, N, 0, 0, _p(x2), K, 1, 0, 0, _p(dw), K, 0, 0, None, N, K, M, lowp=lowp)
         db = None
         if has_b:
             L = lib()
@@ -1726,40 +1734,42 @@ class _Attention(Function):
 
     @staticmethod
     def forward(ctx, q, k, v, heads, keep):
+        lowp = ctx.lowp = _lowp_now()
         _require_cuda(q, "attention input")
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         B, P, E = q.shape
         d = E // heads
         alpha = 1.0 / (d ** 0.5)
         scores = torch.empty((B, heads, P, P), dtype=q.dtype, device=q.device)
-        _gemm(_p(q), E, 1, P * E, d, _p(k), 1, E, P * E, d, _p(scores), P, heads * P * P, P * P, None, P, P, d, B, heads, alpha)
+        _gemm(_p(q), E, 1, P * E, d, _p(k), 1, E, P * E, d, _p(scores), P, heads * P * P, P * P, None, P, P, d, B, heads, alpha, lowp=lowp)
         probs = torch.empty_like(scores)
         lib().call("mi355seg_softmax_rows_f32", _p(scores), _p(probs), B * heads * P, P, _stream())
         pd = probs if keep is None else _mul(probs, keep)
         ctxl = torch.empty((B, P, E), dtype=q.dtype, device=q.device)
-        _gemm(_p(pd), P, 1, heads * P * P, P * P, _p(v), E, 1, P * E, d, _p(ctxl), E, P * E, d, None, P, d, P, B, heads)
+        _gemm(_p(pd), P, 1, heads * P * P, P * P, _p(v), E, 1, P * E, d, _p(ctxl), E, P * E, d, None, P, d, P, B, heads, lowp=lowp)
         ctx.save_for_backward(q, k, v, probs, keep)
         ctx.cfg = (B, P, E, heads, d, alpha)
         return ctxl
 
     @staticmethod
     def backward(ctx, do):
+        lowp = ctx.lowp
         q, k, v, probs, keep = ctx.saved_tensors
         B, P, E, heads, d, alpha = ctx.cfg
         do = do.contiguous()
         pd = probs if keep is None else _mul(probs, keep)
         HPP, PP = heads * P * P, P * P
         dpd = torch.empty_like(probs)                                   # dP = dO V^T
-        _gemm(_p(do), E, 1, P * E, d, _p(v), 1, E, P * E, d, _p(dpd), P, HPP, PP, None, P, P, d, B, heads)
+        _gemm(_p(do), E, 1, P * E, d, _p(v), 1, E, P * E, d, _p(dpd), P, HPP, PP, None, P, P, d, B, heads, lowp=lowp)
         dv = torch.empty_like(v)                                        # dV = Pd^T dO
-        _gemm(_p(pd), 1, P, HPP, PP, _p(do), E, 1, P * E, d, _p(dv), E, P * E, d, None, P, d, P, B, heads)
+        _gemm(_p(pd), 1, P, HPP, PP, _p(do), E, 1, P * E, d, _p(dv), E, P * E, d, None, P, d, P, B, heads, lowp=lowp)
         dp = dpd if keep is None else _mul(dpd, keep, out=dpd)
         ds = torch.empty_like(probs)
         lib().call("mi355seg_softmax_rows_bwd_f32", _p(probs), _p(dp), _p(ds), B * heads * P, P, _stream())
         dq = torch.empty_like(q)                                        # dQ = alpha dS K
-        _gemm(_p(ds), P, 1, HPP, PP, _p(k), E, 1, P * E, d, _p(dq), E, P * E, d, None, P, d, P, B, heads, alpha)
+        _gemm(_p(ds), P, 1, HPP, PP, _p(k), E, 1, P * E, d, _p(dq), E, P * E, d, None, P, d, P, B, heads, alpha, lowp=lowp)
         dk = torch.empty_like(k)                                        # dK = alpha dS^T Q
-        _gemm(_p(ds), 1, P, HPP, PP, _p(q), E, 1, P * E, d, _p(dk), E, P * E, d, None, P, d, P, B, heads, alpha)
+        _gemm(_p(ds), 1, P, HPP, PP, _p(q), E, 1, P * E, d, _p(dk), E, P * E, d, None, P, d, P, B, heads, alpha, lowp=lowp)
         return dq, dk, dv, None, None
 
 
@@ -1770,6 +1780,7 @@ class _AttentionQKV(Function):
 
     @staticmethod
     def forward(ctx, qkv, heads, keep):
+        lowp = ctx.lowp = _lowp_now()
         _require_cuda(qkv, "attention input")
         qkv = qkv.contiguous()
         B, P, E3 = qkv.shape
@@ -1778,18 +1789,19 @@ class _AttentionQKV(Function):
         alpha = 1.0 / (d ** 0.5)
         q, k, v = _p(qkv), _p(qkv) + 4 * E, _p(qkv) + 8 * E
         scores = torch.empty((B, heads, P, P), dtype=qkv.dtype, device=qkv.device)
-        _gemm(q, E3, 1, P * E3, d, k, 1, E3, P * E3, d, _p(scores), P, heads * P * P, P * P, None, P, P, d, B, heads, alpha)
+        _gemm(q, E3, 1, P * E3, d, k, 1, E3, P * E3, d, _p(scores), P, heads * P * P, P * P, None, P, P, d, B, heads, alpha, lowp=lowp)
         probs = torch.empty_like(scores)
         lib().call("mi355seg_softmax_rows_f32", _p(scores), _p(probs), B * heads * P, P, _stream())
         pd = probs if keep is None else _mul(probs, keep)
         ctxl = torch.empty((B, P, E), dtype=qkv.dtype, device=qkv.device)
-        _gemm(_p(pd), P, 1, heads * P * P, P * P, v, E3, 1, P * E3, d, _p(ctxl), E, P * E, d, None, P, d, P, B, heads)
+        _gemm(_p(pd), P, 1, heads * P * P, P * P, v, E3, 1, P * E3, d, _p(ctxl), E, P * E, d, None, P, d, P, B, heads, lowp=lowp)
         ctx.save_for_backward(qkv, probs, keep)
         ctx.cfg = (B, P, E, heads, d, alpha)
         return ctxl
 
     @staticmethod
     def backward(ctx, do):
+        lowp = ctx.lowp
         qkv, probs, keep = ctx.saved_tensors
         B, P, E, heads, d, alpha = ctx.cfg
         E3 = 3 * E
@@ -1800,13 +1812,13 @@ class _AttentionQKV(Function):
         dqkv = torch.empty_like(qkv)
         dq, dk, dv = _p(dqkv), _p(dqkv) + 4 * E, _p(dqkv) + 8 * E
         dpd = torch.empty_like(probs)                                   # dP = dO V^T
-        _gemm(_p(do), E, 1, P * E, d, v, 1, E3, P * E3, d, _p(dpd), P, HPP, PP, None, P, P, d, B, heads)
-        _gemm(_p(pd), 1, P, HPP, PP, _p(do), E, 1, P * E, d, dv, E3, P * E3, d, None, P, d, P, B, heads)             # dV = Pd^T dO
+        _gemm(_p(do), E, 1, P * E, d, v, 1, E3, P * E3, d, _p(dpd), P, HPP, PP, None, P, P, d, B, heads, lowp=lowp)
+        _gemm(_p(pd), 1, P, HPP, PP, _p(do), E, 1, P * E, d, dv, E3, P * E3, d, None, P, d, P, B, heads, lowp=lowp)             # dV = Pd^T dO
         dp = dpd if keep is None else _mul(dpd, keep, out=dpd)
         ds = torch.empty_like(probs)
         lib().call("mi355seg_softmax_rows_bwd_f32", _p(probs), _p(dp), _p(ds), B * heads * P, P, _stream())
-        _gemm(_p(ds), P, 1, HPP, PP, k, E3, 1, P * E3, d, dq, E3, P * E3, d, None, P, d, P, B, heads, alpha)          # dQ = alpha dS K
-        _gemm(_p(ds), 1, P, HPP, PP, q, E3, 1, P * E3, d, dk, E3, P * E3, d, None, P, d, P, B, heads, alpha)          # dK = alpha dS^T Q
+        _gemm(_p(ds), P, 1, HPP, PP, k, E3, 1, P * E3, d, dq, E3, P * E3, d, None, P, d, P, B, heads, alpha, lowp=lowp)          # dQ = alpha dS K
+        _gemm(_p(ds), 1, P, HPP, PP, q, E3, 1, P * E3, d, dk, E3, P * E3, d, None, P, d, P, B, heads, alpha, lowp=lowp)          # dK = alpha dS^T Q
         return dqkv, None, None
 
 

@@ -400,6 +400,15 @@ int mi355seg_gemm_f32(const float* A, long long a_rs, long long a_cs, long long 
                       float* C, long long c_rs, long long c_b0, long long c_b1, const float* bias,
                       int M, int N, int K, int nb0, int nb1, float alpha, int relu, int accumulate,
                       void* ws, size_t ws_bytes, void* stream);
+/* The same GEMM with its products on the bf16 matrix cores: fp32 operands rounded to bf16 (RNE) in registers, v_mfma_f32_32x32x16_bf16,
+ * fp32 accumulation and result -- the arithmetic of the reference's nn.Linear / matmul under torch.autocast(bfloat16)
+ * (/root/reference/models/three_d/unetr.py:59-138), used by the token path inside functional.autocast(torch.bfloat16).  Few-hundred-row
+ * shapes (the small-GEMM kernel); other shapes run the fp32 kernels of mi355seg_gemm_f32. */
+int mi355seg_gemm_lowp_f32(const float* A, long long a_rs, long long a_cs, long long a_b0, long long a_b1,
+                      const float* B, long long b_rs, long long b_cs, long long b_b0, long long b_b1,
+                      float* C, long long c_rs, long long c_b0, long long c_b1, const float* bias,
+                      int M, int N, int K, int nb0, int nb1, float alpha, int relu, int accumulate,
+                      void* ws, size_t ws_bytes, void* stream);
 /* Scratch for the deterministic split-K path (single-batch GEMMs with too few 64x64 tiles to fill 256 CUs); 0 when
  * the shape is not split.  With a smaller / NULL workspace the GEMM runs unsplit. */
 size_t mi355seg_gemm_ws_bytes(int M, int N, int K, int nb0, int nb1);

@@ -367,6 +367,45 @@ def test_gemm_strided(seg, case):
     assert torch.equal(C, C2)
 
 
+@pytest.mark.parametrize("case", GEMM_CASES)
+def test_gemm_lowp_matches_bf16_rounded_operands(seg, case):
+    """mi355seg_gemm_lowp_f32 (the token GEMMs inside functional.autocast(torch.bfloat16): fp32 tensors, operands rounded to bf16 in
+    registers, v_mfma_f32_32x32x16_bf16, fp32 accumulation -- the arithmetic of the reference's nn.Linear / matmul under
+    torch.autocast(bfloat16), unetr.py:59-138) against an fp64 matmul of the bf16-ROUNDED operands: the only difference left is the fp32
+    accumulation order.  The cases include K = 216 and 264 (not multiples of the MFMA's 16: the tail lanes read zeros), K = 8 and the
+    shapes outside the small-GEMM kernel's range (those run the fp32 kernels: also within the bar against rounded operands? no --
+    they are compared with the un-rounded product at the bf16 bound)."""
+    M, N, K, ta, tb, has_bias, relu, acc = case
+    F = seg.functional
+    A = rnd(*((K, M) if ta else (M, K)), seed=1).cuda()
+    B = rnd(*((N, K) if tb else (K, N)), seed=2).cuda()
+    bias = rnd(N, seed=3).cuda() if has_bias else None
+    C0 = rnd(M, N, seed=4).cuda()
+    C = C0.clone()
+    a_rs, a_cs = (1, M) if ta else (K, 1)
+    b_rs, b_cs = (1, K) if tb else (N, 1)
+    F._gemm(A.data_ptr(), a_rs, a_cs, 0, 0, B.data_ptr(), b_rs, b_cs, 0, 0, C.data_ptr(), N, 0, 0,
+            None if bias is None else bias.data_ptr(), M, N, K, alpha=0.5, relu=int(relu), accumulate=int(acc), lowp=True)
+
+    def product(a, b):
+        w = 0.5 * ((a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double()))
+        if has_bias:
+            w = w + bias.double()
+        if acc:
+            w = w + C0.double()
+        return w.clamp_min(0) if relu else w
+    rounded = product(A.bfloat16().float(), B.bfloat16().float())
+    exact = product(A, B)
+    err_r, err_e = float((C.double() - rounded).abs().max()), float((C.double() - exact).abs().max())
+    # either the bf16 kernel ran (fp32-accumulation distance from the rounded product) or the shape fell to the fp32 kernels (exact product)
+    assert min(err_r, err_e) < 2e-5 * max(1.0, K ** 0.5), (err_r, err_e)
+    assert err_e < 2.0 ** -7 * K ** 0.5 * 3.0               # and never further from the true product than bf16 rounding of the operands allows
+    C2 = C0.clone()
+    F._gemm(A.data_ptr(), a_rs, a_cs, 0, 0, B.data_ptr(), b_rs, b_cs, 0, 0, C2.data_ptr(), N, 0, 0,
+            None if bias is None else bias.data_ptr(), M, N, K, alpha=0.5, relu=int(relu), accumulate=int(acc), lowp=True)
+    assert torch.equal(C, C2)
+
+
 @pytest.mark.parametrize("P", [216, 27])
 def test_gemm_batched_attention_shapes(seg, P):
     """Per-(batch, head) Q K^T and P V with the head split expressed in strides (unetr.py:74-98)."""
