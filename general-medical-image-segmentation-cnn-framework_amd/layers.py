@@ -99,7 +99,7 @@ class Dropout3d(nn.Dropout3d):
         if self.forced_masks:
             keep = self.forced_masks.pop(0).to(device=device, dtype=torch.float32).reshape(N, C)
         else:
-            keep = torch.empty((N, C), device=device).bernoulli_(1.0 - self.p)     # one launch (no probability tensor to fill)
+            return torch.nn.functional.dropout(_ones((N, C), device), self.p, True)      # keep / (1 - p) in one launch
         return keep / (1.0 - self.p)
 
     def forward(self, x):
@@ -156,6 +156,17 @@ class LayerNorm(nn.LayerNorm):
         return F.layer_norm(x, self.weight, self.bias, self.eps)
 
 
+_ONES = {}
+
+
+def _ones(shape, device):
+    key = (shape, str(device))
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.ones(shape, device=device)
+    return t
+
+
 class Dropout(nn.Dropout):
     """Element-wise nn.Dropout on token tensors [..., E]; the arithmetic is the channel-scale kernel with one
     "sample" per token row.  ``forced_masks`` as in Dropout3d (mask shape = input shape)."""
@@ -167,7 +178,8 @@ class Dropout(nn.Dropout):
     def draw(self, shape, device):
         if self.forced_masks:
             return self.forced_masks.pop(0).to(device=device, dtype=torch.float32).reshape(shape) / (1.0 - self.p)
-        return torch.empty(shape, device=device).bernoulli_(1.0 - self.p).div_(1.0 - self.p)
+        # one launch: torch's fused dropout on a cached tensor of ones draws the keep mask AND scales it (bernoulli_ + div_ were two)
+        return torch.nn.functional.dropout(_ones(tuple(shape), device), self.p, True)
 
     def forward(self, x):
         if not self.training or self.p == 0.0:
