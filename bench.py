@@ -59,6 +59,31 @@ LEGS = [
 ]
 
 
+LABEL_THRESHOLD = 0.02
+PARITY_GRADS = ["encoder1.enc1conv1.weight", "encoder1.enc1norm1.weight", "bottleneck.bottleneckconv1.weight", "upconv1.weight", "conv.weight", "conv.bias"]
+PARITY_TOL = 1e-4            # north_star: logits / loss / Dice within 1e-4 of the reference's PyTorch-CPU path (fp32)
+PARITY_MARGIN = 2e-4         # a voxel whose reference logit margin is below twice the tolerance is not decisive for the argmax
+
+
+def synthetic_batch(shape, seed, classes=2):
+    """The synthetic batch of SURVEY 8(d): x ~ N(0, 1) (what ZNormalization hands the network, dataloader.py:94) from
+    ``torch.Generator().manual_seed(seed)``, labels = a THRESHOLDED LOW-FREQUENCY FIELD OF THE INPUT (8^3 block means of
+    channel 0, trilinearly interpolated back to the patch; foreground where the field exceeds LABEL_THRESHOLD: about a third of
+    the voxels, in blobs of ~8-16 voxels) -- learnable from x, so the Dice of a step is O(0.1-0.5) and moves with training instead
+    of collapsing to the all-background answer that Bernoulli labels teach.  Built on the CPU by the parent and by the
+    cpu_baseline child alike (same code, same box => same bits; the child reports checksums).  ``classes`` > 2: the field cut
+    at ``classes - 1`` symmetric thresholds."""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(tuple(shape), generator=g)
+    lf = torch.nn.functional.avg_pool3d(x[:, :1], 8, 8)
+    lf = torch.nn.functional.interpolate(lf, size=tuple(shape[2:]), mode="trilinear", align_corners=False)
+    if classes == 2:
+        return x, (lf > LABEL_THRESHOLD).float()
+    cuts = torch.linspace(-1.5 * LABEL_THRESHOLD, 1.5 * LABEL_THRESHOLD, classes - 1)
+    return x, torch.bucketize(lf, cuts)
+
+
 def read_families(L, steps):
     import ctypes
     buf = (ctypes.c_double * 32)()
@@ -125,16 +150,16 @@ def run_leg(L, dev, name, net, shape, classes, loss_kind, flop_per_vox, steps, w
     model.apply(weights_init_normal("kaiming"))
     model = model.to(dev).train()
     opt = make_adam(model.parameters(), lr=1e-3)
-    g = torch.Generator(device="cpu").manual_seed(4321)
-    x = torch.randn((N, C, D, H, W), generator=g).to(dev)
+    x, lab = synthetic_batch((N, C, D, H, W), 4321, classes)
+    x = x.to(dev)
     if classes == 2:
-        gt = (torch.rand((N, 1, D, H, W), generator=g) > 0.9).float().to(dev)
+        gt = lab.to(dev)
 
         def step():
             return train_step(model, opt, x, gt, sync_metric=False, dtype=torch.bfloat16)
         labels = gt.to(torch.int64)
     else:
-        labels = torch.randint(0, classes, (N, 1, D, H, W), generator=g).to(dev)
+        labels = lab.to(dev)
         onehot = torch.cat([(labels == i).float() for i in range(classes)], dim=1)       # data preparation, outside the step
         lab3 = labels[:, 0].contiguous()
         dice_loss = LF.DiceLoss()
@@ -240,9 +265,7 @@ def run_cfg1_leg(dev, conv_math, steps):
     model.apply(weights_init_normal("kaiming"))
     model = model.to(dev).train()
     opt = make_adam(model.parameters(), lr=1e-3)
-    g = torch.Generator(device="cpu").manual_seed(4321)
-    x = torch.randn((1, 1, 64, 64, 64), generator=g).to(dev)
-    gt = (torch.rand((1, 1, 64, 64, 64), generator=g) > 0.9).float().to(dev)
+    x, gt = (t.to(dev) for t in synthetic_batch((1, 1, 64, 64, 64), 4321))
     for _ in range(3):
         out = train_step(model, opt, x, gt, sync_metric=False)
     torch.cuda.synchronize()
@@ -282,9 +305,7 @@ def graph_leg_child(name, steps, gate):
     model.apply(weights_init_normal("kaiming"))
     model = model.to(dev).train()
     opt = make_adam(model.parameters(), lr=1e-3, capturable=True)
-    g = torch.Generator(device="cpu").manual_seed(4321)
-    x = torch.randn((N, C, D, H, W), generator=g).to(dev)
-    gt = (torch.rand((N, 1, D, H, W), generator=g) > 0.9).float().to(dev)
+    x, gt = (t.to(dev) for t in synthetic_batch((N, C, D, H, W), 4321))
     gs = GraphedTrainStep(model, opt, x, gt, warmup=3, dtype=dt)
     for _ in range(2):
         gs(x, gt, sync_metric=False)
@@ -329,7 +350,7 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(sample_shape, steps=3, reserve=0, gate=None):
+def cpu_baseline(sample_shape, steps=3, reserve=0, gate=None, parity_out=None):
     """Oracle (== reference arithmetic on ATen CPU) train step timed on the host cores.  Runs in a child process
     of its own (``--cpu-baseline-child``) that never touches the GPU.  The child is started before the parent's first GPU call
     (a GPU-initialised process must not fork + exec), builds its model, then blocks on ``gate`` (stdin) until the parent has
@@ -344,13 +365,23 @@ def cpu_baseline(sample_shape, steps=3, reserve=0, gate=None):
     m.apply(weights_init_normal("kaiming"))
     m.train()
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)
-    g = torch.Generator().manual_seed(1234)
-    x = torch.randn(sample_shape, generator=g)
-    gt = (torch.rand(sample_shape, generator=g) > 0.9).float()
+    x, gt = synthetic_batch(sample_shape, 1234)               # rank 0's batch of the GPU run (seed 1234 + rank)
     if gate is not None and not gate.readline():          # parent: "go" after its last GPU leg; EOF = the parent is gone
         sys.exit(0)
-    # warm-up at the TIMED shape (oneDNN primitive creation and the first touch of ~20 GB of activations stay out of the timed steps)
-    oracle_step(m, opt, x, gt)
+    # warm-up at the TIMED shape (oneDNN primitive creation and the first touch of ~20 GB of activations stay out of the timed steps).
+    # It is also the FIRST train step from the shared initial weights (manual_seed(0) + kaiming, as the GPU run builds them): its
+    # logits, loss, Dice counters and a few gradients go to ``parity_out`` for the parent's `parity_vs_cpu` block.
+    pred0, mask0, loss0, (jac0, dice0) = oracle_step(m, opt, x, gt)
+    if parity_out:
+        import numpy as np
+        from oracle.metric import confusion_counts
+        c = confusion_counts(gt.numpy(), mask0.numpy())
+        grads = {"grad:" + k: p.grad.detach().numpy() for k, p in m.named_parameters() if k in PARITY_GRADS}
+        np.savez(parity_out, pred=pred0.detach().numpy(), loss=np.float64(loss0.item()), dice=np.float64(dice0), jaccard=np.float64(jac0),
+                 counts=np.array([c["gdth_sum"], c["pred_sum"], c["intersection_sum"], c["union_sum"]], dtype=np.int64),
+                 x_sum=np.float64(x.double().sum().item()), x_abs_sum=np.float64(x.double().abs().sum().item()),
+                 gt_sum=np.int64(gt.sum().item()), **grads)
+    del pred0, mask0, loss0
     times = []
     for _ in range(steps):
         t0 = time.perf_counter()
@@ -360,8 +391,7 @@ def cpu_baseline(sample_shape, steps=3, reserve=0, gate=None):
     vox = x.numel()
     # BASELINE configs[0] (the reference's own CPU-runnable case: batch 1, 64^3, train.py config=unet defaults) on the same cores, and
     # the same steps under torch.autograd.set_detect_anomaly(True), which the reference's loop switches on (train.py:183)
-    x1 = torch.randn((1, 1, 64, 64, 64), generator=g)
-    gt1 = (torch.rand((1, 1, 64, 64, 64), generator=g) > 0.9).float()
+    x1, gt1 = synthetic_batch((1, 1, 64, 64, 64), 4321)
     oracle_step(m, opt, x1, gt1)
     t1 = []
     for _ in range(5):
@@ -386,6 +416,48 @@ def cpu_baseline(sample_shape, steps=3, reserve=0, gate=None):
                       f"process is started before the first GPU call and runs AFTER the last GPU leg (host otherwise idle)"}
 
 
+def parity_vs_cpu(first, parity_file, input_sums):
+    """The metric's second half (BASELINE.json: "Dice vs CPU ref"; /root/reference/train.py:204-221): the GPU run's FIRST train step
+    against the CPU oracle's first step -- same initial weights, same batch, full size.  Untimed."""
+    import numpy as np
+    from mi355seg.utils.metric import metric_from_counts
+    ref = np.load(parity_file)
+    pr, pg = ref["pred"], first["pred"]
+    d = np.abs(pg.astype(np.float64) - pr.astype(np.float64))
+    margin = np.abs(pr[:, 1].astype(np.float64) - pr[:, 0].astype(np.float64))
+    mg, mr = pg.argmax(1), pr.argmax(1)
+    differ = mg != mr
+    decisive = margin > PARITY_MARGIN
+    jac_g, dice_g = metric_from_counts(first["counts"])
+    grads = {}
+    for k, g in first["grads"].items():
+        r = ref["grad:" + k].astype(np.float64)
+        grads[k] = float(np.abs(g.astype(np.float64) - r).max() / max(float(np.abs(r).max()), 1e-30))
+    out = {
+        "what": "first train step (forward, BCE-with-logits, argmax, Dice counters, backward) of the GPU run against the CPU oracle's "
+                "first step (the reference's PyTorch-CPU arithmetic), same initial weights (manual_seed(0) + kaiming), same batch, full size",
+        "voxels_compared": int(d.size), "dlogit_max": float(d.max()), "dlogit_rms": float(np.sqrt((d * d).mean())),
+        "logit_abs_max": float(np.abs(pr).max()),
+        "loss_gpu": first["loss"], "loss_cpu": float(ref["loss"]), "dloss": abs(first["loss"] - float(ref["loss"])),
+        "dice_gpu": dice_g, "dice_cpu": float(ref["dice"]), "ddice": abs(dice_g - float(ref["dice"])),
+        "djaccard": abs(jac_g - float(ref["jaccard"])),
+        "counts_gpu": [int(v) for v in first["counts"]], "counts_cpu": [int(v) for v in ref["counts"]],
+        "masks_differ": int(differ.sum()), "masks_differ_where_decisive": int((differ & decisive).sum()),
+        "excluded_frac": float(1.0 - decisive.mean()), "decisive_margin": PARITY_MARGIN,
+        "grad_rel_err_of_tensor_max": grads,
+        "inputs_identical": bool(input_sums[0] == float(ref["x_sum"]) and input_sums[1] == float(ref["x_abs_sum"]) and input_sums[2] == int(ref["gt_sum"])),
+        "tolerance": PARITY_TOL,
+    }
+    out["pass"] = bool(out["inputs_identical"] and out["dlogit_max"] < PARITY_TOL and out["dloss"] < PARITY_TOL and out["ddice"] < PARITY_TOL
+                       and out["masks_differ_where_decisive"] == 0)
+    try:
+        os.remove(parity_file)
+        os.rmdir(os.path.dirname(parity_file))
+    except OSError:
+        pass
+    return out
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -399,6 +471,7 @@ def parse_args():
     ap.add_argument("--cpu-sample", default="2,1,128,128,128")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-oracle steps after one full-shape warm-up")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--parity-out", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--graph-leg-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-workloads", action="store_true", help="skip the bf16 legs of BASELINE configs 3-5 reported under `workloads`")
     ap.add_argument("--leg-steps", type=int, default=10, help="timed steps per `workloads` leg (3 warm-up steps before them)")
@@ -448,7 +521,7 @@ def main():
     args = parse_args()
     if args.cpu_baseline_child:
         shape = tuple(int(v) for v in args.cpu_sample.split(","))
-        print(json.dumps(cpu_baseline(shape, steps=args.cpu_steps, gate=sys.stdin)))
+        print(json.dumps(cpu_baseline(shape, steps=args.cpu_steps, gate=sys.stdin, parity_out=args.parity_out)))
         return 0
     if args.graph_leg_child:
         print(json.dumps(graph_leg_child(args.graph_leg_child, args.leg_steps, sys.stdin)))
@@ -463,11 +536,17 @@ def main():
         return self_launch(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:])
 
     rank_env, world_env = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    cpu_child = None
+    cpu_child = parity_file = None
     if rank_env == 0 and world_env == 1 and not args.no_cpu_baseline and not args.rehearse_cpu:
-        # CPU baseline in its own process, started BEFORE the first GPU call; it waits at a gate until the GPU legs are done
-        cpu_child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--cpu-sample", args.cpu_sample, "--cpu-steps", str(args.cpu_steps)],
-                                     stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        # CPU baseline in its own process, started BEFORE the first GPU call; it waits at a gate until the GPU legs are done.  When its
+        # sample is the headline's own batch (the default), its first step is also the reference side of `parity_vs_cpu`.
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--cpu-sample", args.cpu_sample, "--cpu-steps", str(args.cpu_steps)]
+        wl = WORKLOADS[args.workload]
+        if tuple(int(v) for v in args.cpu_sample.split(",")) == (wl[3], wl[0], wl[4], wl[5], wl[6]) and not args.hip_graph:
+            import tempfile
+            parity_file = os.path.join(tempfile.mkdtemp(prefix="mi355seg_parity_"), "cpu_first_step.npz")
+            cmd += ["--parity-out", parity_file]
+        cpu_child = subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
 
     graph_children = {}
     if rank_env == 0 and world_env == 1 and not args.no_workloads and not args.rehearse_cpu and not args.hip_graph and args.workload == "unet3d_f32_2x128":
@@ -515,9 +594,11 @@ def main():
         model = model.to(dev).train()
         # train.py:109's Adam as the framework's train.py builds it (engine.make_adam: torch's fused single-kernel Adam on the GPU)
         opt = make_adam(model.parameters(), lr=1e-3, capturable=True) if args.hip_graph else make_adam(model.parameters(), lr=1e-3)
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    x = torch.randn((B, cin, Dd, Hh, Ww), generator=g).to(dev)
-    gt = (torch.rand((B, 1, Dd, Hh, Ww), generator=g) > 0.9).float().to(dev)
+    x_cpu, gt_cpu = synthetic_batch((B, cin, Dd, Hh, Ww), 1234 + rank)
+    x, gt = x_cpu.to(dev), gt_cpu.to(dev)
+    label_foreground_frac = float(gt_cpu.mean())
+    input_sums = (float(x_cpu.double().sum()), float(x_cpu.double().abs().sum()), int(gt_cpu.sum()))
+    del x_cpu, gt_cpu
     reducer = D.setup_replica(model)                # world > 1: rank 0's parameters / buffers everywhere + bucketed gradient reducer
     rank_devices = [str(dev)]
     if world > 1:
@@ -557,14 +638,24 @@ def main():
         if dev.type == "cuda":
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    first = None
+    if parity_file is not None:
+        # the FIRST train step from the initial weights (untimed; it is also the first warm-up step): everything the CPU child's first
+        # step is compared with -- full logits, loss, the integer Dice counters, a few gradients -- copied to the host here
+        out = step()
+        sync()
+        named = dict(model.named_parameters())
+        first = {"pred": out["pred"].detach().float().cpu().numpy(), "loss": float(out["loss"].item()), "counts": out["counts"].cpu().tolist(),
+                 "grads": {k: named[k].grad.detach().cpu().numpy() for k in PARITY_GRADS if k in named and named[k].grad is not None}}
+    for _ in range(args.warmup - (1 if first is not None else 0)):
         out = step()
     sync()
     if world > 1:
         dist.barrier()
     if reducer is not None:                 # the `comm` block counts the timed steps only (the wait timers are off outside a bench)
-        reducer.timer.reset()
-        reducer.timer.enable()
+        for t in (reducer.timer, reducer.pack_timer, reducer.unpack_timer):
+            t.reset()
+            t.enable()
     D.BUFFER_BROADCAST_TIMER.reset()
     D.BUFFER_BROADCAST_TIMER.enable(world > 1)
     # HIP-event bracketing inside the timed region: only the two MFMA conv families (51 launches per step; --prof-all: all ~400), and
@@ -614,7 +705,9 @@ def main():
                    "global_batch": B * world, "patch": [Dd, Hh, Ww], "parallelism": f"dp{world}", "conv_math": args.conv_math,
                    "optimizer": "torch.optim.Adam" + ("(fused=True)" if getattr(opt, "defaults", {}).get("fused") else "")},
         "rccl_ranks": world, "dist_backend": (dist.get_backend() if world > 1 else None), "rank_devices": rank_devices,
-        "loss": float(loss.item()), "dice": dice,
+        "loss": float(loss.item()), "dice": dice, "jaccard": jac,
+        "labels": f"thresholded low-frequency field of the input (8^3 block means of x, trilinear, > {LABEL_THRESHOLD}); foreground fraction "
+                  f"{label_foreground_frac:.4f}; `dice` / `loss` are the LAST timed step's (after {args.warmup + args.steps} Adam steps on the one resident batch)",
     }
     if comm is not None:                    # what a step sends and how long it waited for it (attribution of a scaling shortfall)
         comm["allreduce_wait_frac_of_step"] = comm["allreduce_wait_ms_per_step"] / ms
@@ -741,6 +834,11 @@ def main():
             txt, _ = cpu_child.communicate("go\n", timeout=600)
             res["cpu_baseline"] = json.loads(txt.strip().splitlines()[-1])
             res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+            if first is not None:
+                try:
+                    res["parity_vs_cpu"] = parity_vs_cpu(first, parity_file, input_sums)
+                except Exception as e:
+                    res["parity_vs_cpu"] = {"error": repr(e)}
             leg1 = res.get("workloads", {}).get("unet3d_f32_1x64")
             if leg1 is not None and "error" not in leg1 and res["cpu_baseline"].get("cfg1"):
                 leg1["cpu_baseline"] = res["cpu_baseline"].pop("cfg1")

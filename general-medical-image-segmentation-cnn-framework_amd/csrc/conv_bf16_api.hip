@@ -92,7 +92,7 @@ using namespace seg;
 extern "C" {
 
 int mi355seg_set_b16_tiles(int mode) {
-    SEG_CHECK_ARG(mode >= 0 && mode <= 3, "set_b16_tiles: 0 (auto), 1 (16x16x32 tiles wherever possible), 2 (generic tiles) or 3 (auto + the LDS-DMA weight gradient), got %d", mode);
+    SEG_CHECK_ARG(mode >= 0 && mode <= 2, "set_b16_tiles: 0 (auto), 1 (16x16x32 tiles wherever possible) or 2 (generic tiles), got %d", mode);
     set_b16_tiles(mode);
     return MI355SEG_OK;
 }
@@ -117,7 +117,6 @@ size_t mi355seg_conv3d_ws_bytes_bf16(int N, int D, int H, int W, int Cin, int Co
     if (headpw_lowp_supported(Cin, Cout, k, stride, pad, Cin, Cout) && base < headpw_lowp_ws_bytes(Cin, Cout)) base = headpw_lowp_ws_bytes(Cin, Cout);
     if (stem1k5_lowp_supported(Cin, Cout, k, stride, pad, Cin, Cout) && base < stem1k5_lowp_ws_bytes(Cout)) base = stem1k5_lowp_ws_bytes(Cout);
     if (k == 1 && stride == 1 && pad == 0 && base < pw_wgrad_lowp_ws_bytes((long long)N * D * H * W, Cin, Cout)) base = pw_wgrad_lowp_ws_bytes((long long)N * D * H * W, Cin, Cout);
-    if ((k == 3 || k == 5) && stride == 1 && base < wgrad_b16d_ws_bytes(N, D, H, W, Cin, Cout, k)) base = wgrad_b16d_ws_bytes(N, D, H, W, Cin, Cout, k);
     if (k == 2 && stride == 2 && pad == 0 && base < convt_wgrad_lowp_ws_bytes((long long)N * (D / 2) * (H / 2) * (W / 2), Cout, Cin))
         base = convt_wgrad_lowp_ws_bytes((long long)N * (D / 2) * (H / 2) * (W / 2), Cout, Cin);
     // the fp32 staging copies of the fall-back: for shapes without a native kernel, and -- while they stay under 512 MB -- for
@@ -285,10 +284,6 @@ int mi355seg_conv3d_wgrad_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg
         return stem1k5_wgrad_lowp(dy, lddy, x, dw, N, D, H, W, Cout, accumulate, ws, ws_bytes, st);
     if (nb == NB_HEAD2 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 4) == 0)
         return head2_wgrad_lowp(dy, lddy, x, ldx, dw, N, D, H, W, Cin, accumulate, ws, ws_bytes, st);
-    // mi355seg_set_b16_tiles(3): two co blocks per workgroup, tiles by LDS-DMA (conv_wgrad_b16d.hip: built in r4, measured at 0.55-0.7x of the
-    // one-block kernel -- the lane-linear LDS image of an LDS-DMA cannot carry the row padding the transposing reads need -- and kept off)
-    if (nb == NB_LOWP && al16 && get_b16_tiles() == 3 && wgrad_b16d_supported(N, D, H, W, Cin, Cout, k, stride, pad, ldx, lddy))
-        return conv_wgrad_b16d(dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, accumulate, ws, ws_bytes, st);
     if (nb == NB_LOWP && al16) return conv_wgrad_lowp(MATH_B16, dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, stride, accumulate, ws, ws_bytes, st);
     if (nb == NB_PWL && al16) {
         float* part; int nstrips;

@@ -161,11 +161,6 @@ size_t wgrad_lowp_ws_bytes_geom(int N, int D, int H, int W, int Cin, int Cout, i
 int conv_wgrad_lowp(int math, const void* dy, int lddy, const void* x, int ldx, float* dw, int N, int D, int H, int W, int Cin,
                     int Cout, int k, int stride, int accumulate, void* ws, size_t ws_bytes, hipStream_t st,
                     const float* x_amax = nullptr, const float* dy_amax = nullptr);
-// conv_wgrad_b16d.hip -- k3 / k5 s1 wgrad on bf16 tensors, two co blocks per workgroup, LDS-DMA tiles (Cout % 64 == 0)
-bool wgrad_b16d_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int lddy);
-size_t wgrad_b16d_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k);
-int conv_wgrad_b16d(const bf16* dy, int lddy, const bf16* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout, int k,
-                    int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 size_t wgrad_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k);
 bool wgrad_mfma_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int lddy);
 int conv_wgrad_mfma(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin,

@@ -158,6 +158,10 @@ def comm_report(reducer, steps):
         "buckets": len(reducer.buckets) if reducer is not None else 0,
         "bucket_cap_mb": getattr(reducer, "bucket_mb", None),
         "allreduce_wait_ms_per_step": (reducer.timer.total_ms() / max(1, steps)) if reducer is not None else 0.0,
+        # the reducer's own copies: gradients gathered into the flat buckets (torch.cat, on the compute stream inside backward) and
+        # the means scattered back into p.grad (_foreach_copy_, part of the wait above): 2 x grad_bytes of extra traffic each
+        "bucket_pack_ms_per_step": (reducer.pack_timer.total_ms() / max(1, steps)) if reducer is not None else 0.0,
+        "bucket_unpack_ms_per_step": (reducer.unpack_timer.total_ms() / max(1, steps)) if reducer is not None else 0.0,
         "broadcast_buffers_ms_per_step": BUFFER_BROADCAST_TIMER.total_ms() / max(1, steps),
         "buffer_broadcast_collectives_per_step": BUFFER_BROADCAST_TIMER.calls / max(1, steps),
         "timer": "HIP events on the compute stream of rank 0: time the step waited in GradAllReducer.__call__ (exposed all-reduce + scatter-back) "
@@ -181,7 +185,7 @@ class GradAllReducer:
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.always = always
         self.bucket_mb = bucket_mb
-        self.timer = CommTimer()
+        self.timer, self.pack_timer, self.unpack_timer = CommTimer(), CommTimer(), CommTimer()
         cap = int(bucket_mb * (1 << 20) / 4)
         self.buckets, cur, n = [], [], 0
         for p in reversed(self.params):
@@ -228,7 +232,9 @@ class GradAllReducer:
         if flat is None or flat.numel() != total or flat.device != grads[0].device:
             flat = torch.empty(total, dtype=grads[0].dtype, device=grads[0].device)
             self._flat[bi] = flat
+        token = self.pack_timer.start(flat.device)
         torch.cat([g.reshape(-1) for g in grads], out=flat)
+        self.pack_timer.stop(token)
         # RCCL averages inside the collective (ReduceOp.AVG); gloo only sums, the division follows the wait
         self._avg_in_collective = dist.get_backend() == "nccl"
         op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
@@ -263,7 +269,9 @@ class GradAllReducer:
                     srcs.append(view)
                 off += n
             if dsts:
+                tk = self.unpack_timer.start(flat.device)
                 torch._foreach_copy_(dsts, srcs)              # one multi-tensor launch per bucket instead of one copy per parameter
+                self.unpack_timer.stop(tk)
             self._works[bi] = None
             self._pending[bi] = len(bucket)
         self.timer.stop(token)

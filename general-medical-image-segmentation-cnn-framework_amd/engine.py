@@ -46,7 +46,15 @@ def make_adam(params, lr, **kw):
     return torch.optim.Adam(params, lr=lr, **kw)
 
 
-def train_step(model, optimizer, x, gt, criterion=None, sync_metric=True, grad_hook=None, dtype=None, step_optimizer=True):
+def _forward(model, leaves, *args):
+    """``model(*args)``, or the same forward on ``leaves`` (name -> tensor aliasing the parameter's storage) in place of the
+    module's parameters (torch.func.functional_call): GraphedTrainStep's capture, see there."""
+    if leaves is None:
+        return model(*args)
+    return torch.func.functional_call(model, leaves, args)
+
+
+def train_step(model, optimizer, x, gt, criterion=None, sync_metric=True, grad_hook=None, dtype=None, step_optimizer=True, _leaves=None):
     """One iteration.  ``gt`` is the single-channel label volume [N,1,D,H,W].  ``dtype`` = torch.bfloat16 runs the
     forward under mi355seg.autocast (bf16 activations; the loss and everything after it stay fp32).
     ``grad_hook`` (if given) runs between backward and optimizer.step -- the data-parallel
@@ -65,9 +73,9 @@ def train_step(model, optimizer, x, gt, criterion=None, sync_metric=True, grad_h
         if getattr(model, "takes_frequency_bands", False):      # the IS network, train.py:198-201: second output discarded
             from .models.three_d.IS import frequency_bands
             low_x, high_x = frequency_bands(x)
-            pred, _ = model(x, low_x, high_x)
+            pred, _ = _forward(model, _leaves, x, low_x, high_x)
         else:
-            pred = model(x)
+            pred = _forward(model, _leaves, x)
     F.flush_deferred_waits()                                     # (a model without norm layers)
     if bns:
         torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
@@ -81,6 +89,9 @@ def train_step(model, optimizer, x, gt, criterion=None, sync_metric=True, grad_h
             gt_lab = F.argmax_channels(gt2)
             counts = F.dice_counts(gt_lab, mask)
     loss.backward()
+    if _leaves is not None:                  # the capture's stand-in leaves: their gradients ARE the parameters' (static tensors of the graph pool)
+        for name, p in model.named_parameters():
+            p.grad = _leaves[name].grad
     if grad_hook is not None:
         grad_hook(model)
     if step_optimizer:                       # (GraphedTrainStep with a gradient hook captures the optimizer step as a graph of its own)
@@ -105,23 +116,26 @@ class GraphedTrainStep:
     the launch-bound part of the step is still one ``hipGraphLaunch``).  Three eager warm-up steps run
     on a side stream first -- they size the workspace and set the kernels' LDS attributes -- and, like the captured
     step, they DO update the model, so a freshly built instance has already taken ``warmup`` optimiser steps (``first`` holds
-    the loss and the Dice counters of the last of them).  Build it BEFORE any eager iteration of the same model, or after every
-    reference to an earlier iteration's outputs is gone: a parameter's AccumulateGrad node survives as long as an old autograd
-    graph does, stays bound to the stream it was created on (the default stream), and a default-stream node inside the capture
-    takes the process down in hipStreamEndCapture.
-    Returned tensors are static buffers overwritten by the next call."""
+    the loss and the Dice counters of the last of them).
+    Returned tensors are static buffers overwritten by the next call.
 
-    def __init__(self, model, optimizer, x, gt, criterion=None, warmup=3, dtype=None, grad_hook=None, after_eager_ok=False):
+    **Capturing after eager iterations of the same model** (r5; it used to take the process down in ``hipStreamEndCapture``, where no
+    try / except reaches).  Cause: a parameter's gradient accumulator (autograd's AccumulateGrad node) is bound to the stream that
+    was current when the node was CREATED, and it lives as long as any autograd graph that points at it -- an eager iteration on the
+    default stream whose ``pred`` / ``loss`` somebody still holds keeps default-stream accumulators alive.  A backward inside the
+    capture then hands them their gradients across streams: the engine makes the (legacy) default stream wait for an event of the
+    capturing stream, which a global-mode capture forbids (hipErrorStreamCaptureImplicit); the capture is invalidated and ending it
+    fails inside a destructor.  The accumulators cannot be re-bound or dropped from Python, so the captured iteration does not use
+    them: its forward runs on **stand-in leaves** -- fresh ``detach()`` aliases of the parameters' storage
+    (``torch.func.functional_call``), whose accumulators are created inside the capture, on the capturing stream -- and the stand-ins'
+    gradient tensors are installed as the parameters' ``.grad`` before the captured optimizer step.  Same kernels, same memory, no
+    copies; whatever ran before the capture, on whatever stream, no longer matters (tests/test_gpu_unet.py::
+    test_graphed_step_captures_after_an_eager_step_with_a_live_output)."""
+
+    def __init__(self, model, optimizer, x, gt, criterion=None, warmup=3, dtype=None, grad_hook=None):
         from ._lib import lib
         if not all(g.get("capturable", False) for g in optimizer.param_groups):
             raise ValueError("GraphedTrainStep: build the optimizer with capturable=True (e.g. torch.optim.Adam(..., capturable=True))")
-        # an eager iteration leaves p.grad behind (train_step clears it at the START of the next one) and, as long as anything still
-        # refers to its outputs, gradient accumulators bound to the default stream -- inside a capture those abort the process in
-        # hipStreamEndCapture, which no try / except can catch.  Refuse here instead.
-        if not after_eager_ok and any(p.grad is not None for p in model.parameters()):
-            raise RuntimeError("GraphedTrainStep: this model has already run an eager backward (p.grad is set).  Build the graphed step "
-                               "BEFORE any eager iteration of the same model (or on a fresh model / optimizer with the same state); if every "
-                               "reference to earlier outputs is gone and the gradients were cleared on purpose, pass after_eager_ok=True")
         lib().call("mi355seg_prof_enable", 0)
         self.model, self.optimizer, self.criterion, self.grad_hook = model, optimizer, criterion, grad_hook
         self.x = x.detach().to(torch.float32).clone()
@@ -141,13 +155,19 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         self.opt_graph = None
         F.amax_pool_reset()              # the captured step zero-fills the chunk of operand-maximum slots it draws from INSIDE the capture
+        leaves = {name: p.detach().requires_grad_(p.requires_grad) for name, p in model.named_parameters()}
         if grad_hook is None:
             with torch.cuda.graph(self.graph):
-                self.out = train_step(model, optimizer, self.x, self.gt, criterion, sync_metric=False, dtype=dtype)
+                self.out = train_step(model, optimizer, self.x, self.gt, criterion, sync_metric=False, dtype=dtype, _leaves=leaves)
         else:
             with torch.cuda.graph(self.graph):
-                self.out = train_step(model, optimizer, self.x, self.gt, criterion, sync_metric=False, dtype=dtype, step_optimizer=False)
-            grad_hook(model)                         # the captured backward has not run: these are the last warm-up gradients, reduced once more
+                self.out = train_step(model, optimizer, self.x, self.gt, criterion, sync_metric=False, dtype=dtype, step_optimizer=False, _leaves=leaves)
+            # a parameter the backward does not reach has no static gradient tensor: the reducer would allocate one at its first call
+            # (and the optimizer graph must already see it), so give it zeros now -- no collective here: the captured backward has
+            # not executed, the static gradients hold nothing yet
+            for p in model.parameters():
+                if p.requires_grad and p.grad is None:
+                    p.grad = torch.zeros_like(p)
             self.opt_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.opt_graph, pool=self.graph.pool()):
                 optimizer.step()
@@ -156,6 +176,9 @@ class GraphedTrainStep:
     def __call__(self, x, gt, sync_metric=True):
         self.x.copy_(x, non_blocking=True)
         self.gt.copy_(gt, non_blocking=True)
+        # a buffer broadcast launched ahead of the step (distributed.broadcast_buffers(async_op=True)): a replay runs no Python forward,
+        # so nothing else would wait for it before the captured BatchNorm kernels read and update the running statistics
+        F.flush_deferred_waits()
         self.graph.replay()
         if self.opt_graph is not None:
             self.grad_hook(self.model)               # mean all-reduce of the static gradient tensors, in place

@@ -89,8 +89,8 @@ def train(config, model, logger):
             if world > 1:
                 D.broadcast_buffers(model, async_op=True)               # launched here, waited for at the forward's first norm layer
             if hip_graph and graphed is None:
-                # the first iteration runs inside the constructor (eager, on the capture stream: workspaces sized, kernel attributes
-                # set, the parameters' gradient accumulators created there), then the iteration is captured for the following ones
+                # the first iteration runs inside the constructor (eager, on a side stream: workspaces sized, kernel attributes set),
+                # then the iteration is captured for the following ones; a replay waits for the buffer broadcast launched above
                 graphed = GraphedTrainStep(model, optimizer, x, gt, warmup=1, dtype=act_dtype, grad_hook=reducer)
                 out = dict(graphed.first)
                 out["jaccard"], out["dice"] = metric_from_counts(out["counts"].cpu().tolist())

@@ -82,8 +82,7 @@ int mi355seg_get_x3_shape(void);
 /* Tiling of the k3 / k5 stride-1 convolutions on bf16 TENSORS (forward and input gradient): 0 = automatic (the
  * v_mfma_f32_16x16x32_bf16 kernel of conv_b16s.hip -- eight 16-voxel lines x 32 channels per wave -- where a layer cuts enough
  * tiles to fill the chip, the generic 32x32x16 tiles with split-K otherwise), 1 = conv_b16s.hip wherever its geometry applies,
- * 2 = the generic tiles only, 3 = automatic + the two-co-block LDS-DMA weight gradient (conv_wgrad_b16d.hip: measured slower, kept off
- * by default).  Process-wide, read at each launch (A/B timing, tests of both kernels on one shape). */
+ * 2 = the generic tiles only.  Process-wide, read at each launch (A/B timing, tests of both kernels on one shape). */
 int mi355seg_set_b16_tiles(int mode);
 int mi355seg_get_b16_tiles(void);
 /* The f16x3 weight gradient of k3 s1 convolutions with Cout % 64 == 0 has a second kernel (conv_wgrad_f16w_kernel: four waves, one per

@@ -146,9 +146,12 @@ def _graph_ddp_worker(rank, world, port, out):
         else:
             g = GraphedTrainStep(model, opt, x, gt, warmup=2, grad_hook=reducer)          # two eager steps (x), then replays
             losses = [None, float(g.first["loss"])]
+            from mi355seg import functional as F
             for i in (2, 3):
-                D.broadcast_buffers(model)
+                D.broadcast_buffers(model, async_op=True)                                  # as train.py launches it: the replay must wait for it
+                assert len(F._DEFERRED_WAITS) == 1
                 losses.append(float(g(x + 0.1 * i, gt, sync_metric=False)["loss"]))
+                assert not F._DEFERRED_WAITS
         res[mode] = (losses, {k: v.detach().cpu() for k, v in model.state_dict().items()})
         reducer.detach()
     out[rank] = res
@@ -177,3 +180,40 @@ def test_two_rank_graphed_step_matches_the_eager_data_parallel_step():
         for k, v in out[0][mode][1].items():                                            # running statistics are rank-local until the next broadcast)
             if "running_" not in k:
                 assert torch.equal(v, out[1][mode][1][k]), (mode, k)
+
+
+def _bench(extra, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MI355SEG_DIST_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "unet3d_f32_1x64", "--no-workloads", "--no-cpu-baseline",
+                        "--steps", "8", "--warmup", "2"] + extra, capture_output=True, text=True, env=env, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_whole_hip_path_on_one_gpu():
+    """First contact for the N > 1 bench nobody could run on hardware yet: the REAL ``bench.py --gpus 2`` -- self-launch,
+    rendezvous, setup_replica, the HIP train step with the bucketed reducer and the ahead-of-step buffer broadcast, the in-library
+    HIP-event bracketing, max-over-ranks timing, one JSON line -- with both ranks on this box's one GPU and gloo in RCCL's place
+    (MI355SEG_DIST_BACKEND).  Checked: two ranks formed, the `comm` block (with the reducer's pack / unpack copies timed), `roofline`
+    present, and an aggregate rate that is neither absurdly below nor above two one-rank runs sharing the card."""
+    one = _bench(["--gpus", "1"])
+    two = _bench(["--gpus", "2"])
+    assert one["n_gpus"] == 1 and one["rccl_ranks"] == 1 and "comm" not in one and one["roofline"]["frac"] > 0
+    assert two["n_gpus"] == 2 and two["rccl_ranks"] == 2 and two["dist_backend"] == "gloo" and two["config"]["parallelism"] == "dp2"
+    assert two["config"]["global_batch"] == 2 and two["scaling"] == "weak" and len(two["rank_devices"]) == 2
+    c = two["comm"]
+    assert c["grad_bytes_per_step"] == 4 * 22581250 and c["buckets"] >= 2                     # UNet3D(1, 2, 32): 90.3 MB of gradients
+    assert c["allreduce_wait_ms_per_step"] > 0 and c["bucket_pack_ms_per_step"] > 0 and c["bucket_unpack_ms_per_step"] > 0
+    assert c["buffer_broadcast_collectives_per_step"] == 1.0
+    assert two["roofline"]["bound"] == "mfma" and two["roofline"]["frac"] > 0 and two["roofline"]["launches"] > 0
+    assert 0.0 <= two["dice"] <= 1.0 and two["loss"] > 0
+    # two ranks time-share one GPU and stage 90 MB of gradients through the host (gloo): the aggregate is at best the one-rank rate and
+    # must stay within 2x of "twice as many voxels in twice the time plus the gloo round trip" -- an order-of-magnitude plumbing check
+    assert two["value"] > 0.1 * one["value"] and two["value"] < 2.0 * 2.0 * one["value"], (one["value"], two["value"])

@@ -1,5 +1,6 @@
-"""BASELINE-size checks (cfg 2: UNet3D(1,2,32), x = [2,1,128,128,128]) through size-independent properties:
-the CPU oracle cannot run this size in seconds, so the GPU path is checked by (a) bitwise determinism of a
+"""BASELINE-size checks (cfg 2: UNet3D(1,2,32), x = [2,1,128,128,128]): (0) ONE full-size train step against the CPU oracle's
+(about 10-25 s of host time: logits, loss, Dice, masks, stem / head / bottleneck gradients -- the comparison bench.py also puts
+on its line as `parity_vs_cpu`), and size-independent properties: (a) bitwise determinism of a
 whole train step (no atomics anywhere), (b) exact linearity of the MFMA convolution under power-of-two scaling,
 (c) crops of the full-size result against ATen-CPU on the crop's receptive field (catches 32-bit index overflow
 and tile-edge errors at full extent), (d) invariants of BatchNorm / metric."""
@@ -22,6 +23,60 @@ def seg():
 
 def _rnd(shape, seed):
     return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+
+def test_full_size_first_step_vs_cpu_oracle(seg):
+    """North_star's bar at the benchmark configuration itself: UNet3D(1, 2, 32) on [2, 1, 128^3], first train step from kaiming weights,
+    under every conv math -- logits within 1e-4 of the CPU oracle's (== the reference's PyTorch-CPU arithmetic, /root/reference/
+    models/three_d/unet3d.py:50-71, train.py:187-221), loss and Dice within 1e-4, masks identical wherever the oracle's logit margin is
+    decisive, gradients of the stem, the head, the bottleneck, an up-convolution and a BatchNorm scale within 1e-3 of the tensor's
+    maximum (sums over 4.2 M voxels; the three maths' measured figures are printed).  The batch is bench.py's (labels = a
+    thresholded low-frequency field of the input), so Dice is a number that could disagree."""
+    import bench
+    from mi355seg.engine import make_adam, train_step, weights_init_normal
+    from mi355seg.models.three_d.unet3d import UNet3D
+    from mi355seg.utils.metric import metric_from_counts
+    from oracle.nets import UNet3D as OracleUNet
+    from oracle.step import train_step as oracle_step, weights_init_normal as oracle_init
+    x, gt = bench.synthetic_batch((2, 1, 128, 128, 128), 1234)
+    torch.manual_seed(0)
+    ref = OracleUNet(1, 2, 32)
+    ref.apply(oracle_init("kaiming"))
+    ref.train()
+    pr, mr, lr, (jr, dr) = oracle_step(ref, torch.optim.Adam(ref.parameters(), lr=1e-3), x, gt)
+    pr = pr.detach()
+    assert 0.05 < dr < 0.95, dr
+    rgrads = {k: p.grad.clone() for k, p in ref.named_parameters() if k in bench.PARITY_GRADS}
+    del ref
+    margin = (pr[:, 1] - pr[:, 0]).abs()
+    decisive = margin > 2e-4
+    xg, gg = x.cuda(), gt.cuda()
+    try:
+        for math in ("f16x3", "bf16x6", "fp32"):
+            seg.set_conv_math(math)
+            torch.manual_seed(0)
+            m = UNet3D(1, 2, 32)
+            m.apply(weights_init_normal("kaiming"))
+            m = m.cuda().train()
+            out = train_step(m, make_adam(m.parameters(), lr=1e-3), xg, gg)
+            pg = out["pred"].detach().cpu()
+            dl = float((pg - pr).abs().max())
+            differ = (pg.argmax(1) != pr.argmax(1))
+            named = dict(m.named_parameters())
+            gerr = {k: float((named[k].grad.cpu() - g).abs().max() / g.abs().max()) for k, g in rgrads.items()}
+            print(f"[{math}] dlogit_max {dl:.3e} dloss {abs(out['loss'].item() - lr.item()):.3e} ddice {abs(out['dice'] - dr):.3e} (dice {dr:.4f}) "
+                  f"masks differ {int(differ.sum())} (decisive {int((differ & decisive).sum())}, excluded {1 - float(decisive.float().mean()):.2e}) "
+                  f"grad rel err {max(gerr.values()):.3e}")
+            assert dl < 1e-4, (math, dl)
+            assert abs(out["loss"].item() - lr.item()) < 1e-5, math
+            assert abs(out["dice"] - dr) < 1e-4 and abs(out["jaccard"] - jr) < 1e-4, (math, out["dice"], dr)
+            assert int((differ & decisive).sum()) == 0, math
+            assert float(decisive.float().mean()) > 0.99
+            for k, e in gerr.items():
+                assert e < 1e-3, (math, k, e)
+            del m, out
+    finally:
+        seg.set_conv_math("f16x3")
 
 
 def test_full_size_train_step_is_bitwise_deterministic_and_consistent(seg):
