@@ -84,6 +84,15 @@ def synthetic_batch(shape, seed, classes=2):
     return x, torch.bucketize(lf, cuts)
 
 
+def batch_checksums(x, gt):
+    """Order-independent exact checksums of a batch (integer sums of the fp32 bit patterns, plain and index-weighted, and the label
+    count): the parent and the cpu_baseline child must have built the same bits."""
+    import torch
+    bits = x.contiguous().view(torch.int32).to(torch.int64).flatten()
+    w = (torch.arange(bits.numel(), dtype=torch.int64) % 8191) + 1
+    return (int(bits.sum()), int((bits * w).sum()), int(gt.sum()))
+
+
 def read_families(L, steps):
     import ctypes
     buf = (ctypes.c_double * 32)()
@@ -379,8 +388,7 @@ def cpu_baseline(sample_shape, steps=3, reserve=0, gate=None, parity_out=None):
         grads = {"grad:" + k: p.grad.detach().numpy() for k, p in m.named_parameters() if k in PARITY_GRADS}
         np.savez(parity_out, pred=pred0.detach().numpy(), loss=np.float64(loss0.item()), dice=np.float64(dice0), jaccard=np.float64(jac0),
                  counts=np.array([c["gdth_sum"], c["pred_sum"], c["intersection_sum"], c["union_sum"]], dtype=np.int64),
-                 x_sum=np.float64(x.double().sum().item()), x_abs_sum=np.float64(x.double().abs().sum().item()),
-                 gt_sum=np.int64(gt.sum().item()), **grads)
+                 input_checksums=np.array(batch_checksums(x, gt), dtype=np.int64), **grads)
     del pred0, mask0, loss0
     times = []
     for _ in range(steps):
@@ -445,7 +453,11 @@ def parity_vs_cpu(first, parity_file, input_sums):
         "masks_differ": int(differ.sum()), "masks_differ_where_decisive": int((differ & decisive).sum()),
         "excluded_frac": float(1.0 - decisive.mean()), "decisive_margin": PARITY_MARGIN,
         "grad_rel_err_of_tensor_max": grads,
-        "inputs_identical": bool(input_sums[0] == float(ref["x_sum"]) and input_sums[1] == float(ref["x_abs_sum"]) and input_sums[2] == int(ref["gt_sum"])),
+        "grad_note": "information only (not part of `pass`): max |g_gpu - g_cpu| / max |g_cpu| per tensor.  Through 18 training-mode BatchNorm layers at a random "
+                     "init the fp32 backward is ill-conditioned towards the deep layers (single ReLU sign flips over 1,024 bottleneck voxels); the reference's own "
+                     "fp32 gradients sit 4e-3 (stem) / 6e-3 (bottleneck) from an fp64 run of the same step -- graded against that fp64 run in "
+                     "tests/test_gpu_fullsize.py::test_full_size_first_step_vs_cpu_oracle",
+        "inputs_identical": bool(list(input_sums) == [int(v) for v in ref["input_checksums"]]),
         "tolerance": PARITY_TOL,
     }
     out["pass"] = bool(out["inputs_identical"] and out["dlogit_max"] < PARITY_TOL and out["dloss"] < PARITY_TOL and out["ddice"] < PARITY_TOL
@@ -597,7 +609,7 @@ def main():
     x_cpu, gt_cpu = synthetic_batch((B, cin, Dd, Hh, Ww), 1234 + rank)
     x, gt = x_cpu.to(dev), gt_cpu.to(dev)
     label_foreground_frac = float(gt_cpu.mean())
-    input_sums = (float(x_cpu.double().sum()), float(x_cpu.double().abs().sum()), int(gt_cpu.sum()))
+    input_sums = batch_checksums(x_cpu, gt_cpu)
     del x_cpu, gt_cpu
     reducer = D.setup_replica(model)                # world > 1: rank 0's parameters / buffers everywhere + bucketed gradient reducer
     rank_devices = [str(dev)]

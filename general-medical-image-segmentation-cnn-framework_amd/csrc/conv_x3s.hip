@@ -43,6 +43,9 @@ namespace {
 #ifndef X3S_XD
 #define X3S_XD 2
 #endif
+#ifndef X3S_HALO_AUX
+#define X3S_HALO_AUX 0          // cache policy of the halo loads (A/B knob: 2 = nt, 16 = sc1)
+#endif
 constexpr int XBX = 16, XTY = 4, XHX = XBX + 2, XHY = XTY + 2;
 
 template <int LW, bool F16 = false, int WN = 1>
@@ -82,6 +85,27 @@ __device__ __forceinline__ void x3_epilogue(const IgemmArgs& a, f32x4 (&acc)[LW]
     const int n0 = n0_tile + wn * NT;
     // ---- epilogue: bias, 16-byte stores, optional BatchNorm partial statistics
     // acc[j][t][e] = y[voxel (line j, x = r)][channel n0 + 16 t + 4 g + e]
+    const int gx = x0 + r;
+    // BatchNorm-backward column sums of the layer in front (input-gradient launch, no bias / activation / split): the tile about to be
+    // stored is d(activation); that layer's pre-norm tensor is read at the same voxels.  r5: ALL of these loads are issued here, ahead of
+    // the scaling and the stores, unconditionally and at clamped coordinates (a voxel outside the volume contributes through a zero
+    // mask) -- under the per-line `if (inside)` they were 2 LW load -> s_waitcnt vmcnt(0) -> reduce round trips per wave, each also
+    // waiting for the tile's own stores: 14 us per tile (0.756 ms against the plain kernel's 0.53 on 32 -> 32 @ 2 x 128^3)
+    // (groups of eight fragments: the first is requested here, the next behind the stores once the previous one is reduced -- all
+    // LW x NTW fragments at once next to the accumulators spill)
+    constexpr int LH = (8 / NTW) < LW ? (8 / NTW) : LW;
+    f32x4 bxv[LH][NTW];
+    auto load_bnx = [&](int j0) {
+#pragma unroll
+        for (int j = 0; j < LH; ++j) {
+            const int line = line0 + min(j0 + j, LW - 1);
+            const int cz = min(z0 + line / XTY, a.D - 1), cy = min(y0 + line % XTY, a.H - 1), cx = min(gx, a.W - 1);
+            const float* src = a.bnx + ((((long long)n * a.D + cz) * a.H + cy) * a.W + cx) * a.ldbnx + n0 + 4 * g;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) bxv[j][t] = *reinterpret_cast<const f32x4*>(src + 16 * t);
+        }
+    };
+    if (a.bnpart) load_bnx(0);
     if (scale_exp != 0) {
 #pragma unroll
         for (int j = 0; j < LW; ++j)
@@ -91,7 +115,6 @@ __device__ __forceinline__ void x3_epilogue(const IgemmArgs& a, f32x4 (&acc)[LW]
                 for (int e = 0; e < 4; ++e) acc[j][t][e] = __builtin_ldexpf(acc[j][t][e], scale_exp);
     }
     float* yslab = reinterpret_cast<float*>(a.y) + (long long)ks * a.split_stride;     // ksplit > 1: raw partial sums of this split (split_stride 0 otherwise)
-    const int gx = x0 + r;
     float ssum[NTW][4];
 #pragma unroll
     for (int t = 0; t < NTW; ++t)
@@ -118,30 +141,40 @@ __device__ __forceinline__ void x3_epilogue(const IgemmArgs& a, f32x4 (&acc)[LW]
         }
     }
     if (a.bnpart) {
-        // BatchNorm-backward column sums of the layer in front (input-gradient launch, no bias / activation / split): the tile just
-        // stored is d(activation); read that layer's pre-norm tensor at the same voxels and reduce dz and dz * xhat per channel
+        // reduce dz and dz * xhat per channel over the tile (dz = d(activation) * act'(gamma xhat + beta))
         float sa[NTW][4], sb[NTW][4];
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            const int c = n0 + 16 * t + 4 * g;
-            const f32x4 mu = *reinterpret_cast<const f32x4*>(a.bn_mean + c), rs = *reinterpret_cast<const f32x4*>(a.bn_rstd + c);
-            const f32x4 ga = *reinterpret_cast<const f32x4*>(a.bn_gamma + c), be = *reinterpret_cast<const f32x4*>(a.bn_beta + c);
+        for (int t = 0; t < NTW; ++t)
 #pragma unroll
             for (int e = 0; e < 4; ++e) { sa[t][e] = 0.f; sb[t][e] = 0.f; }
+        auto reduce = [&](int j0, auto grad) {
 #pragma unroll
-            for (int j = 0; j < LW; ++j) {
-                const int line = line0 + j;
-                const int gz = z0 + line / XTY, gy = y0 + line % XTY;
-                if (gz < a.D && gy < a.H && gx < a.W) {
-                    const f32x4 xv = *reinterpret_cast<const f32x4*>(a.bnx + ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.ldbnx + c);
+            for (int t = 0; t < NTW; ++t) {
+                const int c = n0 + 16 * t + 4 * g;
+                const f32x4 mu = *reinterpret_cast<const f32x4*>(a.bn_mean + c), rs = *reinterpret_cast<const f32x4*>(a.bn_rstd + c);
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(a.bn_gamma + c), be = *reinterpret_cast<const f32x4*>(a.bn_beta + c);
+#pragma unroll
+                for (int j = 0; j < LH; ++j) {
+                    if (j0 + j >= LW) continue;
+                    const int line = line0 + j0 + j;
+                    const float m = ((z0 + line / XTY) < a.D && (y0 + line % XTY) < a.H && gx < a.W) ? 1.f : 0.f;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float xh = (xv[e] - mu[e]) * rs[e];
-                        const float dz = acc[j][t][e] * act_grad(fmaf(xh, ga[e], be[e]), a.bn_act, a.bn_slope);
+                        const float xh = (bxv[j][t][e] - mu[e]) * rs[e];
+                        const float dz = acc[j0 + j][t][e] * grad(fmaf(xh, ga[e], be[e])) * m;
                         sa[t][e] += dz; sb[t][e] = fmaf(dz, xh, sb[t][e]);
                     }
                 }
             }
+        };
+        const int bact = a.bn_act;
+        const float bslope = a.bn_slope;
+        auto relu_grad = [](float z) { return z > 0.f ? 1.f : 0.f; };                       // (the U-Net's case: no per-element switch)
+        auto any_grad = [&](float z) { return act_grad(z, bact, bslope); };
+#pragma unroll
+        for (int j0 = 0; j0 < LW; j0 += LH) {
+            if (j0 > 0) load_bnx(j0);
+            if (bact == MI355SEG_ACT_RELU) reduce(j0, relu_grad); else reduce(j0, any_grad);
         }
         float* lds = reinterpret_cast<float*>(lds_raw);
         __syncthreads();                 // LDS halo no longer needed
@@ -302,13 +335,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xsample + chunk * 16), 0, sample_bytes, 0x00020000);
 #pragma unroll
         for (int it = 0; it < G::NITER; ++it)
-            stage[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[it], 0, 0));
+            stage[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[it], 0, X3S_HALO_AUX));
     };
     // one piece of the NEXT chunk's halo (the main loop requests one per scheduling region: a burst of all of them in front
     // of the loop would sit in front of every weight fragment requested after it -- vmcnt retires in order)
     auto load_piece = [&](int chunk, int it) {
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xsample + chunk * 16), 0, sample_bytes, 0x00020000);
-        stage[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[it], 0, 0));
+        stage[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[it], 0, X3S_HALO_AUX));
     };
     // x = h + m + l for a pair of values: three packed conversions, the remainders formed from the packed words
     auto split_pair = [](float x0_, float x1_, unsigned& h2, unsigned& m2, unsigned& l2) {
@@ -553,7 +586,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3w_kernel(IgemmArgs a) {
     f32x4 ring[RING];
     auto load_piece = [&](int chunk, int it) {
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xsample + chunk * 16), 0, sample_bytes, 0x00020000);
-        ring[it % RING] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[it], 0, 0));
+        ring[it % RING] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[it], 0, X3S_HALO_AUX));
     };
     auto split_pair_h = [&](float x0_, float x1_, unsigned& h2, unsigned& l2) {
         const float s0 = x0_ * xscale, s1 = x1_ * xscale;

@@ -19,7 +19,7 @@ def _first_step(shape):
     pred, mask, loss, _ = train_step(m, torch.optim.Adam(m.parameters(), lr=1e-3), x, gt)
     c = confusion_counts(gt.numpy(), mask.numpy())
     named = dict(m.named_parameters())
-    sums = (float(x.double().sum()), float(x.double().abs().sum()), int(gt.sum()))
+    sums = bench.batch_checksums(x, gt)
     return {"pred": pred.detach().numpy().copy(), "loss": float(loss), "counts": [c["gdth_sum"], c["pred_sum"], c["intersection_sum"], c["union_sum"]],
             "grads": {k: named[k].grad.numpy().copy() for k in bench.PARITY_GRADS}}, sums
 
@@ -53,7 +53,7 @@ def test_parity_block_against_the_cpu_childs_first_step(tmp_path):
     assert r["value"] > 0 and r["cfg1"]["value"] > 0
     first, sums = _first_step(shape)
     rec = np.load(out)
-    assert rec["pred"].shape == (2, 2, 16, 16, 16) and rec["counts"].tolist()[0] == sums[2]
+    assert rec["pred"].shape == (2, 2, 16, 16, 16) and rec["counts"].tolist()[0] == sums[2] and rec["input_checksums"].tolist() == list(sums)
     import shutil
     shutil.copy(out, str(tmp_path / "copy.npz"))
     p = bench.parity_vs_cpu(first, out, sums)

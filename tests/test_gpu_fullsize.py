@@ -29,28 +29,45 @@ def test_full_size_first_step_vs_cpu_oracle(seg):
     """North_star's bar at the benchmark configuration itself: UNet3D(1, 2, 32) on [2, 1, 128^3], first train step from kaiming weights,
     under every conv math -- logits within 1e-4 of the CPU oracle's (== the reference's PyTorch-CPU arithmetic, /root/reference/
     models/three_d/unet3d.py:50-71, train.py:187-221), loss and Dice within 1e-4, masks identical wherever the oracle's logit margin is
-    decisive, gradients of the stem, the head, the bottleneck, an up-convolution and a BatchNorm scale within 1e-3 of the tensor's
-    maximum (sums over 4.2 M voxels; the three maths' measured figures are printed).  The batch is bench.py's (labels = a
-    thresholded low-frequency field of the input), so Dice is a number that could disagree."""
+    decisive.  Gradients (stem, a BatchNorm scale, bottleneck, an up-convolution, head): through eighteen training-mode BatchNorm
+    layers at a random init the fp32 backward is ill-conditioned towards the deep layers (a ReLU whose argument is rounding noise away
+    from zero switches a whole voxel's gradient on or off; the bottleneck has 1,024 voxels per channel) -- the reference's own fp32
+    result sits 3e-3 (stem) to 6e-3 (bottleneck) of the tensor away from an fp64 run of the same step -- so they are graded the way the
+    Residual U-Net's are (test_gpu_models.py): the oracle step is repeated in fp64 and each GPU gradient must lie within 2x of the
+    REFERENCE's own fp32 distance from it in the L2 norm (measured r5: 0.99-1.1x under f16x3, 1.0-1.15x bf16x6, 1.3-1.5x exact fp32) and
+    within 10x in the maximum norm (single flipped voxels: 0.75-6.2x / 0.7-2.7x / 1.1-7.8x).  The batch is bench.py's (labels = a thresholded low-frequency field of the
+    input), so Dice is a number that could disagree."""
     import bench
     from mi355seg.engine import make_adam, train_step, weights_init_normal
     from mi355seg.models.three_d.unet3d import UNet3D
-    from mi355seg.utils.metric import metric_from_counts
     from oracle.nets import UNet3D as OracleUNet
     from oracle.step import train_step as oracle_step, weights_init_normal as oracle_init
     x, gt = bench.synthetic_batch((2, 1, 128, 128, 128), 1234)
-    torch.manual_seed(0)
-    ref = OracleUNet(1, 2, 32)
-    ref.apply(oracle_init("kaiming"))
-    ref.train()
-    pr, mr, lr, (jr, dr) = oracle_step(ref, torch.optim.Adam(ref.parameters(), lr=1e-3), x, gt)
-    pr = pr.detach()
+
+    def oracle(dtype):
+        torch.manual_seed(0)
+        ref = OracleUNet(1, 2, 32)
+        ref.apply(oracle_init("kaiming"))                       # (fp32 draws, then widened: the same initial weights in both precisions)
+        ref = ref.to(dtype).train()
+        pr, _, lr, (jr, dr) = oracle_step(ref, torch.optim.Adam(ref.parameters(), lr=1e-3), x.to(dtype), gt.to(dtype)) if dtype == torch.float32 \
+            else _oracle_step_any_dtype(ref, x.to(dtype), gt.to(dtype))
+        grads = {k: p.grad.clone() for k, p in ref.named_parameters() if k in bench.PARITY_GRADS}
+        return pr.detach(), float(lr), jr, dr, grads
+
+    pr, lr, jr, dr, rgrads = oracle(torch.float32)
     assert 0.05 < dr < 0.95, dr
-    rgrads = {k: p.grad.clone() for k, p in ref.named_parameters() if k in bench.PARITY_GRADS}
-    del ref
+    p64, l64, _, _, g64 = oracle(torch.float64)
+    emax = lambda g, k: float((g.double() - g64[k]).abs().max() / g64[k].abs().max())
+    el2 = lambda g, k: float((g.double() - g64[k]).norm() / g64[k].norm())
+    ref_err = {k: emax(rgrads[k], k) for k in g64}
+    ref_l2 = {k: el2(rgrads[k], k) for k in g64}
+    print("reference fp32 vs fp64: dlogit_max %.3e dloss %.3e grads max %s l2 %s" % (float((pr.double() - p64).abs().max()), abs(lr - l64),
+          {k: "%.2e" % v for k, v in ref_err.items()}, {k: "%.2e" % v for k, v in ref_l2.items()}))
+    del p64
     margin = (pr[:, 1] - pr[:, 0]).abs()
     decisive = margin > 2e-4
     xg, gg = x.cuda(), gt.cuda()
+    report = {}
     try:
         for math in ("f16x3", "bf16x6", "fp32"):
             seg.set_conv_math(math)
@@ -60,23 +77,38 @@ def test_full_size_first_step_vs_cpu_oracle(seg):
             m = m.cuda().train()
             out = train_step(m, make_adam(m.parameters(), lr=1e-3), xg, gg)
             pg = out["pred"].detach().cpu()
-            dl = float((pg - pr).abs().max())
             differ = (pg.argmax(1) != pr.argmax(1))
             named = dict(m.named_parameters())
-            gerr = {k: float((named[k].grad.cpu() - g).abs().max() / g.abs().max()) for k, g in rgrads.items()}
-            print(f"[{math}] dlogit_max {dl:.3e} dloss {abs(out['loss'].item() - lr.item()):.3e} ddice {abs(out['dice'] - dr):.3e} (dice {dr:.4f}) "
-                  f"masks differ {int(differ.sum())} (decisive {int((differ & decisive).sum())}, excluded {1 - float(decisive.float().mean()):.2e}) "
-                  f"grad rel err {max(gerr.values()):.3e}")
-            assert dl < 1e-4, (math, dl)
-            assert abs(out["loss"].item() - lr.item()) < 1e-5, math
-            assert abs(out["dice"] - dr) < 1e-4 and abs(out["jaccard"] - jr) < 1e-4, (math, out["dice"], dr)
-            assert int((differ & decisive).sum()) == 0, math
-            assert float(decisive.float().mean()) > 0.99
-            for k, e in gerr.items():
-                assert e < 1e-3, (math, k, e)
+            report[math] = {"dlogit": float((pg - pr).abs().max()), "dloss": abs(out["loss"].item() - lr), "ddice": abs(out["dice"] - dr),
+                            "djac": abs(out["jaccard"] - jr), "differ": int(differ.sum()), "differ_decisive": int((differ & decisive).sum()),
+                            "gerr64": {k: emax(named[k].grad.cpu(), k) for k in g64}, "gl2": {k: el2(named[k].grad.cpu(), k) for k in g64}}
+            print(f"[{math}] dlogit_max {report[math]['dlogit']:.3e} dloss {report[math]['dloss']:.3e} ddice {report[math]['ddice']:.3e} (dice {dr:.4f}) "
+                  f"masks differ {report[math]['differ']} (decisive {report[math]['differ_decisive']}, excluded {1 - float(decisive.float().mean()):.2e}) "
+                  f"grads vs fp64 max { {k: '%.2e' % v for k, v in report[math]['gerr64'].items()} } l2 { {k: '%.2e' % v for k, v in report[math]['gl2'].items()} }")
             del m, out
     finally:
         seg.set_conv_math("f16x3")
+    assert float(decisive.float().mean()) > 0.99
+    for math, rp in report.items():
+        assert rp["dlogit"] < 1e-4, (math, rp["dlogit"])
+        assert rp["dloss"] < 1e-5 and rp["ddice"] < 1e-4 and rp["djac"] < 1e-4, (math, rp)
+        assert rp["differ_decisive"] == 0, (math, rp["differ"])
+        for k, e in rp["gerr64"].items():
+            assert e <= 10.0 * ref_err[k] + 1e-4, (math, k, e, ref_err[k])
+            assert rp["gl2"][k] <= 2.0 * ref_l2[k] + 1e-5, (math, k, rp["gl2"][k], ref_l2[k])
+
+
+def _oracle_step_any_dtype(model, x, gt):
+    """oracle.step.train_step without its ``.float()`` casts (the fp64 repetition of the step; no optimizer step needed)."""
+    from oracle.losses import bce_with_logits
+    from oracle.metric import metric
+    from oracle.step import two_channel_gt
+    gt2 = two_channel_gt(gt)
+    pred = model(x)
+    mask = pred.argmax(dim=1, keepdim=True)
+    loss = bce_with_logits(pred, gt2)
+    loss.backward()
+    return pred, mask, loss, metric(gt2.argmax(dim=1, keepdim=True), mask)
 
 
 def test_full_size_train_step_is_bitwise_deterministic_and_consistent(seg):

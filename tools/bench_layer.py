@@ -53,6 +53,18 @@ if dtype == "f32" and L.query("mi355seg_conv_math_takes_amax") and "--measure-am
     run("fwd", lambda: L.call("mi355seg_conv3d_fwd_ax_f32", x.data_ptr(), Cin, w.data_ptr(), b.data_ptr(), y.data_ptr(), Cout, N, D, H, W, Cin, Cout, k, stride, pad, None, None, ax, aw, ws.data_ptr(), ws.numel(), st))
     L.call("mi355seg_amax_f32", y.data_ptr(), Cout, N * Do * Ho * Wo, Cout, am.data_ptr() + 8, st)
     run("dgrad", lambda: L.call("mi355seg_conv3d_dgrad_ax_f32", y.data_ptr(), Cout, w.data_ptr(), dx.data_ptr(), Cin, N, D, H, W, Cin, Cout, k, stride, pad, ay, aw, ws.data_ptr(), ws.numel(), st))
+    if k == 3 and stride == 1:
+        # the input gradient with the BatchNorm-backward column sums of the layer in front in its epilogue (conv2 of a double-conv block)
+        bnx = torch.randn(N, D, H, W, Cin, device="cuda")
+        mean, rstd, gam, bet = torch.zeros(Cin, device="cuda"), torch.ones(Cin, device="cuda"), torch.ones(Cin, device="cuda"), torch.zeros(Cin, device="cuda")
+        s12 = torch.zeros(4, Cin, device="cuda")
+        wsn = F.workspace(max(ws.numel(), L.query("mi355seg_norm_ws_bytes", N * D * H * W, 1, Cin)), x.device) if hasattr(L, "query") else ws
+        try:
+            run("dgbn", lambda: L.call("mi355seg_conv3d_dgrad_bnsums_ax_f32", y.data_ptr(), Cout, w.data_ptr(), dx.data_ptr(), Cin, N, D, H, W, Cin, Cout, k, stride, pad,
+                                       bnx.data_ptr(), Cin, mean.data_ptr(), rstd.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1, 0.0,
+                                       s12[0].data_ptr(), s12[1].data_ptr(), s12[2].data_ptr(), s12[3].data_ptr(), ay, aw, wsn.data_ptr(), wsn.numel(), st))
+        except Exception as e:
+            print("dgbn: ", repr(e)[:200])
     run("wgrad", lambda: L.call("mi355seg_conv3d_wgrad_ax_f32", y.data_ptr(), Cout, x.data_ptr(), Cin, dw.data_ptr(), None, N, D, H, W, Cin, Cout, k, stride, pad, 0, ay, ax, ws.data_ptr(), ws.numel(), st))
     sys.exit(0)
 run("fwd", lambda: L.call("mi355seg_conv3d_fwd" + sfx, x.data_ptr(), Cin, w.data_ptr(), b.data_ptr(), y.data_ptr(), Cout, N, D, H, W, Cin, Cout, k, stride, pad, None, None, ws.data_ptr(), ws.numel(), st))
