@@ -796,7 +796,10 @@ class _DoubleConvBnAct(Function):
     epilogue (mi355seg_conv3d_dgrad_bnsums_f32) instead of a separate pass over d(act) and y1."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, g1, be1, rm1, rv1, w2, b2, g2, be2, rm2, rv2, geo1, geo2, mom1, eps1, mom2, eps2, act, slope, left_pad):
+    def forward(ctx, x, w1, b1, g1, be1, rm1, rv1, w2, b2, g2, be2, rm2, rv2, geo1, geo2, mom1, eps1, mom2, eps2, act, slope, left_pad,
+                wh=None, bh=None):
+        """wh / bh: the 1x1x1 output head behind the block (unet3d.py:46-48,71).  The node then returns the head's LOGITS: norm2 +
+        activation + head run as one kernel and the block's activation is never written (csrc/bn_head.hip)."""
         xa_in = _get_amax(x)
         x, ldx = cl_view(x, "conv3d input")
         L = lib()
@@ -804,7 +807,7 @@ class _DoubleConvBnAct(Function):
         N = x.shape[0]
         ax = _takes_amax(x)           # f16x3: operand maxima ride along
 
-        def layer(inp, ldin, w, b, g, be, rm, rv, geo, mom, eps, lp, xa):
+        def layer(inp, ldin, w, b, g, be, rm, rv, geo, mom, eps, lp, xa, head=None):
             D, H, W, Cin = inp.shape[1:]
             Cout, k = w.shape[0], w.shape[2]
             stride, pad = geo
@@ -829,25 +832,38 @@ class _DoubleConvBnAct(Function):
             rstd = torch.empty(Cout, dtype=torch.float32, device=dev)
             L.call("mi355seg_norm_stats_from_sums_f32", sums.data_ptr(), sums.data_ptr() + 8 * Cout, rows, Cout, eps,
                    _p(mean), _p(rstd), _p(rm), _p(rv), mom, _stream())
+            cfg = (N, D, H, W, Cin, Cout, k, stride, pad, ldin, b is not None, rows)
+            if head is not None:             # norm + activation + 1x1x1 head: logits, no activation tensor
+                hw, hb = head
+                K = hw.shape[0]
+                lg = torch.empty((N, Do, Ho, Wo, K), dtype=inp.dtype, device=dev)
+                L.call("mi355seg_bn_act_head_fwd_f32", _p(y), Cout, _p(mean), _p(rstd), _p(g), _p(be), act, slope, _p(hw), _p(hb),
+                       _p(lg), K, rows, Cout, K, _stream())
+                return y, mean, rstd, lg, cfg, (xa, wa, None)
             full = torch.empty((N, Do, Ho, Wo, lp + Cout), dtype=inp.dtype, device=dev)
             a = full[..., lp:] if lp else full
             if ax:
                 aa = _amax_slot(dev)
             L.call("mi355seg_norm_act_fwd_ax_f32", _p(y), Cout, _p(mean), _p(rstd), _p(g), _p(be), None, 0,
                    a.data_ptr(), lp + Cout, rows, 1, Cout, act, slope, _p(aa), _stream())
-            return y, mean, rstd, a, (N, D, H, W, Cin, Cout, k, stride, pad, ldin, b is not None, rows), (xa, wa, aa)
+            return y, mean, rstd, a, cfg, (xa, wa, aa)
 
         w1, w2 = w1.contiguous(), w2.contiguous()
+        head = None
+        if wh is not None:
+            wh = wh.contiguous()
+            head = (wh, bh)
         y1, mean1, rstd1, a1, cfg1, am1 = layer(x, ldx, w1, b1, g1, be1, rm1, rv1, geo1, mom1, eps1, 0, xa_in)
-        y2, mean2, rstd2, a2, cfg2, am2 = layer(a1, a1.shape[-1], w2, b2, g2, be2, rm2, rv2, geo2, mom2, eps2, left_pad, am1[2])
-        ctx.save_for_backward(x, w1, y1, mean1, rstd1, g1, be1, a1, w2, y2, mean2, rstd2, g2, be2)
+        y2, mean2, rstd2, a2, cfg2, am2 = layer(a1, a1.shape[-1], w2, b2, g2, be2, rm2, rv2, geo2, mom2, eps2, left_pad, am1[2], head)
+        ctx.save_for_backward(x, w1, y1, mean1, rstd1, g1, be1, a1, w2, y2, mean2, rstd2, g2, be2, wh)
         ctx.cfg = (cfg1, cfg2, act, slope)
         ctx.amax = (am1, am2)
-        return _set_amax(a2, am2[2])
+        ctx.head_bias = head is not None and bh is not None
+        return a2 if head is not None else _set_amax(a2, am2[2])
 
     @staticmethod
     def backward(ctx, da2):
-        x, w1, y1, mean1, rstd1, g1, be1, a1, w2, y2, mean2, rstd2, g2, be2 = ctx.saved_tensors
+        x, w1, y1, mean1, rstd1, g1, be1, a1, w2, y2, mean2, rstd2, g2, be2, wh = ctx.saved_tensors
         cfg1, cfg2, act, slope = ctx.cfg
         N, D1, H1, W1, Cin1, C1, k1, st1, pd1, ldx, has_b1, rows1 = cfg1
         _, D2, H2, W2, _, C2, k2, st2, pd2, lda1, has_b2, rows2 = cfg2
@@ -855,7 +871,8 @@ class _DoubleConvBnAct(Function):
         dev = x.device
         da2, ldda2 = cl_view(_like(da2, x), "conv+norm grad")
         ws = workspace(max(_conv_ws(L, x, N, D1, H1, W1, Cin1, C1, k1, st1, pd1), _conv_ws(L, a1, N, D2, H2, W2, C1, C2, k2, st2, pd2),
-                           L.query("mi355seg_norm_ws_bytes", rows1, 1, C1), L.query("mi355seg_norm_ws_bytes", rows2, 1, C2)), dev)
+                           L.query("mi355seg_norm_ws_bytes", rows1, 1, C1), L.query("mi355seg_norm_ws_bytes", rows2, 1, C2),
+                           L.query("mi355seg_bn_act_head_ws_bytes", C2, wh.shape[0]) if wh is not None else 0), dev)
         f32 = dict(dtype=torch.float32, device=dev)
         # layer 2: BatchNorm + activation backward (its dx column sums are conv2's bias gradient)
         dy2 = torch.empty_like(y2)
@@ -865,8 +882,21 @@ class _DoubleConvBnAct(Function):
         # f16x3: the two gradients d(conv output) take their maxima from the norm-backward kernels that write them
         dya2 = _amax_slot(dev) if (wa2 is not None or xa2 is not None) else None
         dya1 = _amax_slot(dev) if (wa1 is not None or xa1 is not None) else None
-        L.call("mi355seg_norm_act_bwd_colsum_ax_f32", _p(da2), ldda2, _p(y2), C2, _p(mean2), _p(rstd2), _p(g2), _p(be2), None, 0,
-               _p(dy2), C2, _p(dg2), _p(dbe2), None, 0, _p(db2), _p(dya2), rows2, 1, C2, act, slope, _p(ws), ws.numel(), _stream())
+        dwh = dbh = None
+        if wh is not None:
+            # da2 here is d(logits) [rows2, K]: the norm backward's column sums, the head's weight / bias gradients (one pass over
+            # y2 and d(logits)), then dy2 with conv2's bias gradient and its f16x3 maximum (a second pass)
+            K = wh.shape[0]
+            sh = torch.empty(2 * C2, **f32)
+            dwh = torch.empty_like(wh)
+            dbh = torch.empty(K, **f32) if ctx.head_bias else None
+            L.call("mi355seg_bn_act_head_bwd_sums_f32", _p(da2), ldda2, _p(y2), C2, _p(mean2), _p(rstd2), _p(g2), _p(be2), act, slope, _p(wh),
+                   sh.data_ptr(), sh.data_ptr() + 4 * C2, _p(dg2), _p(dbe2), _p(dwh), _p(dbh), rows2, C2, K, _p(ws), ws.numel(), _stream())
+            L.call("mi355seg_bn_act_head_bwd_apply_f32", _p(da2), ldda2, _p(y2), C2, _p(mean2), _p(rstd2), _p(g2), _p(be2), act, slope, _p(wh),
+                   sh.data_ptr(), sh.data_ptr() + 4 * C2, _p(dy2), C2, _p(db2), _p(dya2), rows2, C2, K, _p(ws), ws.numel(), _stream())
+        else:
+            L.call("mi355seg_norm_act_bwd_colsum_ax_f32", _p(da2), ldda2, _p(y2), C2, _p(mean2), _p(rstd2), _p(g2), _p(be2), None, 0,
+                   _p(dy2), C2, _p(dg2), _p(dbe2), None, 0, _p(db2), _p(dya2), rows2, 1, C2, act, slope, _p(ws), ws.numel(), _stream())
         # conv2 input gradient = d(act1); BN1's two column sums come out of the same kernel
         da1 = torch.empty((N, D2, H2, W2, C1), dtype=x.dtype, device=dev)
         s12 = torch.empty(2 * C1, **f32)
@@ -893,17 +923,27 @@ class _DoubleConvBnAct(Function):
             dw1 = torch.empty_like(w1)
             L.call("mi355seg_conv3d_wgrad_ax_f32", _p(dy1), C1, _p(x), ldx, _p(dw1), None, N, D1, H1, W1, Cin1, C1, k1, st1, pd1,
                    0, _p(dya1), _p(xa1), _p(ws), ws.numel(), _stream())
-        return (dx, dw1, db1, dg1, dbe1, None, None, dw2, db2, dg2, dbe2, None, None) + (None,) * 9
+        return (dx, dw1, db1, dg1, dbe1, None, None, dw2, db2, dg2, dbe2, None, None) + (None,) * 9 + (dwh, dbh)
 
 
-def double_conv_bn_act(x, conv1, bn1, conv2, bn2, act=ACT_NONE, slope=0.01, left_pad=0):
+def double_conv_bn_act(x, conv1, bn1, conv2, bn2, act=ACT_NONE, slope=0.01, left_pad=0, head=None):
     """act(bn2(conv2(act(bn1(conv1(x)))))): training mode on fp32 tensors runs as one autograd node (_DoubleConvBnAct), everything
-    else as two conv_bn_act layers."""
+    else as two conv_bn_act layers.  ``head`` (a layers.Conv3d with kernel_size 1: the output head behind the LAST block,
+    unet3d.py:46-48,71): the result is ``head(block(x))``; in the fused node norm2 + activation + head are one kernel."""
     fused = bn1.training and bn2.training and torch.is_grad_enabled() and compute_dtype() == torch.float32 and x.dtype == torch.float32
     for bn in (bn1, bn2):
         fused = fused and bn.momentum is not None and bn.affine and bn.track_running_stats
     if not fused:
-        return conv_bn_act(conv_bn_act(x, conv1, bn1, act, slope), conv2, bn2, act, slope, left_pad=left_pad)
+        a = conv_bn_act(conv_bn_act(x, conv1, bn1, act, slope), conv2, bn2, act, slope, left_pad=left_pad)
+        return a if head is None else head(a)
+    head_fused = False
+    if head is not None:
+        hk = head.kernel_size[0] if isinstance(head.kernel_size, (tuple, list)) else head.kernel_size
+        hs = head.stride[0] if isinstance(head.stride, (tuple, list)) else head.stride
+        hp = head.padding[0] if isinstance(head.padding, (tuple, list)) else head.padding
+        head_fused = (hk, hs, hp) == (1, 1, 0) and head.groups == 1 and head.weight.dtype == torch.float32 and left_pad == 0 and \
+            head.in_channels == conv2.out_channels and not os.environ.get("MI355SEG_NO_HEAD_FUSION") and \
+            lib().query("mi355seg_bn_act_head_supported_f32", 1, conv2.out_channels, head.out_channels, conv2.out_channels) != 0
 
     def geo(conv):
         st = conv.stride[0] if isinstance(conv.stride, (tuple, list)) else conv.stride
@@ -911,10 +951,14 @@ def double_conv_bn_act(x, conv1, bn1, conv2, bn2, act=ACT_NONE, slope=0.01, left
         return int(st), int(pd)
     bump_counter(bn1)
     bump_counter(bn2)
-    return _DoubleConvBnAct.apply(x, conv1.weight, conv1.bias, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
-                                  conv2.weight, conv2.bias, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var,
-                                  geo(conv1), geo(conv2), float(bn1.momentum), float(bn1.eps), float(bn2.momentum), float(bn2.eps),
-                                  int(act), float(slope), int(left_pad))
+    args = (x, conv1.weight, conv1.bias, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
+            conv2.weight, conv2.bias, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var,
+            geo(conv1), geo(conv2), float(bn1.momentum), float(bn1.eps), float(bn2.momentum), float(bn2.eps),
+            int(act), float(slope), int(left_pad))
+    if head_fused:
+        return _DoubleConvBnAct.apply(*args, head.weight, head.bias)
+    a = _DoubleConvBnAct.apply(*args)
+    return a if head is None else head(a)
 
 
 class _Act(Function):

@@ -19,13 +19,15 @@ class _DoubleConv(nn.Sequential):
     """(conv k3 p1 -> BN -> ReLU) x 2 with the reference's child names (unet3d.py:73-104).
     ``forward`` fuses each BN with its ReLU."""
 
-    def forward(self, x, left_pad=0):
+    def forward(self, x, left_pad=0, head=None):
         """``left_pad`` > 0: the block's output is the right channel slice of a buffer with ``left_pad`` free channels
-        on its left, ready for the decoder's concat-free up-convolution (encoder blocks only)."""
+        on its left, ready for the decoder's concat-free up-convolution (encoder blocks only).  ``head``: the 1x1x1 output
+        convolution behind the last block -- the result is then ``head(block(x))`` (in training: norm2 + ReLU + head as one kernel,
+        the block's activation never written)."""
         conv1, norm1, _r1, conv2, norm2, _r2 = self.children()
         # (conv + batch statistics + BN + ReLU) x 2; in training the whole block is one autograd node whose backward takes norm1's
         # column sums out of conv2's input-gradient kernel
-        return F.double_conv_bn_act(x, conv1, norm1, conv2, norm2, F.ACT_RELU, left_pad=left_pad)
+        return F.double_conv_bn_act(x, conv1, norm1, conv2, norm2, F.ACT_RELU, left_pad=left_pad, head=head)
 
 
 class UNet3D(nn.Module):
@@ -72,7 +74,8 @@ class UNet3D(nn.Module):
         p3, enc3 = F.max_pool3d_2x_and_skip(self.encoder3(p2, left_pad=self.upconv3.out_channels))
         p4, enc4 = F.max_pool3d_2x_and_skip(self.encoder4(p3, left_pad=self.upconv4.out_channels))
         h = self.bottleneck(p4)
-        for up, dec, skip in ((self.upconv4, self.decoder4, enc4), (self.upconv3, self.decoder3, enc3),
-                              (self.upconv2, self.decoder2, enc2), (self.upconv1, self.decoder1, enc1)):
+        for up, dec, skip in ((self.upconv4, self.decoder4, enc4), (self.upconv3, self.decoder3, enc3), (self.upconv2, self.decoder2, enc2)):
             h = dec(F.conv_transpose3d_k2s2_cat(h, up.weight, up.bias, skip))
-        return F.to_channels_first(self.conv(h))
+        # decoder1 and the output head (unet3d.py:68-71) together: head(decoder1(cat))
+        h = self.decoder1(F.conv_transpose3d_k2s2_cat(h, self.upconv1.weight, self.upconv1.bias, enc1), head=self.conv)
+        return F.to_channels_first(h)

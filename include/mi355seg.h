@@ -243,6 +243,29 @@ int mi355seg_norm_act_bwd_colsum_f32(const float* dy, int lddy, const float* x, 
                                      long long rows, int groups, int C, int act, float slope,
                                      void* ws, size_t ws_bytes, void* stream);
 
+/* BatchNorm + activation of the LAST double-conv block fused with the 1x1x1 output head (/root/reference/models/three_d/unet3d.py:46-48,
+ * 68-71: ``self.conv(dec1)`` behind decoder1's norm2 (:100) + relu2 (:101); head = nn.Conv3d(features, out_channels, kernel_size=1)).
+ * The activation a = act(BN(y)) has the head as its only consumer and is never written:
+ *   fwd        logits[r, k] = bh[k] + sum_c wh[k, c] * act(gamma[c] * xhat[r, c] + beta[c])          (same bits as norm_act_fwd + conv3d_fwd k1)
+ *   bwd_sums   one pass over (y, dlogits): s1 / s2 of the norm backward (dz = (sum_k dlogits[r, k] wh[k, c]) * act'(z)), dgamma = s2,
+ *              dbeta = s1, AND the head's gradients dwh[k, c] = sum_r dlogits[r, k] a[r, c], dbh[k] = sum_r dlogits[r, k]
+ *   bwd_apply  dy = rstd gamma (dz - s1 / rows - xhat s2 / rows), dy_colsum[c] = sum_r dy (bias gradient of the convolution in front),
+ *              dy_amax (f16x3 operand maximum; max-combined into a zeroed scalar).  C a power of two in 4..256, K = 1..4, fp32.
+ * ws: mi355seg_bn_act_head_ws_bytes(C, K). */
+int mi355seg_bn_act_head_supported_f32(long long rows, int C, int K, int ldy);
+size_t mi355seg_bn_act_head_ws_bytes(int C, int K);
+int mi355seg_bn_act_head_fwd_f32(const float* y, int ldy, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                 int act, float slope, const float* wh, const float* bh, float* logits, int ldl,
+                                 long long rows, int C, int K, void* stream);
+int mi355seg_bn_act_head_bwd_sums_f32(const float* dlogits, int lddl, const float* y, int ldy, const float* mean, const float* rstd,
+                                      const float* gamma, const float* beta, int act, float slope, const float* wh,
+                                      float* s1, float* s2, float* dgamma, float* dbeta, float* dwh, float* dbh,
+                                      long long rows, int C, int K, void* ws, size_t ws_bytes, void* stream);
+int mi355seg_bn_act_head_bwd_apply_f32(const float* dlogits, int lddl, const float* y, int ldy, const float* mean, const float* rstd,
+                                       const float* gamma, const float* beta, int act, float slope, const float* wh,
+                                       const float* s1, const float* s2, float* dy, int lddy, float* dy_colsum, float* dy_amax,
+                                       long long rows, int C, int K, void* ws, size_t ws_bytes, void* stream);
+
 /* The same backward in its two halves (the conv -> BN -> ReLU -> conv chains of unet3d.py:73-104: the first half can ride in the
  * epilogue of the kernel that produces dy, see mi355seg_conv3d_dgrad_bnsums_f32):
  *   sums:  s1[g, c] = sum_rows dz, s2[g, c] = sum_rows dz * xhat, dz = dy * act'(z)  (+ dgamma = s2, dbeta = s1; groups == 1)

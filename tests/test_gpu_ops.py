@@ -823,3 +823,64 @@ def test_prelu_against_aten(seg, C, res):
     if res:
         assert (cf(rg.grad) - rr.grad).abs().max() < 1e-6
     assert rel_err(ag.grad.cpu(), ar.grad) < 1e-5
+
+
+@pytest.mark.parametrize("shape,C,K,act", [((2, 7, 9, 11), 32, 2, "relu"), ((1, 4, 4, 6), 8, 3, "relu"), ((1, 5, 6, 7), 64, 4, "lrelu"),
+                                            ((1, 3, 3, 5), 256, 1, "relu"), ((1, 1, 1, 5), 32, 2, "relu"), ((2, 16, 16, 16), 32, 2, "elu")])
+def test_bn_act_head_fused_kernels(seg, shape, C, K, act):
+    """csrc/bn_head.hip through the C-ABI: BatchNorm + activation + 1x1x1 head as one forward kernel and the backward's two passes
+    (column sums + head gradients; dy + its column sums + its maximum), against the chain of torch-CPU ops in fp64
+    (/root/reference/models/three_d/unet3d.py:46-48,68-71,100-101: relu2(norm2(.)) then ``self.conv``) and, for the forward, BIT-FOR-BIT
+    against the library's own unfused chain (norm_act_fwd + the k1 convolution) where that runs the same head kernel (K = 2, 4)."""
+    F = seg.functional
+    L = seg.lib()
+    N, D, H, W = shape
+    rows = N * D * H * W
+    y = (rnd(rows, C, seed=1) * 1.7 + 0.3)
+    mean, var = y.mean(0), y.var(0, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    gamma, beta = 1 + 0.2 * rnd(C, seed=2), 0.3 * rnd(C, seed=3)
+    wh, bh = rnd(K, C, seed=4) * 0.3, rnd(K, seed=5) * 0.1
+    dl = rnd(rows, K, seed=6)
+    code, slope = {"relu": (F.ACT_RELU, 0.0), "lrelu": (F.ACT_LRELU, 0.01), "elu": (F.ACT_ELU, 1.0)}[act]
+    actf = {"relu": torch.relu, "lrelu": lambda z: TF.leaky_relu(z, 0.01), "elu": TF.elu}[act]
+    # fp64 reference of the whole chain, training-mode batch statistics
+    y64 = y.double().requires_grad_(True)
+    g64, b64, w64, hb64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True), wh.double().requires_grad_(True), bh.double().requires_grad_(True)
+    m64 = y64.mean(0)
+    xh = (y64 - m64) / torch.sqrt(y64.var(0, unbiased=False) + 1e-5)
+    a64 = actf(xh * g64 + b64)
+    lg64 = a64 @ w64.t() + hb64
+    lg64.backward(dl.double())
+    dev = "cuda"
+    yg, mg, rg, gg, bg, wg, hbg, dlg = [t.to(dev).contiguous() for t in (y, mean, rstd, gamma, beta, wh, bh, dl)]
+    st = torch.cuda.current_stream().cuda_stream
+    lg = torch.empty(rows, K, device=dev)
+    L.call("mi355seg_bn_act_head_fwd_f32", yg.data_ptr(), C, mg.data_ptr(), rg.data_ptr(), gg.data_ptr(), bg.data_ptr(), code, slope,
+           wg.data_ptr(), hbg.data_ptr(), lg.data_ptr(), K, rows, C, K, st)
+    assert (lg.cpu().double() - lg64.detach()).abs().max() < 2e-5 * max(1.0, float(lg64.abs().max()))
+    if K in (2, 4) and C >= 16:
+        a = torch.empty(rows, C, device=dev)
+        L.call("mi355seg_norm_act_fwd_f32", yg.data_ptr(), C, mg.data_ptr(), rg.data_ptr(), gg.data_ptr(), bg.data_ptr(), None, 0,
+               a.data_ptr(), C, rows, 1, C, code, slope, st)
+        lg2 = F.conv3d(a.view(N, D, H, W, C), wg.view(K, C, 1, 1, 1), hbg, 1, 0).reshape(rows, K)
+        assert torch.equal(lg, lg2)                             # same arithmetic as the unfused chain: identical logits
+    ws = F.workspace(L.query("mi355seg_bn_act_head_ws_bytes", C, K), torch.device(dev))
+    out = torch.zeros(4 * C + K * C + K, device=dev)
+    s1, s2, dg, db = [out[i * C:(i + 1) * C] for i in range(4)]
+    dwh, dbh = out[4 * C:4 * C + K * C], out[4 * C + K * C:]
+    L.call("mi355seg_bn_act_head_bwd_sums_f32", dlg.data_ptr(), K, yg.data_ptr(), C, mg.data_ptr(), rg.data_ptr(), gg.data_ptr(), bg.data_ptr(), code, slope,
+           wg.data_ptr(), s1.data_ptr(), s2.data_ptr(), dg.data_ptr(), db.data_ptr(), dwh.data_ptr(), dbh.data_ptr(), rows, C, K, ws.data_ptr(), ws.numel(), st)
+    dy = torch.empty(rows, C, device=dev)
+    col, amax = torch.zeros(C, device=dev), torch.zeros(1, device=dev)
+    L.call("mi355seg_bn_act_head_bwd_apply_f32", dlg.data_ptr(), K, yg.data_ptr(), C, mg.data_ptr(), rg.data_ptr(), gg.data_ptr(), bg.data_ptr(), code, slope,
+           wg.data_ptr(), s1.data_ptr(), s2.data_ptr(), dy.data_ptr(), C, col.data_ptr(), amax.data_ptr(), rows, C, K, ws.data_ptr(), ws.numel(), st)
+    torch.cuda.synchronize()
+    tol = lambda ref: 3e-5 * max(1e-3, float(ref.abs().max()))
+    assert (dg.cpu().double() - g64.grad).abs().max() < tol(g64.grad) and (db.cpu().double() - b64.grad).abs().max() < tol(b64.grad)
+    assert torch.equal(s1, db) and torch.equal(s2, dg)
+    assert (dwh.cpu().double().view(K, C) - w64.grad).abs().max() < tol(w64.grad)
+    assert (dbh.cpu().double() - hb64.grad).abs().max() < tol(hb64.grad)
+    assert (dy.cpu().double() - y64.grad).abs().max() < tol(y64.grad) * 3
+    assert (col.cpu().double() - dy.cpu().double().sum(0)).abs().max() < 1e-4 * max(1e-3, float(dy.abs().max()))
+    assert float(amax) == float(dy.abs().max())
