@@ -250,6 +250,153 @@ __global__ __launch_bounds__(256) void bn_head_bwd_apply_kernel(BhArgs a) {
     if (a.amax) block_amax_commit(amax, a.amax);
 }
 
+// ---------------------------------------------------------------- BatchNorm + activation + MaxPool3d(2, 2) of an ENCODER block
+// unet3d.py:19-25,51-58: ``pool1(enc1)`` where enc1 = relu2(norm2(.)) also feeds the skip concatenation.  Forward: thread = (pooled voxel,
+// channel quad) normalises its eight children, writes them into the skip tensor (a channel slice of the level's concat buffer) AND
+// their maximum + 3-bit argmax code: the activation is not re-read by a pooling pass.  Backward: d(act) = d(skip) + scatter(d(pooled))
+// is formed on the fly in both passes of the norm backward (no pool-backward pass, no d(act) tensor).
+struct BpArgs {
+    const float* y; int ldy;                        // pre-norm tensor [N, D, H, W, C]
+    const float* mean; const float* rstd; const float* gamma; const float* beta;
+    float* a; int lda;                              // forward: activation out (skip)
+    float* p; uint8_t* idx;                         // forward: pooled out [N, D/2, H/2, W/2, C] + codes
+    const float* ds; int ldds;                      // backward: d(skip)
+    const float* dp;                                // backward: d(pooled), pitch C
+    const uint8_t* cidx;
+    float* dy; int lddy;                            // apply: d(pre-norm)
+    const float* s1; const float* s2;
+    float* part; unsigned* amax;
+    int N, D, H, W, C, act; float slope;
+};
+
+__device__ __forceinline__ long long bp_child(const BpArgs& a, int n, int od, int oh, int ow, int t) {
+    return (((long long)n * a.D + 2 * od + (t >> 2)) * a.H + 2 * oh + ((t >> 1) & 1)) * a.W + 2 * ow + (t & 1);
+}
+
+__global__ __launch_bounds__(256) void bn_pool_fwd_kernel(BpArgs a) {
+    const int LPV = a.C / 4, VPB = 256 / LPV;
+    const int c4 = threadIdx.x % LPV, vl = threadIdx.x / LPV;
+    const int Do = a.D / 2, Ho = a.H / 2, Wo = a.W / 2;
+    const long long npool = (long long)a.N * Do * Ho * Wo;
+    f32x4_t al, be;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        al[j] = a.rstd[c4 * 4 + j] * (a.gamma ? a.gamma[c4 * 4 + j] : 1.f);
+        be[j] = (a.beta ? a.beta[c4 * 4 + j] : 0.f) - a.mean[c4 * 4 + j] * al[j];
+    }
+    float amax = 0.f;
+    for (long long pv = (long long)blockIdx.x * VPB + vl; pv < npool; pv += (long long)gridDim.x * VPB) {
+        const int ow = (int)(pv % Wo); long long r = pv / Wo;
+        const int oh = (int)(r % Ho); r /= Ho;
+        const int od = (int)(r % Do); const int n = (int)(r / Do);
+        float4 x[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x[t] = ldf4(a.y + bp_child(a, n, od, oh, ow, t) * a.ldy + c4 * 4);
+        float best[4]; int code[4];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            float o[4];
+            o[0] = act_apply(fmaf(x[t].x, al[0], be[0]), a.act, a.slope); o[1] = act_apply(fmaf(x[t].y, al[1], be[1]), a.act, a.slope);
+            o[2] = act_apply(fmaf(x[t].z, al[2], be[2]), a.act, a.slope); o[3] = act_apply(fmaf(x[t].w, al[3], be[3]), a.act, a.slope);
+            stf4(a.a + bp_child(a, n, od, oh, ow, t) * a.lda + c4 * 4, make_float4(o[0], o[1], o[2], o[3]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                amax = fmaxf(amax, fabsf(o[j]));
+                if (t == 0 || o[j] > best[j] || o[j] != o[j]) { best[j] = o[j]; code[j] = t; }       // maxpool2_fwd_kernel's rule (PyTorch's)
+            }
+        }
+        stf4(a.p + pv * a.C + c4 * 4, make_float4(best[0], best[1], best[2], best[3]));
+        *reinterpret_cast<uchar4*>(a.idx + pv * a.C + c4 * 4) = make_uchar4((uint8_t)code[0], (uint8_t)code[1], (uint8_t)code[2], (uint8_t)code[3]);
+    }
+    if (a.amax) block_amax_commit(amax, a.amax);
+}
+
+// APPLY = false: per-block partials part[blk][2 C] = s1 | s2;  APPLY = true: dy written, part[blk][C] = column sums of dy, max |dy|
+template <bool APPLY>
+__global__ __launch_bounds__(256) void bn_pool_bwd_kernel(BpArgs a) {
+    __shared__ float sred[4 * 64 * 8];
+    const int LPV = a.C / 4, VPB = 256 / LPV;
+    const int c4 = threadIdx.x % LPV, vl = threadIdx.x / LPV;
+    const int Do = a.D / 2, Ho = a.H / 2, Wo = a.W / 2;
+    const long long npool = (long long)a.N * Do * Ho * Wo;
+    f32x4_t m, rs, ga, be, k1 = {0.f, 0.f, 0.f, 0.f}, k2 = k1, sc = k1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        m[j] = a.mean[c4 * 4 + j]; rs[j] = a.rstd[c4 * 4 + j];
+        ga[j] = a.gamma ? a.gamma[c4 * 4 + j] : 1.f; be[j] = a.beta ? a.beta[c4 * 4 + j] : 0.f;
+    }
+    if (APPLY) {
+        const float invM = 1.f / (float)((long long)a.N * a.D * a.H * a.W);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { k1[j] = a.s1[c4 * 4 + j] * invM; k2[j] = a.s2[c4 * 4 + j] * invM; sc[j] = ga[j] * rs[j]; }
+    }
+    f32x4_t acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = acc1;
+    float amax = 0.f;
+    for (long long pv = (long long)blockIdx.x * VPB + vl; pv < npool; pv += (long long)gridDim.x * VPB) {
+        const int ow = (int)(pv % Wo); long long r = pv / Wo;
+        const int oh = (int)(r % Ho); r /= Ho;
+        const int od = (int)(r % Do); const int n = (int)(r / Do);
+        const float4 g = ldf4(a.dp + pv * a.C + c4 * 4);
+        const uchar4 cd = *reinterpret_cast<const uchar4*>(a.cidx + pv * a.C + c4 * 4);
+        float4 x[8], d[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const long long v = bp_child(a, n, od, oh, ow, t);
+            x[t] = ldf4(a.y + v * a.ldy + c4 * 4);
+            d[t] = ldf4(a.ds + v * a.ldds + c4 * 4);
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            // maxpool2_bwd_kernel's merge: the pooled gradient goes to the arg-max child, then the skip gradient is added
+            const float dv[4] = {(cd.x == t ? g.x : 0.f) + d[t].x, (cd.y == t ? g.y : 0.f) + d[t].y, (cd.z == t ? g.z : 0.f) + d[t].z, (cd.w == t ? g.w : 0.f) + d[t].w};
+            const float xv[4] = {x[t].x, x[t].y, x[t].z, x[t].w};
+            f32x4_t od4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (xv[j] - m[j]) * rs[j];
+                const float dz = dv[j] * act_grad(fmaf(xh, ga[j], be[j]), a.act, a.slope);
+                if (APPLY) {
+                    od4[j] = sc[j] * (dz - k1[j] - xh * k2[j]);
+                    acc1[j] += od4[j];
+                    amax = fmaxf(amax, fabsf(od4[j]));
+                } else {
+                    acc1[j] += dz; acc2[j] = fmaf(dz, xh, acc2[j]);
+                }
+            }
+            if (APPLY) stf4(a.dy + bp_child(a, n, od, oh, ow, t) * a.lddy + c4 * 4, make_float4(od4[0], od4[1], od4[2], od4[3]));
+        }
+    }
+    if (a.part) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        float vals[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { vals[j] = acc1[j]; vals[4 + j] = acc2[j]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float s = vals[i];
+            for (int o = 32; o >= LPV; o >>= 1) s += __shfl_xor(s, o, 64);
+            vals[i] = s;
+        }
+        if (lane < (LPV < 64 ? LPV : 64)) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sred[(wave * 64 + lane) * 8 + i] = vals[i];
+        }
+        __syncthreads();
+        const int ncol = APPLY ? a.C : 2 * a.C;
+        for (int i = threadIdx.x; i < ncol; i += 256) {
+            const int which = i / a.C, c = i % a.C;
+            float s = 0.f;
+            for (int w = 0; w < 4; ++w) s += sred[(w * 64 + (c / 4) % 64) * 8 + which * 4 + c % 4];
+            a.part[(long long)blockIdx.x * ncol + i] = s;
+        }
+    }
+    if (APPLY && a.amax) block_amax_commit(amax, a.amax);
+}
+
+bool bp_ok(int N, int D, int H, int W, int C, int ldy) {
+    return N > 0 && D >= 2 && H >= 2 && W >= 2 && (D % 2) == 0 && (H % 2) == 0 && (W % 2) == 0 && C >= 4 && C <= 256 && (C & (C - 1)) == 0 && (ldy % 4) == 0;
+}
+
 int bh_grid(long long rows, int vpb) {
     long long b = (rows + vpb - 1) / vpb;
     b = (b + 15) / 16;                                  // >= 8 two-voxel trips per block
@@ -335,6 +482,73 @@ int mi355seg_bn_act_head_bwd_apply_f32(const float* dlogits, int lddl, const flo
     {
         ProfScope ps(PF_NORM, 2.0 * rows * C * K, 4.0 * rows * (2.0 * C + K), st);
         BH_DISPATCH(bn_head_bwd_apply_kernel, K, grid, st, a);
+        SEG_CHECK_LAUNCH();
+    }
+    if (dy_colsum) {
+        hipLaunchKernelGGL(bh_finalize_kernel, dim3(C), dim3(64), 0, st, (const float*)ws, grid, C, dy_colsum, C, (float*)nullptr, 0, (float*)nullptr, 0,
+                           (float*)nullptr, (float*)nullptr, (float*)nullptr);
+        SEG_CHECK_LAUNCH();
+    }
+    return MI355SEG_OK;
+}
+
+int mi355seg_bn_act_pool_supported_f32(int N, int D, int H, int W, int C, int ldy) { return bp_ok(N, D, H, W, C, ldy) ? 1 : 0; }
+
+size_t mi355seg_bn_act_pool_ws_bytes(int C) { return align_up((size_t)2 * kBhMaxBlocks * 2 * C * sizeof(float), 256) + 1024; }
+
+int mi355seg_bn_act_pool_fwd_f32(const float* y, int ldy, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                 int act, float slope, float* a, int lda, float* pooled, unsigned char* idx, float* a_amax,
+                                 int N, int D, int H, int W, int C, void* stream) {
+    SEG_CHECK_ARG(y && mean && rstd && a && pooled && idx && bp_ok(N, D, H, W, C, ldy) && (lda % 4) == 0 && act >= 0 && act <= 4, "bn_act_pool_fwd: bad arguments");
+    SEG_CHECK_ARG(((uintptr_t)y % 16) == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)pooled % 16) == 0 && ((uintptr_t)idx % 4) == 0, "bn_act_pool_fwd: tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    BpArgs b{};
+    b.y = y; b.ldy = ldy; b.mean = mean; b.rstd = rstd; b.gamma = gamma; b.beta = beta; b.a = a; b.lda = lda; b.p = pooled; b.idx = idx;
+    b.amax = (unsigned*)a_amax; b.N = N; b.D = D; b.H = H; b.W = W; b.C = C; b.act = act; b.slope = slope;
+    const long long npool = (long long)N * (D / 2) * (H / 2) * (W / 2);
+    const int vpb = 256 / (C / 4);
+    long long nb = (npool + vpb - 1) / vpb;
+    nb = (nb + 3) / 4;
+    const int grid = (int)(nb < 1 ? 1 : (nb > 4096 ? 4096 : nb));
+    ProfScope ps(PF_NORM, 0.0, 4.0 * npool * C * (16.0 + 1.25), st);
+    hipLaunchKernelGGL(bn_pool_fwd_kernel, dim3(grid), dim3(256), 0, st, b);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+/* The norm backward of that block with d(act) = dskip + maxpool_backward(dpooled, idx) formed on the fly: s1 / s2 (dgamma = s2,
+ * dbeta = s1), then dy = rstd gamma (dz - s1 / rows - xhat s2 / rows) with its column sums (dy_colsum, may be NULL) and maximum
+ * (dy_amax, may be NULL).  ws: mi355seg_bn_act_pool_ws_bytes(C). */
+int mi355seg_bn_act_pool_bwd_f32(const float* dskip, int ldds, const float* dpooled, const unsigned char* idx, const float* y, int ldy,
+                                 const float* mean, const float* rstd, const float* gamma, const float* beta, int act, float slope,
+                                 float* s1, float* s2, float* dgamma, float* dbeta, float* dy, int lddy, float* dy_colsum, float* dy_amax,
+                                 int N, int D, int H, int W, int C, void* ws, size_t ws_bytes, void* stream) {
+    SEG_CHECK_ARG(dskip && dpooled && idx && y && mean && rstd && s1 && s2 && dy && bp_ok(N, D, H, W, C, ldy) && (ldds % 4) == 0 && (lddy % 4) == 0 && act >= 0 && act <= 4,
+                  "bn_act_pool_bwd: bad arguments");
+    SEG_CHECK_ARG(((uintptr_t)y % 16) == 0 && ((uintptr_t)dskip % 16) == 0 && ((uintptr_t)dpooled % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)idx % 4) == 0,
+                  "bn_act_pool_bwd: tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    BpArgs b{};
+    b.y = y; b.ldy = ldy; b.mean = mean; b.rstd = rstd; b.gamma = gamma; b.beta = beta; b.ds = dskip; b.ldds = ldds; b.dp = dpooled; b.cidx = idx;
+    b.dy = dy; b.lddy = lddy; b.N = N; b.D = D; b.H = H; b.W = W; b.C = C; b.act = act; b.slope = slope;
+    const long long npool = (long long)N * (D / 2) * (H / 2) * (W / 2);
+    const int vpb = 256 / (C / 4);
+    long long nb = (npool + vpb - 1) / vpb;
+    nb = (nb + 3) / 4;
+    const int grid = (int)(nb < 1 ? 1 : (nb > 2 * kBhMaxBlocks ? 2 * kBhMaxBlocks : nb));
+    SEG_CHECK_WS((size_t)grid * 2 * C * sizeof(float), ws_bytes);
+    b.part = (float*)ws;
+    {
+        ProfScope ps(PF_NORM, 0.0, 4.0 * npool * C * (16.0 + 1.25), st);
+        hipLaunchKernelGGL(bn_pool_bwd_kernel<false>, dim3(grid), dim3(256), 0, st, b);
+        SEG_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(bh_finalize_kernel, dim3(2 * C), dim3(64), 0, st, (const float*)ws, grid, 2 * C, s1, C, s2, C, (float*)nullptr, 0, (float*)nullptr, dbeta, dgamma);
+    SEG_CHECK_LAUNCH();
+    b.s1 = s1; b.s2 = s2; b.amax = (unsigned*)dy_amax; b.part = dy_colsum ? (float*)ws : nullptr;
+    {
+        ProfScope ps(PF_NORM, 0.0, 4.0 * npool * C * (24.0 + 1.25), st);
+        hipLaunchKernelGGL(bn_pool_bwd_kernel<true>, dim3(grid), dim3(256), 0, st, b);
         SEG_CHECK_LAUNCH();
     }
     if (dy_colsum) {

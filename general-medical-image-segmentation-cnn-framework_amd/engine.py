@@ -69,13 +69,18 @@ def train_step(model, optimizer, x, gt, criterion=None, sync_metric=True, grad_h
     # launched ahead of the step (distributed.broadcast_buffers(async_op=True)) is waited for
     bns = [m for m in model.modules()
            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training and m.num_batches_tracked is not None]
-    with F.autocast(dtype or F.compute_dtype()), F.counters_batched(bns):
-        if getattr(model, "takes_frequency_bands", False):      # the IS network, train.py:198-201: second output discarded
-            from .models.three_d.IS import frequency_bands
-            low_x, high_x = frequency_bands(x)
-            pred, _ = _forward(model, _leaves, x, low_x, high_x)
-        else:
-            pred = _forward(model, _leaves, x)
+    if (dtype or F.compute_dtype()) == torch.float32:
+        F.prefetch_weight_amax(model)        # f16x3: the k3 weights' maxima by one multi-tensor launch (valid for this step only)
+    try:
+        with F.autocast(dtype or F.compute_dtype()), F.counters_batched(bns):
+            if getattr(model, "takes_frequency_bands", False):      # the IS network, train.py:198-201: second output discarded
+                from .models.three_d.IS import frequency_bands
+                low_x, high_x = frequency_bands(x)
+                pred, _ = _forward(model, _leaves, x, low_x, high_x)
+            else:
+                pred = _forward(model, _leaves, x)
+    finally:
+        F.clear_weight_amax()                # (the backward reuses the scalars the forward handed to each layer, not the table)
     F.flush_deferred_waits()                                     # (a model without norm layers)
     if bns:
         torch._foreach_add_([m.num_batches_tracked for m in bns], 1)

@@ -328,7 +328,36 @@ def _measure_amax(t, ld, rows, C, slot=None):
     return slot
 
 
+_WEIGHT_AMAX = {}
+
+
+def prefetch_weight_amax(model):
+    """max |w| of every 3x3x3 convolution weight of ``model`` by ONE multi-tensor launch (torch._foreach_norm, inf-norm) instead of
+    one small launch per layer and forward (19 per U-Net step).  engine.train_step calls it ahead of the forward and drops the
+    table (clear_weight_amax) when the step ends: the entries never outlive the weights they were measured on.  Keyed by the
+    storage address, so stand-in leaves that alias a parameter (engine.GraphedTrainStep) find their entry too."""
+    _WEIGHT_AMAX.clear()
+    if lib().query("mi355seg_conv_math_takes_amax") == 0:
+        return
+    ws = [m.weight for m in model.modules()
+          if isinstance(m, torch.nn.Conv3d) and m.weight is not None and m.weight.is_cuda and m.weight.dtype == torch.float32
+          and m.weight.is_contiguous() and tuple(m.weight.shape[2:]) == (3, 3, 3)]
+    if len(ws) < 2:
+        return
+    with torch.no_grad():
+        norms = torch._foreach_norm(ws, float("inf"))
+    for w, a in zip(ws, norms):
+        _WEIGHT_AMAX[w.data_ptr()] = (a.reshape(1), w.numel())
+
+
+def clear_weight_amax():
+    _WEIGHT_AMAX.clear()
+
+
 def _weight_amax(w):
+    rec = _WEIGHT_AMAX.get(w.data_ptr())
+    if rec is not None and rec[1] == w.numel() and rec[0].device == w.device:
+        return rec[0]
     return _measure_amax(w, w.numel(), 1, w.numel())
 
 
@@ -797,9 +826,12 @@ class _DoubleConvBnAct(Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, g1, be1, rm1, rv1, w2, b2, g2, be2, rm2, rv2, geo1, geo2, mom1, eps1, mom2, eps2, act, slope, left_pad,
-                wh=None, bh=None):
+                wh=None, bh=None, pool=False):
         """wh / bh: the 1x1x1 output head behind the block (unet3d.py:46-48,71).  The node then returns the head's LOGITS: norm2 +
-        activation + head run as one kernel and the block's activation is never written (csrc/bn_head.hip)."""
+        activation + head run as one kernel and the block's activation is never written (csrc/bn_head.hip).
+        pool: the MaxPool3d(2, 2) behind an encoder block (unet3d.py:51-58).  The node then returns (pooled, activation): norm2 +
+        activation + pooling are one kernel, and the backward forms d(activation) = d(skip) + pool_backward(d(pooled)) inside the
+        norm backward's two passes."""
         xa_in = _get_amax(x)
         x, ldx = cl_view(x, "conv3d input")
         L = lib()
@@ -807,7 +839,7 @@ class _DoubleConvBnAct(Function):
         N = x.shape[0]
         ax = _takes_amax(x)           # f16x3: operand maxima ride along
 
-        def layer(inp, ldin, w, b, g, be, rm, rv, geo, mom, eps, lp, xa, head=None):
+        def layer(inp, ldin, w, b, g, be, rm, rv, geo, mom, eps, lp, xa, head=None, pool=False):
             D, H, W, Cin = inp.shape[1:]
             Cout, k = w.shape[0], w.shape[2]
             stride, pad = geo
@@ -844,6 +876,12 @@ class _DoubleConvBnAct(Function):
             a = full[..., lp:] if lp else full
             if ax:
                 aa = _amax_slot(dev)
+            if pool:                         # norm + activation + MaxPool3d(2, 2): the skip tensor, the pooled tensor and the argmax codes
+                pd = torch.empty((N, Do // 2, Ho // 2, Wo // 2, Cout), dtype=inp.dtype, device=dev)
+                idx = torch.empty((N, Do // 2, Ho // 2, Wo // 2, Cout), dtype=torch.uint8, device=dev)
+                L.call("mi355seg_bn_act_pool_fwd_f32", _p(y), Cout, _p(mean), _p(rstd), _p(g), _p(be), act, slope, a.data_ptr(), lp + Cout,
+                       _p(pd), _p(idx), _p(aa), N, Do, Ho, Wo, Cout, _stream())
+                return y, mean, rstd, (a, pd, idx), cfg, (xa, wa, aa)
             L.call("mi355seg_norm_act_fwd_ax_f32", _p(y), Cout, _p(mean), _p(rstd), _p(g), _p(be), None, 0,
                    a.data_ptr(), lp + Cout, rows, 1, Cout, act, slope, _p(aa), _stream())
             return y, mean, rstd, a, cfg, (xa, wa, aa)
@@ -854,25 +892,32 @@ class _DoubleConvBnAct(Function):
             wh = wh.contiguous()
             head = (wh, bh)
         y1, mean1, rstd1, a1, cfg1, am1 = layer(x, ldx, w1, b1, g1, be1, rm1, rv1, geo1, mom1, eps1, 0, xa_in)
-        y2, mean2, rstd2, a2, cfg2, am2 = layer(a1, a1.shape[-1], w2, b2, g2, be2, rm2, rv2, geo2, mom2, eps2, left_pad, am1[2], head)
-        ctx.save_for_backward(x, w1, y1, mean1, rstd1, g1, be1, a1, w2, y2, mean2, rstd2, g2, be2, wh)
+        y2, mean2, rstd2, a2, cfg2, am2 = layer(a1, a1.shape[-1], w2, b2, g2, be2, rm2, rv2, geo2, mom2, eps2, left_pad, am1[2], head, pool)
+        idx = None
+        if pool:
+            a2, pd, idx = a2
+        ctx.save_for_backward(x, w1, y1, mean1, rstd1, g1, be1, a1, w2, y2, mean2, rstd2, g2, be2, wh, idx)
         ctx.cfg = (cfg1, cfg2, act, slope)
         ctx.amax = (am1, am2)
         ctx.head_bias = head is not None and bh is not None
+        if pool:                             # max |max_pool(a)| <= max |a| (equal for the non-negative outputs of a ReLU)
+            return _set_amax(pd, am2[2]), _set_amax(a2, am2[2])
         return a2 if head is not None else _set_amax(a2, am2[2])
 
     @staticmethod
-    def backward(ctx, da2):
-        x, w1, y1, mean1, rstd1, g1, be1, a1, w2, y2, mean2, rstd2, g2, be2, wh = ctx.saved_tensors
+    def backward(ctx, da2, dskip=None):
+        x, w1, y1, mean1, rstd1, g1, be1, a1, w2, y2, mean2, rstd2, g2, be2, wh, idx = ctx.saved_tensors
         cfg1, cfg2, act, slope = ctx.cfg
         N, D1, H1, W1, Cin1, C1, k1, st1, pd1, ldx, has_b1, rows1 = cfg1
         _, D2, H2, W2, _, C2, k2, st2, pd2, lda1, has_b2, rows2 = cfg2
         L = lib()
         dev = x.device
-        da2, ldda2 = cl_view(_like(da2, x), "conv+norm grad")
+        if da2 is not None:
+            da2, ldda2 = cl_view(_like(da2, x), "conv+norm grad")
         ws = workspace(max(_conv_ws(L, x, N, D1, H1, W1, Cin1, C1, k1, st1, pd1), _conv_ws(L, a1, N, D2, H2, W2, C1, C2, k2, st2, pd2),
                            L.query("mi355seg_norm_ws_bytes", rows1, 1, C1), L.query("mi355seg_norm_ws_bytes", rows2, 1, C2),
-                           L.query("mi355seg_bn_act_head_ws_bytes", C2, wh.shape[0]) if wh is not None else 0), dev)
+                           L.query("mi355seg_bn_act_head_ws_bytes", C2, wh.shape[0]) if wh is not None else 0,
+                           L.query("mi355seg_bn_act_pool_ws_bytes", C2) if idx is not None else 0), dev)
         f32 = dict(dtype=torch.float32, device=dev)
         # layer 2: BatchNorm + activation backward (its dx column sums are conv2's bias gradient)
         dy2 = torch.empty_like(y2)
@@ -883,7 +928,19 @@ class _DoubleConvBnAct(Function):
         dya2 = _amax_slot(dev) if (wa2 is not None or xa2 is not None) else None
         dya1 = _amax_slot(dev) if (wa1 is not None or xa1 is not None) else None
         dwh = dbh = None
-        if wh is not None:
+        if idx is not None:
+            # encoder block behind a max-pool: da2 is d(pooled), dskip the skip connection's gradient; d(activation) = dskip +
+            # pool_backward(d(pooled)) exists only inside the two passes of the norm backward
+            if dskip is None:                # (an unused skip output / pooled output: its gradient is zero)
+                dskip = torch.zeros((N, D2, H2, W2, C2), **f32)
+            if da2 is None:
+                da2 = torch.zeros((N, D2 // 2, H2 // 2, W2 // 2, C2), **f32)
+            ds, ldds = cl_view(_like(dskip, x), "skip grad")
+            da2 = da2.contiguous()
+            sp = torch.empty(2 * C2, **f32)
+            L.call("mi355seg_bn_act_pool_bwd_f32", _p(ds), ldds, _p(da2), _p(idx), _p(y2), C2, _p(mean2), _p(rstd2), _p(g2), _p(be2), act, slope,
+                   sp.data_ptr(), sp.data_ptr() + 4 * C2, _p(dg2), _p(dbe2), _p(dy2), C2, _p(db2), _p(dya2), N, D2, H2, W2, C2, _p(ws), ws.numel(), _stream())
+        elif wh is not None:
             # da2 here is d(logits) [rows2, K]: the norm backward's column sums, the head's weight / bias gradients (one pass over
             # y2 and d(logits)), then dy2 with conv2's bias gradient and its f16x3 maximum (a second pass)
             K = wh.shape[0]
@@ -923,18 +980,22 @@ class _DoubleConvBnAct(Function):
             dw1 = torch.empty_like(w1)
             L.call("mi355seg_conv3d_wgrad_ax_f32", _p(dy1), C1, _p(x), ldx, _p(dw1), None, N, D1, H1, W1, Cin1, C1, k1, st1, pd1,
                    0, _p(dya1), _p(xa1), _p(ws), ws.numel(), _stream())
-        return (dx, dw1, db1, dg1, dbe1, None, None, dw2, db2, dg2, dbe2, None, None) + (None,) * 9 + (dwh, dbh)
+        return (dx, dw1, db1, dg1, dbe1, None, None, dw2, db2, dg2, dbe2, None, None) + (None,) * 9 + (dwh, dbh, None)
 
 
-def double_conv_bn_act(x, conv1, bn1, conv2, bn2, act=ACT_NONE, slope=0.01, left_pad=0, head=None):
+def double_conv_bn_act(x, conv1, bn1, conv2, bn2, act=ACT_NONE, slope=0.01, left_pad=0, head=None, pool=False):
     """act(bn2(conv2(act(bn1(conv1(x)))))): training mode on fp32 tensors runs as one autograd node (_DoubleConvBnAct), everything
     else as two conv_bn_act layers.  ``head`` (a layers.Conv3d with kernel_size 1: the output head behind the LAST block,
     unet3d.py:46-48,71): the result is ``head(block(x))``; in the fused node norm2 + activation + head are one kernel."""
     fused = bn1.training and bn2.training and torch.is_grad_enabled() and compute_dtype() == torch.float32 and x.dtype == torch.float32
     for bn in (bn1, bn2):
         fused = fused and bn.momentum is not None and bn.affine and bn.track_running_stats
+    if pool and head is not None:
+        raise Mi355SegError("double_conv_bn_act: a block feeds either the output head or a max-pool, not both")
     if not fused:
         a = conv_bn_act(conv_bn_act(x, conv1, bn1, act, slope), conv2, bn2, act, slope, left_pad=left_pad)
+        if pool:
+            return max_pool3d_2x_and_skip(a)
         return a if head is None else head(a)
     head_fused = False
     if head is not None:
@@ -957,6 +1018,17 @@ def double_conv_bn_act(x, conv1, bn1, conv2, bn2, act=ACT_NONE, slope=0.01, left
             int(act), float(slope), int(left_pad))
     if head_fused:
         return _DoubleConvBnAct.apply(*args, head.weight, head.bias)
+    if pool:
+        # ``pool``: (max_pool3d_2x(block(x)), block(x)) -- in the fused node norm2 + activation + pooling are one kernel and the pool's
+        # backward rides in the norm backward; geometry the fused kernels do not take (odd extents) pools separately
+        _, D, H, W, _ = x.shape if x.dim() == 5 else (0, 0, 0, 0, 0)
+        k2, (s2_, p2_) = conv2.weight.shape[2], geo(conv2)
+        k1, (s1_, p1_) = conv1.weight.shape[2], geo(conv1)
+        ext = [((e + 2 * p1_ - k1) // s1_ + 1 + 2 * p2_ - k2) // s2_ + 1 for e in (D, H, W)]
+        if not os.environ.get("MI355SEG_NO_POOL_FUSION") and \
+                lib().query("mi355seg_bn_act_pool_supported_f32", int(x.shape[0]), ext[0], ext[1], ext[2], conv2.out_channels, conv2.out_channels) != 0:
+            return _DoubleConvBnAct.apply(*args, None, None, True)
+        return max_pool3d_2x_and_skip(_DoubleConvBnAct.apply(*args))
     a = _DoubleConvBnAct.apply(*args)
     return a if head is None else head(a)
 

@@ -19,15 +19,16 @@ class _DoubleConv(nn.Sequential):
     """(conv k3 p1 -> BN -> ReLU) x 2 with the reference's child names (unet3d.py:73-104).
     ``forward`` fuses each BN with its ReLU."""
 
-    def forward(self, x, left_pad=0, head=None):
+    def forward(self, x, left_pad=0, head=None, pool=False):
         """``left_pad`` > 0: the block's output is the right channel slice of a buffer with ``left_pad`` free channels
         on its left, ready for the decoder's concat-free up-convolution (encoder blocks only).  ``head``: the 1x1x1 output
         convolution behind the last block -- the result is then ``head(block(x))`` (in training: norm2 + ReLU + head as one kernel,
-        the block's activation never written)."""
+        the block's activation never written).  ``pool``: the result is (max_pool3d_2x(block(x)), block(x)) -- the pooled tensor for
+        the next level and the block's output for the skip connection (in training: norm2 + ReLU + pooling as one kernel)."""
         conv1, norm1, _r1, conv2, norm2, _r2 = self.children()
         # (conv + batch statistics + BN + ReLU) x 2; in training the whole block is one autograd node whose backward takes norm1's
         # column sums out of conv2's input-gradient kernel
-        return F.double_conv_bn_act(x, conv1, norm1, conv2, norm2, F.ACT_RELU, left_pad=left_pad, head=head)
+        return F.double_conv_bn_act(x, conv1, norm1, conv2, norm2, F.ACT_RELU, left_pad=left_pad, head=head, pool=pool)
 
 
 class UNet3D(nn.Module):
@@ -69,10 +70,10 @@ class UNet3D(nn.Module):
         # each encoder output is written as the RIGHT half of its level's concat buffer; the matching up-convolution
         # later fills the LEFT half (torch.cat((up, skip), dim=1) of unet3d.py:59-68 without the copy)
         # pool + skip leave each encoder block as one autograd node (their two gradients are summed in the pool backward)
-        p1, enc1 = F.max_pool3d_2x_and_skip(self.encoder1(h, left_pad=self.upconv1.out_channels))
-        p2, enc2 = F.max_pool3d_2x_and_skip(self.encoder2(p1, left_pad=self.upconv2.out_channels))
-        p3, enc3 = F.max_pool3d_2x_and_skip(self.encoder3(p2, left_pad=self.upconv3.out_channels))
-        p4, enc4 = F.max_pool3d_2x_and_skip(self.encoder4(p3, left_pad=self.upconv4.out_channels))
+        p1, enc1 = self.encoder1(h, left_pad=self.upconv1.out_channels, pool=True)
+        p2, enc2 = self.encoder2(p1, left_pad=self.upconv2.out_channels, pool=True)
+        p3, enc3 = self.encoder3(p2, left_pad=self.upconv3.out_channels, pool=True)
+        p4, enc4 = self.encoder4(p3, left_pad=self.upconv4.out_channels, pool=True)
         h = self.bottleneck(p4)
         for up, dec, skip in ((self.upconv4, self.decoder4, enc4), (self.upconv3, self.decoder3, enc3), (self.upconv2, self.decoder2, enc2)):
             h = dec(F.conv_transpose3d_k2s2_cat(h, up.weight, up.bias, skip))

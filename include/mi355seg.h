@@ -266,6 +266,22 @@ int mi355seg_bn_act_head_bwd_apply_f32(const float* dlogits, int lddl, const flo
                                        const float* s1, const float* s2, float* dy, int lddy, float* dy_colsum, float* dy_amax,
                                        long long rows, int C, int K, void* ws, size_t ws_bytes, void* stream);
 
+/* BatchNorm + activation of an ENCODER block fused with the MaxPool3d(2, 2) behind it (/root/reference/models/three_d/unet3d.py:19-25,
+ * 51-58: ``self.pool1(enc1)`` with enc1 = relu2(norm2(.)) also kept for the skip concatenation :59-68).  fwd: one kernel writes the
+ * activation a (pitch lda: a channel slice of the level's concat buffer), the pooled tensor [N, D/2, H/2, W/2, C] and the 3-bit argmax
+ * codes (nn.MaxPool3d's first-maximum / NaN rule), + max |a| into a zeroed scalar (may be NULL).  bwd: the norm backward with
+ * d(a) = dskip + maxpool_backward(dpooled, idx) formed on the fly -- no pool-backward pass, no d(a) tensor: s1 / s2 (dgamma = s2,
+ * dbeta = s1; may be NULL), dy, dy_colsum (may be NULL), dy_amax (may be NULL).  D, H, W even, C a power of two in 4..256, fp32. */
+int mi355seg_bn_act_pool_supported_f32(int N, int D, int H, int W, int C, int ldy);
+size_t mi355seg_bn_act_pool_ws_bytes(int C);
+int mi355seg_bn_act_pool_fwd_f32(const float* y, int ldy, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                 int act, float slope, float* a, int lda, float* pooled, unsigned char* idx, float* a_amax,
+                                 int N, int D, int H, int W, int C, void* stream);
+int mi355seg_bn_act_pool_bwd_f32(const float* dskip, int ldds, const float* dpooled, const unsigned char* idx, const float* y, int ldy,
+                                 const float* mean, const float* rstd, const float* gamma, const float* beta, int act, float slope,
+                                 float* s1, float* s2, float* dgamma, float* dbeta, float* dy, int lddy, float* dy_colsum, float* dy_amax,
+                                 int N, int D, int H, int W, int C, void* ws, size_t ws_bytes, void* stream);
+
 /* The same backward in its two halves (the conv -> BN -> ReLU -> conv chains of unet3d.py:73-104: the first half can ride in the
  * epilogue of the kernel that produces dy, see mi355seg_conv3d_dgrad_bnsums_f32):
  *   sums:  s1[g, c] = sum_rows dz, s2[g, c] = sum_rows dz * xhat, dz = dy * act'(z)  (+ dgamma = s2, dbeta = s1; groups == 1)

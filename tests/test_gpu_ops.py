@@ -884,3 +884,58 @@ def test_bn_act_head_fused_kernels(seg, shape, C, K, act):
     assert (dy.cpu().double() - y64.grad).abs().max() < tol(y64.grad) * 3
     assert (col.cpu().double() - dy.cpu().double().sum(0)).abs().max() < 1e-4 * max(1e-3, float(dy.abs().max()))
     assert float(amax) == float(dy.abs().max())
+
+
+@pytest.mark.parametrize("shape,C,lp,act", [((2, 8, 6, 10), 32, 32, "relu"), ((1, 4, 4, 4), 8, 0, "relu"), ((1, 2, 6, 18), 64, 64, "lrelu"),
+                                             ((1, 4, 2, 2), 256, 0, "relu"), ((2, 16, 16, 16), 32, 32, "relu")])
+def test_bn_act_pool_fused_kernels(seg, shape, C, lp, act):
+    """csrc/bn_head.hip, the encoder form: BatchNorm + activation + MaxPool3d(2, 2) as one forward kernel -- BIT-FOR-BIT the library's
+    own chain norm_act_fwd + maxpool2_fwd (activation into a channel slice of a wider buffer, pooled tensor, argmax codes, maximum) -- and the
+    norm backward with d(act) = dskip + pool_backward(dpooled) formed on the fly, against the unfused chain maxpool2_bwd_add +
+    norm_act_bwd_colsum (same per-element arithmetic; the column sums in another order).  /root/reference/models/three_d/unet3d.py:19-25,51-58,100-101."""
+    F = seg.functional
+    L = seg.lib()
+    N, D, H, W = shape
+    rows, prow = N * D * H * W, N * (D // 2) * (H // 2) * (W // 2)
+    dev = "cuda"
+    y = (rnd(rows, C, seed=1) * 1.7 + 0.3).to(dev)
+    y[3, :4] = y[2, :4]                                       # an exact tie inside a window: the first maximum must win
+    mean, var = y.mean(0), y.var(0, unbiased=False)
+    rstd = (1.0 / torch.sqrt(var + 1e-5)).contiguous()
+    gamma, beta = (1 + 0.2 * rnd(C, seed=2)).to(dev), (0.3 * rnd(C, seed=3)).to(dev)
+    code, slope = {"relu": (F.ACT_RELU, 0.0), "lrelu": (F.ACT_LRELU, 0.01)}[act]
+    st = torch.cuda.current_stream().cuda_stream
+    ld = lp + C
+    full1, full2 = torch.zeros(rows, ld, device=dev), torch.zeros(rows, ld, device=dev)
+    a1, a2 = full1[:, lp:], full2[:, lp:]
+    p1, p2 = torch.empty(prow, C, device=dev), torch.empty(prow, C, device=dev)
+    i1, i2 = torch.empty(prow, C, dtype=torch.uint8, device=dev), torch.empty(prow, C, dtype=torch.uint8, device=dev)
+    am1, am2 = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    L.call("mi355seg_bn_act_pool_fwd_f32", y.data_ptr(), C, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), code, slope,
+           a1.data_ptr(), ld, p1.data_ptr(), i1.data_ptr(), am1.data_ptr(), N, D, H, W, C, st)
+    L.call("mi355seg_norm_act_fwd_ax_f32", y.data_ptr(), C, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, 0,
+           a2.data_ptr(), ld, rows, 1, C, code, slope, am2.data_ptr(), st)
+    L.call("mi355seg_maxpool2_fwd_f32", a2.data_ptr(), ld, p2.data_ptr(), C, i2.data_ptr(), N, D, H, W, C, st)
+    torch.cuda.synchronize()
+    assert torch.equal(full1, full2) and torch.equal(p1, p2) and torch.equal(i1, i2) and torch.equal(am1, am2)
+    # backward
+    dskip_full = rnd(rows, ld, seed=5).to(dev)
+    dskip = dskip_full[:, lp:]
+    dp = rnd(prow, C, seed=6).to(dev)
+    ws = F.workspace(max(L.query("mi355seg_bn_act_pool_ws_bytes", C), L.query("mi355seg_norm_ws_bytes", rows, 1, C)), torch.device(dev))
+    s12, dgb = torch.empty(2 * C, device=dev), torch.empty(2 * C, device=dev)
+    dy1, col1, dam1 = torch.empty(rows, C, device=dev), torch.empty(C, device=dev), torch.zeros(1, device=dev)
+    L.call("mi355seg_bn_act_pool_bwd_f32", dskip.data_ptr(), ld, dp.data_ptr(), i1.data_ptr(), y.data_ptr(), C, mean.data_ptr(), rstd.data_ptr(),
+           gamma.data_ptr(), beta.data_ptr(), code, slope, s12.data_ptr(), s12.data_ptr() + 4 * C, dgb.data_ptr(), dgb.data_ptr() + 4 * C,
+           dy1.data_ptr(), C, col1.data_ptr(), dam1.data_ptr(), N, D, H, W, C, ws.data_ptr(), ws.numel(), st)
+    da = torch.empty(rows, C, device=dev)
+    L.call("mi355seg_maxpool2_bwd_add_f32", dp.data_ptr(), C, i2.data_ptr(), dskip.data_ptr(), ld, da.data_ptr(), C, N, D, H, W, C, st)
+    dy2, dg2, db2, col2, dam2 = torch.empty(rows, C, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev), torch.zeros(1, device=dev)
+    L.call("mi355seg_norm_act_bwd_colsum_ax_f32", da.data_ptr(), C, y.data_ptr(), C, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, 0,
+           dy2.data_ptr(), C, dg2.data_ptr(), db2.data_ptr(), None, 0, col2.data_ptr(), dam2.data_ptr(), rows, 1, C, code, slope, ws.data_ptr(), ws.numel(), st)
+    torch.cuda.synchronize()
+    scale = lambda t: max(1e-3, float(t.abs().max()))
+    assert (dgb[:C] - dg2).abs().max() < 2e-5 * scale(dg2) and (dgb[C:] - db2).abs().max() < 2e-5 * scale(db2)
+    assert torch.equal(s12[:C], dgb[C:]) and torch.equal(s12[C:], dgb[:C])           # s1 = dbeta, s2 = dgamma
+    assert (dy1 - dy2).abs().max() < 2e-5 * scale(dy2)
+    assert (col1 - col2).abs().max() < 1e-4 * scale(dy2) and abs(float(dam1) - float(dam2)) < 2e-5 * scale(dy2)
