@@ -208,7 +208,7 @@ __device__ __forceinline__ void s1_stage(float* tile, const T* __restrict__ x, i
 // threads' triples pairwise-exactly (Chan et al.) into spart[blk][c] = {sum, M2, n} -- the format of the MFMA kernels' per-tile
 // triples, finalised by the same two-stage fp64 reduction (tile_stats_finalize2).
 template <typename T, bool STATS>
-__global__ __launch_bounds__(256) void stem1_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256, 3) void stem1_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
         const float* __restrict__ bias, T* __restrict__ y, float* __restrict__ spart, SmallGeom g, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Cout = g.Cout, LPV = Cout / 4, TX = 256 / LPV, HX = TX + 2, HY = S1_TY + 2;
@@ -232,7 +232,9 @@ __global__ __launch_bounds__(256) void stem1_fwd_kernel(const T* __restrict__ x,
         __syncthreads();
         s1_stage(sm, x, g.ldx, n, z0, y0, x0, TX, g.D, g.H, g.W);
         __syncthreads();
-#pragma unroll
+        // (two lines per trip, three workgroups per CU: fully unrolled the eight lines' 216 LDS reads are hoisted and the kernel takes 256+
+        // registers -- one or two waves per SIMD on a kernel that waits on HBM stores)
+#pragma unroll 2
         for (int line = 0; line < S1_TZ * S1_TY; ++line) {
             const int lz = line / S1_TY, ly = line % S1_TY;
             const float* tp = sm + (lz * HY + ly) * HX + xs;
