@@ -591,6 +591,77 @@ int mi355seg_conv3d_fwd_ax_f32(const float* x, int ldx, const float* w, const fl
     return conv_fwd_generic(x, ldx, w, bias, y, ldy, g, stats_sum, stats_sq, ws, ws_bytes, st);
 }
 
+// ---- conv2 of a double-conv block reading conv1's RAW output (r5): the norm + activation between them is a prologue of conv2's staging
+// (forward and weight gradient), so that activation is never written.  Supported where both passes run the f16x3 kernels.
+int mi355seg_conv3d_pro_supported_f32(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int act) {
+    if (!x3_f16() || f32_conv_policy() != MATH_X3 || k != 3 || stride != 1 || pad != 1 || Cin > 512 || !conv_pro_act_ok(act)) return 0;
+    if (!conv_fwd_takes_amax(N, D, H, W, Cin, Cout, k, stride, pad)) return 0;
+    return wgrad_lowp_supported(MATH_X3, N, D, H, W, Cin, Cout, k, stride, pad, Cin, Cout) ? 1 : 0;
+}
+
+// mi355seg_conv3d_fwd_ax_f32 that also hands back max |y| (max-combined into the zeroed device scalar *y_amax): from the kernel's
+// epilogue where the f16x3 kernels run the whole K in one launch, by a pass over y elsewhere
+int mi355seg_conv3d_fwd_yamax_ax_f32(const float* x, int ldx, const float* w, const float* bias,
+                                     float* y, int ldy, int N, int D, int H, int W, int Cin, int Cout,
+                                     int k, int stride, int pad, double* stats_sum, double* stats_sq, const float* x_amax, const float* w_amax,
+                                     float* y_amax, void* ws, size_t ws_bytes, void* stream) {
+    SEG_CHECK_ARG(y_amax, "conv3d_fwd_yamax: y_amax is null");
+    hipStream_t st = (hipStream_t)stream;
+    const int pol = f32_conv_policy();
+    if (x && w && y && ldx >= Cin && ldy >= Cout && stride == 1 && pol != MATH_F32 && conv_mfma_supported(pol, N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy)) {
+        SEG_CHECK_ARG((stats_sum == nullptr) == (stats_sq == nullptr), "conv3d_fwd: stats_sum/stats_sq must come together");
+        return conv_fwd_mfma(pol, x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, /*dgrad=*/0, stats_sum, stats_sq, ws, ws_bytes, st,
+                             nullptr, 0, 0.f, nullptr, x_amax, w_amax, nullptr, 0, nullptr, nullptr, y_amax);
+    }
+    int rc = mi355seg_conv3d_fwd_ax_f32(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, stride, pad, stats_sum, stats_sq, x_amax, w_amax, ws, ws_bytes, stream);
+    if (rc) return rc;
+    ConvGeom g{N, D, H, W, Cin, Cout, k, stride, pad, 0, 0, 0};
+    rc = check_geom(&g, "conv3d_fwd_yamax");
+    if (rc) return rc;
+    tensor_amax(y, ldy, (long long)N * g.Do * g.Ho * g.Wo, Cout, nullptr, y_amax, st);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
+// y = conv3d(act(pro_al[c] * x + pro_be[c]), w) + bias: x is the pre-norm tensor of the layer in front (unet3d.py:80-101: conv2 behind
+// norm1 + relu1), pro_al / pro_be its folded BatchNorm (mi355seg_norm_fold_f32), x_amax an upper bound of the prologue's OUTPUT
+int mi355seg_conv3d_fwd_pro_ax_f32(const float* x, int ldx, const float* pro_al, const float* pro_be, int pro_act, float pro_slope,
+                                   const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W, int Cin, int Cout,
+                                   int k, int stride, int pad, double* stats_sum, double* stats_sq, const float* x_amax, const float* w_amax,
+                                   void* ws, size_t ws_bytes, void* stream) {
+    ConvGeom g{N, D, H, W, Cin, Cout, k, stride, pad, 0, 0, 0};
+    int rc = check_geom(&g, "conv3d_fwd_pro");
+    if (rc) return rc;
+    SEG_CHECK_ARG(x && w && y && pro_al && pro_be && x_amax && ldx >= Cin && ldy >= Cout, "conv3d_fwd_pro: null pointer or pitch < channels");
+    SEG_CHECK_ARG((stats_sum == nullptr) == (stats_sq == nullptr), "conv3d_fwd_pro: stats_sum/stats_sq must come together");
+    SEG_CHECK_ARG(mi355seg_conv3d_pro_supported_f32(N, D, H, W, Cin, Cout, k, stride, pad, pro_act) && conv_mfma_supported(MATH_X3, N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy),
+                  "conv3d_fwd_pro: no prologue form for this layer under the selected conv math (ask mi355seg_conv3d_pro_supported_f32)");
+    ConvPro pro{pro_al, pro_be, pro_act, pro_slope};
+    return conv_fwd_mfma(MATH_X3, x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, /*dgrad=*/0, stats_sum, stats_sq, ws, ws_bytes, (hipStream_t)stream,
+                         nullptr, 0, 0.f, nullptr, x_amax, w_amax, nullptr, 0, nullptr, &pro, nullptr);
+}
+
+// dw (+ db) of that convolution: the same prologue on the x operand of the weight-gradient kernels
+int mi355seg_conv3d_wgrad_pro_ax_f32(const float* dy, int lddy, const float* x, int ldx, const float* pro_al, const float* pro_be, int pro_act, float pro_slope,
+                                     float* dw, float* db, int N, int D, int H, int W, int Cin, int Cout,
+                                     int k, int stride, int pad, int accumulate, const float* dy_amax, const float* x_amax,
+                                     void* ws, size_t ws_bytes, void* stream) {
+    ConvGeom g{N, D, H, W, Cin, Cout, k, stride, pad, 0, 0, 0};
+    int rc = check_geom(&g, "conv3d_wgrad_pro");
+    if (rc) return rc;
+    SEG_CHECK_ARG(dy && x && dw && pro_al && pro_be && x_amax && lddy >= Cout && ldx >= Cin, "conv3d_wgrad_pro: null pointer or pitch < channels");
+    SEG_CHECK_ARG(mi355seg_conv3d_pro_supported_f32(N, D, H, W, Cin, Cout, k, stride, pad, pro_act) && wgrad_lowp_supported(MATH_X3, N, D, H, W, Cin, Cout, k, stride, pad, ldx, lddy) &&
+                  ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0,
+                  "conv3d_wgrad_pro: no prologue form for this layer under the selected conv math (ask mi355seg_conv3d_pro_supported_f32)");
+    hipStream_t st = (hipStream_t)stream;
+    if (db) {
+        rc = channel_sums(dy, lddy, (long long)N * g.Do * g.Ho * g.Wo, Cout, nullptr, nullptr, db, accumulate, ws, ws_bytes, st);
+        if (rc) return rc;
+    }
+    ConvPro pro{pro_al, pro_be, pro_act, pro_slope};
+    return conv_wgrad_lowp(MATH_X3, dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, stride, accumulate, ws, ws_bytes, st, x_amax, dy_amax, &pro);
+}
+
 int mi355seg_conv3d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
                               int N, int D, int H, int W, int Cin, int Cout,
                               int k, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {

@@ -432,6 +432,8 @@ static bool igemm_plan(int math, int KS, int N, int D, int H, int W, int Kc, int
     return true;
 }
 
+bool conv_pro_act_ok(int act) { return act == MI355SEG_ACT_RELU || act == MI355SEG_ACT_LRELU; }    // max(z, slope z), slope in [0, 1): positively homogeneous
+
 static bool igemm_shape_ok(int k, int stride, int pad) {
     return stride == 1 && ((k == 1 && pad == 0) || (k == 3 && pad == 1) || (k == 5 && pad == 2));
 }
@@ -528,7 +530,7 @@ static double matrix_bytes(int math, double act_elems, double w_elems) { return 
 int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int N, int D, int H, int W,
                   int Cin, int Cout, int k, int dgrad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st,
                   const float* oscale, int act, float slope, BnBwdEpi* bne, const float* x_amax, const float* w_amax, const void* res, int ldres,
-                  int* res_fused) {
+                  int* res_fused, const ConvPro* pro, float* y_amax) {
     IgemmPlan p;
     if (res_fused) *res_fused = 0;
     SEG_CHECK_ARG(igemm_plan(math, k, N, D, H, W, Cin, Cout, 1, &p), "conv_fwd_mfma: unsupported shape");
@@ -584,6 +586,13 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
     a.Di = a.Do = D; a.Hi = a.Ho = H; a.Wi = a.Wo = W;
     a.act = ksplit > 1 ? 0 : act; a.slope = slope;
     if (f16) { a.amax_x = x_amax; a.amax_w = w_amax; }
+    if (pro) {
+        SEG_CHECK_ARG(f16 && !dgrad && pro->al && pro->be && conv_pro_act_ok(pro->act) && Cin <= 512, "conv_fwd_mfma: the norm + activation prologue needs the f16x3 conv_x3s kernels (Cin <= 512, act relu / leaky relu with a slope in [0, 1))");
+        a.pro_al = pro->al; a.pro_be = pro->be; a.pro_act = pro->act; a.pro_slope = pro->act == MI355SEG_ACT_RELU ? 0.f : pro->slope;
+        SEG_CHECK_ARG(a.pro_slope >= 0.f && a.pro_slope < 1.f, "conv_fwd_mfma: prologue slope must lie in [0, 1)");
+    }
+    const bool ymax_epi = y_amax && x3s && ksplit == 1 && math != MATH_B16;
+    if (ymax_epi) a.amax_y = reinterpret_cast<unsigned*>(y_amax);
     if (res && res_fused && b16s && ksplit == 1 && !ssum && (ldres % 8) == 0 && ((uintptr_t)res % 16) == 0) { a.res = res; a.ldres = ldres; *res_fused = 1; }
     if (bn_epi) {
         a.bnx = bne->x; a.ldbnx = bne->ldx; a.bn_mean = bne->mean; a.bn_rstd = bne->rstd; a.bn_gamma = bne->gamma; a.bn_beta = bne->beta;
@@ -608,6 +617,11 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
         norm_bwd_finalize(bnpart, p.nM, Cout, bne->s1, bne->s2, bne->dgamma, bne->dbeta, rtmp, st);
         SEG_CHECK_LAUNCH();
         bne->done = 1;
+    }
+    if (y_amax && !ymax_epi) {
+        SEG_CHECK_ARG(math != MATH_B16, "conv_fwd_mfma: y_amax is for fp32 tensors");
+        tensor_amax((const float*)y, ldy, nvox, Cout, nullptr, y_amax, st);
+        SEG_CHECK_LAUNCH();
     }
     if (ssum) {
         if (ksplit > 1) {

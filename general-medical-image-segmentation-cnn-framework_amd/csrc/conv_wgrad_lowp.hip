@@ -73,6 +73,9 @@ struct LWgradArgs {
     int Do, Ho, Wo;                            // output (dy) extents
     int ntx, nty, ntz, ntiles, nstrips, npairs, ncob, ntaps_total;
     const float* amax_x; const float* amax_dy;     // NP = 2: device scalars >= max |x|, max |dy|
+    // norm + activation prologue of the x operand (f16x3, r5): x is the pre-norm tensor of the layer in front, the staged value is
+    // act(pro_al[c] x + pro_be[c]) (zero padding stays zero); amax_x then bounds the prologue's output (internal.h, ConvPro)
+    const float* pro_al; const float* pro_be; int pro_act; float pro_slope;
     int dbg;                                       // -DMI355SEG_TUNE timing probes (MI355SEG_DBG): 8 no tile loads after the first, 16 no split / LDS writes after the
                                                    // first, 64 every tile loads the strip's FIRST tile again (same instructions, cache-resident data)
 };
@@ -90,7 +93,9 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* lds, int off0, 
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <int BX, int KS, int NP, typename IN_T, int S = 1>
+// PRO (r5): the norm + activation prologue of the x operand (LWgradArgs::pro_al) -- its own instantiation: these kernels sit at their
+// register limits and the plain launches must keep their allocation
+template <int BX, int KS, int NP, typename IN_T, int S = 1, bool PRO = false>
 __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradArgs a) {
     using T = LTile<BX, KS, NP, S>;
     constexpr int EPP = std::is_same<IN_T, float>::value ? 4 : 8;            // elements per staged 16-byte piece
@@ -238,7 +243,36 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
             *reinterpret_cast<bf16x8_t*>(dst) = v;
         }
     };
+    // prologue table of this workgroup's 32 input channels behind the tiles: al * 2^sx | be * 2^sx (the activation is positively
+    // homogeneous, so the f16x3 scale rides in the table); a piece's four channels are (tid % PPV) * 4 .. for every piece of a thread
+    float* const ptab = reinterpret_cast<float*>(lds + T::LDS_BYTES);
+    if constexpr (PRO) {
+        if (tid < 32) { ptab[tid] = a.pro_al[ci0 + tid] * xscale; ptab[32 + tid] = a.pro_be[ci0 + tid] * xscale; }
+    }
     auto write_stage = [&]() {
+        if constexpr (PRO) {
+            {
+                const f32x4 pal = *reinterpret_cast<const f32x4*>(ptab + (tid % PPV) * 4), pbe = *reinterpret_cast<const f32x4*>(ptab + 32 + (tid % PPV) * 4);
+#pragma unroll
+                for (int it = 0; it < XITER; ++it) {
+                    const int pc = it * LW_THREADS + tid;
+                    if (pc < XPIECES) {
+                        const int u = xA - crd[it], v = crd[it] + xB;
+                        const bool ok = ((u & v) & 0x808080) == 0x808080;       // (the bounds of the tile these pieces were loaded for)
+                        f32x4 z;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float t = fmaf(stx[it][e], pal[e], pbe[e]);
+                            z[e] = ok ? fmaxf(t, t * a.pro_slope) : 0.f;          // ReLU (slope 0) / LeakyReLU
+                        }
+                        put(xs, pc, z, 1.f);
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < DITER; ++it) put(ds, it * LW_THREADS + tid, std_[it], dscale);
+                return;
+            }
+        }
 #pragma unroll
         for (int it = 0; it < XITER; ++it) {
             const int pc = it * LW_THREADS + tid;
@@ -393,7 +427,7 @@ struct FTile {
     static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the LDS");
 };
 
-template <int BX, int KS, typename IN_T>
+template <int BX, int KS, typename IN_T, bool PRO = false>
 __global__ __launch_bounds__(FW_THREADS, 1) void conv_wgrad_wide_kernel(LWgradArgs a) {
     constexpr bool F32 = std::is_same<IN_T, float>::value;
     constexpr int NP = F32 ? 2 : 1, NPR = F32 ? 3 : 1;           // operand planes, MFMA products per fragment pair
@@ -509,11 +543,32 @@ __global__ __launch_bounds__(FW_THREADS, 1) void conv_wgrad_wide_kernel(LWgradAr
     // f16x3: the splits run inside the MFMA stream (FW_SPLIT), in the registers the piece arrived in: between the barriers only the LDS
     // writes remain
     f16x4_t cvh[F32 && FW_SPLIT ? NPC : 1], cvl[F32 && FW_SPLIT ? NPC : 1];
+    // norm + activation prologue of the x pieces (f16x3): this thread's four channels are the same for every piece
+    // (the table sits in LDS behind the tiles and is read per piece: eight more long-lived registers spill in the MFMA stream)
+    float* const ptab = reinterpret_cast<float*>(lds + F::LDS_BYTES);
+    constexpr bool pro = PRO;
+    if constexpr (PRO) {
+        if (tid < 32) { ptab[tid] = a.pro_al[ci0 + tid] * xscale; ptab[32 + tid] = a.pro_be[ci0 + tid] * xscale; }
+        __syncthreads();
+    }
+    auto pro_x = [&](int j, f32x4 v) {                            // (xA / xB: the bounds of the tile piece j was loaded for)
+        const int u = xA - crd[j], w = crd[j] + xB;
+        const bool ok = ((u & w) & 0x808080) == 0x808080;
+        const f32x4 pal = *reinterpret_cast<const f32x4*>(ptab + (tid % PPX) * 4), pbe = *reinterpret_cast<const f32x4*>(ptab + 32 + (tid % PPX) * 4);
+        f32x4 z;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = fmaf(v[e], pal[e], pbe[e]);
+            z[e] = ok ? fmaxf(t, t * a.pro_slope) : 0.f;                  // ReLU (slope 0) / LeakyReLU
+        }
+        return z;
+    };
     auto split_piece = [&](int j) {
         if constexpr (F32 && FW_SPLIT) {
-            const float sc = j < XITER ? xscale : dscale;
+            float sc = j < XITER ? xscale : dscale;
             f32x4 v;
             if (j < XITER) v = stx[j]; else v = std_[j - XITER];
+            if (j < XITER && pro) { v = pro_x(j, v); sc = 1.f; }
 #pragma unroll
             for (int e = 0; e < 4; ++e) { _Float16 bh, bl; split2h(v[e] * sc, bh, bl); cvh[j][e] = bh; cvl[j][e] = bl; }
         }
@@ -529,9 +584,10 @@ __global__ __launch_bounds__(FW_THREADS, 1) void conv_wgrad_wide_kernel(LWgradAr
                 *reinterpret_cast<f16x4_t*>(dst) = cvh[j];
                 *reinterpret_cast<f16x4_t*>(dst + (j < XITER ? 64 : 128)) = cvl[j];
             } else {
-                const float sc = j < XITER ? xscale : dscale;
+                float sc = j < XITER ? xscale : dscale;
                 f32x4 v;
                 if (j < XITER) v = stx[j]; else v = std_[j < XITER ? 0 : j - XITER];
+                if (j < XITER && pro) { v = pro_x(j, v); sc = 1.f; }
                 f16x4_t qh, ql;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { _Float16 bh, bl; split2h(v[e] * sc, bh, bl); qh[e] = bh; ql[e] = bl; }
@@ -739,6 +795,13 @@ size_t wgrad_lowp_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k)
 template <int BX, int KS, int NP, typename IN_T, int S = 1>
 static void launch_lwgrad(const LWgradArgs& a, int nwg, hipStream_t st) {
     using T = LTile<BX, KS, NP, S>;
+    if constexpr (NP == 2 && std::is_same<IN_T, float>::value && S == 1 && KS == 3) {
+        if (a.pro_al) {                       // + the prologue table
+            SEG_SET_LDS((conv_wgrad_lowp_kernel<BX, KS, NP, IN_T, S, true>), T::LDS_BYTES + 256);
+            hipLaunchKernelGGL((conv_wgrad_lowp_kernel<BX, KS, NP, IN_T, S, true>), dim3(nwg), dim3(LW_THREADS), T::LDS_BYTES + 256, st, a);
+            return;
+        }
+    }
     SEG_SET_LDS((conv_wgrad_lowp_kernel<BX, KS, NP, IN_T, S>), T::LDS_BYTES);
     hipLaunchKernelGGL((conv_wgrad_lowp_kernel<BX, KS, NP, IN_T, S>), dim3(nwg), dim3(LW_THREADS), T::LDS_BYTES, st, a);
 }
@@ -746,6 +809,13 @@ static void launch_lwgrad(const LWgradArgs& a, int nwg, hipStream_t st) {
 template <int BX, int KS, typename IN_T>
 static void launch_wide(const LWgradArgs& a, int nwg, hipStream_t st) {
     using F = FTile<BX, KS, std::is_same<IN_T, float>::value ? 2 : 1>;
+    if constexpr (std::is_same<IN_T, float>::value && KS == 3) {
+        if (a.pro_al) {
+            SEG_SET_LDS((conv_wgrad_wide_kernel<BX, KS, IN_T, true>), F::LDS_BYTES + 256);
+            hipLaunchKernelGGL((conv_wgrad_wide_kernel<BX, KS, IN_T, true>), dim3(nwg), dim3(FW_THREADS), F::LDS_BYTES + 256, st, a);
+            return;
+        }
+    }
     SEG_SET_LDS((conv_wgrad_wide_kernel<BX, KS, IN_T>), F::LDS_BYTES);
     hipLaunchKernelGGL((conv_wgrad_wide_kernel<BX, KS, IN_T>), dim3(nwg), dim3(FW_THREADS), F::LDS_BYTES, st, a);
 }
@@ -766,7 +836,8 @@ static void dispatch_lwgrad(int math, const LWgradPlan& p, const LWgradArgs& a, 
 }
 
 int conv_wgrad_lowp(int math, const void* dy, int lddy, const void* x, int ldx, float* dw, int N, int D, int H, int W, int Cin,
-                    int Cout, int k, int stride, int accumulate, void* ws, size_t ws_bytes, hipStream_t st, const float* x_amax, const float* dy_amax) {
+                    int Cout, int k, int stride, int accumulate, void* ws, size_t ws_bytes, hipStream_t st, const float* x_amax, const float* dy_amax,
+                    const ConvPro* pro) {
     LWgradPlan p;
     const int pad = k / 2, Do = lw_out(D, k, stride, pad), Ho = lw_out(H, k, stride, pad), Wo = lw_out(W, k, stride, pad);
     // f16x3, k3 s1, Cout % 64 == 0: the wide kernel (mi355seg_set_wgrad_wide)
@@ -779,7 +850,7 @@ int conv_wgrad_lowp(int math, const void* dy, int lddy, const void* x, int ldx, 
     const bool f16 = math == MATH_X3 && x3_f16();
     float* amax = f16 ? cv.take<float>(2) : nullptr;
     SEG_CHECK_WS(cv.used(), ws_bytes);
-    LWgradArgs a{x, dy, part, ldx, lddy, N, D, H, W, Cin, Cout, Do, Ho, Wo, p.ntx, p.nty, p.ntz, p.ntiles, p.nstrips, p.npairs, Cout / p.cob, p.taps, nullptr, nullptr, 0};
+    LWgradArgs a{x, dy, part, ldx, lddy, N, D, H, W, Cin, Cout, Do, Ho, Wo, p.ntx, p.nty, p.ntz, p.ntiles, p.nstrips, p.npairs, Cout / p.cob, p.taps, nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0};
     if (f16) {
         if (!x_amax || !dy_amax) {
             if (hipMemsetAsync(amax, 0, 2 * sizeof(float), st) != hipSuccess) { set_error("conv_wgrad_lowp: hipMemsetAsync failed"); return MI355SEG_EHIP; }
@@ -788,6 +859,11 @@ int conv_wgrad_lowp(int math, const void* dy, int lddy, const void* x, int ldx, 
             SEG_CHECK_LAUNCH();
         }
         a.amax_x = x_amax; a.amax_dy = dy_amax;
+    }
+    if (pro) {
+        SEG_CHECK_ARG(f16 && stride == 1 && k == 3 && pro->al && pro->be && conv_pro_act_ok(pro->act) && x_amax, "conv_wgrad_lowp: the norm + activation prologue needs the f16x3 k3 kernels and the caller's bound on the prologue's output");
+        a.pro_al = pro->al; a.pro_be = pro->be; a.pro_act = pro->act; a.pro_slope = pro->act == MI355SEG_ACT_RELU ? 0.f : pro->slope;
+        SEG_CHECK_ARG(a.pro_slope >= 0.f && a.pro_slope < 1.f, "conv_wgrad_lowp: prologue slope must lie in [0, 1)");
     }
 #ifdef MI355SEG_TUNE
     { static const char* e = getenv("MI355SEG_DBG"); a.dbg = e ? atoi(e) : 0; }

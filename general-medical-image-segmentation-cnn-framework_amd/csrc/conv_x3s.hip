@@ -29,6 +29,7 @@
 #include "common.h"
 #include "internal.h"
 #include "igemm_kernel.h"
+#include <type_traits>
 
 namespace seg {
 
@@ -47,6 +48,7 @@ namespace {
 #define X3S_HALO_AUX 0          // cache policy of the halo loads (A/B knob: 2 = nt, 16 = sc1)
 #endif
 constexpr int XBX = 16, XTY = 4, XHX = XBX + 2, XHY = XTY + 2;
+constexpr int X3S_PRO_MAX_CIN = 512;             // the prologue table (8 bytes per input channel) must fit beside two halo tiles per CU
 
 template <int LW, bool F16 = false, int WN = 1>
 struct Geo {
@@ -120,6 +122,7 @@ __device__ __forceinline__ void x3_epilogue(const IgemmArgs& a, f32x4 (&acc)[LW]
     for (int t = 0; t < NTW; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e) ssum[t][e] = 0.f;
+    float ymax = 0.f;                    // max |y| of this lane's stored values (a.amax_y)
     f32x4 bv[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) bv[t] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n0 + 16 * t + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -137,9 +140,11 @@ __device__ __forceinline__ void x3_epilogue(const IgemmArgs& a, f32x4 (&acc)[LW]
                 *reinterpret_cast<f32x4*>(dst + 16 * t) = v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ssum[t][e] += v[e];
+                if (a.amax_y) ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
             }
         }
     }
+    if (a.amax_y) { __syncthreads(); block_amax_commit(ymax, a.amax_y); }
     if (a.bnpart) {
         // reduce dz and dz * xhat per channel over the tile (dz = d(activation) * act'(gamma xhat + beta))
         float sa[NTW][4], sb[NTW][4];
@@ -262,7 +267,9 @@ __device__ __forceinline__ void x3_epilogue(const IgemmArgs& a, f32x4 (&acc)[LW]
 // WN = 2 (r4, f16x3): 2 x 2 wave grid on the 64 NBW-channel tile -- a wave owns LW lines and ONE of the two channel blocks, so it loads
 // half of the tile's weight fragments and each feeds twice the MFMAs (the r4 probes: weight-fragment loads are the first bound of
 // the three-MFMA loop: 43 B/clk/CU of L1 traffic on the <4, 2> tile)
-template <int LW, int NBW, bool F16, int WN = 1>
+// PRO (r5, f16x3): the norm + activation prologue of IgemmArgs::pro_al -- a separate instantiation, so that the plain launches keep their
+// register allocation (the <8, 1> tile sits at 256)
+template <int LW, int NBW, bool F16, int WN = 1, bool PRO = false>
 __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
     using G = Geo<LW, F16, WN>;
     constexpr int NPL = G::NPL;
@@ -311,6 +318,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
     int sx = 0, sw = 0;
     if constexpr (F16) { sx = f16x_scale_exp(*a.amax_x); sw = f16x_scale_exp(*a.amax_w); }
     const float xscale = pow2f(sx);
+    // norm + activation prologue (f16x3): per input channel al * 2^sx | be * 2^sx behind the halo tile (act is positively homogeneous:
+    // act(z) 2^sx = act(z 2^sx), so the scale rides in the table); visible after the first barrier of the chunk loop
+    float* const ptab = reinterpret_cast<float*>(lds_raw + G::LDS_BYTES);
+    const int pcin = a.nchunks * 16;
+    if constexpr (PRO) {
+        for (int i = tid; i < pcin; i += 256) { ptab[i] = a.pro_al[i] * xscale; ptab[pcin + i] = a.pro_be[i] * xscale; }
+    }
 
     // ---- halo staging: global -> registers (issue early) -> split3 -> LDS (write late).
     // Piece p = it * 256 + tid is (halo voxel p / 4, four channels p % 4) of the chunk.  Its byte offset inside sample n is the
@@ -353,8 +367,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
         l2 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{q0, q1}, bf16x2_t));
     };
     // f16x3: v 2^s = h + l, two packed conversions; the remainder is one v_fma_mix per value (f16 operand read in place)
-    auto split_pair_h = [&](float x0_, float x1_, unsigned& h2, unsigned& l2) {
-        const float s0 = x0_ * xscale, s1 = x1_ * xscale;
+    auto split_pair_h = [&](float x0_, float x1_, unsigned& h2, unsigned& l2, float sc) {
+        const float s0 = x0_ * sc, s1 = x1_ * sc;
         const f16x2_t hh = __builtin_convertvector(f32x2_t{s0, s1}, f16x2_t);
         h2 = __builtin_bit_cast(unsigned, hh);
         const float r0 = __builtin_fmaf((float)hh[0], -1.f, s0), r1 = __builtin_fmaf((float)hh[1], -1.f, s1);
@@ -362,7 +376,15 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
     };
     // piece p = it * 256 + tid sits at LDS byte  ((part >> 1) * PS + tid / 4) * 16 + (part & 1) * 8  +  it * 1024
     unsigned char* const wdst = lds_raw + (((tid & 3) >> 1) * PS + (tid >> 2)) * 16 + (tid & 1) * 8;
-    auto write_stage = [&]() {
+    // PRO: the norm + activation prologue on the staged values (this thread's four channels of the chunk: part = tid & 3 for every
+    // piece); MASK: the tile touches the volume's border -- pieces that were requested past the descriptor read as zeros and must
+    // STAY zero (the padding pads the activation, not its pre-norm tensor); RELU: the U-Net's activation without the generic switch
+    auto write_stage = [&](int chunk, auto WPRO, auto MASK, auto RELU) {
+        f32x4 pal = {0.f, 0.f, 0.f, 0.f}, pbe = pal;
+        if constexpr (decltype(WPRO)::value) {
+            pal = *reinterpret_cast<const f32x4*>(ptab + chunk * 16 + (tid & 3) * 4);
+            pbe = *reinterpret_cast<const f32x4*>(ptab + pcin + chunk * 16 + (tid & 3) * 4);
+        }
 #pragma unroll
         for (int it = 0; it < G::NITER; ++it) {
             if (it * 256 + tid < G::NPIECE) {
@@ -370,8 +392,20 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
                 unsigned char* dst = wdst + it * 1024;
                 if constexpr (F16) {
                     unsigned h0, l0, h1, l1;
-                    split_pair_h(stage[it][0], stage[it][1], h0, l0);
-                    split_pair_h(stage[it][2], stage[it][3], h1, l1);
+                    if constexpr (decltype(WPRO)::value) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float z = fmaf(stage[it][e], pal[e], pbe[e]);
+                            v[e] = decltype(RELU)::value ? fmaxf(z, 0.f) : fmaxf(z, z * a.pro_slope);       // LeakyReLU, slope in [0, 1)
+                        }
+                        if constexpr (decltype(MASK)::value) { if (voff[it] == 0x7FFFFFF0) v = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                        split_pair_h(v[0], v[1], h0, l0, 1.f);
+                        split_pair_h(v[2], v[3], h1, l1, 1.f);
+                    } else {
+                        split_pair_h(stage[it][0], stage[it][1], h0, l0, xscale);
+                        split_pair_h(stage[it][2], stage[it][3], h1, l1, xscale);
+                    }
                     const u32x2 qh = {h0, h1}, ql = {l0, l1};
                     *reinterpret_cast<u32x2*>(dst) = qh;
                     *reinterpret_cast<u32x2*>(dst + 2 * PS * 16) = ql;
@@ -404,6 +438,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
     for (int j = 0; j < LW; ++j)
 #pragma unroll
         for (int t = 0; t < NTW; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (wave-uniform) the whole halo box lies inside the volume: no piece of this tile was zero-filled
+    const bool interior = x0 >= 1 && y0 >= 1 && z0 >= 1 && x0 + XBX + 1 <= a.W && y0 + XTY + 1 <= a.H && z0 + G::TZ + 1 <= a.D;
 
     const bf16* wlane = reinterpret_cast<const bf16*>(a.wq) + (long long)ntile * a.nchunks * (NUP * UNIT) + lane * 8;
     load_stage(c0);
@@ -413,7 +449,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
         // requested XD regions ahead.  f16x3 (r4 ablation: weights loaded once per chunk +28-41 % on <4, 2> at one unit = 384 cycles of
         // lead, +13 % on <4, 1> at two; voxel fragments read once +14-17 % at one region = 96 cycles of lead): the two-plane fragments
         // leave the registers for three units and two regions
-        constexpr int WD = F16 ? X3S_WD : (NBW == 2 && LW == 4 ? 1 : 2);
+        // (the prologue variant of the <8, 1> tile runs two units ahead: its table registers would otherwise push the per-tile offsets into scratch)
+        constexpr int WD = F16 ? ((PRO && LW == 8 && WN == 1) ? 2 : X3S_WD) : (NBW == 2 && LW == 4 ? 1 : 2);
         constexpr int XD = F16 ? X3S_XD : 1;
         bf16x8_t wf[WD + 1][2][NPL], xf[XD + 1][NPL];
         auto load_w = [&](int u) {
@@ -429,7 +466,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
         //  unit of a chunk only, 8 = voxel fragments read for the first (unit, line) only; same MFMAs, garbage results)
         if (!SEG_DBG(a, 1) || chunk == c0) {
         __syncthreads();                                         // every wave is done reading the previous chunk
-        if (!SEG_DBG(a, 4) || chunk == c0) write_stage();
+        if (!SEG_DBG(a, 4) || chunk == c0) {
+            using TT = std::true_type; using FF = std::false_type;
+            if constexpr (!PRO) write_stage(chunk, FF{}, FF{}, FF{});
+            else if (a.pro_act == MI355SEG_ACT_RELU) { if (interior) write_stage(chunk, TT{}, FF{}, TT{}); else write_stage(chunk, TT{}, TT{}, TT{}); }
+            else write_stage(chunk, TT{}, TT{}, FF{});
+        }
         __syncthreads();
         }
         const bool more = chunk + 1 < c1;
@@ -495,6 +537,13 @@ template <int LW, int NBW, bool F16, int WN = 1>
 void launch_x3s(const IgemmArgs& a, int nwg, hipStream_t st) {
     constexpr int LDSB = Geo<LW, F16, WN>::LDS_BYTES;
     static_assert(LDSB >= 8 * 64 * 4, "the statistics epilogue needs 8 x NT floats");
+    if constexpr (F16) {
+        if (a.pro_al) {                       // the prologue's per-channel table sits behind the halo tile
+            SEG_SET_LDS((conv_x3s_kernel<LW, NBW, true, WN, true>), LDSB + X3S_PRO_MAX_CIN * 8);
+            hipLaunchKernelGGL((conv_x3s_kernel<LW, NBW, true, WN, true>), dim3(nwg), dim3(256), LDSB + a.nchunks * 16 * 8, st, a);
+            return;
+        }
+    }
     SEG_SET_LDS((conv_x3s_kernel<LW, NBW, F16, WN>), LDSB);
     hipLaunchKernelGGL((conv_x3s_kernel<LW, NBW, F16, WN>), dim3(nwg), dim3(256), LDSB, st, a);
 }

@@ -120,6 +120,13 @@ struct IgemmArgs {
     // ---- residual sum in the epilogue (conv_b16s.hip, whole-K launches): y = bf16(bf16(conv + bias) + res), the value of the reference's
     // separate `conv(x) + res` on bf16 tensors (residual_unet3d.py:121,140-168); res has y's geometry at pitch ldres
     const void* res; int ldres;
+    // ---- norm + activation PROLOGUE (conv_x3s.hip, f16x3; r5): x is the PRE-NORM tensor of the layer in front and every staged value
+    // becomes act(pro_al[c] * x + pro_be[c]) on its way into LDS (the zero padding stays zero) -- conv2 of a double-conv block reads
+    // conv1's raw output and the activation between them is never written (unet3d.py:80-101).  amax_x then bounds max |act(...)|.
+    const float* pro_al; const float* pro_be; int pro_act; float pro_slope;
+    // ---- max |y| (bias included) max-combined into this device scalar from the epilogue (whole-K launches): what bounds the next
+    // layer's prologue output
+    unsigned* amax_y;
 };
 
 

@@ -114,10 +114,17 @@ struct BnBwdEpi {
 size_t part_reduce_ws_bytes(int C);
 void norm_bwd_finalize(const float* part, int nblk, int C, float* s1, float* s2, float* dgamma, float* dbeta, double* tmp, hipStream_t st);
 bool tile_stats_finalize2(const float* spart, int nM, int C, double* sum, double* sq, double* tmp, hipStream_t st);
+// norm + activation prologue of a convolution's input (r5, f16x3 kernels): the operand is act(al[c] * x + be[c]) of the tensor handed
+// over -- the folded BatchNorm of the layer in front (al = rstd gamma, be = beta - mean al) -- formed while the tiles are staged
+struct ConvPro { const float* al; const float* be; int act; float slope; };
+bool conv_pro_act_ok(int act);
 int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int N, int D, int H, int W,
                   int Cin, int Cout, int k, int dgrad, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st,
                   const float* oscale = nullptr, int act = 0, float slope = 0.f, BnBwdEpi* bne = nullptr,
-                  const float* x_amax = nullptr, const float* w_amax = nullptr, const void* res = nullptr, int ldres = 0, int* res_fused = nullptr);
+                  const float* x_amax = nullptr, const float* w_amax = nullptr, const void* res = nullptr, int ldres = 0, int* res_fused = nullptr,
+                  const ConvPro* pro = nullptr, float* y_amax = nullptr);
+// (pro: fp32 tensors under f16x3 on the conv_x3s kernels only -- ask conv_fwd_takes_amax; x_amax must then bound the prologue's OUTPUT.
+//  y_amax: max |y| max-combined into this zeroed device scalar: from the kernel's epilogue on whole-K conv_x3s launches, by a pass over y otherwise)
 // (res: a tensor of y's geometry to add to the result; *res_fused = 1 when the launch took it into its epilogue -- bf16 16x16x32 tiles,
 // whole-K, no statistics --, else 0 and the caller adds it)
 // max |x| of a rows x C tensor at pitch ld (times |rowscale[row]| when given), max-combined into the zeroed device scalar *slot
@@ -160,7 +167,7 @@ size_t wgrad_lowp_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k)
 size_t wgrad_lowp_ws_bytes_geom(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad);
 int conv_wgrad_lowp(int math, const void* dy, int lddy, const void* x, int ldx, float* dw, int N, int D, int H, int W, int Cin,
                     int Cout, int k, int stride, int accumulate, void* ws, size_t ws_bytes, hipStream_t st,
-                    const float* x_amax = nullptr, const float* dy_amax = nullptr);
+                    const float* x_amax = nullptr, const float* dy_amax = nullptr, const ConvPro* pro = nullptr);
 size_t wgrad_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k);
 bool wgrad_mfma_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int ldx, int lddy);
 int conv_wgrad_mfma(const float* dy, int lddy, const float* x, int ldx, float* dw, int N, int D, int H, int W, int Cin,

@@ -775,6 +775,50 @@ int mi355seg_norm_stats_from_sums_f32(const double* sum, const double* sq, long 
     return MI355SEG_OK;
 }
 
+// mi355seg_norm_stats_from_sums_f32 + the FOLDED form of the normalisation, al = rstd gamma, be = beta - mean al (what
+// norm_act_fwd_kernel computes per thread), + an upper bound of max |act(al x + be)| from max |x|: bound = max_c (|al_c| X + |be_c|)
+// (ReLU: max_c max(0, |al_c| X + be_c)) -- the operand maximum of a convolution that applies the norm + activation as a prologue
+__global__ __launch_bounds__(256) void norm_fold_kernel(const double* __restrict__ sum, const double* __restrict__ sq, int C, double rows, float eps,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                       float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                       float momentum, const float* __restrict__ x_amax, float* __restrict__ al, float* __restrict__ be,
+                                                       float* __restrict__ a_amax) {
+    __shared__ float sh[4];
+    const float X = x_amax ? *x_amax : 0.f;
+    float bound = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double m = sum[c] / rows;
+        double var = sq[c] / rows - m * m;
+        if (var < 0.0) var = 0.0;
+        const float mf = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
+        mean[c] = mf; rstd[c] = rs;
+        if (rmean) {
+            double unb = rows > 1.0 ? var * rows / (rows - 1.0) : var;
+            rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * m);
+            rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
+        }
+        const float a = rs * (gamma ? gamma[c] : 1.f);
+        const float b = (beta ? beta[c] : 0.f) - mf * a;
+        al[c] = a; be[c] = b;
+        const float hi = fabsf(a) * X;
+        bound = fmaxf(bound, act == MI355SEG_ACT_RELU ? fmaxf(hi + b, 0.f) : hi + fabsf(b));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bound = fmaxf(bound, __shfl_xor(bound, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = bound;
+    __syncthreads();
+    if (threadIdx.x == 0 && a_amax) *a_amax = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])) * 1.0000002f;      // (one ulp up: al x + be is rounded)
+}
+int mi355seg_norm_fold_f32(const double* sum, const double* sq, long long rows, int C, float eps, const float* gamma, const float* beta, int act,
+                           float* mean, float* rstd, float* running_mean, float* running_var, float momentum,
+                           const float* x_amax, float* al, float* be, float* a_amax, void* stream) {
+    SEG_CHECK_ARG(sum && sq && mean && rstd && al && be && rows > 0 && C > 0 && act >= 0 && act <= 4, "norm_fold: bad arguments");
+    hipLaunchKernelGGL(norm_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sum, sq, C, (double)rows, eps, gamma, beta, act, mean, rstd,
+                       running_mean, running_var, momentum, x_amax, al, be, a_amax);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+
 // eval-mode BatchNorm as a per-channel affine map of the convolution's raw output: scale = gamma / sqrt(var + eps),
 // shift = beta + (conv_bias - mean) * scale
 __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,

@@ -839,7 +839,10 @@ class _DoubleConvBnAct(Function):
         N = x.shape[0]
         ax = _takes_amax(x)           # f16x3: operand maxima ride along
 
-        def layer(inp, ldin, w, b, g, be, rm, rv, geo, mom, eps, lp, xa, head=None, pool=False):
+        def layer(inp, ldin, w, b, g, be, rm, rv, geo, mom, eps, lp, xa, head=None, pool=False, fold=False, pro=None):
+            """conv + batch statistics + (norm + activation).  fold: the norm + activation is NOT applied -- the layer hands back its
+            folded form (al, be) and a bound on the activation's maximum for the next convolution's prologue; pro = (al, be): this
+            convolution's input is the previous layer's RAW output, normalised + activated while its tiles are staged."""
             D, H, W, Cin = inp.shape[1:]
             Cout, k = w.shape[0], w.shape[2]
             stride, pad = geo
@@ -858,13 +861,27 @@ class _DoubleConvBnAct(Function):
                 xa = None
             elif xa is None and (use & 1) and (use & 4):
                 xa = _measure_amax(inp, ldin, N * D * H * W, Cin)
-            L.call("mi355seg_conv3d_fwd_ax_f32", _p(inp), ldin, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
-                   sums.data_ptr(), sums.data_ptr() + 8 * Cout, _p(xa), _p(wa), _p(ws), ws.numel(), _stream())
+            ya = _amax_slot(dev) if fold else None
+            if pro is not None:
+                L.call("mi355seg_conv3d_fwd_pro_ax_f32", _p(inp), ldin, _p(pro[0]), _p(pro[1]), act, slope, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout,
+                       k, stride, pad, sums.data_ptr(), sums.data_ptr() + 8 * Cout, _p(xa), _p(wa), _p(ws), ws.numel(), _stream())
+            elif fold:
+                L.call("mi355seg_conv3d_fwd_yamax_ax_f32", _p(inp), ldin, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
+                       sums.data_ptr(), sums.data_ptr() + 8 * Cout, _p(xa), _p(wa), _p(ya), _p(ws), ws.numel(), _stream())
+            else:
+                L.call("mi355seg_conv3d_fwd_ax_f32", _p(inp), ldin, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout, k, stride, pad,
+                       sums.data_ptr(), sums.data_ptr() + 8 * Cout, _p(xa), _p(wa), _p(ws), ws.numel(), _stream())
             mean = torch.empty(Cout, dtype=torch.float32, device=dev)
             rstd = torch.empty(Cout, dtype=torch.float32, device=dev)
+            cfg = (N, D, H, W, Cin, Cout, k, stride, pad, ldin, b is not None, rows)
+            if fold:                         # statistics + folded normalisation + the bound of the activation's maximum: one small launch
+                alb = torch.empty(2 * Cout, dtype=torch.float32, device=dev)
+                aa = _amax_slot(dev)
+                L.call("mi355seg_norm_fold_f32", sums.data_ptr(), sums.data_ptr() + 8 * Cout, rows, Cout, eps, _p(g), _p(be), act,
+                       _p(mean), _p(rstd), _p(rm), _p(rv), mom, _p(ya), alb.data_ptr(), alb.data_ptr() + 4 * Cout, _p(aa), _stream())
+                return y, mean, rstd, (alb[:Cout], alb[Cout:]), cfg, (xa, wa, aa)
             L.call("mi355seg_norm_stats_from_sums_f32", sums.data_ptr(), sums.data_ptr() + 8 * Cout, rows, Cout, eps,
                    _p(mean), _p(rstd), _p(rm), _p(rv), mom, _stream())
-            cfg = (N, D, H, W, Cin, Cout, k, stride, pad, ldin, b is not None, rows)
             if head is not None:             # norm + activation + 1x1x1 head: logits, no activation tensor
                 hw, hb = head
                 K = hw.shape[0]
@@ -891,12 +908,24 @@ class _DoubleConvBnAct(Function):
         if wh is not None:
             wh = wh.contiguous()
             head = (wh, bh)
-        y1, mean1, rstd1, a1, cfg1, am1 = layer(x, ldx, w1, b1, g1, be1, rm1, rv1, geo1, mom1, eps1, 0, xa_in)
-        y2, mean2, rstd2, a2, cfg2, am2 = layer(a1, a1.shape[-1], w2, b2, g2, be2, rm2, rv2, geo2, mom2, eps2, left_pad, am1[2], head, pool)
+        # norm1 + activation as a PROLOGUE of conv2 (its forward and its weight gradient read conv1's raw output): where both run the
+        # f16x3 kernels the activation between the two convolutions is never written (mi355seg_conv3d_fwd_pro_ax_f32)
+        C1, k1_, (s1_, p1_) = w1.shape[0], w1.shape[2], geo1
+        e1 = [(e + 2 * p1_ - k1_) // s1_ + 1 for e in x.shape[1:4]]
+        fuse1 = ax and not os.environ.get("MI355SEG_NO_PRO_FUSION") and \
+            L.query("mi355seg_conv3d_pro_supported_f32", N, e1[0], e1[1], e1[2], C1, w2.shape[0], w2.shape[2], geo2[0], geo2[1], act) != 0
+        y1, mean1, rstd1, a1, cfg1, am1 = layer(x, ldx, w1, b1, g1, be1, rm1, rv1, geo1, mom1, eps1, 0, xa_in, fold=fuse1)
+        pro1 = None
+        if fuse1:
+            pro1, a1 = a1, None
+            y2, mean2, rstd2, a2, cfg2, am2 = layer(y1, C1, w2, b2, g2, be2, rm2, rv2, geo2, mom2, eps2, left_pad, am1[2], head, pool, pro=pro1)
+        else:
+            y2, mean2, rstd2, a2, cfg2, am2 = layer(a1, a1.shape[-1], w2, b2, g2, be2, rm2, rv2, geo2, mom2, eps2, left_pad, am1[2], head, pool)
         idx = None
         if pool:
             a2, pd, idx = a2
-        ctx.save_for_backward(x, w1, y1, mean1, rstd1, g1, be1, a1, w2, y2, mean2, rstd2, g2, be2, wh, idx)
+        ctx.save_for_backward(x, w1, y1, mean1, rstd1, g1, be1, a1, w2, y2, mean2, rstd2, g2, be2, wh, idx,
+                              pro1[0] if fuse1 else None, pro1[1] if fuse1 else None)
         ctx.cfg = (cfg1, cfg2, act, slope)
         ctx.amax = (am1, am2)
         ctx.head_bias = head is not None and bh is not None
@@ -906,7 +935,7 @@ class _DoubleConvBnAct(Function):
 
     @staticmethod
     def backward(ctx, da2, dskip=None):
-        x, w1, y1, mean1, rstd1, g1, be1, a1, w2, y2, mean2, rstd2, g2, be2, wh, idx = ctx.saved_tensors
+        x, w1, y1, mean1, rstd1, g1, be1, a1, w2, y2, mean2, rstd2, g2, be2, wh, idx, al1, bl1 = ctx.saved_tensors
         cfg1, cfg2, act, slope = ctx.cfg
         N, D1, H1, W1, Cin1, C1, k1, st1, pd1, ldx, has_b1, rows1 = cfg1
         _, D2, H2, W2, _, C2, k2, st2, pd2, lda1, has_b2, rows2 = cfg2
@@ -914,7 +943,7 @@ class _DoubleConvBnAct(Function):
         dev = x.device
         if da2 is not None:
             da2, ldda2 = cl_view(_like(da2, x), "conv+norm grad")
-        ws = workspace(max(_conv_ws(L, x, N, D1, H1, W1, Cin1, C1, k1, st1, pd1), _conv_ws(L, a1, N, D2, H2, W2, C1, C2, k2, st2, pd2),
+        ws = workspace(max(_conv_ws(L, x, N, D1, H1, W1, Cin1, C1, k1, st1, pd1), _conv_ws(L, y1, N, D2, H2, W2, C1, C2, k2, st2, pd2),
                            L.query("mi355seg_norm_ws_bytes", rows1, 1, C1), L.query("mi355seg_norm_ws_bytes", rows2, 1, C2),
                            L.query("mi355seg_bn_act_head_ws_bytes", C2, wh.shape[0]) if wh is not None else 0,
                            L.query("mi355seg_bn_act_pool_ws_bytes", C2) if idx is not None else 0), dev)
@@ -962,8 +991,12 @@ class _DoubleConvBnAct(Function):
                _p(y1), C1, _p(mean1), _p(rstd1), _p(g1), _p(be1), act, slope, s12.data_ptr(), s12.data_ptr() + 4 * C1, _p(dg1), _p(dbe1),
                _p(dya2), _p(wa2), _p(ws), ws.numel(), _stream())
         dw2 = torch.empty_like(w2)
-        L.call("mi355seg_conv3d_wgrad_ax_f32", _p(dy2), C2, _p(a1), lda1, _p(dw2), None, N, D2, H2, W2, C1, C2, k2, st2, pd2,
-               0, _p(dya2), _p(xa2), _p(ws), ws.numel(), _stream())
+        if al1 is not None:                  # conv2 read conv1's raw output through the norm + activation prologue: so does its weight gradient
+            L.call("mi355seg_conv3d_wgrad_pro_ax_f32", _p(dy2), C2, _p(y1), C1, _p(al1), _p(bl1), act, slope, _p(dw2), None,
+                   N, D2, H2, W2, C1, C2, k2, st2, pd2, 0, _p(dya2), _p(xa2), _p(ws), ws.numel(), _stream())
+        else:
+            L.call("mi355seg_conv3d_wgrad_ax_f32", _p(dy2), C2, _p(a1), lda1, _p(dw2), None, N, D2, H2, W2, C1, C2, k2, st2, pd2,
+                   0, _p(dya2), _p(xa2), _p(ws), ws.numel(), _stream())
         del dy2
         # layer 1: the apply half of the norm backward (+ conv1's bias gradient), then conv1's gradients
         dy1 = torch.empty_like(y1)

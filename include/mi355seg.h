@@ -152,6 +152,32 @@ int mi355seg_conv3d_fwd_fused_bf16(const mi355seg_bf16* x, int ldx, const float*
                                    mi355seg_bf16* y, int ldy, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad,
                                    void* ws, size_t ws_bytes, void* stream);
 
+/* ---- conv2 of a double-conv block on conv1's RAW output (/root/reference/models/three_d/unet3d.py:80-101: conv1 -> norm1 -> relu1 ->
+ * conv2): norm1 + relu1 run as a PROLOGUE of conv2's tile staging, in its forward and in its weight gradient, so the activation between
+ * the two convolutions is never written or re-read.  f16x3 math, k3 s1 p1, act none / relu / leaky relu.
+ *   mi355seg_conv3d_fwd_yamax_ax_f32   conv1's forward, also handing back max |y| (zeroed device scalar, max-combined into)
+ *   mi355seg_norm_fold_f32             norm_stats_from_sums + the folded normalisation al = rstd gamma, be = beta - mean al (+ running
+ *                                      statistics) + a_amax >= max |act(al x + be)| from x_amax = max |x|
+ *   mi355seg_conv3d_fwd_pro_ax_f32     y = conv3d(act(pro_al[c] x + pro_be[c]), w) + bias (+ batch statistics of y); x_amax bounds the prologue's output
+ *   mi355seg_conv3d_wgrad_pro_ax_f32   dw (+ db) of that convolution, the same prologue on its x operand
+ * Same values as norm_act_fwd followed by the plain entry points (the prologue is the same fma + activation per element). */
+int mi355seg_conv3d_pro_supported_f32(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int act);
+int mi355seg_conv3d_fwd_yamax_ax_f32(const float* x, int ldx, const float* w, const float* bias,
+                                     float* y, int ldy, int N, int D, int H, int W, int Cin, int Cout,
+                                     int k, int stride, int pad, double* stats_sum, double* stats_sq, const float* x_amax, const float* w_amax,
+                                     float* y_amax, void* ws, size_t ws_bytes, void* stream);
+int mi355seg_norm_fold_f32(const double* sum, const double* sq, long long rows, int C, float eps, const float* gamma, const float* beta, int act,
+                           float* mean, float* rstd, float* running_mean, float* running_var, float momentum,
+                           const float* x_amax, float* al, float* be, float* a_amax, void* stream);
+int mi355seg_conv3d_fwd_pro_ax_f32(const float* x, int ldx, const float* pro_al, const float* pro_be, int pro_act, float pro_slope,
+                                   const float* w, const float* bias, float* y, int ldy, int N, int D, int H, int W, int Cin, int Cout,
+                                   int k, int stride, int pad, double* stats_sum, double* stats_sq, const float* x_amax, const float* w_amax,
+                                   void* ws, size_t ws_bytes, void* stream);
+int mi355seg_conv3d_wgrad_pro_ax_f32(const float* dy, int lddy, const float* x, int ldx, const float* pro_al, const float* pro_be, int pro_act, float pro_slope,
+                                     float* dw, float* db, int N, int D, int H, int W, int Cin, int Cout,
+                                     int k, int stride, int pad, int accumulate, const float* dy_amax, const float* x_amax,
+                                     void* ws, size_t ws_bytes, void* stream);
+
 /* dx = conv_backward_input(dy, w).  D,H,W are the INPUT extents (of x/dx). */
 int mi355seg_conv3d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
                               int N, int D, int H, int W, int Cin, int Cout,

@@ -939,3 +939,57 @@ def test_bn_act_pool_fused_kernels(seg, shape, C, lp, act):
     assert torch.equal(s12[:C], dgb[C:]) and torch.equal(s12[C:], dgb[:C])           # s1 = dbeta, s2 = dgamma
     assert (dy1 - dy2).abs().max() < 2e-5 * scale(dy2)
     assert (col1 - col2).abs().max() < 1e-4 * scale(dy2) and abs(float(dam1) - float(dam2)) < 2e-5 * scale(dy2)
+
+
+@pytest.mark.parametrize("shape,chans", [((2, 16, 16, 32), (32, 64, 64)), ((1, 9, 7, 33), (64, 32, 32)), ((2, 8, 8, 16), (32, 32, 32)), ((1, 16, 16, 16), (128, 128, 128))])
+def test_double_conv_with_norm_prologue_matches_the_unfused_block(seg, shape, chans, monkeypatch):
+    """r5: conv2 of a double-conv block reads conv1's RAW output and applies norm1 + ReLU while it stages its tiles (forward:
+    mi355seg_conv3d_fwd_pro_ax_f32, weight gradient: mi355seg_conv3d_wgrad_pro_ax_f32; /root/reference/models/three_d/unet3d.py:80-101).
+    Same per-element arithmetic as norm_act_fwd + the plain kernels -- only the f16x3 scale of conv2's input differs (a bound from
+    max |y1| instead of the measured maximum) -- so the block's output, every gradient and the running statistics must agree with the
+    unfused block to fp32 rounding; interior tiles, border tiles (zero padding must stay zero behind the prologue) and ragged extents."""
+    import os
+    F = seg.functional
+    from mi355seg.layers import BatchNorm3d, Conv3d
+    N, D, H, W = shape
+    c0, c1, c2 = chans
+    torch.manual_seed(3)
+    conv1, bn1, conv2, bn2 = Conv3d(c0, c1, 3, padding=1).cuda(), BatchNorm3d(c1).cuda(), Conv3d(c1, c2, 3, padding=1).cuda(), BatchNorm3d(c2).cuda()
+    with torch.no_grad():
+        bn1.weight.copy_(1 + 0.3 * torch.randn(c1)); bn1.bias.copy_(0.5 * torch.randn(c1))
+        bn2.weight.copy_(1 + 0.3 * torch.randn(c2)); bn2.bias.copy_(0.2 * torch.randn(c2))
+    x = (rnd(N, D, H, W, c0, seed=5) * 1.3).cuda()
+    g = rnd(N, D, H, W, c2, seed=6).cuda()
+    params = [conv1.weight, conv1.bias, bn1.weight, bn1.bias, conv2.weight, conv2.bias, bn2.weight, bn2.bias]
+
+    def run(no_fusion):
+        if no_fusion:
+            monkeypatch.setenv("MI355SEG_NO_PRO_FUSION", "1")
+        else:
+            monkeypatch.delenv("MI355SEG_NO_PRO_FUSION", raising=False)
+        for m in (bn1, bn2):
+            m.running_mean.zero_(); m.running_var.fill_(1.0); m.num_batches_tracked.zero_()
+        for p in params:
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        torch.cuda.reset_peak_memory_stats()
+        y = F.double_conv_bn_act(xi, conv1, bn1, conv2, bn2, F.ACT_RELU)
+        y.backward(g)
+        torch.cuda.synchronize()
+        return (y.detach().clone(), xi.grad.clone(), [p.grad.clone() for p in params],
+                [b.clone() for m in (bn1, bn2) for b in (m.running_mean, m.running_var)])
+
+    fused = seg.lib().query("mi355seg_conv3d_pro_supported_f32", N, D, H, W, c1, c2, 3, 1, 1, F.ACT_RELU) == 1
+    assert fused or shape == (1, 9, 7, 33)                    # (a geometry outside the f16x3 kernels' plans simply stays unfused)
+    yf, dxf, gf, rf = run(False)
+    yu, dxu, gu, ru = run(True)
+    sc = lambda t: max(1e-6, float(t.abs().max()))
+    assert (yf - yu).abs().max() < 2e-5 * sc(yu)
+    assert (dxf - dxu).abs().max() < 1e-4 * sc(dxu)
+    for name, a, b in zip(["w1", "b1", "g1", "be1", "w2", "b2", "g2", "be2"], gf, gu):
+        if name in ("b1", "b2"):             # bias gradients in front of a BatchNorm are rounding noise around an exact zero
+            assert (a - b).abs().max() < 1e-3 * sc(gu[0])
+        else:
+            assert (a - b).abs().max() < 1e-4 * sc(b), name
+    for a, b in zip(rf, ru):
+        assert (a - b).abs().max() < 1e-6 * max(1.0, sc(b))
