@@ -539,10 +539,14 @@ int mi355seg_conv3d_amax_use_f32(int N, int D, int H, int W, int Cin, int Cout, 
     return m;
 }
 
-int mi355seg_conv3d_fwd_ax_f32(const float* x, int ldx, const float* w, const float* bias,
+}  // extern "C"
+
+// y_amax (may be NULL): max |y| max-combined into a zeroed device scalar by the paths that can do it inside their kernel; *amax_done says
+// whether the path that ran did
+static int conv3d_fwd_impl(const float* x, int ldx, const float* w, const float* bias,
                             float* y, int ldy, int N, int D, int H, int W, int Cin, int Cout,
                             int k, int stride, int pad, double* stats_sum, double* stats_sq, const float* x_amax, const float* w_amax,
-                            void* ws, size_t ws_bytes, void* stream) {
+                            void* ws, size_t ws_bytes, void* stream, float* y_amax, bool* amax_done) {
     ConvGeom g{N, D, H, W, Cin, Cout, k, stride, pad, 0, 0, 0};
     int rc = check_geom(&g, "conv3d_fwd");
     if (rc) return rc;
@@ -550,9 +554,11 @@ int mi355seg_conv3d_fwd_ax_f32(const float* x, int ldx, const float* w, const fl
     SEG_CHECK_ARG((stats_sum == nullptr) == (stats_sq == nullptr), "conv3d_fwd: stats_sum/stats_sq must come together");
     hipStream_t st = (hipStream_t)stream;
     const int pol = f32_conv_policy();
-    if (pol != MATH_F32 && conv_mfma_supported(pol, N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy))
+    if (pol != MATH_F32 && conv_mfma_supported(pol, N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy)) {
+        if (y_amax) *amax_done = true;
         return conv_fwd_mfma(pol, x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, /*dgrad=*/0, stats_sum, stats_sq, ws, ws_bytes, st,
-                             nullptr, 0, 0.f, nullptr, x_amax, w_amax);
+                             nullptr, 0, 0.f, nullptr, x_amax, w_amax, nullptr, 0, nullptr, nullptr, y_amax);
+    }
     if (conv_mfma_supported(MATH_F32, N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy))
         return conv_fwd_mfma(MATH_F32, x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, /*dgrad=*/0, stats_sum, stats_sq, ws, ws_bytes, st);
     if (patch_embed_supported(D, H, W, Cin, k, stride, pad)) {
@@ -577,7 +583,7 @@ int mi355seg_conv3d_fwd_ax_f32(const float* x, int ldx, const float* w, const fl
         return channel_sums(y, ldy, (long long)N * D * H * W, Cout, stats_sum, stats_sq, nullptr, 0, ws, ws_bytes, st);
     }
     if (stem_supported(Cin, Cout, k, stride, pad, ldy))
-        return stem_fwd(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, stats_sum, stats_sq, ws, ws_bytes, st);
+        return stem_fwd(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, stats_sum, stats_sq, ws, ws_bytes, st, y_amax, amax_done);
     if (tinypw_supported(Cin, Cout, k, stride, pad)) {
         rc = tinypw_fwd(x, ldx, w, bias, y, ldy, (long long)N * D * H * W, Cin, Cout, st);
         if (rc || !stats_sum) return rc;
@@ -589,6 +595,15 @@ int mi355seg_conv3d_fwd_ax_f32(const float* x, int ldx, const float* w, const fl
         return channel_sums(y, ldy, (long long)N * D * H * W, Cout, stats_sum, stats_sq, nullptr, 0, ws, ws_bytes, st);
     }
     return conv_fwd_generic(x, ldx, w, bias, y, ldy, g, stats_sum, stats_sq, ws, ws_bytes, st);
+}
+
+extern "C" {
+
+int mi355seg_conv3d_fwd_ax_f32(const float* x, int ldx, const float* w, const float* bias,
+                            float* y, int ldy, int N, int D, int H, int W, int Cin, int Cout,
+                            int k, int stride, int pad, double* stats_sum, double* stats_sq, const float* x_amax, const float* w_amax,
+                            void* ws, size_t ws_bytes, void* stream) {
+    return conv3d_fwd_impl(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, stride, pad, stats_sum, stats_sq, x_amax, w_amax, ws, ws_bytes, stream, nullptr, nullptr);
 }
 
 // ---- conv2 of a double-conv block reading conv1's RAW output (r5): the norm + activation between them is a prologue of conv2's staging
@@ -606,19 +621,13 @@ int mi355seg_conv3d_fwd_yamax_ax_f32(const float* x, int ldx, const float* w, co
                                      int k, int stride, int pad, double* stats_sum, double* stats_sq, const float* x_amax, const float* w_amax,
                                      float* y_amax, void* ws, size_t ws_bytes, void* stream) {
     SEG_CHECK_ARG(y_amax, "conv3d_fwd_yamax: y_amax is null");
-    hipStream_t st = (hipStream_t)stream;
-    const int pol = f32_conv_policy();
-    if (x && w && y && ldx >= Cin && ldy >= Cout && stride == 1 && pol != MATH_F32 && conv_mfma_supported(pol, N, D, H, W, Cin, Cout, k, stride, pad, ldx, ldy)) {
-        SEG_CHECK_ARG((stats_sum == nullptr) == (stats_sq == nullptr), "conv3d_fwd: stats_sum/stats_sq must come together");
-        return conv_fwd_mfma(pol, x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, /*dgrad=*/0, stats_sum, stats_sq, ws, ws_bytes, st,
-                             nullptr, 0, 0.f, nullptr, x_amax, w_amax, nullptr, 0, nullptr, nullptr, y_amax);
-    }
-    int rc = mi355seg_conv3d_fwd_ax_f32(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, stride, pad, stats_sum, stats_sq, x_amax, w_amax, ws, ws_bytes, stream);
-    if (rc) return rc;
+    bool done = false;
+    int rc = conv3d_fwd_impl(x, ldx, w, bias, y, ldy, N, D, H, W, Cin, Cout, k, stride, pad, stats_sum, stats_sq, x_amax, w_amax, ws, ws_bytes, stream, y_amax, &done);
+    if (rc || done) return rc;
     ConvGeom g{N, D, H, W, Cin, Cout, k, stride, pad, 0, 0, 0};
     rc = check_geom(&g, "conv3d_fwd_yamax");
     if (rc) return rc;
-    tensor_amax(y, ldy, (long long)N * g.Do * g.Ho * g.Wo, Cout, nullptr, y_amax, st);
+    tensor_amax(y, ldy, (long long)N * g.Do * g.Ho * g.Wo, Cout, nullptr, y_amax, (hipStream_t)stream);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }

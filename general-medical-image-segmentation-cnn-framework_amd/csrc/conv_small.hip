@@ -209,7 +209,7 @@ __device__ __forceinline__ void s1_stage(float* tile, const T* __restrict__ x, i
 // triples, finalised by the same two-stage fp64 reduction (tile_stats_finalize2).
 template <typename T, bool STATS>
 __global__ __launch_bounds__(256, 3) void stem1_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
-        const float* __restrict__ bias, T* __restrict__ y, float* __restrict__ spart, SmallGeom g, int ntiles) {
+        const float* __restrict__ bias, T* __restrict__ y, float* __restrict__ spart, SmallGeom g, int ntiles, unsigned* __restrict__ amax_out) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Cout = g.Cout, LPV = Cout / 4, TX = 256 / LPV, HX = TX + 2, HY = S1_TY + 2;
     const int cq = threadIdx.x % LPV, xs = threadIdx.x / LPV;
@@ -221,6 +221,7 @@ __global__ __launch_bounds__(256, 3) void stem1_fwd_kernel(const T* __restrict__
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias) bv = ld4(bias + cq * 4);
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, piv = s1;
+    float ymax = 0.f;                    // max |y| of this thread's outputs (STATS launches: the next layer's prologue bound)
     int cnt = 0;
     const int ntx = g.W / TX, nty = g.H / S1_TY, ntz = g.D / S1_TZ;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(256, 3) void stem1_fwd_kernel(const T* __restrict__
                 if (cnt == 0 && line == 0) piv = acc;
                 const f32x4 d = acc - piv;
                 s1 += d; s2 += d * d;
+                ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(acc[0]), fabsf(acc[1]))), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
             }
         }
         cnt += S1_TZ * S1_TY;
@@ -281,6 +283,7 @@ __global__ __launch_bounds__(256, 3) void stem1_fwd_kernel(const T* __restrict__
             float* dst = spart + ((long long)blockIdx.x * Cout + c) * 3;
             dst[0] = (float)(na * ma); dst[1] = (float)m2a; dst[2] = (float)na;
         }
+        if (amax_out) { __syncthreads(); block_amax_commit(ymax, amax_out); }
     }
 }
 
@@ -805,7 +808,7 @@ size_t small_ws_bytes(int Cin, int Cout, int k) {
 
 template <typename T>
 int stem_fwd(const T* x, int ldx, const float* w, const float* bias, T* y, int ldy, int N, int D, int H, int W, int Cin,
-             int Cout, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st) {
+             int Cout, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st, float* y_amax, bool* amax_done) {
     SmallGeom g{N, D, H, W, Cin, Cout, ldx, ldy};
     const long long nvox = (long long)N * D * H * W;
     const int vpb = 256 / (Cout / 4);
@@ -824,8 +827,11 @@ int stem_fwd(const T* x, int ldx, const float* w, const float* bias, T* y, int l
         if (in_kernel) spart = (float*)ws;
         {
             ProfScope ps(PF_DIRECT, 2.0 * nvox * 27.0 * Cin * Cout, (double)sizeof(T) * nvox * (Cin + Cout), st);
-            if (in_kernel) hipLaunchKernelGGL((stem1_fwd_kernel<T, true>), dim3(nb), dim3(256), stem1_lds(Cout), st, x, w, bias, y, spart, g, ntiles);
-            else hipLaunchKernelGGL((stem1_fwd_kernel<T, false>), dim3(nb), dim3(256), stem1_lds(Cout), st, x, w, bias, y, spart, g, ntiles);
+            if (in_kernel) {
+                hipLaunchKernelGGL((stem1_fwd_kernel<T, true>), dim3(nb), dim3(256), stem1_lds(Cout), st, x, w, bias, y, spart, g, ntiles, (unsigned*)y_amax);
+                if (y_amax && amax_done) *amax_done = true;
+            }
+            else hipLaunchKernelGGL((stem1_fwd_kernel<T, false>), dim3(nb), dim3(256), stem1_lds(Cout), st, x, w, bias, y, spart, g, ntiles, (unsigned*)nullptr);
             SEG_CHECK_LAUNCH();
         }
         if (in_kernel) {
@@ -969,7 +975,7 @@ int tinypw_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, long lon
 #define SEG_INST(T) \
     template int smallcin_wgrad<T>(const T*, int, const T*, int, float*, int, int, int, int, int, int, int, int, int, int, void*, size_t, hipStream_t); \
     template int smallcout_wgrad<T>(const T*, int, const T*, int, float*, int, int, int, int, int, int, int, int, int, int, void*, size_t, hipStream_t); \
-    template int stem_fwd<T>(const T*, int, const float*, const float*, T*, int, int, int, int, int, int, int, double*, double*, void*, size_t, hipStream_t); \
+    template int stem_fwd<T>(const T*, int, const float*, const float*, T*, int, int, int, int, int, int, int, double*, double*, void*, size_t, hipStream_t, float*, bool*); \
     template int stem_wgrad<T>(const T*, int, const T*, int, float*, int, int, int, int, int, int, int, void*, size_t, hipStream_t); \
     template int head_fwd<T>(const T*, int, const float*, const float*, T*, int, int, int, int, int, int, int, hipStream_t); \
     template int head_dgrad<T>(const T*, int, const float*, T*, int, int, int, int, int, int, int, hipStream_t); \

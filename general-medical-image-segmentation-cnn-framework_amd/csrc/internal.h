@@ -25,7 +25,7 @@ int stem4_wgrad_lowp(const bf16* dy, int lddy, const bf16* x, float* dw, int N, 
 bool head_supported(int Cin, int Cout, int k, int stride, int pad, int ldx);
 size_t small_ws_bytes(int Cin, int Cout, int k);
 template <typename T> int stem_fwd(const T* x, int ldx, const float* w, const float* bias, T* y, int ldy, int N, int D, int H, int W, int Cin,
-             int Cout, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st);
+             int Cout, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st, float* y_amax = nullptr, bool* amax_done = nullptr);
 template <typename T> int stem_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
                int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 template <typename T> int head_fwd(const T* x, int ldx, const float* w, const float* bias, T* y, int ldy, int N, int D, int H, int W, int Cin,
