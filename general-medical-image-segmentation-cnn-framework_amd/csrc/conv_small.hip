@@ -819,7 +819,7 @@ int stem_fwd(const T* x, int ldx, const float* w, const float* bias, T* y, int l
     if (lds < 256 * 8 * 4) lds = 256 * 8 * 4;
     if (stem1_tiled_ok(g)) {
         const int ntiles = (int)(nvox / ((long long)S1_TZ * S1_TY * (256 / (Cout / 4))));   // tile = 2 x 4 x TX voxels
-        int nb = ntiles < 1024 ? ntiles : 1024;
+        int nb = ntiles < 768 ? ntiles : 768;          // three workgroups per CU x 256 CUs: one full round (1024 left a third-full second round)
         // statistics from the kernel (per-block {sum, M2, n} triples, pivoted per thread) when there are enough blocks for the
         // two-stage fp64 finalise and the workspace holds the triples
         const size_t sp_bytes = align_up((size_t)nb * Cout * 3 * sizeof(float), 256);
