@@ -81,6 +81,18 @@ __global__ __launch_bounds__(256, 2) void convt_wgrad_lowp_kernel(CwArgs a) {
     const long long nvox = (long long)a.N * a.D * a.H * a.W;
     using stage_t = typename std::conditional<EPP == 4, f32x4, bf16x8_t>::type;
     stage_t sx[XIT], sd[DIT];
+    // r5: when a tile's V consecutive base voxels lie in ONE x-row (W % V == 0: every level but the deepest) the children's addresses are
+    // a per-tile base (wave-uniform: one decode per tile) + a per-piece offset that never changes -- the three integer divisions per
+    // piece of the general path (24 per thread and tile, more VALU time than the tile's MFMAs) are gone
+    // (W < V: a tile is V / W whole x-rows of one z-plane when V % W == 0 and H % (V / W) == 0 -- the deep levels)
+    const bool rowtile = (a.W % C::V) == 0 || (C::V % a.W == 0 && a.H % (C::V / a.W) == 0);
+    int reld[DIT];
+#pragma unroll
+    for (int it = 0; it < DIT; ++it) {
+        const int pc = it * 256 + tid, part = pc % PPV, vl = (pc / PPV) % C::V, tap = pc / (PPV * C::V);
+        const int r = a.W >= C::V ? 0 : vl / a.W, xo = a.W >= C::V ? vl : vl % a.W;
+        reld[it] = (((tap >> 2) * (2 * a.H) + 2 * r + ((tap >> 1) & 1)) * (2 * a.W) + 2 * xo + (tap & 1)) * a.lddy + part * EPP;
+    }
     auto load_stage = [&](int tile) {
         const long long v0 = (long long)tile * C::V;
 #pragma unroll
@@ -89,6 +101,21 @@ __global__ __launch_bounds__(256, 2) void convt_wgrad_lowp_kernel(CwArgs a) {
             stage_t xv = {};
             if (v0 + vl < nvox && ci0 + part * EPP < a.Cin) xv = *reinterpret_cast<const stage_t*>(xin + (v0 + vl) * a.ldx + ci0 + part * EPP);
             sx[it] = xv;
+        }
+        if (rowtile) {
+            long long v = v0;
+            const int xw = (int)(v % a.W); v /= a.W;
+            const int yh = (int)(v % a.H); v /= a.H;
+            const int zd = (int)(v % a.D); const int n = (int)(v / a.D);
+            const IN_T* base = din + ((((long long)n * (2 * a.D) + 2 * zd) * (2 * a.H) + 2 * yh) * (2 * a.W) + 2 * xw) * a.lddy + co0;
+#pragma unroll
+            for (int it = 0; it < DIT; ++it) {
+                const int pc = it * 256 + tid, part = pc % PPV;
+                stage_t dv = {};
+                if (v0 < nvox && co0 + part * EPP < a.Cout) dv = *reinterpret_cast<const stage_t*>(base + reld[it]);
+                sd[it] = dv;
+            }
+            return;
         }
 #pragma unroll
         for (int it = 0; it < DIT; ++it) {
