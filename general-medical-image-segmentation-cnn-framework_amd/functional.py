@@ -307,10 +307,34 @@ def _amax_use(x, N, D, H, W, Cin, Cout, k, stride, pad):
     return use
 
 
+_CHECK_AMAX = bool(os.environ.get("MI355SEG_CHECK_AMAX"))
+
+
+def check_amax(enable=True):
+    """Debug mode (also MI355SEG_CHECK_AMAX=1): every operand maximum a convolution is handed is compared with the tensor's true
+    maximum (one synchronising reduction per use).  INVARIANT the carried scalars rest on: ``_seg_amax`` is keyed by the tensor's
+    version counter, and the library's kernels write through ``data_ptr()`` without bumping it -- so whatever writes an fp32
+    activation in place through a raw pointer AFTER its maximum was recorded must delete or refresh the attribute.  A too-SMALL
+    maximum makes the f16x3 high part overflow fp16 silently; a too-large one only costs headroom."""
+    global _CHECK_AMAX
+    _CHECK_AMAX = bool(enable)
+
+
+def _assert_amax(value, slot, what):
+    """value: the operand tensor (any layout; only its values matter) or its true maximum as a float."""
+    if not _CHECK_AMAX or slot is None:
+        return
+    true = float(value.detach().abs().max()) if torch.is_tensor(value) else float(value)
+    have = float(slot.reshape(-1)[0])
+    if not (have >= true * (1.0 - 1e-6)):
+        raise Mi355SegError(f"operand maximum handed to {what} is too small: carried {have!r}, tensor has {true!r}")
+
+
 def _get_amax(t):
     rec = getattr(t, "_seg_amax", None)
     if rec is None or rec[1] != t._version or rec[0].device != t.device:
         return None
+    _assert_amax(t, rec[0], "a convolution (the tensor's _seg_amax attribute)")
     return rec[0]
 
 
@@ -862,6 +886,13 @@ class _DoubleConvBnAct(Function):
             elif xa is None and (use & 1) and (use & 4):
                 xa = _measure_amax(inp, ldin, N * D * H * W, Cin)
             ya = _amax_slot(dev) if fold else None
+            if _CHECK_AMAX:
+                _assert_amax(w, wa, "conv weights")
+                if pro is not None:          # the bound on the prologue's output against the activation it stands for
+                    z = inp * pro[0] + pro[1]
+                    _assert_amax(torch.where(z > 0, z, z * (slope if act == ACT_LRELU else 0.0)), xa, "the norm prologue's bound")
+                elif xa is not None:
+                    _assert_amax(inp, xa, "conv input")
             if pro is not None:
                 L.call("mi355seg_conv3d_fwd_pro_ax_f32", _p(inp), ldin, _p(pro[0]), _p(pro[1]), act, slope, _p(w), _p(b), _p(y), Cout, N, D, H, W, Cin, Cout,
                        k, stride, pad, sums.data_ptr(), sums.data_ptr() + 8 * Cout, _p(xa), _p(wa), _p(ws), ws.numel(), _stream())

@@ -413,3 +413,35 @@ def test_make_adam_matches_default_adam(seg):
         assert (a - b).abs().max() <= 2e-6 * max(1.0, float(b.abs().max()))
     # CPU parameters: the default implementation, no error
     assert not make_adam([torch.zeros(3, requires_grad=True)], lr=1e-3).defaults.get("fused")
+
+
+def test_carried_operand_maxima_bound_the_tensors(seg, monkeypatch):
+    """the f16x3 operand maxima ride along as tensor attributes / device scalars and are never re-measured; a too-SMALL one
+    would overflow the fp16 high part silently.  Debug mode ``functional.check_amax()`` compares every maximum a convolution is handed with
+    the tensor's true maximum: a whole U-Net train step (double-conv nodes with the norm prologue's BOUND, pool- and head-fused blocks,
+    concat buffers, ConvT, weights from the multi-tensor prefetch) must pass it, and a tensor modified through a raw pointer after its
+    maximum was recorded -- the case the invariant in functional.check_amax's docstring forbids -- must be caught."""
+    from mi355seg.engine import make_adam, train_step
+    from mi355seg.models.three_d.unet3d import UNet3D
+    from oracle.fill import fill_module_, make_input, make_labels
+    F = seg.functional
+    if seg.get_conv_math() != "f16x3":
+        pytest.skip("operand maxima are an f16x3 matter")
+    F.check_amax(True)
+    try:
+        m = fill_module_(UNet3D(1, 2, 32)).cuda().train()
+        x, gt = make_input((1, 1, 32, 32, 32)).cuda(), make_labels((1, 1, 32, 32, 32)).cuda()
+        out = train_step(m, make_adam(m.parameters(), lr=1e-3), x, gt)
+        assert np.isfinite(out["loss"].item())
+        # the forbidden case: a raw-pointer write behind the recorded maximum (copy_ would bump the version; the library's kernels do not)
+        t = torch.rand(1, 8, 8, 16, 32, device="cuda")
+        F._set_amax(t, F._measure_amax(t, 32, 8 * 8 * 16, 32))
+        assert F._get_amax(t) is not None
+        five = t * 0 + 5.0
+        seg.lib().call("mi355seg_act_fwd_f32", five.data_ptr(), 32, None, 0, t.data_ptr(), 32, 8 * 8 * 16, 32, F.ACT_NONE, 0.0,
+                       torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        with pytest.raises(seg.Mi355SegError, match="too small"):
+            F._get_amax(t)
+    finally:
+        F.check_amax(False)
