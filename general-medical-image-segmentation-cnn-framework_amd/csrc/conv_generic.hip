@@ -266,6 +266,38 @@ __global__ __launch_bounds__(256) void wgrad_reduce_cols_kernel(const float* __r
     }
 }
 
+// the slabs of a weight gradient that ran with the operands' ROLES SWAPPED (conv_wgrad_lowp: x as the centred operand, dy as the haloed one,
+// so that a 64 -> 32 layer can use the 32 x 64 wide kernel): part[strip][T - 1 - tap][co][ci]  ->  dw[co][ci][tap]
+__global__ __launch_bounds__(256) void wgrad_reduce_cols_swapped_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits, int T, int Cin,
+                                                                        int Cout, int accumulate) {
+    __shared__ double sh[8][32];
+    const long long total = (long long)T * Cin * Cout;
+    const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const long long col = (long long)blockIdx.x * 32 + c;
+    double s0 = 0.0, s1 = 0.0;
+    if (col < total) {
+        const float* p = part + col;
+        int k = q;
+        for (; k + 8 < splits; k += 16) { s0 += (double)p[(long long)k * total]; s1 += (double)p[(long long)(k + 8) * total]; }
+        if (k < splits) s0 += (double)p[(long long)k * total];
+    }
+    sh[q][c] = s0 + s1;
+    __syncthreads();
+    if (q == 0 && col < total) {
+        double s = sh[0][c];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) s += sh[j][c];
+        const int ci = (int)(col % Cin); const long long r = col / Cin;          // the slab's columns: [tap'][co][ci]
+        const int co = (int)(r % Cout), tp = (int)(r / Cout);
+        const long long o = ((long long)co * Cin + ci) * T + (T - 1 - tp);
+        dw[o] = accumulate ? dw[o] + (float)s : (float)s;
+    }
+}
+void wgrad_reduce_swapped(const float* part, float* dw, int splits, int T, int Cin, int Cout, int accumulate, hipStream_t st) {
+    const long long total = (long long)T * Cin * Cout;
+    hipLaunchKernelGGL(wgrad_reduce_cols_swapped_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, part, dw, splits, T, Cin, Cout, accumulate);
+}
+
 void wgrad_reduce(const float* part, float* dw, int splits, int T, int Cin, int Cout, int accumulate, hipStream_t st) {
     const int TT = T > 256 ? 256 : T;
     int CIT = 256 / TT;

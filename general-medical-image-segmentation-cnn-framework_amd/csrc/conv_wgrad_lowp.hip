@@ -842,6 +842,39 @@ int conv_wgrad_lowp(int math, const void* dy, int lddy, const void* x, int ldx, 
     const int pad = k / 2, Do = lw_out(D, k, stride, pad), Ho = lw_out(H, k, stride, pad), Wo = lw_out(W, k, stride, pad);
     // f16x3, k3 s1, Cout % 64 == 0: the wide kernel (mi355seg_set_wgrad_wide)
     const bool wide = g_wgrad_wide != 0 && (math == MATH_B16 || (math == MATH_X3 && x3_f16())) && lwgrad_plan(math, k, stride, N, Do, Ho, Wo, Cin, Cout, &p, true);
+    // r5: a k3 s1 layer with Cin % 64 == 0 but Cout = 32 (dec1conv1, 64 -> 32 @ 128^3: the largest weight gradient of cfg 2) has no 64-wide co
+    // block for the wide kernel -- but dW[tap][ci][co] = sum_v x[v + tap][ci] dy[v][co] = sum_u dy[u - tap][co] x[u][ci] is the same
+    // weight gradient with the operands' roles swapped and the taps mirrored (both tensors are zero outside the same volume): x becomes the
+    // centred 64-channel operand, dy the haloed 32-channel one, and the slabs come out as [27 - 1 - tap][co][ci] (wgrad_reduce_swapped)
+    LWgradPlan psw;
+    const bool swap = !wide && !pro && g_wgrad_wide != 0 && math == MATH_X3 && x3_f16() && k == 3 && stride == 1 && Cin % 64 == 0 && Cout % 64 != 0 &&
+                      lwgrad_plan(math, k, stride, N, Do, Ho, Wo, Cout, Cin, &psw, true) && psw.nstrips >= 8 && lw_offsets_fit(math, Ho, Wo, lddy, H, W, ldx);
+    if (swap) {
+        SEG_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, "conv_wgrad_lowp: pointers must be 16-byte aligned");
+        Carver cv(ws);
+        float* part = cv.take<float>((size_t)psw.nstrips * psw.taps * Cin * Cout);
+        float* amax = cv.take<float>(2);
+        SEG_CHECK_WS(cv.used(), ws_bytes);
+        LWgradArgs a{dy, x, part, lddy, ldx, N, D, H, W, Cout, Cin, Do, Ho, Wo, psw.ntx, psw.nty, psw.ntz, psw.ntiles, psw.nstrips, psw.npairs, Cin / psw.cob, psw.taps,
+                     nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0};
+        if (!x_amax || !dy_amax) {
+            if (hipMemsetAsync(amax, 0, 2 * sizeof(float), st) != hipSuccess) { set_error("conv_wgrad_lowp: hipMemsetAsync failed"); return MI355SEG_EHIP; }
+            if (!x_amax) { tensor_amax((const float*)x, ldx, (long long)N * D * H * W, Cin, nullptr, amax, st); x_amax = amax; }
+            if (!dy_amax) { tensor_amax((const float*)dy, lddy, (long long)N * Do * Ho * Wo, Cout, nullptr, amax + 1, st); dy_amax = amax + 1; }
+            SEG_CHECK_LAUNCH();
+        }
+        a.amax_x = dy_amax; a.amax_dy = x_amax;                    // (roles swapped)
+        const int nwg = psw.nstrips * psw.npairs * psw.planes;
+        const double vox = (double)N * Do * Ho * Wo;
+        {
+            ProfScope ps(PF_WGRAD, 2.0 * vox * psw.taps * Cin * Cout, 4.0 * vox * (Cin + Cout) + 4.0 * psw.taps * Cin * Cout, st);
+            if (psw.BX == 16) launch_wide<16, 3, float>(a, nwg, st); else launch_wide<8, 3, float>(a, nwg, st);
+            SEG_CHECK_LAUNCH();
+        }
+        wgrad_reduce_swapped(part, dw, psw.nstrips, psw.taps, Cin, Cout, accumulate, st);
+        SEG_CHECK_LAUNCH();
+        return MI355SEG_OK;
+    }
     SEG_CHECK_ARG(wide || lwgrad_plan(math, k, stride, N, Do, Ho, Wo, Cin, Cout, &p), "conv_wgrad_lowp: unsupported shape");
     SEG_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, "conv_wgrad_lowp: pointers must be 16-byte aligned");
     SEG_CHECK_ARG(lw_offsets_fit(math, H, W, ldx, Ho, Wo, lddy), "conv_wgrad_lowp: a tile's halo spans more than 2 GB (wgrad_lowp_supported says so)");

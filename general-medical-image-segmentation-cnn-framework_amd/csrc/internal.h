@@ -88,6 +88,7 @@ bool x3_f16();             // the split-precision kernels run the two-piece fp16
 void pack_w_fwd(const float* w, float* wp, int Cout, int Cin, int T, hipStream_t st);
 void pack_w_dgrad(const float* w, float* wd, int Cout, int Cin, int T, int flip, hipStream_t st);
 void wgrad_reduce(const float* part, float* dw, int splits, int T, int Cin, int Cout, int accumulate, hipStream_t st);
+void wgrad_reduce_swapped(const float* part, float* dw, int splits, int T, int Cin, int Cout, int accumulate, hipStream_t st);   // slabs [strip][T - 1 - tap][co][ci]
 
 // conv_mfma.hip / igemm_kernel.h -- implicit-GEMM Conv3d / ConvTranspose3d on the matrix cores.  `math` is the arithmetic
 // policy of igemm_kernel.h: MATH_F32 (0: fp32 tensors, fp32 MFMA), MATH_X3 (1: fp32 tensors, bf16x6 split) or MATH_B16

@@ -599,10 +599,13 @@ def test_bf16x6_16x16x32_kernel_against_fp64_and_the_32x32x16_kernel(seg, case):
         assert torch.allclose(e16[3], want.pow(2).sum(dim=(0, 1, 2, 3)), rtol=2e-6, atol=1e-9)
 
 
-@pytest.mark.parametrize("case", [(1, 8, 16, 32, 32, 64), (2, 5, 9, 40, 64, 128), (1, 3, 7, 21, 32, 64), (1, 16, 48, 64, 128, 128)],
+@pytest.mark.parametrize("case", [(1, 8, 16, 32, 32, 64), (2, 5, 9, 40, 64, 128), (1, 3, 7, 21, 32, 64), (1, 16, 48, 64, 128, 128),
+                                  (2, 16, 16, 32, 64, 32), (1, 9, 7, 40, 128, 32), (1, 32, 32, 64, 64, 32)],
                          ids=lambda c: "x".join(map(str, c)))
 def test_f16x3_wide_weight_gradient(seg, case):
-    """conv_wgrad_f16w_kernel (f16x3, k3 s1, Cout % 64 == 0: four waves, a 32 x 64 channel block per workgroup; include/mi355seg.h,
+    """(r5: the last three cases have Cin % 64 == 0 and Cout = 32 -- the wide kernel then runs with the operands' roles SWAPPED, x the
+    centred 64-channel operand, dy the haloed one, mirrored taps, slabs transposed back by wgrad_reduce_swapped: dec1conv1 of cfg 2.)
+    conv_wgrad_f16w_kernel (f16x3, k3 s1, Cout % 64 == 0: four waves, a 32 x 64 channel block per workgroup; include/mi355seg.h,
     mi355seg_set_wgrad_wide): forced on wherever the geometry allows (mode 2: full, ragged and BX = 8 tiles, D smaller than a tile,
     and -- last case -- a shape the default mode 1 sends there), against the fp64 weight gradient by the criteria of
     test_split_precision_conv_is_fp32_accurate, and against the 32 x 32 kernel (mode 0): both sum the same products."""
