@@ -703,6 +703,22 @@ int mi355seg_conv3d_wgrad_pro_ax_f32(const float* dy, int lddy, const float* x, 
     return conv_wgrad_lowp(MATH_X3, dy, lddy, x, ldx, dw, N, D, H, W, Cin, Cout, k, stride, accumulate, ws, ws_bytes, st, x_amax, dy_amax, &pro);
 }
 
+// The 1-channel stem behind a BatchNorm + activation (unet3d.py:80-89) when the stem's input needs no gradient: dw (+ db) of the stem
+// straight from d(activation) da and the pre-norm tensor y -- the norm backward's apply half (dy = rstd gamma (dz - s1 / rows - xhat s2 /
+// rows), dz = da act'(z)) is formed inside the weight-gradient kernel, dy is never written.  s1 / s2: the norm backward's column sums.
+int mi355seg_stem_wgrad_bnbwd_supported_f32(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
+    return stem_wgrad_bn_supported(N, D, H, W, Cin, Cout, k, stride, pad) ? 1 : 0;
+}
+int mi355seg_stem_wgrad_bnbwd_f32(const float* da, int ldda, const float* y, int ldy, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                  int act, float slope, const float* s1, const float* s2, const float* x, int ldx, float* dw, float* db,
+                                  int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
+    SEG_CHECK_ARG(da && y && mean && rstd && s1 && s2 && x && dw && ldda >= Cout && ldy >= Cout && (ldda % 4) == 0 && (ldy % 4) == 0 && ldx >= 1 && act >= 0 && act <= 4,
+                  "stem_wgrad_bnbwd: bad arguments");
+    SEG_CHECK_ARG(stem_wgrad_bn_supported(N, D, H, W, Cin, Cout, k, stride, pad) && ((uintptr_t)da % 16) == 0 && ((uintptr_t)y % 16) == 0,
+                  "stem_wgrad_bnbwd: unsupported geometry (ask mi355seg_stem_wgrad_bnbwd_supported_f32)");
+    return stem_wgrad_bn(da, ldda, y, ldy, mean, rstd, gamma, beta, act, slope, s1, s2, x, ldx, dw, db, N, D, H, W, Cout, ws, ws_bytes, (hipStream_t)stream);
+}
+
 int mi355seg_conv3d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
                               int N, int D, int H, int W, int Cin, int Cout,
                               int k, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {

@@ -350,6 +350,120 @@ __global__ __launch_bounds__(256) void stem1_wgrad_kernel(const T* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------- Cin == 1 stem wgrad with the norm backward's APPLY half as its prologue (r5)
+// unet3d.py:80-89 (enc1conv1 -> enc1norm1 -> enc1relu1): the stem's input needs no gradient, so d(conv1 output) = rstd gamma (dz - s1 / n -
+// xhat s2 / n) has ONE consumer, this weight gradient.  It is formed here from d(activation) and the pre-norm tensor (norm_act_bwd_apply_kernel's
+// expression, operation for operation) instead of being written (537 MB at 2 x 128^3) and read back; its column sums (conv1's bias gradient)
+// come out of the same pass.  part[blk][tap][co] as stem1_wgrad_kernel, cpart[blk][co].
+struct StemBn { const float* da; int ldda; const float* y; int ldy; const float* mean; const float* rstd; const float* gamma; const float* beta;
+                const float* s1; const float* s2; int act; float slope; float invM; };
+
+__global__ __launch_bounds__(256, 2) void stem1_wgrad_bn_kernel(const float* __restrict__ x, StemBn b, float* __restrict__ part, float* __restrict__ cpart,
+                                                               SmallGeom g, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Cout = g.Cout, LPV = Cout / 4, TX = 256 / LPV, HX = TX + 2, HY = S1_TY + 2;
+    const int cq = threadIdx.x % LPV, xs = threadIdx.x / LPV;
+    // per-channel constants in LDS behind the reduction scratch (six quads per thread and tile, live only while d is formed: held in
+    // registers across the 27-tap loop they spill)
+    float* const ctab = sm + 4 * 28 * Cout;
+    float* const dtab = ctab + 6 * Cout;              // [8 lines][256 threads] quads of d(conv output)
+    for (int c = threadIdx.x; c < Cout; c += 256) {
+        ctab[c] = b.mean[c]; ctab[Cout + c] = b.rstd[c]; ctab[2 * Cout + c] = b.gamma ? b.gamma[c] : 1.f; ctab[3 * Cout + c] = b.beta ? b.beta[c] : 0.f;
+        ctab[4 * Cout + c] = b.s1[c] * b.invM; ctab[5 * Cout + c] = b.s2[c] * b.invM;
+    }
+    f32x4 acc[27], col = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ntx = g.W / TX, nty = g.H / S1_TY, ntz = g.D / S1_TZ;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int mt = tile;
+        const int txi = mt % ntx; mt /= ntx;
+        const int tyi = mt % nty; mt /= nty;
+        const int tzi = mt % ntz; const int n = mt / ntz;
+        const int x0 = txi * TX, y0 = tyi * S1_TY, z0 = tzi * S1_TZ;
+        f32x4 dreg[S1_TZ * S1_TY], yreg[S1_TZ * S1_TY];
+#pragma unroll
+        for (int line = 0; line < S1_TZ * S1_TY; ++line) {
+            const int lz = line / S1_TY, ly = line % S1_TY;
+            const long long v = (((long long)n * g.D + z0 + lz) * g.H + y0 + ly) * g.W + x0 + xs;
+            dreg[line] = ld4(b.da + v * b.ldda + cq * 4);
+            yreg[line] = ld4(b.y + v * b.ldy + cq * 4);
+        }
+        __syncthreads();
+        s1_stage(sm, x, g.ldx, n, z0, y0, x0, TX, g.D, g.H, g.W);
+        __syncthreads();
+        // d(conv output) of the eight lines first, parked in this thread's own LDS slots (the pre-norm values, d(activation) and the
+        // per-channel constants are dead before the 27-tap loop starts; the loop then runs two lines per trip as stem1_fwd_kernel does --
+        // fully unrolled with everything in registers the kernel spills 50-250 VGPRs)
+        {
+            const f32x4 m = ld4(ctab + cq * 4), rs = ld4(ctab + Cout + cq * 4), ga = ld4(ctab + 2 * Cout + cq * 4), be = ld4(ctab + 3 * Cout + cq * 4);
+            const f32x4 k1 = ld4(ctab + 4 * Cout + cq * 4), k2 = ld4(ctab + 5 * Cout + cq * 4);
+#pragma unroll
+            for (int line = 0; line < S1_TZ * S1_TY; ++line) {
+                f32x4 d;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (yreg[line][j] - m[j]) * rs[j];
+                    const float z = fmaf(xh, ga[j], be[j]);
+                    const float dz = dreg[line][j] * act_grad(z, b.act, b.slope);
+                    d[j] = ga[j] * rs[j] * (dz - k1[j] - xh * k2[j]);
+                }
+                col += d;
+                st4(dtab + (line * 256 + threadIdx.x) * 4, d);
+            }
+        }
+#pragma unroll 2
+        for (int line = 0; line < S1_TZ * S1_TY; ++line) {
+            const int lz = line / S1_TY, ly = line % S1_TY;
+            const float* tp = sm + (lz * HY + ly) * HX + xs;
+            const f32x4 d = ld4(dtab + (line * 256 + threadIdx.x) * 4);
+#pragma unroll
+            for (int t = 0; t < 27; ++t) {
+                const int dz = t / 9, dyy = (t / 3) % 3, dx = t % 3;
+                acc[t] += tp[(dz * HY + dyy) * HX + dx] * d;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = acc[t][j];
+            for (int o = 32; o >= LPV; o >>= 1) s += __shfl_xor(s, o, 64);
+            acc[t][j] = s;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float s = col[j];
+        for (int o = 32; o >= LPV; o >>= 1) s += __shfl_xor(s, o, 64);
+        col[j] = s;
+    }
+    __syncthreads();
+    if (lane < LPV) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t) st4(sm + ((wave * 28 + t) * LPV + lane) * 4, acc[t]);
+        st4(sm + ((wave * 28 + 27) * LPV + lane) * 4, col);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 28 * Cout; i += 256) {
+        const int t = i / Cout, co = i % Cout;
+        float s = 0.f;
+        for (int w = 0; w < 4; ++w) s += sm[((w * 28 + t) * LPV + co / 4) * 4 + co % 4];
+        if (t < 27) part[((long long)blockIdx.x * 27 + t) * Cout + co] = s;
+        else cpart[(long long)blockIdx.x * Cout + co] = s;
+    }
+}
+
+__global__ __launch_bounds__(64) void colpart_finalize_kernel(const float* __restrict__ cpart, int nblk, int C, float* __restrict__ out) {
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int k = threadIdx.x; k < nblk; k += 64) s += (double)cpart[(long long)k * C + c];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[c] = (float)s;
+}
+
 // ---------------------------------------------------------------- Cin == 1, k5 p2 stem wgrad (V-Net InputTransition, vnet3d.py:47)
 // grid = (blocks, 5 dz planes).  As stem1_wgrad_kernel, with the 25 (dy, dx) taps of one dz plane per block: the LDS tile is
 // the z-shifted slab S1_TZ x (S1_TY+4) x (TX+4) of the one-channel input.  part[blk][tap][0][co], tap = dz*25 + dy*5 + dx.
@@ -484,6 +598,41 @@ static size_t stem1_lds(int Cout) {
     size_t a = (size_t)(TX + 2) * (S1_TY + 2) * (S1_TZ + 2) * 4, b = 256 * 9 * 4, c = (size_t)4 * 27 * Cout * 4;
     size_t m = a > b ? a : b;
     return m > c ? m : c;
+}
+
+bool stem_wgrad_bn_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
+    if (!(k == 3 && stride == 1 && pad == 1 && Cin == 1 && Cout % 4 == 0 && Cout >= 4 && Cout <= 64 && ((Cout / 4) & (Cout / 4 - 1)) == 0)) return false;
+    SmallGeom g{N, D, H, W, Cin, Cout, 1, Cout};
+    return stem1_tiled_ok(g) && (size_t)4 * 28 * Cout * 4 <= 64 * 1024;
+}
+
+int stem_wgrad_bn(const float* da, int ldda, const float* y, int ldy, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                  int act, float slope, const float* s1, const float* s2, const float* x, int ldx, float* dw, float* db,
+                  int N, int D, int H, int W, int Cout, void* ws, size_t ws_bytes, hipStream_t st) {
+    SmallGeom g{N, D, H, W, 1, Cout, ldx, 0};
+    const long long nvox = (long long)N * D * H * W;
+    const int ntiles = (int)(nvox / ((long long)S1_TZ * S1_TY * (256 / (Cout / 4))));
+    const int nb = ntiles < 512 ? ntiles : 512;                  // two workgroups per CU
+    Carver cv(ws);
+    float* part = cv.take<float>((size_t)nb * 27 * Cout);
+    float* cpart = cv.take<float>((size_t)nb * Cout);
+    SEG_CHECK_WS(cv.used(), ws_bytes);
+    StemBn b{da, ldda, y, ldy, mean, rstd, gamma, beta, s1, s2, act, slope, 1.f / (float)nvox};
+    size_t lds = stem1_lds(Cout);
+    if (lds < (size_t)4 * 28 * Cout * 4) lds = (size_t)4 * 28 * Cout * 4;
+    lds = (size_t)4 * 28 * Cout * 4 + (size_t)6 * Cout * 4 + (size_t)S1_TZ * S1_TY * 256 * 16;       // reduction scratch | constants | parked d (32 KB)
+    {
+        ProfScope ps(PF_DIRECT, 2.0 * nvox * 27.0 * Cout, 4.0 * nvox * (1 + 2.0 * Cout), st);
+        hipLaunchKernelGGL(stem1_wgrad_bn_kernel, dim3(nb), dim3(256), lds, st, x, b, part, cpart, g, ntiles);
+        SEG_CHECK_LAUNCH();
+    }
+    wgrad_reduce(part, dw, nb, 27, 1, Cout, 0, st);
+    SEG_CHECK_LAUNCH();
+    if (db) {
+        hipLaunchKernelGGL(colpart_finalize_kernel, dim3(Cout), dim3(64), 0, st, cpart, nb, Cout, db);
+        SEG_CHECK_LAUNCH();
+    }
+    return MI355SEG_OK;
 }
 
 // ---------------------------------------------------------------- pointwise (k1) small-Cout head

@@ -26,6 +26,11 @@ bool head_supported(int Cin, int Cout, int k, int stride, int pad, int ldx);
 size_t small_ws_bytes(int Cin, int Cout, int k);
 template <typename T> int stem_fwd(const T* x, int ldx, const float* w, const float* bias, T* y, int ldy, int N, int D, int H, int W, int Cin,
              int Cout, double* ssum, double* ssq, void* ws, size_t ws_bytes, hipStream_t st, float* y_amax = nullptr, bool* amax_done = nullptr);
+// conv_small.hip (r5): weight gradient (+ bias gradient) of the 1-channel stem with the norm backward's apply half as its prologue
+bool stem_wgrad_bn_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad);
+int stem_wgrad_bn(const float* da, int ldda, const float* y, int ldy, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                  int act, float slope, const float* s1, const float* s2, const float* x, int ldx, float* dw, float* db,
+                  int N, int D, int H, int W, int Cout, void* ws, size_t ws_bytes, hipStream_t st);
 template <typename T> int stem_wgrad(const T* dy, int lddy, const T* x, int ldx, float* dw, int N, int D, int H, int W, int Cin, int Cout,
                int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 template <typename T> int head_fwd(const T* x, int ldx, const float* w, const float* bias, T* y, int ldy, int N, int D, int H, int W, int Cin,

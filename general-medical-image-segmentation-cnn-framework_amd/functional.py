@@ -1029,6 +1029,16 @@ class _DoubleConvBnAct(Function):
             L.call("mi355seg_conv3d_wgrad_ax_f32", _p(dy2), C2, _p(a1), lda1, _p(dw2), None, N, D2, H2, W2, C1, C2, k2, st2, pd2,
                    0, _p(dya2), _p(xa2), _p(ws), ws.numel(), _stream())
         del dy2
+        # the 1-channel stem whose input needs no gradient (enc1conv1, unet3d.py:80-89): d(conv1 output) has ONE consumer, the stem's weight
+        # gradient, which forms it from d(act1) and y1 on the fly -- the apply pass and the 537-MB tensor it writes are gone
+        if not ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and Cin1 == 1 and not os.environ.get("MI355SEG_NO_STEM_FUSION") and \
+                L.query("mi355seg_stem_wgrad_bnbwd_supported_f32", N, D1, H1, W1, Cin1, C1, k1, st1, pd1) != 0:
+            dw1 = torch.empty_like(w1)
+            db1 = torch.empty(C1, **f32) if has_b1 else None
+            L.call("mi355seg_stem_wgrad_bnbwd_f32", _p(da1), C1, _p(y1), C1, _p(mean1), _p(rstd1), _p(g1), _p(be1), act, slope,
+                   s12.data_ptr(), s12.data_ptr() + 4 * C1, _p(x), ldx, _p(dw1), _p(db1), N, D1, H1, W1, Cin1, C1, k1, st1, pd1,
+                   _p(ws), ws.numel(), _stream())
+            return (None, dw1, db1, dg1, dbe1, None, None, dw2, db2, dg2, dbe2, None, None) + (None,) * 9 + (dwh, dbh, None)
         # layer 1: the apply half of the norm backward (+ conv1's bias gradient), then conv1's gradients
         dy1 = torch.empty_like(y1)
         db1 = torch.empty(C1, **f32) if has_b1 else None

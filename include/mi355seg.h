@@ -178,6 +178,15 @@ int mi355seg_conv3d_wgrad_pro_ax_f32(const float* dy, int lddy, const float* x, 
                                      int k, int stride, int pad, int accumulate, const float* dy_amax, const float* x_amax,
                                      void* ws, size_t ws_bytes, void* stream);
 
+/* The 1-channel stem of a double-conv block (/root/reference/models/three_d/unet3d.py:80-89: enc1conv1 -> enc1norm1 -> enc1relu1) when the block's
+ * input needs no gradient: dw (+ db) of the stem straight from da = d(activation) and the pre-norm tensor y.  The norm backward's apply half
+ * (dy = rstd gamma (dz - s1 / rows - xhat s2 / rows), dz = da act'(z); s1 / s2 = its column sums, e.g. from mi355seg_conv3d_dgrad_bnsums_f32) is
+ * formed inside the weight-gradient kernel: the same values as mi355seg_norm_act_bwd_apply_f32 + mi355seg_conv3d_wgrad_f32 without writing dy. */
+int mi355seg_stem_wgrad_bnbwd_supported_f32(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad);
+int mi355seg_stem_wgrad_bnbwd_f32(const float* da, int ldda, const float* y, int ldy, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                  int act, float slope, const float* s1, const float* s2, const float* x, int ldx, float* dw, float* db,
+                                  int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
+
 /* dx = conv_backward_input(dy, w).  D,H,W are the INPUT extents (of x/dx). */
 int mi355seg_conv3d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
                               int N, int D, int H, int W, int Cin, int Cout,

@@ -996,3 +996,44 @@ def test_double_conv_with_norm_prologue_matches_the_unfused_block(seg, shape, ch
             assert (a - b).abs().max() < 1e-4 * sc(b), name
     for a, b in zip(rf, ru):
         assert (a - b).abs().max() < 1e-6 * max(1.0, sc(b))
+
+
+@pytest.mark.parametrize("shape,C,act", [((2, 8, 8, 32), 32, "relu"), ((1, 4, 8, 64), 16, "relu"), ((1, 6, 12, 32), 32, "lrelu"), ((2, 16, 16, 64), 32, "relu")])
+def test_stem_weight_gradient_with_norm_backward_prologue(seg, shape, C, act):
+    """r5, mi355seg_stem_wgrad_bnbwd_f32: the 1-channel stem's weight + bias gradient formed straight from d(activation) and the pre-norm tensor
+    (the norm backward's apply half inside the kernel; /root/reference/models/three_d/unet3d.py:80-89) against the library's own two-step chain
+    norm_act_bwd_apply + conv3d_wgrad (same per-element expression: the weight gradients agree to fp32 summation order) and against fp64."""
+    F = seg.functional
+    L = seg.lib()
+    N, D, H, W = shape
+    rows = N * D * H * W
+    dev = "cuda"
+    x = rnd(rows, 1, seed=1).to(dev)
+    y = (rnd(rows, C, seed=2) * 1.5 + 0.2).to(dev)
+    da = rnd(rows, C, seed=3).to(dev)
+    mean, rstd = y.mean(0), (1.0 / torch.sqrt(y.var(0, unbiased=False) + 1e-5)).contiguous()
+    gamma, beta = (1 + 0.2 * rnd(C, seed=4)).to(dev), (0.3 * rnd(C, seed=5)).to(dev)
+    code, slope = {"relu": (F.ACT_RELU, 0.0), "lrelu": (F.ACT_LRELU, 0.01)}[act]
+    assert L.query("mi355seg_stem_wgrad_bnbwd_supported_f32", N, D, H, W, 1, C, 3, 1, 1) == 1
+    st = torch.cuda.current_stream().cuda_stream
+    ws = F.workspace(max(L.query("mi355seg_conv3d_ws_bytes", N, D, H, W, 1, C, 3, 1, 1), L.query("mi355seg_norm_ws_bytes", rows, 1, C)), torch.device(dev))
+    s12, dgb = torch.empty(2 * C, device=dev), torch.empty(2 * C, device=dev)
+    L.call("mi355seg_norm_act_bwd_sums_f32", da.data_ptr(), C, y.data_ptr(), C, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, 0,
+           s12.data_ptr(), s12.data_ptr() + 4 * C, dgb.data_ptr(), dgb.data_ptr() + 4 * C, rows, 1, C, code, slope, ws.data_ptr(), ws.numel(), st)
+    dw1, db1 = torch.empty(C, 1, 3, 3, 3, device=dev), torch.empty(C, device=dev)
+    L.call("mi355seg_stem_wgrad_bnbwd_f32", da.data_ptr(), C, y.data_ptr(), C, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), code, slope,
+           s12.data_ptr(), s12.data_ptr() + 4 * C, x.data_ptr(), 1, dw1.data_ptr(), db1.data_ptr(), N, D, H, W, 1, C, 3, 1, 1, ws.data_ptr(), ws.numel(), st)
+    dy, db2 = torch.empty(rows, C, device=dev), torch.empty(C, device=dev)
+    L.call("mi355seg_norm_act_bwd_apply_f32", da.data_ptr(), C, y.data_ptr(), C, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, 0,
+           s12.data_ptr(), s12.data_ptr() + 4 * C, dy.data_ptr(), C, None, 0, db2.data_ptr(), rows, 1, C, code, slope, ws.data_ptr(), ws.numel(), st)
+    dw2 = torch.empty(C, 1, 3, 3, 3, device=dev)
+    L.call("mi355seg_conv3d_wgrad_f32", dy.data_ptr(), C, x.data_ptr(), 1, dw2.data_ptr(), None, N, D, H, W, 1, C, 3, 1, 1, 0, ws.data_ptr(), ws.numel(), st)
+    torch.cuda.synchronize()
+    sc = max(1e-6, float(dw2.abs().max()))
+    assert (dw1 - dw2).abs().max() < 2e-5 * sc
+    assert (db1 - db2).abs().max() < 2e-4 * max(1e-6, float(dy.abs().max())) + 1e-5
+    # fp64: dw[co][0][tap] = sum_v x[v + tap] dy[v][co] with dy from the unfused library kernel (itself covered by test_batchnorm_act_train)
+    xv = x.view(N, 1, D, H, W).double().cpu()
+    dyv = dy.view(N, D, H, W, C).permute(0, 4, 1, 2, 3).double().cpu()
+    want = torch.nn.grad.conv3d_weight(xv, (C, 1, 3, 3, 3), dyv, padding=1)
+    assert (dw1.cpu().double() - want).abs().max() < 3e-5 * float(want.abs().max())
