@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""Per-launch timeline of the last of N identical steps from a rocprofv3 kernel trace: step_trace.py kernel_trace.csv N
+"""Per-launch timeline of the last of N identical steps from a rocprofv3 kernel trace: step_trace.py kernel_trace.csv N [marker]
 (launch order, duration, idle gap in front of each launch; the trace is cut into N equal runs of launches from its end)."""
 import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 n = int(sys.argv[2])
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # find the period: the launch count of one step = distance between the last two launches of the (once-per-step) loss kernel
-marks = [i for i, r in enumerate(rows) if "bce_argmax_dice_kernel" in r["Kernel_Name"]]
+marker = sys.argv[3] if len(sys.argv) > 3 else "bce_argmax_dice_kernel"      # a kernel launched once per step
+marks = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
 per = marks[-1] - marks[-2]
 last = rows[marks[-2] + 1: marks[-1] + 1]
 # rotate so that the step starts at its first kernel after the optimizer (the fused Adam launches end a step)
