@@ -17,6 +17,7 @@ struct GemmArgs {
     float alpha; int relu, accumulate;
     int S, kchunk, avec, bvec;      // split-K factor, K range per split, float4 global reads allowed for A / B
     float* slabs;                   // [S][M][N] partial products when S > 1
+    float* arowsum;                 // (direct kernels, one batch) arowsum[m] = sum_k A[m][k]: a Linear layer's bias gradient out of its weight-gradient GEMM
 };
 
 constexpr int GT = 64, GK = 32, LDA_S = GK + 1, LDB_S = GT + 1;
@@ -190,6 +191,8 @@ __global__ __launch_bounds__(GD_WAVES * 64) void gemm_direct_kernel(GemmArgs g) 
             lda(j, xa[u]); ldb(j, xb[u]);
         }
     };
+    const bool rowsum = g.arowsum != nullptr && blockIdx.x == 0;                  // (workgroup-uniform) the first column of tiles also sums A's rows
+    float rs = 0.f;
     auto mm = [&](int jt, const float (&xa)[U][4], const float (&xb)[U][4]) {
         if (jt >= trips) return;
 #pragma unroll
@@ -197,6 +200,7 @@ __global__ __launch_bounds__(GD_WAVES * 64) void gemm_direct_kernel(GemmArgs g) 
             if (jt * U + u < mine) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][e], xb[u][e], acc, 0, 0, 0);
+                if (rowsum) rs += (xa[u][0] + xa[u][1]) + (xa[u][2] + xa[u][3]);
             }
     };
     fetch(0, ra[0], rb[0]);
@@ -225,6 +229,17 @@ __global__ __launch_bounds__(GD_WAVES * 64) void gemm_direct_kernel(GemmArgs g) 
             if (g.accumulate) val += *dst;
             if (g.relu) val = val > 0.f ? val : 0.f;
             *dst = val;
+        }
+    }
+    if (rowsum) {                                   // lane (h, i) of wave w summed row m0 + i over its share of k: fixed order over (w, h)
+        __syncthreads();
+        red[wave * 64 + lane] = rs;
+        __syncthreads();
+        if (tid < 32 && m0 + tid < g.M) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < GD_WAVES; ++w) t += red[w * 64 + tid] + red[w * 64 + 32 + tid];
+            g.arowsum[m0 + tid] = t;
         }
     }
 }
@@ -275,6 +290,8 @@ __global__ __launch_bounds__(GD_WAVES * 64) void gemm_direct_lowp_kernel(GemmArg
             ld8(ap, g.a_cs, AK, j, xa[u]); ld8(bp, g.b_rs, BK, j, xb[u]);
         }
     };
+    const bool rowsum = g.arowsum != nullptr && blockIdx.x == 0;                  // (workgroup-uniform) the first column of tiles also sums A's rows
+    float rs = 0.f;                                                                // (of the fp32 values, before the bf16 rounding)
     auto mm = [&](int jt, const float (&xa)[U][8], const float (&xb)[U][8]) {
         if (jt >= trips) return;
 #pragma unroll
@@ -284,6 +301,7 @@ __global__ __launch_bounds__(GD_WAVES * 64) void gemm_direct_lowp_kernel(GemmArg
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { va[e] = (bf16)xa[u][e]; vb[e] = (bf16)xb[u][e]; }
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, vb, acc, 0, 0, 0);
+                if (rowsum) rs += ((xa[u][0] + xa[u][1]) + (xa[u][2] + xa[u][3])) + ((xa[u][4] + xa[u][5]) + (xa[u][6] + xa[u][7]));
             }
     };
     fetch(0, ra[0], rb[0]);
@@ -312,6 +330,17 @@ __global__ __launch_bounds__(GD_WAVES * 64) void gemm_direct_lowp_kernel(GemmArg
             if (g.accumulate) val += *dst;
             if (g.relu) val = val > 0.f ? val : 0.f;
             *dst = val;
+        }
+    }
+    if (rowsum) {                                   // lane (h, i) of wave w summed row m0 + i over its share of k: fixed order over (w, h)
+        __syncthreads();
+        red[wave * 64 + lane] = rs;
+        __syncthreads();
+        if (tid < 32 && m0 + tid < g.M) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < GD_WAVES; ++w) t += red[w * 64 + tid] + red[w * 64 + 32 + tid];
+            g.arowsum[m0 + tid] = t;
         }
     }
 }
@@ -474,8 +503,9 @@ static int gemm_impl(int lowp, const float* A, long long a_rs, long long a_cs, l
                      const float* B, long long b_rs, long long b_cs, long long b_b0, long long b_b1,
                      float* C, long long c_rs, long long c_b0, long long c_b1, const float* bias,
                      int M, int N, int K, int nb0, int nb1, float alpha, int relu, int accumulate,
-                     void* ws, size_t ws_bytes, void* stream) {
+                     void* ws, size_t ws_bytes, void* stream, float* arowsum = nullptr, int* arowsum_done = nullptr) {
     SEG_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && nb0 > 0 && nb1 > 0 && (long long)nb0 * nb1 < 4096, "gemm: bad arguments");
+    if (arowsum_done) *arowsum_done = 0;
     int S, kchunk;
     gemm_plan(M, N, K, nb0 * nb1, S, kchunk);
     if (S > 1 && (!ws || ws_bytes < (size_t)S * M * N * sizeof(float))) { S = 1; kchunk = (int)cdiv(K, GK) * GK; }   // no room: unsplit
@@ -486,7 +516,8 @@ static int gemm_impl(int lowp, const float* A, long long a_rs, long long a_cs, l
         const long long tiles32 = (long long)cdiv(M, 32) * cdiv(N, 32) * nb0 * nb1;
         if (K % 8 == 0 && a_ok && b_ok && tiles32 <= 4096 && (long long)nb0 * nb1 < 65536) {
             GemmArgs g{A, B, C, bias, a_rs, a_cs, a_b0, a_b1, b_rs, b_cs, b_b0, b_b1, c_rs, c_b0, c_b1, M, N, K, nb1, alpha, relu, accumulate,
-                       1, K, 0, 0, nullptr};
+                       1, K, 0, 0, nullptr, nullptr};
+            if (arowsum && nb0 * nb1 == 1) { g.arowsum = arowsum; if (arowsum_done) *arowsum_done = 1; }
             dim3 grid(cdiv(N, 32), cdiv(M, 32), nb0 * nb1);
             if (lowp) {
                 if (ak && bk) hipLaunchKernelGGL((gemm_direct_lowp_kernel<true, true>), grid, dim3(GD_WAVES * 64), 0, (hipStream_t)stream, g);
@@ -509,7 +540,7 @@ static int gemm_impl(int lowp, const float* A, long long a_rs, long long a_cs, l
     const int avec = vec_ok(A, a_ofast ? a_rs : a_cs, a_ofast ? a_cs : a_rs, a_b0, a_b1);
     const int bvec = vec_ok(B, b_ofast ? b_cs : b_rs, b_ofast ? b_rs : b_cs, b_b0, b_b1);
     GemmArgs g{A, B, C, bias, a_rs, a_cs, a_b0, a_b1, b_rs, b_cs, b_b0, b_b1, c_rs, c_b0, c_b1, M, N, K, nb1, alpha, relu, accumulate,
-               S, kchunk, avec, bvec, (float*)ws};
+               S, kchunk, avec, bvec, (float*)ws, nullptr};
     dim3 grid(cdiv(N, GT), cdiv(M, GT), nb0 * nb1 * S);
     hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
     SEG_CHECK_LAUNCH();
@@ -536,6 +567,19 @@ int mi355seg_gemm_lowp_f32(const float* A, long long a_rs, long long a_cs, long 
                            int M, int N, int K, int nb0, int nb1, float alpha, int relu, int accumulate,
                            void* ws, size_t ws_bytes, void* stream) {
     return gemm_impl(1, A, a_rs, a_cs, a_b0, a_b1, B, b_rs, b_cs, b_b0, b_b1, C, c_rs, c_b0, c_b1, bias, M, N, K, nb0, nb1, alpha, relu, accumulate, ws, ws_bytes, stream);
+}
+
+// dW[N][K] = dY^T X of a Linear layer together with its bias gradient db[n] = sum_m dY[m][n] -- the row sums of the GEMM's A operand
+// (A(n, m) = dY[m][n]: a_rs = 1, a_cs = ldy), taken by the first column of tiles of the small-GEMM kernels from the values they load
+// anyway (fixed summation order); other shapes: the GEMM, then mi355seg_colsum_f32 on dY.  lowp: products on the bf16 matrix cores.
+int mi355seg_colsum_f32(const float* x, int ldx, long long rows, int C, float* out, void* ws, size_t ws_bytes, void* stream);
+int mi355seg_linear_wgrad_f32(int lowp, const float* dy, int lddy, const float* x, int ldx, float* dw, float* db, int M, int N, int K,
+                              void* ws, size_t ws_bytes, void* stream) {
+    SEG_CHECK_ARG(dy && x && dw && M > 0 && N > 0 && K > 0 && lddy >= N && ldx >= K, "linear_wgrad: bad arguments");
+    int done = 0;
+    int rc = gemm_impl(lowp ? 1 : 0, dy, 1, lddy, 0, 0, x, ldx, 1, 0, 0, dw, K, 0, 0, nullptr, N, K, M, 1, 1, 1.f, 0, 0, ws, ws_bytes, stream, db, &done);
+    if (rc || !db || done) return rc;
+    return mi355seg_colsum_f32(dy, lddy, M, N, db, ws, ws_bytes, stream);
 }
 
 int mi355seg_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,

@@ -1871,14 +1871,12 @@ class _Linear(Function):
             dy2 = g
         dx = torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
         _gemm(_p(dy2), N, 1, 0, 0, _p(w), K, 1, 0, 0, _p(dx), K, 0, 0, None, M, K, N, lowp=lowp)
+        # weight gradient; the bias gradient (column sums of dy) rides in the same launch on the token encoder's shapes
         dw = torch.empty_like(w)
-        _gemm(_p(dy2), 1, N, 0, 0, _p(x2), K, 1, 0, 0, _p(dw), K, 0, 0, None, N, K, M, lowp=lowp)
-        db = None
-        if has_b:
-            L = lib()
-            ws = workspace(L.query("mi355seg_norm_ws_bytes", M, 1, N), dy2.device)
-            db = torch.empty(N, dtype=dy2.dtype, device=dy2.device)
-            L.call("mi355seg_colsum_f32", _p(dy2), N, M, N, _p(db), _p(ws), ws.numel(), _stream())
+        db = torch.empty(N, dtype=dy2.dtype, device=dy2.device) if has_b else None
+        L = lib()
+        ws = workspace(max(L.query("mi355seg_gemm_ws_bytes", N, K, M, 1, 1), L.query("mi355seg_norm_ws_bytes", M, 1, N)), dy2.device)
+        L.call("mi355seg_linear_wgrad_f32", int(lowp), _p(dy2), N, _p(x2), K, _p(dw), _p(db), M, N, K, _p(ws), ws.numel(), _stream())
         return dx.view(*shp), dw, db, None
 
 

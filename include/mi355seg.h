@@ -482,6 +482,13 @@ int mi355seg_gemm_lowp_f32(const float* A, long long a_rs, long long a_cs, long 
                       float* C, long long c_rs, long long c_b0, long long c_b1, const float* bias,
                       int M, int N, int K, int nb0, int nb1, float alpha, int relu, int accumulate,
                       void* ws, size_t ws_bytes, void* stream);
+/* Weight and bias gradient of nn.Linear in one call (r5; /root/reference/models/three_d/unetr.py:61-66,120-121 backward):
+ * dw[N][K] = dy^T x and db[n] = sum_m dy[m][n] -- on the few-hundred-row shapes of the token encoder the bias gradient is summed by the
+ * weight-gradient GEMM's first column of tiles from the dy values it loads anyway (one launch instead of two per layer; fixed
+ * summation order); other shapes run the GEMM and mi355seg_colsum_f32.  lowp != 0: products on the bf16 matrix cores
+ * (mi355seg_gemm_lowp_f32).  db may be NULL.  ws: max(mi355seg_gemm_ws_bytes(N, K, M, 1, 1), mi355seg_norm_ws_bytes(M, 1, N)). */
+int mi355seg_linear_wgrad_f32(int lowp, const float* dy, int lddy, const float* x, int ldx, float* dw, float* db, int M, int N, int K,
+                              void* ws, size_t ws_bytes, void* stream);
 /* Scratch for the deterministic split-K path (single-batch GEMMs with too few 64x64 tiles to fill 256 CUs); 0 when
  * the shape is not split.  With a smaller / NULL workspace the GEMM runs unsplit. */
 size_t mi355seg_gemm_ws_bytes(int M, int N, int K, int nb0, int nb1);

@@ -1037,3 +1037,35 @@ def test_stem_weight_gradient_with_norm_backward_prologue(seg, shape, C, act):
     dyv = dy.view(N, D, H, W, C).permute(0, 4, 1, 2, 3).double().cpu()
     want = torch.nn.grad.conv3d_weight(xv, (C, 1, 3, 3, 3), dyv, padding=1)
     assert (dw1.cpu().double() - want).abs().max() < 3e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("lowp", [0, 1])
+@pytest.mark.parametrize("shape", [(216, 768, 768), (216, 3072, 768), (216, 768, 3072), (150, 200, 96), (64, 4096, 4096), (1100, 40, 64)])
+def test_linear_weight_and_bias_gradient_in_one_call(seg, shape, lowp):
+    """r5, mi355seg_linear_wgrad_f32: dw = dy^T x and db = column sums of dy (the backward of nn.Linear, unetr.py:61-66,120-121) -- on the
+    token encoder's shapes db is summed inside the weight-gradient GEMM from the dy values it loads anyway.  dw must be BIT-identical to
+    the plain GEMM entry point's (same kernel, same order), db equal to the separate column-sum kernel's to fp32 summation order and to
+    fp64.  The last two shapes take the fallback inside the entry point (too many 32 x 32 tiles; rows beyond the small-GEMM kernel's)."""
+    F, L = seg.functional, seg.lib()
+    M, N, K = shape
+    dev = "cuda"
+    dy = rnd(M, N, seed=41).to(dev)
+    x = rnd(M, K, seed=42).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    ws = F.workspace(max(L.query("mi355seg_gemm_ws_bytes", N, K, M, 1, 1), L.query("mi355seg_norm_ws_bytes", M, 1, N)), torch.device(dev))
+    dw1, db1 = torch.empty(N, K, device=dev), torch.full((N,), float("nan"), device=dev)
+    L.call("mi355seg_linear_wgrad_f32", lowp, dy.data_ptr(), N, x.data_ptr(), K, dw1.data_ptr(), db1.data_ptr(), M, N, K, ws.data_ptr(), ws.numel(), st)
+    dw2, db2 = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+    L.call("mi355seg_gemm_lowp_f32" if lowp else "mi355seg_gemm_f32", dy.data_ptr(), 1, N, 0, 0, x.data_ptr(), K, 1, 0, 0, dw2.data_ptr(), K, 0, 0, None,
+           N, K, M, 1, 1, 1.0, 0, 0, ws.data_ptr(), ws.numel(), st)
+    L.call("mi355seg_colsum_f32", dy.data_ptr(), N, M, N, db2.data_ptr(), ws.data_ptr(), ws.numel(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(dw1, dw2)
+    want = dy.double().sum(0)
+    bound = 4e-6 * dy.double().abs().sum(0) + 1e-30
+    assert ((db1.double() - want).abs() <= bound).all() and ((db2.double() - want).abs() <= bound).all()
+    # without a bias: db = NULL is allowed
+    dw3 = torch.empty(N, K, device=dev)
+    L.call("mi355seg_linear_wgrad_f32", lowp, dy.data_ptr(), N, x.data_ptr(), K, dw3.data_ptr(), None, M, N, K, ws.data_ptr(), ws.numel(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(dw3, dw2)
