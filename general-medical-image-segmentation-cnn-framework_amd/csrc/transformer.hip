@@ -18,6 +18,7 @@ struct GemmArgs {
     int S, kchunk, avec, bvec;      // split-K factor, K range per split, float4 global reads allowed for A / B
     float* slabs;                   // [S][M][N] partial products when S > 1
     float* arowsum;                 // (direct kernels, one batch) arowsum[m] = sum_k A[m][k]: a Linear layer's bias gradient out of its weight-gradient GEMM
+    const float* emul; const float* eadd; long long e_rs;      // (direct kernels, one batch) after bias / ReLU: C = C * emul[m][n] + eadd[m][n] (dropout mask, residual)
 };
 
 constexpr int GT = 64, GK = 32, LDA_S = GK + 1, LDB_S = GT + 1;
@@ -228,6 +229,8 @@ __global__ __launch_bounds__(GD_WAVES * 64) void gemm_direct_kernel(GemmArgs g) 
             float val = g.alpha * sum + (g.bias ? g.bias[n0 + c] : 0.f);
             if (g.accumulate) val += *dst;
             if (g.relu) val = val > 0.f ? val : 0.f;
+            if (g.emul) val *= g.emul[(long long)(m0 + r) * g.e_rs + n0 + c];
+            if (g.eadd) val += g.eadd[(long long)(m0 + r) * g.e_rs + n0 + c];
             *dst = val;
         }
     }
@@ -329,6 +332,8 @@ __global__ __launch_bounds__(GD_WAVES * 64) void gemm_direct_lowp_kernel(GemmArg
             float val = g.alpha * sum + (g.bias ? g.bias[n0 + c] : 0.f);
             if (g.accumulate) val += *dst;
             if (g.relu) val = val > 0.f ? val : 0.f;
+            if (g.emul) val *= g.emul[(long long)(m0 + r) * g.e_rs + n0 + c];
+            if (g.eadd) val += g.eadd[(long long)(m0 + r) * g.e_rs + n0 + c];
             *dst = val;
         }
     }
@@ -472,6 +477,39 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __re
     dot = wave_sum(dot);
     for (int c = lane; c < L; c += 64) dx[row * L + c] = y[row * L + c] * (dy[row * L + c] - dot);
 }
+// softmax followed by an elementwise factor (attention dropout: keep / (1 - p)): y = softmax(x) and yk = y * keep from one pass, and the
+// backward of the pair: dy = dyk * keep, dx = y (dy - sum y dy) -- the same products, in the same order, as the two-kernel chains
+__global__ __launch_bounds__(256) void softmax_rows_keep_kernel(const float* __restrict__ x, const float* __restrict__ keep, float* __restrict__ y,
+        float* __restrict__ yk, long long rows, int L) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[LN_MAXJ];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) { const int c = lane + 64 * j; v[j] = c < L ? x[row * L + c] : -INFINITY; mx = fmaxf(mx, v[j]); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) { const int c = lane + 64 * j; v[j] = c < L ? expf(v[j] - mx) : 0.f; s += v[j]; }
+    const float inv = 1.f / wave_sum(s);
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+        const int c = lane + 64 * j;
+        if (c < L) { const float pv = v[j] * inv; y[row * L + c] = pv; yk[row * L + c] = pv * keep[row * L + c]; }
+    }
+}
+__global__ __launch_bounds__(256) void softmax_rows_keep_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dyk, const float* __restrict__ keep,
+        float* __restrict__ dx, long long rows, int L) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float dot = 0.f;
+    for (int c = lane; c < L; c += 64) dot += y[row * L + c] * (dyk[row * L + c] * keep[row * L + c]);
+    dot = wave_sum(dot);
+    for (int c = lane; c < L; c += 64) dx[row * L + c] = y[row * L + c] * (dyk[row * L + c] * keep[row * L + c] - dot);
+}
 
 }  // namespace seg
 
@@ -503,9 +541,11 @@ static int gemm_impl(int lowp, const float* A, long long a_rs, long long a_cs, l
                      const float* B, long long b_rs, long long b_cs, long long b_b0, long long b_b1,
                      float* C, long long c_rs, long long c_b0, long long c_b1, const float* bias,
                      int M, int N, int K, int nb0, int nb1, float alpha, int relu, int accumulate,
-                     void* ws, size_t ws_bytes, void* stream, float* arowsum = nullptr, int* arowsum_done = nullptr) {
+                     void* ws, size_t ws_bytes, void* stream, float* arowsum = nullptr, int* arowsum_done = nullptr,
+                     const float* emul = nullptr, const float* eadd = nullptr, long long e_rs = 0, int* epi_done = nullptr) {
     SEG_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && nb0 > 0 && nb1 > 0 && (long long)nb0 * nb1 < 4096, "gemm: bad arguments");
     if (arowsum_done) *arowsum_done = 0;
+    if (epi_done) *epi_done = 0;
     int S, kchunk;
     gemm_plan(M, N, K, nb0 * nb1, S, kchunk);
     if (S > 1 && (!ws || ws_bytes < (size_t)S * M * N * sizeof(float))) { S = 1; kchunk = (int)cdiv(K, GK) * GK; }   // no room: unsplit
@@ -516,8 +556,9 @@ static int gemm_impl(int lowp, const float* A, long long a_rs, long long a_cs, l
         const long long tiles32 = (long long)cdiv(M, 32) * cdiv(N, 32) * nb0 * nb1;
         if (K % 8 == 0 && a_ok && b_ok && tiles32 <= 4096 && (long long)nb0 * nb1 < 65536) {
             GemmArgs g{A, B, C, bias, a_rs, a_cs, a_b0, a_b1, b_rs, b_cs, b_b0, b_b1, c_rs, c_b0, c_b1, M, N, K, nb1, alpha, relu, accumulate,
-                       1, K, 0, 0, nullptr, nullptr};
+                       1, K, 0, 0, nullptr, nullptr, nullptr, nullptr, 0};
             if (arowsum && nb0 * nb1 == 1) { g.arowsum = arowsum; if (arowsum_done) *arowsum_done = 1; }
+            if ((emul || eadd) && nb0 * nb1 == 1) { g.emul = emul; g.eadd = eadd; g.e_rs = e_rs; if (epi_done) *epi_done = 1; }
             dim3 grid(cdiv(N, 32), cdiv(M, 32), nb0 * nb1);
             if (lowp) {
                 if (ak && bk) hipLaunchKernelGGL((gemm_direct_lowp_kernel<true, true>), grid, dim3(GD_WAVES * 64), 0, (hipStream_t)stream, g);
@@ -540,7 +581,7 @@ static int gemm_impl(int lowp, const float* A, long long a_rs, long long a_cs, l
     const int avec = vec_ok(A, a_ofast ? a_rs : a_cs, a_ofast ? a_cs : a_rs, a_b0, a_b1);
     const int bvec = vec_ok(B, b_ofast ? b_cs : b_rs, b_ofast ? b_rs : b_cs, b_b0, b_b1);
     GemmArgs g{A, B, C, bias, a_rs, a_cs, a_b0, a_b1, b_rs, b_cs, b_b0, b_b1, c_rs, c_b0, c_b1, M, N, K, nb1, alpha, relu, accumulate,
-               S, kchunk, avec, bvec, (float*)ws, nullptr};
+               S, kchunk, avec, bvec, (float*)ws, nullptr, nullptr, nullptr, 0};
     dim3 grid(cdiv(N, GT), cdiv(M, GT), nb0 * nb1 * S);
     hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
     SEG_CHECK_LAUNCH();
@@ -582,6 +623,22 @@ int mi355seg_linear_wgrad_f32(int lowp, const float* dy, int lddy, const float* 
     return mi355seg_colsum_f32(dy, lddy, M, N, db, ws, ws_bytes, stream);
 }
 
+// nn.Linear forward with what follows it in the token encoder folded into the GEMM's epilogue (unetr.py:98-100,120-138,159-166):
+// y = (relu?)(x W^T + b) * emul + eadd -- emul: an element-wise dropout factor keep / (1 - p), eadd: the residual stream; both [M][N] at
+// pitch N, either may be NULL.  Small-GEMM shapes: one launch; other shapes: the GEMM, then the two element-wise kernels in place.
+int mi355seg_mul_f32(const float* a, const float* b, float* out, long long n, void* stream);
+int mi355seg_act_fwd_f32(const float* x, int ldx, const float* res, int ldres, float* y, int ldy, long long rows, int C, int act, float slope, void* stream);
+int mi355seg_linear_fwd_f32(int lowp, const float* x, int ldx, const float* w, const float* b, int relu, const float* emul, const float* eadd,
+                            float* y, int M, int N, int K, void* ws, size_t ws_bytes, void* stream) {
+    SEG_CHECK_ARG(x && w && y && M > 0 && N > 0 && K > 0 && ldx >= K, "linear_fwd: bad arguments");
+    int done = 0;
+    int rc = gemm_impl(lowp ? 1 : 0, x, ldx, 1, 0, 0, w, 1, K, 0, 0, y, N, 0, 0, b, M, N, K, 1, 1, 1.f, relu, 0, ws, ws_bytes, stream, nullptr, nullptr, emul, eadd, N, &done);
+    if (rc || done) return rc;
+    if (emul) { rc = mi355seg_mul_f32(y, emul, y, (long long)M * N, stream); if (rc) return rc; }
+    if (eadd) rc = mi355seg_act_fwd_f32(y, N, eadd, N, y, N, M, N, MI355SEG_ACT_NONE, 0.f, stream);
+    return rc;
+}
+
 int mi355seg_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                                long long rows, int E, float eps, void* stream) {
     SEG_CHECK_ARG(x && gamma && beta && y && mean && rstd && rows > 0 && E > 0 && E <= 64 * LN_MAXJ, "layernorm_fwd: bad arguments (E <= %d)", 64 * LN_MAXJ);
@@ -607,6 +664,18 @@ int mi355seg_softmax_rows_f32(const float* x, float* y, long long rows, int L, v
 int mi355seg_softmax_rows_bwd_f32(const float* y, const float* dy, float* dx, long long rows, int L, void* stream) {
     SEG_CHECK_ARG(y && dy && dx && rows > 0 && L > 0, "softmax_rows_bwd: bad arguments");
     hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, rows, L);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_softmax_rows_keep_f32(const float* x, const float* keep, float* y, float* yk, long long rows, int L, void* stream) {
+    SEG_CHECK_ARG(x && keep && y && yk && rows > 0 && L > 0 && L <= 64 * LN_MAXJ, "softmax_rows_keep: bad arguments (L <= %d)", 64 * LN_MAXJ);
+    hipLaunchKernelGGL(softmax_rows_keep_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, keep, y, yk, rows, L);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_softmax_rows_keep_bwd_f32(const float* y, const float* dyk, const float* keep, float* dx, long long rows, int L, void* stream) {
+    SEG_CHECK_ARG(y && dyk && keep && dx && rows > 0 && L > 0, "softmax_rows_keep_bwd: bad arguments");
+    hipLaunchKernelGGL(softmax_rows_keep_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, y, dyk, keep, dx, rows, L);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }

@@ -69,6 +69,7 @@ def train_step(model, optimizer, x, gt, criterion=None, sync_metric=True, grad_h
     # launched ahead of the step (distributed.broadcast_buffers(async_op=True)) is waited for
     bns = [m for m in model.modules()
            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training and m.num_batches_tracked is not None]
+    F.dropout_pool_begin_step()              # the element-wise dropout masks of the step from one draw (once their total is known)
     if (dtype or F.compute_dtype()) == torch.float32:
         F.prefetch_weight_amax(model)        # f16x3: the k3 weights' maxima by one multi-tensor launch (valid for this step only)
     try:

@@ -1826,6 +1826,68 @@ def _mul(a, b, out=None):
     return out
 
 
+def _softmax_keep(scores, keep, rows, Lr):
+    """(softmax(scores), softmax(scores) * keep) over the last dim -- one launch; keep None: the second is the first."""
+    probs = torch.empty_like(scores)
+    if keep is None:
+        lib().call("mi355seg_softmax_rows_f32", _p(scores), _p(probs), rows, Lr, _stream())
+        return probs, probs
+    keep = keep.contiguous()
+    if keep.shape != scores.shape:
+        raise Mi355SegError(f"attention: dropout mask {tuple(keep.shape)} does not match the scores {tuple(scores.shape)}")
+    pd = torch.empty_like(scores)
+    lib().call("mi355seg_softmax_rows_keep_f32", _p(scores), _p(keep), _p(probs), _p(pd), rows, Lr, _stream())
+    return probs, pd
+
+
+def _softmax_keep_bwd(probs, dpd, keep, rows, Lr):
+    ds = torch.empty_like(probs)
+    if keep is None:
+        lib().call("mi355seg_softmax_rows_bwd_f32", _p(probs), _p(dpd), _p(ds), rows, Lr, _stream())
+    else:
+        lib().call("mi355seg_softmax_rows_keep_bwd_f32", _p(probs), _p(dpd), _p(keep.contiguous()), _p(ds), rows, Lr, _stream())
+    return ds
+
+
+# ---- element-wise dropout masks of one training step from ONE draw (r5).  nn.Dropout layers on token tensors (unetr.py:70-71,93,100,
+# 124,133,149) each drew their keep / (1 - p) mask with a launch of their own: 37 per UNETR step.  Between two `dropout_pool_begin_step()`
+# calls (engine.train_step makes them) the layers' requests are tallied; from the next step on one launch draws that many values and the
+# layers take consecutive slices.  A request the pool cannot serve (no begin_step caller, a first step, a changed shape) draws by itself.
+class _MaskPool(threading.local):
+    def __init__(self):
+        self.pools = {}                      # (p, device) -> [buffer or None, offset, values taken since the last begin_step]
+
+
+_MASKS = _MaskPool()
+_POOL_ONES = {}
+
+
+def dropout_pool_begin_step():
+    for (p, dev), st in _MASKS.pools.items():
+        need = st[2]
+        st[0], st[1], st[2] = None, 0, 0
+        if need > 0 and not os.environ.get("MI355SEG_NO_MASK_POOL"):
+            ones = _POOL_ONES.get((need, dev))
+            if ones is None:
+                _POOL_ONES.clear()
+                ones = _POOL_ONES[(need, dev)] = torch.ones(need, device=dev)
+            st[0] = torch.nn.functional.dropout(ones, p, True)       # keep / (1 - p), one launch for the whole step
+
+
+def dropout_pool_take(shape, p, device, fallback):
+    """A keep / (1 - p) mask of ``shape``: a slice of the step's pooled draw, else ``fallback()`` (an individual draw)."""
+    n = 1
+    for e in shape:
+        n *= int(e)
+    st = _MASKS.pools.setdefault((float(p), str(device)), [None, 0, 0])
+    st[2] += n
+    if st[0] is not None and st[1] + n <= st[0].numel() and n % 4 == 0:
+        m = st[0][st[1]:st[1] + n].view(*shape)
+        st[1] += n
+        return m
+    return fallback()
+
+
 # ----------------------------------------------------------------------------- UNETR encoder ops
 def _lowp_now():
     """Inside autocast(torch.bfloat16) the token path's GEMMs take bf16 products (fp32 accumulate), as the reference's nn.Linear / matmul do
@@ -1843,10 +1905,13 @@ def _gemm(A, a_rs, a_cs, a_b0, a_b1, B, b_rs, b_cs, b_b0, b_b1, C, c_rs, c_b0, c
 
 
 class _Linear(Function):
-    """y[M,N] = x[M,K] @ W[N,K]^T + b, optionally followed by ReLU (fused into the GEMM epilogue)."""
+    """y[M,N] = x[M,K] @ W[N,K]^T + b, optionally followed -- inside the GEMM's epilogue -- by ReLU, an element-wise factor ``mask``
+    (a dropout layer's keep / (1 - p)) and the sum with ``residual``: y = relu?(x W^T + b) * mask + residual (r5,
+    mi355seg_linear_fwd_f32: the token encoder's out-projection + dropout + residual and its two feed-forward layers, unetr.py:98-100,
+    120-138,159-166, as one launch each)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu):
+    def forward(ctx, x, w, b, relu, mask=None, residual=None):
         lowp = ctx.lowp = _lowp_now()
         _require_cuda(x, "linear input")
         shp = x.shape
@@ -1854,18 +1919,38 @@ class _Linear(Function):
         w = w.contiguous()
         M, K, N = x2.shape[0], x2.shape[1], w.shape[0]
         y = torch.empty((M, N), dtype=x.dtype, device=x.device)
-        _gemm(_p(x2), K, 1, 0, 0, _p(w), 1, K, 0, 0, _p(y), N, 0, 0, _p(b), M, N, K, relu=int(relu), lowp=lowp)
-        ctx.save_for_backward(x2, w, y if relu else None)
-        ctx.cfg = (shp, M, N, K, bool(relu), b is not None)
+        if relu and residual is not None:
+            raise Mi355SegError("linear: ReLU and a residual sum in one call are not supported (the backward keys the ReLU on the output)")
+        if mask is None and residual is None:
+            _gemm(_p(x2), K, 1, 0, 0, _p(w), 1, K, 0, 0, _p(y), N, 0, 0, _p(b), M, N, K, relu=int(relu), lowp=lowp)
+        else:
+            if mask is not None:
+                mask = mask.contiguous()
+                if mask.numel() != M * N or mask.dtype != x.dtype:
+                    raise Mi355SegError(f"linear: mask of {mask.numel()} {mask.dtype} values for an output of {M} x {N} {x.dtype}")
+            if residual is not None:
+                residual = residual.contiguous()
+                if residual.numel() != M * N or residual.dtype != x.dtype:
+                    raise Mi355SegError(f"linear: residual of {residual.numel()} {residual.dtype} values for an output of {M} x {N} {x.dtype}")
+            L = lib()
+            need = L.query("mi355seg_gemm_ws_bytes", M, N, K, 1, 1)
+            ws = workspace(need, x.device) if need else None
+            L.call("mi355seg_linear_fwd_f32", int(lowp), _p(x2), K, _p(w), _p(b), int(relu), _p(mask), _p(residual), _p(y), M, N, K,
+                   _p(ws), ws.numel() if ws is not None else 0, _stream())
+        ctx.save_for_backward(x2, w, y if relu else None, mask)
+        ctx.cfg = (shp, M, N, K, bool(relu), b is not None, residual is not None)
         return y.view(*shp[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
         lowp = ctx.lowp
-        x2, w, yrelu = ctx.saved_tensors
-        shp, M, N, K, relu, has_b = ctx.cfg
+        x2, w, yrelu, mask = ctx.saved_tensors
+        shp, M, N, K, relu, has_b, has_res = ctx.cfg
         dy2 = dy.contiguous().view(M, N)
-        if relu:                                            # dy * 1[y > 0]: the ReLU backward kernel, keyed on the saved output
+        dres = dy if has_res else None                       # d(... + residual) / d residual = dy itself: no kernel
+        if mask is not None:
+            dy2 = _mul(dy2, mask.view(M, N))
+        if relu:                                            # dy * 1[y > 0]: the ReLU backward kernel, keyed on the saved output (mask 0 => y 0 and dy 0)
             g = torch.empty_like(dy2)
             lib().call("mi355seg_act_bwd_f32", _p(dy2), N, _p(yrelu), N, None, 0, _p(g), N, M, N, ACT_RELU, 0.0, _stream())
             dy2 = g
@@ -1877,11 +1962,12 @@ class _Linear(Function):
         L = lib()
         ws = workspace(max(L.query("mi355seg_gemm_ws_bytes", N, K, M, 1, 1), L.query("mi355seg_norm_ws_bytes", M, 1, N)), dy2.device)
         L.call("mi355seg_linear_wgrad_f32", int(lowp), _p(dy2), N, _p(x2), K, _p(dw), _p(db), M, N, K, _p(ws), ws.numel(), _stream())
-        return dx.view(*shp), dw, db, None
+        return dx.view(*shp), dw, db, None, None, dres
 
 
-def linear(x, weight, bias=None, relu=False):
-    return _Linear.apply(x, weight, bias, relu)
+def linear(x, weight, bias=None, relu=False, mask=None, residual=None):
+    """nn.Linear; ``mask`` / ``residual``: see _Linear (y = relu?(x W^T + b) * mask + residual in one launch)."""
+    return _Linear.apply(x, weight, bias, relu, mask, residual)
 
 
 class _LayerNorm(Function):
@@ -1930,30 +2016,27 @@ class _Attention(Function):
         alpha = 1.0 / (d ** 0.5)
         scores = torch.empty((B, heads, P, P), dtype=q.dtype, device=q.device)
         _gemm(_p(q), E, 1, P * E, d, _p(k), 1, E, P * E, d, _p(scores), P, heads * P * P, P * P, None, P, P, d, B, heads, alpha, lowp=lowp)
-        probs = torch.empty_like(scores)
-        lib().call("mi355seg_softmax_rows_f32", _p(scores), _p(probs), B * heads * P, P, _stream())
-        pd = probs if keep is None else _mul(probs, keep)
+        probs, pd = _softmax_keep(scores, keep, B * heads * P, P)
         ctxl = torch.empty((B, P, E), dtype=q.dtype, device=q.device)
         _gemm(_p(pd), P, 1, heads * P * P, P * P, _p(v), E, 1, P * E, d, _p(ctxl), E, P * E, d, None, P, d, P, B, heads, lowp=lowp)
-        ctx.save_for_backward(q, k, v, probs, keep)
+        ctx.save_for_backward(q, k, v, probs, keep, pd if keep is not None else None)
         ctx.cfg = (B, P, E, heads, d, alpha)
         return ctxl
 
     @staticmethod
     def backward(ctx, do):
         lowp = ctx.lowp
-        q, k, v, probs, keep = ctx.saved_tensors
+        q, k, v, probs, keep, pd = ctx.saved_tensors
         B, P, E, heads, d, alpha = ctx.cfg
         do = do.contiguous()
-        pd = probs if keep is None else _mul(probs, keep)
+        if pd is None:
+            pd = probs
         HPP, PP = heads * P * P, P * P
         dpd = torch.empty_like(probs)                                   # dP = dO V^T
         _gemm(_p(do), E, 1, P * E, d, _p(v), 1, E, P * E, d, _p(dpd), P, HPP, PP, None, P, P, d, B, heads, lowp=lowp)
         dv = torch.empty_like(v)                                        # dV = Pd^T dO
         _gemm(_p(pd), 1, P, HPP, PP, _p(do), E, 1, P * E, d, _p(dv), E, P * E, d, None, P, d, P, B, heads, lowp=lowp)
-        dp = dpd if keep is None else _mul(dpd, keep, out=dpd)
-        ds = torch.empty_like(probs)
-        lib().call("mi355seg_softmax_rows_bwd_f32", _p(probs), _p(dp), _p(ds), B * heads * P, P, _stream())
+        ds = _softmax_keep_bwd(probs, dpd, keep, B * heads * P, P)
         dq = torch.empty_like(q)                                        # dQ = alpha dS K
         _gemm(_p(ds), P, 1, HPP, PP, _p(k), E, 1, P * E, d, _p(dq), E, P * E, d, None, P, d, P, B, heads, alpha, lowp=lowp)
         dk = torch.empty_like(k)                                        # dK = alpha dS^T Q
@@ -1978,33 +2061,30 @@ class _AttentionQKV(Function):
         q, k, v = _p(qkv), _p(qkv) + 4 * E, _p(qkv) + 8 * E
         scores = torch.empty((B, heads, P, P), dtype=qkv.dtype, device=qkv.device)
         _gemm(q, E3, 1, P * E3, d, k, 1, E3, P * E3, d, _p(scores), P, heads * P * P, P * P, None, P, P, d, B, heads, alpha, lowp=lowp)
-        probs = torch.empty_like(scores)
-        lib().call("mi355seg_softmax_rows_f32", _p(scores), _p(probs), B * heads * P, P, _stream())
-        pd = probs if keep is None else _mul(probs, keep)
+        probs, pd = _softmax_keep(scores, keep, B * heads * P, P)
         ctxl = torch.empty((B, P, E), dtype=qkv.dtype, device=qkv.device)
         _gemm(_p(pd), P, 1, heads * P * P, P * P, v, E3, 1, P * E3, d, _p(ctxl), E, P * E, d, None, P, d, P, B, heads, lowp=lowp)
-        ctx.save_for_backward(qkv, probs, keep)
+        ctx.save_for_backward(qkv, probs, keep, pd if keep is not None else None)
         ctx.cfg = (B, P, E, heads, d, alpha)
         return ctxl
 
     @staticmethod
     def backward(ctx, do):
         lowp = ctx.lowp
-        qkv, probs, keep = ctx.saved_tensors
+        qkv, probs, keep, pd = ctx.saved_tensors
         B, P, E, heads, d, alpha = ctx.cfg
         E3 = 3 * E
         q, k, v = _p(qkv), _p(qkv) + 4 * E, _p(qkv) + 8 * E
         do = do.contiguous()
-        pd = probs if keep is None else _mul(probs, keep)
+        if pd is None:
+            pd = probs
         HPP, PP = heads * P * P, P * P
         dqkv = torch.empty_like(qkv)
         dq, dk, dv = _p(dqkv), _p(dqkv) + 4 * E, _p(dqkv) + 8 * E
         dpd = torch.empty_like(probs)                                   # dP = dO V^T
         _gemm(_p(do), E, 1, P * E, d, v, 1, E3, P * E3, d, _p(dpd), P, HPP, PP, None, P, P, d, B, heads, lowp=lowp)
         _gemm(_p(pd), 1, P, HPP, PP, _p(do), E, 1, P * E, d, dv, E3, P * E3, d, None, P, d, P, B, heads, lowp=lowp)             # dV = Pd^T dO
-        dp = dpd if keep is None else _mul(dpd, keep, out=dpd)
-        ds = torch.empty_like(probs)
-        lib().call("mi355seg_softmax_rows_bwd_f32", _p(probs), _p(dp), _p(ds), B * heads * P, P, _stream())
+        ds = _softmax_keep_bwd(probs, dpd, keep, B * heads * P, P)
         _gemm(_p(ds), P, 1, HPP, PP, k, E3, 1, P * E3, d, dq, E3, P * E3, d, None, P, d, P, B, heads, alpha, lowp=lowp)          # dQ = alpha dS K
         _gemm(_p(ds), 1, P, HPP, PP, q, E3, 1, P * E3, d, dk, E3, P * E3, d, None, P, d, P, B, heads, alpha, lowp=lowp)          # dK = alpha dS^T Q
         return dqkv, None, None

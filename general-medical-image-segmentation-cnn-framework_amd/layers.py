@@ -142,11 +142,12 @@ def act_code(m):
 class Linear(nn.Linear):
     """nn.Linear on the MFMA GEMM; ``forward_relu`` fuses a following ReLU into the epilogue."""
 
-    def forward(self, x):
-        return F.linear(x, self.weight, self.bias)
+    def forward(self, x, mask=None, residual=None):
+        """``mask`` (a dropout layer's keep / (1 - p) factors) and ``residual``: (x W^T + b) * mask + residual in the GEMM's epilogue."""
+        return F.linear(x, self.weight, self.bias, mask=mask, residual=residual)
 
-    def forward_relu(self, x):
-        return F.linear(x, self.weight, self.bias, relu=True)
+    def forward_relu(self, x, mask=None):
+        return F.linear(x, self.weight, self.bias, relu=True, mask=mask)
 
 
 class LayerNorm(nn.LayerNorm):
@@ -178,8 +179,19 @@ class Dropout(nn.Dropout):
     def draw(self, shape, device):
         if self.forced_masks:
             return self.forced_masks.pop(0).to(device=device, dtype=torch.float32).reshape(shape) / (1.0 - self.p)
-        # one launch: torch's fused dropout on a cached tensor of ones draws the keep mask AND scales it (bernoulli_ + div_ were two)
-        return torch.nn.functional.dropout(_ones(tuple(shape), device), self.p, True)
+        # a slice of the step's pooled draw (functional.dropout_pool_*: one launch per training step for all layers), else one launch:
+        # torch's fused dropout on a cached tensor of ones draws the keep mask AND scales it (bernoulli_ + div_ were two)
+        return F.dropout_pool_take(tuple(shape), self.p, device, lambda: torch.nn.functional.dropout(_ones(tuple(shape), device), self.p, True))
+
+    def mask_for(self, shape, device):
+        """The keep / (1 - p) factors this layer would apply to a tensor of ``shape`` ([..., E]), or None when it is the identity
+        (eval, p = 0): for callers that fold the product into the producing GEMM's epilogue (functional.linear(..., mask=))."""
+        if not self.training or self.p == 0.0:
+            return None
+        rows = 1
+        for e in shape[:-1]:
+            rows *= int(e)
+        return self.draw((rows, int(shape[-1])), device)
 
     def forward(self, x):
         if not self.training or self.p == 0.0:

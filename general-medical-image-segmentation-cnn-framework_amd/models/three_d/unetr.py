@@ -120,7 +120,9 @@ class SelfAttention(nn.Module):
         self.softmax = nn.Softmax(dim=-1)            # kept for interface parity; the fused kernel does the work
         self.vis = False
 
-    def forward(self, hidden_states):
+    def forward(self, hidden_states, residual=None):
+        """``residual``: the block's residual stream -- the result is then residual + proj_dropout(out(attention)) (unetr.py:98-100,160),
+        the dropout product and the sum in the out-projection's GEMM epilogue."""
         # the three projections as ONE GEMM on the concatenated weights (the parameters stay separate: state_dict keys query / key /
         # value of unetr.py:66-68; the concat's backward hands each its rows of the fused weight gradient)
         w = torch.cat((self.query.weight, self.key.weight, self.value.weight), dim=0)
@@ -131,7 +133,9 @@ class SelfAttention(nn.Module):
             n, p = qkv.shape[0], qkv.shape[1]
             mask = self.attn_dropout.draw((n, self.num_attention_heads, p, p), qkv.device)
         mixed = F.attention_qkv(qkv, self.num_attention_heads, mask)
-        return self.proj_dropout(self.out(mixed)), None
+        if residual is None:
+            return self.proj_dropout(self.out(mixed)), None
+        return self.out(mixed, mask=self.proj_dropout.mask_for(tuple(mixed.shape[:-1]) + (self.out.out_features,), mixed.device), residual=residual), None
 
 
 class PositionwiseFeedForward(nn.Module):
@@ -142,9 +146,10 @@ class PositionwiseFeedForward(nn.Module):
         self.w_1, self.w_2 = Linear(d_model, d_ff), Linear(d_ff, d_model)
         self.dropout = Dropout(dropout)
 
-    def forward(self, x):
-        hidden = self.w_1.forward_relu(x)            # bias + ReLU in the GEMM epilogue
-        return self.w_2(self.dropout(hidden))
+    def forward(self, x, residual=None):
+        # bias + ReLU + the dropout product in w_1's GEMM epilogue; bias + the block's residual sum (unetr.py:166) in w_2's
+        hidden = self.w_1.forward_relu(x, mask=self.dropout.mask_for(tuple(x.shape[:-1]) + (self.w_1.out_features,), x.device))
+        return self.w_2(hidden, residual=residual)
 
 
 def _patch_count(cube, patch):
@@ -181,9 +186,8 @@ class TransformerBlock(nn.Module):
         self.attn = SelfAttention(num_heads, embed_dim, dropout)
 
     def forward(self, x):
-        attended, weights = self.attn(self.attention_norm(x))
-        x = _token_sum(attended, x)
-        return _token_sum(self.mlp(self.mlp_norm(x)), x), weights
+        x, weights = self.attn(self.attention_norm(x), residual=x)
+        return self.mlp(self.mlp_norm(x), residual=x), weights
 
 
 class Transformer(nn.Module):

@@ -482,6 +482,13 @@ int mi355seg_gemm_lowp_f32(const float* A, long long a_rs, long long a_cs, long 
                       float* C, long long c_rs, long long c_b0, long long c_b1, const float* bias,
                       int M, int N, int K, int nb0, int nb1, float alpha, int relu, int accumulate,
                       void* ws, size_t ws_bytes, void* stream);
+/* nn.Linear forward with the element-wise operations that follow it in the token encoder in the GEMM's epilogue (r5;
+ * /root/reference/models/three_d/unetr.py:98-100,120-138,159-166): y[M][N] = (relu?)(x W^T + b) * emul + eadd, emul = a dropout layer's
+ * keep / (1 - p) factors, eadd = the residual stream the block adds its output to, both [M][N] at pitch N, either may be NULL.  One launch
+ * on the few-hundred-row shapes (each of the two was a launch of its own); other shapes: the GEMM, then the element-wise kernels in place.
+ * lowp != 0: products on the bf16 matrix cores (mi355seg_gemm_lowp_f32).  ws: mi355seg_gemm_ws_bytes(M, N, K, 1, 1). */
+int mi355seg_linear_fwd_f32(int lowp, const float* x, int ldx, const float* w, const float* b, int relu, const float* emul, const float* eadd,
+                            float* y, int M, int N, int K, void* ws, size_t ws_bytes, void* stream);
 /* Weight and bias gradient of nn.Linear in one call (r5; /root/reference/models/three_d/unetr.py:61-66,120-121 backward):
  * dw[N][K] = dy^T x and db[n] = sum_m dy[m][n] -- on the few-hundred-row shapes of the token encoder the bias gradient is summed by the
  * weight-gradient GEMM's first column of tiles from the dy values it loads anyway (one launch instead of two per layer; fixed
@@ -500,6 +507,11 @@ int mi355seg_layernorm_bwd_f32(const float* dy, const float* x, const float* gam
 /* nn.Softmax(dim=-1) on [rows, L] (unetr.py:71,90) and its backward dx = y * (dy - sum(dy*y)) */
 int mi355seg_softmax_rows_f32(const float* x, float* y, long long rows, int L, void* stream);
 int mi355seg_softmax_rows_bwd_f32(const float* y, const float* dy, float* dx, long long rows, int L, void* stream);
+/* softmax over the last dim followed by an elementwise factor (the attention dropout of /root/reference/models/three_d/unetr.py:92-93,
+ * keep = mask / (1 - p)): y = softmax(x) and yk = y * keep from one pass over x; backward of the pair from d(yk): dx = y (dy - sum y dy),
+ * dy = dyk * keep (r5: three launches per attention layer and direction were softmax, mask product, [mask product]). */
+int mi355seg_softmax_rows_keep_f32(const float* x, const float* keep, float* y, float* yk, long long rows, int L, void* stream);
+int mi355seg_softmax_rows_keep_bwd_f32(const float* y, const float* dyk, const float* keep, float* dx, long long rows, int L, void* stream);
 /* out[c] = sum over rows of x[r, c] (bias gradient of nn.Linear); ws >= mi355seg_norm_ws_bytes(rows, 1, C) */
 int mi355seg_colsum_f32(const float* x, int ldx, long long rows, int C, float* out, void* ws, size_t ws_bytes, void* stream);
 

@@ -75,6 +75,7 @@ def main():
 
     def step():
         opt.zero_grad(set_to_none=True)
+        F.dropout_pool_begin_step()                  # (as engine.train_step: the step's element-wise dropout masks from one draw)
         with mi355seg.autocast(dtype):
             pred = m(x)
         loss = F.bce_with_logits(pred, tgt)
