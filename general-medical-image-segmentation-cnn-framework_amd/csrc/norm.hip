@@ -500,6 +500,40 @@ __global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ dy, int 
     }
 }
 
+// eight channels per thread (16-byte accesses on bf16 tensors, 32-byte on fp32), no per-channel slopes; BWD: out = addend + dy * act'(x + res)
+// -- `addend` (optional) is a second gradient of the same tensor: a residual fork's sum d(x) = d_skip + d_act * act'(x) without a separate add
+// pass (residual_unet3d.py:110-121: the level-1 tensor feeds a LeakyReLU and, unchanged, a later block sum)
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void act8_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx,
+        const T* __restrict__ res, int ldres, const T* __restrict__ addend, int ldadd, T* __restrict__ out, int ldo, long long rows, int C,
+        int lanes, int rpi, int act, float slope) {
+    const int cw = C / 8;
+    const int rsub = threadIdx.x / lanes;
+    if (rsub >= rpi) return;
+    for (int cc = threadIdx.x % lanes; cc < cw; cc += lanes) {
+        const int c = cc * 8;
+        for (long long r = (long long)blockIdx.x * rpi + rsub; r < rows; r += (long long)gridDim.x * rpi) {
+            float v[8], q[8], d[8], ad[8], o[8];
+            ld8(x + r * ldx + c, v);
+            if (res) {
+                ld8(res + r * ldres + c, q);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += q[j];
+            }
+            if (BWD) {
+                ld8(dy + r * lddy + c, d);
+                if (addend) ld8(addend + r * ldadd + c, ad);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (addend ? ad[j] : 0.f) + d[j] * act_grad(v[j], act, slope);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = act_apply(v[j], act, slope);
+            }
+            st8(out + r * ldo + c, o);
+        }
+    }
+}
+
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void scale_channels_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ scale,
         T* __restrict__ y, int ldy, long long rows, int C, int lanes, int rpi) {

@@ -1144,6 +1144,43 @@ def activation(x, act, slope=0.01, residual=None):
     return _Act.apply(x, residual, int(act), float(slope))
 
 
+class _ActFork(Function):
+    """(act(x), x): the activation of a tensor that ALSO continues unchanged (a residual fork, residual_unet3d.py:110-121).  The backward forms
+    d(x) = d(pass-through) + d(act) * act'(x) in one pass (mi355seg_act_bwd_add_*) -- autograd would run the activation's backward and then
+    add the two gradients with a kernel of its own."""
+
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        xv, ldx = cl_view(x, "activation input")
+        N, D, H, W, C = xv.shape
+        y = torch.empty((N, D, H, W, C), dtype=xv.dtype, device=xv.device)
+        rows = N * D * H * W
+        lib().call("mi355seg_act_fwd_" + _sfx(xv), _p(xv), ldx, None, 0, _p(y), C, rows, C, act, slope, _stream())
+        ctx.cfg = (ldx, rows, C, act, slope)
+        ctx.save_for_backward(xv)
+        ctx.set_materialize_grads(False)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dpass):
+        ldx, rows, C, act, slope = ctx.cfg
+        (x,) = ctx.saved_tensors
+        if dy is None:
+            return dpass, None, None
+        dy, lddy = cl_view(_like(dy, x), "activation grad")
+        add = ldadd = None
+        if dpass is not None:
+            add, ldadd = cl_view(_like(dpass, x), "pass-through grad")
+        dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        lib().call("mi355seg_act_bwd_add_" + _sfx(x), _p(dy), lddy, _p(x), ldx, None, 0, _p(add), ldadd or 0, _p(dx), C, rows, C, act, slope, _stream())
+        return dx, None, None
+
+
+def activation_fork(x, act, slope=0.01):
+    """(act(x), x) for a tensor that feeds an activation and continues unchanged; see _ActFork."""
+    return _ActFork.apply(x, int(act), float(slope))
+
+
 class _PReLU(Function):
     @staticmethod
     def forward(ctx, x, res, slope):

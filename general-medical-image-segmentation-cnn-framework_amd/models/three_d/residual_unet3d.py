@@ -110,11 +110,13 @@ class UNet(nn.Module):
         h = F.to_channels_last(x)
         # level 1 context (:110-121): the sum feeds LeakyReLU (context_1) and InstanceNorm->LeakyReLU
         h = self.conv3d_c1_1(h)
-        res = h
-        h = self.conv3d_c1_2(self.lrelu(h))
+        # (:110-121) the level-1 tensor feeds a LeakyReLU and, unchanged, the block sum: one backward pass forms both gradients' sum
+        a, res = F.activation_fork(h, F.ACT_LRELU, self.lrelu.negative_slope)
+        h = self.conv3d_c1_2(a)
         act1, conv1 = self.lrelu_conv_c1.children()
         h = conv1(act1(self.dropout3d(h)), residual=res)       # (:121) conv + residual in one launch
-        ctx = [self.lrelu(h)]
+        c1, h = F.activation_fork(h, F.ACT_LRELU, self.lrelu.negative_slope)     # context_1 = lrelu(sum); the sum itself goes on into the norm
+        ctx = [c1]
         h = self.inorm3d_c1.forward_act(h, *_LRELU)
         for lvl in (2, 3, 4, 5):                               # (:123-168)
             h = getattr(self, f"conv3d_c{lvl}")(h)

@@ -358,6 +358,11 @@ int mi355seg_norm_act_bwd_apply_ax_f32(const float* dy, int lddy, const float* x
 int mi355seg_rstd_from_var_f32(const float* var, float eps, float* rstd, int C, void* stream);
 
 /* Stand-alone activation (residual_unet3d.py:112,116 LeakyReLU; vnet ELU): y = act(x [+ res]) */
+/* dx = addend + dy * act'(x + res) (r5): an activation's backward together with the sum of a SECOND gradient of the same tensor -- the
+ * residual forks of /root/reference/models/three_d/residual_unet3d.py:110-121 (the level's tensor feeds a LeakyReLU and, unchanged, the
+ * block sum): one pass instead of the activation backward and autograd's add.  addend NULL: mi355seg_act_bwd. */
+int mi355seg_act_bwd_add_f32(const float* dy, int lddy, const float* x, int ldx, const float* res, int ldres, const float* addend, int ldadd,
+                             float* dx, int lddx, long long rows, int C, int act, float slope, void* stream);
 int mi355seg_act_fwd_f32(const float* x, int ldx, const float* res, int ldres, float* y, int ldy,
                          long long rows, int C, int act, float slope, void* stream);
 /* dx = dy * act'(x [+ res]) */
@@ -596,6 +601,7 @@ int mi355seg_norm_act_bwd_sums_bf16(const mi355seg_bf16* dy, int lddy, const mi3
 int mi355seg_norm_act_bwd_apply_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, const float* mean, const float* rstd, const float* gamma, const float* beta, const mi355seg_bf16* res, int ldres, const float* s1, const float* s2, mi355seg_bf16* dx, int lddx, mi355seg_bf16* dres, int lddres, float* dx_colsum, long long rows, int groups, int C, int act, float slope, void* ws, size_t ws_bytes, void* stream);
 int mi355seg_scale_channels_bf16(const mi355seg_bf16* x, int ldx, const float* scale, mi355seg_bf16* y, int ldy, long long rows, int groups, int C, void* stream);
 int mi355seg_act_fwd_bf16(const mi355seg_bf16* x, int ldx, const mi355seg_bf16* res, int ldres, mi355seg_bf16* y, int ldy, long long rows, int C, int act, float slope, void* stream);
+int mi355seg_act_bwd_add_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, const mi355seg_bf16* res, int ldres, const mi355seg_bf16* addend, int ldadd, mi355seg_bf16* dx, int lddx, long long rows, int C, int act, float slope, void* stream);
 int mi355seg_act_bwd_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, const mi355seg_bf16* res, int ldres, mi355seg_bf16* dx, int lddx, long long rows, int C, int act, float slope, void* stream);
 int mi355seg_prelu_fwd_bf16(const mi355seg_bf16* x, int ldx, const mi355seg_bf16* res, int ldres, const float* slope, mi355seg_bf16* y, int ldy, long long rows, int C, void* stream);
 int mi355seg_prelu_bwd_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, const mi355seg_bf16* res, int ldres, const float* slope, mi355seg_bf16* dx, int lddx, float* dslope, long long rows, int C, void* ws, size_t ws_bytes, void* stream);

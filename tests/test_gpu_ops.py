@@ -1069,3 +1069,31 @@ def test_linear_weight_and_bias_gradient_in_one_call(seg, shape, lowp):
     L.call("mi355seg_linear_wgrad_f32", lowp, dy.data_ptr(), N, x.data_ptr(), K, dw3.data_ptr(), None, M, N, K, ws.data_ptr(), ws.numel(), st)
     torch.cuda.synchronize()
     assert torch.equal(dw3, dw2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(1, 8, 12, 16, 16), (2, 5, 6, 7, 12), (1, 4, 4, 8, 64)])
+def test_activation_fork_sums_both_gradients_in_one_pass(seg, shape, dtype):
+    """r5, functional.activation_fork / mi355seg_act_bwd_add_*: (lrelu(x), x) whose backward is d(pass-through) + d(act) * lrelu'(x)
+    (the residual forks of residual_unet3d.py:110-121) against autograd on the two separate uses; 12 channels: the fallback inside the
+    entry point (activation backward, then the in-place sum)."""
+    F = seg.functional
+    x = rnd(*shape, seed=51).cuda().to(dtype)
+    g1, g2 = rnd(*shape, seed=52).cuda().to(dtype), rnd(*shape, seed=53).cuda().to(dtype)
+    xa = x.clone().requires_grad_(True)
+    a, p = F.activation_fork(xa, F.ACT_LRELU, 0.01)
+    assert torch.equal(p.detach(), x)
+    (a.float() * g1.float()).sum().backward(retain_graph=True)
+    only_act = xa.grad.clone()
+    xa.grad = None
+    ((a.float() * g1.float()).sum() + (p.float() * g2.float()).sum()).backward()
+    xr = x.clone().float().requires_grad_(True)
+    ar = torch.nn.functional.leaky_relu(xr, 0.01)
+    (ar * g1.float()).sum().backward(retain_graph=True)
+    ref_act = xr.grad.clone()
+    xr.grad = None
+    ((ar * g1.float()).sum() + (xr * g2.float()).sum()).backward()
+    tol = 1e-6 if dtype == torch.float32 else 2.0 ** -7
+    assert (a.detach().float() - ar.detach()).abs().max() <= tol * max(1.0, float(ar.abs().max()))
+    assert (only_act.float() - ref_act).abs().max() <= tol * max(1.0, float(ref_act.abs().max()))
+    assert (xa.grad.float() - xr.grad).abs().max() <= tol * max(1.0, float(xr.grad.abs().max()))
