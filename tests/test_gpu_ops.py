@@ -1097,3 +1097,40 @@ def test_activation_fork_sums_both_gradients_in_one_pass(seg, shape, dtype):
     assert (a.detach().float() - ar.detach()).abs().max() <= tol * max(1.0, float(ar.abs().max()))
     assert (only_act.float() - ref_act).abs().max() <= tol * max(1.0, float(ref_act.abs().max()))
     assert (xa.grad.float() - xr.grad).abs().max() <= tol * max(1.0, float(xr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("lowp", [False, True])
+@pytest.mark.parametrize("case", [(216, 768, 768, False), (216, 3072, 768, True), (150, 200, 96, False), (64, 4096, 4096, False)])
+def test_linear_with_mask_and_residual_in_the_gemm_epilogue(seg, case, lowp):
+    """r5, functional.linear(..., mask=, residual=) / mi355seg_linear_fwd_f32: y = relu?(x W^T + b) * mask + residual in the GEMM's epilogue
+    (unetr.py:98-100,120-138,159-166) against the same chain in ATen, forward and all gradients (x, W, b, residual); the last shape takes
+    the fallback inside the entry point (the GEMM, then the element-wise kernels in place).  lowp: bf16 products (compared with ATen on
+    bf16-rounded operands at a correspondingly looser tolerance)."""
+    import torch.nn.functional as TF
+    F = seg.functional
+    M, N, K, relu = case
+    g = torch.Generator().manual_seed(7)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g) * 0.1
+    keep = (torch.rand(M, N, generator=g) > 0.1).float() / 0.9
+    res = None if relu else torch.randn(M, N, generator=g)
+    go = torch.randn(M, N, generator=g)
+    rd = lambda t: t.to(torch.bfloat16).float() if lowp else t
+    xr, wr, br = rd(x).clone().requires_grad_(True), rd(w).clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rr = None if res is None else res.clone().requires_grad_(True)
+    yr = TF.linear(xr, wr, br)
+    yr = (torch.relu(yr) if relu else yr) * keep
+    if rr is not None:
+        yr = yr + rr
+    yr.backward(go)
+    xg, wg, bg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    rg = None if res is None else res.cuda().requires_grad_(True)
+    with F.autocast(torch.bfloat16 if lowp else torch.float32):
+        yg = F.linear(xg, wg, bg, relu=relu, mask=keep.cuda(), residual=rg)
+    yg.backward(go.cuda())
+    tol = 2e-2 if lowp else 2e-5
+    sc = lambda t: max(1.0, float(t.abs().max()))
+    assert (yg.detach().cpu() - yr.detach()).abs().max() < tol * sc(yr)
+    for a, r in ((xg, xr), (wg, wr), (bg, br)) + (((rg, rr),) if rr is not None else ()):
+        assert (a.grad.cpu() - r.grad).abs().max() < tol * sc(r.grad)
+    if rr is not None:
+        assert torch.equal(rg.grad.cpu(), go)          # the residual's gradient is dy itself
