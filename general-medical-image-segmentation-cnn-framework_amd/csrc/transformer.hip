@@ -404,7 +404,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
         const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
-        float* __restrict__ dx, long long rows, int E) {
+        float* __restrict__ dx, long long rows, int E, const float* __restrict__ addend) {
+    // addend (optional): a second gradient of x (the residual stream that bypasses the norm, unetr.py:160,166): dx = addend + LN backward
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -420,7 +421,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __re
     }
     s1 = wave_sum(s1) / (float)E; s2 = wave_sum(s2) / (float)E;
 #pragma unroll
-    for (int j = 0; j < LN_MAXJ; ++j) { const int c = lane + 64 * j; if (c < E) dx[row * E + c] = rs * (g[j] - s1 - xh[j] * s2); }
+    for (int j = 0; j < LN_MAXJ; ++j) {
+        const int c = lane + 64 * j;
+        if (c < E) dx[row * E + c] = rs * (g[j] - s1 - xh[j] * s2) + (addend ? addend[row * E + c] : 0.f);
+    }
 }
 
 // dgamma[c] = sum_rows dy * xhat, dbeta[c] = sum_rows dy.  Block = 32 columns x 8 row groups (rows r = g, g+8, ...);
@@ -649,7 +653,16 @@ int mi355seg_layernorm_fwd_f32(const float* x, const float* gamma, const float* 
 int mi355seg_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                                float* dx, float* dgamma, float* dbeta, long long rows, int E, void* stream) {
     SEG_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0 && E > 0 && E <= 64 * LN_MAXJ, "layernorm_bwd: bad arguments");
-    hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd, dx, rows, E);
+    hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd, dx, rows, E, (const float*)nullptr);
+    SEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(layernorm_bwd_affine_kernel, dim3(cdiv(E, 32)), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, dgamma, dbeta, rows, E);
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
+}
+int mi355seg_layernorm_bwd_add_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, const float* addend,
+                                   float* dx, float* dgamma, float* dbeta, long long rows, int E, void* stream) {
+    SEG_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0 && E > 0 && E <= 64 * LN_MAXJ, "layernorm_bwd_add: bad arguments");
+    hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd, dx, rows, E, addend);
     SEG_CHECK_LAUNCH();
     hipLaunchKernelGGL(layernorm_bwd_affine_kernel, dim3(cdiv(E, 32)), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, dgamma, dbeta, rows, E);
     SEG_CHECK_LAUNCH();

@@ -2035,6 +2035,47 @@ class _LayerNorm(Function):
         return dx.view(*ctx.shp), dg, db, None
 
 
+class _LayerNormFork(Function):
+    """(LayerNorm(x), x): the norm of a tensor that also continues unchanged -- a pre-norm transformer block's x + f(LN(x)) (unetr.py:159-166).
+    The backward writes d(x) = d(pass-through) + LN-backward(d(norm)) from the kernel that forms the LayerNorm gradient
+    (mi355seg_layernorm_bwd_add_f32); autograd would add the two with a launch of its own."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _require_cuda(x, "layer_norm input")
+        shp = x.shape
+        E = shp[-1]
+        x2 = x.contiguous().view(-1, E)
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        lib().call("mi355seg_layernorm_fwd_f32", _p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, E, eps, _stream())
+        ctx.save_for_backward(x2, gamma, mean, rstd)
+        ctx.shp = shp
+        ctx.set_materialize_grads(False)
+        return y.view(*shp), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dpass):
+        x2, gamma, mean, rstd = ctx.saved_tensors
+        rows, E = x2.shape
+        if dy is None:
+            return dpass, None, None, None
+        dy2 = dy.contiguous().view(rows, E)
+        add = dpass.contiguous().view(rows, E) if dpass is not None else None
+        dx = torch.empty_like(x2)
+        dg = torch.empty(E, dtype=torch.float32, device=x2.device)
+        db = torch.empty(E, dtype=torch.float32, device=x2.device)
+        lib().call("mi355seg_layernorm_bwd_add_f32", _p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(add), _p(dx), _p(dg), _p(db), rows, E, _stream())
+        return dx.view(*ctx.shp), dg, db, None
+
+
+def layer_norm_fork(x, gamma, beta, eps=1e-5):
+    """(LayerNorm(x), x) for a tensor that is normalised and also continues unchanged; see _LayerNormFork."""
+    return _LayerNormFork.apply(x, gamma, beta, float(eps))
+
+
 def layer_norm(x, gamma, beta, eps=1e-5):
     return _LayerNorm.apply(x, gamma, beta, float(eps))
 

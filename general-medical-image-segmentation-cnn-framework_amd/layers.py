@@ -156,6 +156,12 @@ class LayerNorm(nn.LayerNorm):
             raise NotImplementedError("LayerNorm: only 1-D normalized_shape with affine is implemented")
         return F.layer_norm(x, self.weight, self.bias, self.eps)
 
+    def forward_fork(self, x):
+        """(LayerNorm(x), x): for x + f(LN(x)) blocks -- the backward sums the residual stream's gradient inside the norm's backward kernel."""
+        if len(self.normalized_shape) != 1 or not self.elementwise_affine:
+            raise NotImplementedError("LayerNorm: only 1-D normalized_shape with affine is implemented")
+        return F.layer_norm_fork(x, self.weight, self.bias, self.eps)
+
 
 _ONES = {}
 

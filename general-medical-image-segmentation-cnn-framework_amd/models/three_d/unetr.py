@@ -186,8 +186,11 @@ class TransformerBlock(nn.Module):
         self.attn = SelfAttention(num_heads, embed_dim, dropout)
 
     def forward(self, x):
-        x, weights = self.attn(self.attention_norm(x), residual=x)
-        return self.mlp(self.mlp_norm(x), residual=x), weights
+        # x + f(LN(x)) twice (unetr.py:159-166): the norm node hands x on unchanged so that its backward kernel sums both gradients of x
+        n, x = self.attention_norm.forward_fork(x)
+        x, weights = self.attn(n, residual=x)
+        n, x = self.mlp_norm.forward_fork(x)
+        return self.mlp(n, residual=x), weights
 
 
 class Transformer(nn.Module):

@@ -509,6 +509,11 @@ int mi355seg_layernorm_fwd_f32(const float* x, const float* gamma, const float* 
                                long long rows, int E, float eps, void* stream);
 int mi355seg_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                                float* dx, float* dgamma, float* dbeta, long long rows, int E, void* stream);
+/* The same with dx = addend + (LayerNorm backward of dy): `addend` is a second gradient of x -- the residual stream that bypasses the norm in a
+ * pre-norm transformer block (x + f(LN(x)), /root/reference/models/three_d/unetr.py:159-166) -- summed in the kernel that writes dx instead of
+ * by a separate add (r5).  addend NULL: mi355seg_layernorm_bwd_f32. */
+int mi355seg_layernorm_bwd_add_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, const float* addend,
+                                   float* dx, float* dgamma, float* dbeta, long long rows, int E, void* stream);
 /* nn.Softmax(dim=-1) on [rows, L] (unetr.py:71,90) and its backward dx = y * (dy - sum(dy*y)) */
 int mi355seg_softmax_rows_f32(const float* x, float* y, long long rows, int L, void* stream);
 int mi355seg_softmax_rows_bwd_f32(const float* y, const float* dy, float* dx, long long rows, int L, void* stream);

@@ -1134,3 +1134,29 @@ def test_linear_with_mask_and_residual_in_the_gemm_epilogue(seg, case, lowp):
         assert (a.grad.cpu() - r.grad).abs().max() < tol * sc(r.grad)
     if rr is not None:
         assert torch.equal(rg.grad.cpu(), go)          # the residual's gradient is dy itself
+
+
+def test_layer_norm_fork_sums_both_gradients_in_the_norm_backward(seg):
+    """r5, functional.layer_norm_fork / mi355seg_layernorm_bwd_add_f32: (LayerNorm(x), x) whose backward is d(pass-through) + LN-backward
+    (x + f(LN(x)), unetr.py:159-166) against ATen's layer_norm with the two uses kept apart; one output unused: the other's gradient alone."""
+    import torch.nn.functional as TF
+    F = seg.functional
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 108, 768, generator=g) * 2 + 0.5
+    ga, be = torch.rand(768, generator=g) + 0.5, torch.randn(768, generator=g)
+    g1, g2 = torch.randn(2, 108, 768, generator=g), torch.randn(2, 108, 768, generator=g)
+    xr, gr, br = x.clone().requires_grad_(True), ga.clone().requires_grad_(True), be.clone().requires_grad_(True)
+    yr = TF.layer_norm(xr, (768,), gr, br, 1e-6)
+    ((yr * g1).sum() + (xr * g2).sum()).backward()
+    xg, gg, bg = x.cuda().requires_grad_(True), ga.cuda().requires_grad_(True), be.cuda().requires_grad_(True)
+    n, p = F.layer_norm_fork(xg, gg, bg, 1e-6)
+    assert torch.equal(p.detach().cpu(), x) and (n.detach().cpu() - yr.detach()).abs().max() < 1e-5
+    ((n * g1.cuda()).sum() + (p * g2.cuda()).sum()).backward()
+    assert (xg.grad.cpu() - xr.grad).abs().max() < 2e-5 * max(1.0, float(xr.grad.abs().max()))
+    assert (gg.grad.cpu() - gr.grad).abs().max() < 1e-4 * max(1.0, float(gr.grad.abs().max()))
+    assert (bg.grad.cpu() - br.grad).abs().max() < 1e-4 * max(1.0, float(br.grad.abs().max()))
+    # only the pass-through is used: its gradient comes back as it is
+    x2 = x.cuda().requires_grad_(True)
+    _, p2 = F.layer_norm_fork(x2, gg.detach(), bg.detach(), 1e-6)
+    (p2 * g2.cuda()).sum().backward()
+    assert torch.equal(x2.grad.cpu(), g2)
