@@ -257,6 +257,27 @@ int mi355seg_conv3d_dgrad_bf16(const mi355seg_bf16* dy, int lddy, const float* w
     return MI355SEG_OK;
 }
 
+// dx = conv3d_dgrad(dy) + res on bf16 tensors, each of the two operations rounded to bf16 (what autograd's sum of the two gradients of a
+// forked tensor computes): the sum rides in the input-gradient kernel's epilogue on the k3 / k5 stride-1 16x16x32 tiles (whole-K launches),
+// else the library adds it in place after the input gradient.  res: dx's geometry at pitch ldres.
+int mi355seg_conv3d_dgrad_res_bf16(const mi355seg_bf16* dy, int lddy, const float* w, const mi355seg_bf16* res, int ldres, mi355seg_bf16* dx, int lddx,
+                                   int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                                   void* ws, size_t ws_bytes, void* stream) {
+    SEG_CHECK_ARG(dy && w && dx && res && N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && lddy >= Cout && lddx >= Cin && ldres >= Cin,
+                  "conv3d_dgrad_res_bf16: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (stride == 1 && 2 * pad == k - 1 && ((uintptr_t)dy % 16) == 0 && native_dgrad(N, D, H, W, Cin, Cout, k, stride, pad, lddy, lddx) == NB_IGEMM) {
+        int fused = 0;
+        int rc = conv_fwd_mfma(MATH_B16, dy, lddy, w, nullptr, dx, lddx, N, D, H, W, Cout, Cin, k, /*dgrad=*/1, nullptr, nullptr, ws, ws_bytes, st,
+                               nullptr, 0, 0.f, nullptr, nullptr, nullptr, res, ldres, &fused);
+        if (rc || fused) return rc;
+    } else {
+        int rc = mi355seg_conv3d_dgrad_bf16(dy, lddy, w, dx, lddx, N, D, H, W, Cin, Cout, k, stride, pad, ws, ws_bytes, stream);
+        if (rc) return rc;
+    }
+    return mi355seg_act_fwd_bf16(dx, lddx, res, ldres, dx, lddx, (long long)N * D * H * W, Cin, 0, 0.f, stream);
+}
+
 int mi355seg_conv3d_wgrad_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, float* dw, float* db,
                                int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int accumulate,
                                void* ws, size_t ws_bytes, void* stream) {

@@ -693,8 +693,11 @@ class _ConvBnAct(Function):
     pass (no separate pass over dy).  Training mode only updates running stats exactly as nn.BatchNorm3d."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, rmean, rvar, stride, pad, training, momentum, eps, act, slope, left_pad, inference=False):
+    def forward(ctx, x, w, b, gamma, beta, rmean, rvar, stride, pad, training, momentum, eps, act, slope, left_pad, inference=False, fork=False):
+        # fork (training): the result is (act(bn(conv(x))), x) -- x also continues unchanged (a residual block's input, vnet3d.py:61-104), and
+        # the backward sums the pass-through's gradient into the input gradient it computes (bf16: in that kernel's epilogue)
         xa_in = _get_amax(x)
+        x_arg = x
         x, ldx = cl_view(x, "conv3d input")
         N, D, H, W, Cin = x.shape
         Cout, k = w.shape[0], w.shape[2]
@@ -768,14 +771,21 @@ class _ConvBnAct(Function):
                    a.data_ptr(), left_pad + Cout, rows, 1, Cout, act, slope, _stream())
         ctx.save_for_backward(x, w, y, mean, rstd, gamma, beta)
         ctx.cfg = (N, D, H, W, Cin, Cout, k, stride, pad, ldx, b is not None, rows, act, slope, bool(training))
+        if fork:
+            ctx.set_materialize_grads(False)
+            return a, x_arg.view_as(x_arg)
         return a
 
     @staticmethod
-    def backward(ctx, da):
+    def backward(ctx, da, dpass=None):
         x, w, y, mean, rstd, gamma, beta = ctx.saved_tensors
         N, D, H, W, Cin, Cout, k, stride, pad, ldx, has_b, rows, act, slope, training = ctx.cfg
         if not training:
             raise Mi355SegError("backward through eval-mode BatchNorm (running statistics) is not supported")
+        if da is None:                       # (fork, only the pass-through was used)
+            return (dpass,) + (None,) * 16
+        if dpass is not None:
+            dpass, lddp = cl_view(_like(dpass, x), "pass-through grad")
         da, ldda = cl_view(_like(da, x), "conv+norm grad")
         L = lib()
         dev = x.device
@@ -795,23 +805,35 @@ class _ConvBnAct(Function):
                 dx = torch.empty((N, D, H, W, Cin), dtype=x.dtype, device=dev)
                 L.call("mi355seg_conv3d_dgrad_ax_f32", _p(dy), Cout, _p(w), _p(dx), Cin, N, D, H, W, Cin, Cout, k, stride, pad,
                        _p(dya), _p(wa), _p(ws), ws.numel(), _stream())
+                if dpass is not None:
+                    L.call("mi355seg_act_fwd_f32", _p(dx), Cin, _p(dpass), lddp, _p(dx), Cin, N * D * H * W, Cin, ACT_NONE, 0.0, _stream())
+            elif dpass is not None:
+                dx = dpass
             if ctx.needs_input_grad[1]:
                 dw = torch.empty_like(w)
                 L.call("mi355seg_conv3d_wgrad_ax_f32", _p(dy), Cout, _p(x), ldx, _p(dw), None, N, D, H, W, Cin, Cout, k, stride, pad,
                        0, _p(dya), _p(xa), _p(ws), ws.numel(), _stream())
-            return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
+            return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None, None
         L.call("mi355seg_norm_act_bwd_colsum_" + _sfx(x), _p(da), ldda, _p(y), Cout, _p(mean), _p(rstd), _p(gamma), _p(beta), None, 0,
                _p(dy), Cout, _p(dgamma), _p(dbeta), None, 0, _p(db), rows, 1, Cout, act, slope, _p(ws), ws.numel(), _stream())
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((N, D, H, W, Cin), dtype=x.dtype, device=dev)
-            L.call("mi355seg_conv3d_dgrad_" + _sfx(x), _p(dy), Cout, _p(w), _p(dx), Cin, N, D, H, W, Cin, Cout, k, stride, pad,
-                   _p(ws), ws.numel(), _stream())
+            if dpass is not None and x.dtype == torch.bfloat16:       # input gradient + the pass-through's gradient: the sum in the kernel's epilogue
+                L.call("mi355seg_conv3d_dgrad_res_bf16", _p(dy), Cout, _p(w), _p(dpass), lddp, _p(dx), Cin, N, D, H, W, Cin, Cout, k, stride, pad,
+                       _p(ws), ws.numel(), _stream())
+            else:
+                L.call("mi355seg_conv3d_dgrad_" + _sfx(x), _p(dy), Cout, _p(w), _p(dx), Cin, N, D, H, W, Cin, Cout, k, stride, pad,
+                       _p(ws), ws.numel(), _stream())
+                if dpass is not None:
+                    L.call("mi355seg_act_fwd_" + _sfx(x), _p(dx), Cin, _p(dpass), lddp, _p(dx), Cin, N * D * H * W, Cin, ACT_NONE, 0.0, _stream())
+        elif dpass is not None:
+            dx = dpass
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             L.call("mi355seg_conv3d_wgrad_" + _sfx(x), _p(dy), Cout, _p(x), ldx, _p(dw), None, N, D, H, W, Cin, Cout, k, stride, pad,
                    0, _p(ws), ws.numel(), _stream())
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def conv_in_act(x, conv, norm, act=ACT_NONE, slope=0.01):
@@ -825,11 +847,13 @@ def conv_in_act(x, conv, norm, act=ACT_NONE, slope=0.01):
     stride = conv.stride[0] if isinstance(conv.stride, (tuple, list)) else conv.stride
     pad = conv.padding[0] if isinstance(conv.padding, (tuple, list)) else conv.padding
     return _ConvBnAct.apply(x, conv.weight, conv.bias, None, None, None, None, int(stride), int(pad), True, 0.0, float(norm.eps),
-                            int(act), float(slope), 0, False)
+                            int(act), float(slope), 0, False, False)
 
 
-def conv_bn_act(x, conv, bn, act=ACT_NONE, slope=0.01, left_pad=0):
-    """act(bn(conv(x))) for a layers.Conv3d / layers.BatchNorm3d pair (module objects carry the parameters)."""
+def conv_bn_act(x, conv, bn, act=ACT_NONE, slope=0.01, left_pad=0, fork=False):
+    """act(bn(conv(x))) for a layers.Conv3d / layers.BatchNorm3d pair (module objects carry the parameters).  ``fork`` (training mode):
+    returns (act(bn(conv(x))), x) -- x continues unchanged beside the convolution (the input of a residual block) and the node's backward
+    adds the pass-through's gradient to the input gradient it computes instead of leaving the sum to autograd."""
     if bn.momentum is None or not bn.affine or not bn.track_running_stats:
         raise NotImplementedError("conv_bn_act: BatchNorm3d must be affine with running statistics and a momentum")
     stride = conv.stride[0] if isinstance(conv.stride, (tuple, list)) else conv.stride
@@ -837,9 +861,11 @@ def conv_bn_act(x, conv, bn, act=ACT_NONE, slope=0.01, left_pad=0):
     if bn.training:
         bump_counter(bn)
     # eval mode under torch.no_grad() (predict.py:79-81,133) takes the folded one-pass form where the layer has one
-    return _ConvBnAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, int(stride), int(pad),
-                            bool(bn.training), float(bn.momentum), float(bn.eps), int(act), float(slope), int(left_pad),
-                            not torch.is_grad_enabled())
+    forked = bool(fork) and bn.training and torch.is_grad_enabled()
+    out = _ConvBnAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, int(stride), int(pad),
+                           bool(bn.training), float(bn.momentum), float(bn.eps), int(act), float(slope), int(left_pad),
+                           not torch.is_grad_enabled(), forked)
+    return (out, x) if (fork and not forked) else out
 
 
 class _DoubleConvBnAct(Function):

@@ -38,6 +38,19 @@ def _conv_bn_act(x, conv, bn, relu):
     return relu(F.conv_bn_act(x, conv, bn, F.ACT_NONE))
 
 
+def _units_and_input(ops, x, elu_mode):
+    """(units(x), x) for a residual block: with the fused ELU units the FIRST unit's node hands x on unchanged, so that its backward adds
+    the block sum's gradient of x inside the input-gradient kernel (functional.conv_bn_act(..., fork=True)) instead of autograd's own sum."""
+    units = list(ops.children()) if isinstance(ops, nn.Sequential) else []
+    if not (elu_mode and units and isinstance(units[0], LUConv)):
+        return ops(x), x
+    first = units[0]
+    h, x = F.conv_bn_act(x, first.conv1, first.bn1, F.ACT_ELU, fork=True)
+    for unit in units[1:]:
+        h = unit(h)
+    return h, x
+
+
 def _add_act(x, residual, relu):
     if isinstance(relu, ELU):
         return F.activation(x, F.ACT_ELU, residual=residual)
@@ -90,6 +103,9 @@ class DownTransition(nn.Module):
 
     def forward(self, x):
         down = _conv_bn_act(x, self.down_conv, self.bn1, self.relu1)
+        if isinstance(self.do1, nn.Identity):
+            out, down = _units_and_input(self.ops, down, isinstance(self.relu2, ELU))
+            return _add_act(out, down, self.relu2)
         return _add_act(self.ops(self.do1(down)), down, self.relu2)
 
 
@@ -115,7 +131,8 @@ class UpTransition(nn.Module):
             kept_skip = self.do2(skipx)                  # the reference draws the skip mask first (vnet3d.py:99)
             up = _bn_act(self.bn1, self.up_conv(self.do1(x)), self.relu1)
             both = F.cat_channels(up, kept_skip)
-        return _add_act(self.ops(both), both, self.relu2)
+        out, both = _units_and_input(self.ops, both, isinstance(self.relu2, ELU))
+        return _add_act(out, both, self.relu2)
 
 
 class OutputTransition(nn.Module):

@@ -633,6 +633,11 @@ int mi355seg_conv3d_fwd_bf16(const mi355seg_bf16* x, int ldx, const float* w, co
  * (k3 / k5 s1 on the 16x16x32 tiles, whole-K), else the library adds it in place after the convolution.  res: y's geometry at pitch ldres. */
 int mi355seg_conv3d_fwd_res_bf16(const mi355seg_bf16* x, int ldx, const float* w, const float* bias, const mi355seg_bf16* res, int ldres, mi355seg_bf16* y, int ldy, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
 int mi355seg_conv3d_dgrad_bf16(const mi355seg_bf16* dy, int lddy, const float* w, mi355seg_bf16* dx, int lddx, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
+/* dx = conv3d_dgrad(dy) + res on bf16 tensors (r5): a convolution's input gradient together with the sum of a SECOND gradient of its input --
+ * the residual blocks of /root/reference/models/three_d/vnet3d.py:61-104 (`down` / the concat feed the first k5 unit AND the block's final
+ * sum) -- each of the two operations rounded to bf16 as autograd's own sum of the two gradients would be (bit-identical to
+ * mi355seg_conv3d_dgrad_bf16 followed by the sum); in the input-gradient kernel's epilogue on the 16x16x32 tiles, in place after it elsewhere. */
+int mi355seg_conv3d_dgrad_res_bf16(const mi355seg_bf16* dy, int lddy, const float* w, const mi355seg_bf16* res, int ldres, mi355seg_bf16* dx, int lddx, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
 int mi355seg_conv3d_wgrad_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg_bf16* x, int ldx, float* dw, float* db, int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, void* stream);
 int mi355seg_cast_f32_to_bf16(const float* src, int ldsrc, mi355seg_bf16* dst, int lddst, long long rows, int C, void* stream);
 int mi355seg_cast_bf16_to_f32(const mi355seg_bf16* src, int ldsrc, float* dst, int lddst, long long rows, int C, void* stream);
