@@ -541,3 +541,27 @@ def test_ernet_train_step_vs_reference_fixture(seg, golden_dir):
         assert gpu_err <= 4.0 * ref_err + 3e-4 * max(1e-3, np.abs(t).max()), (k, gpu_err, ref_err)
         checked += 1
     assert checked == 14
+
+
+def test_unetr_graph_replays_draw_fresh_dropout_masks(seg):
+    """r5: with the step's element-wise dropout masks drawn by ONE launch (functional.dropout_pool_*), a captured UNETR step
+    (engine.GraphedTrainStep, config.hip_graph=true) must still see NEW masks at every replay (the draw is inside the graph; torch advances
+    the generator's offset per replay) -- and the same number of launches-worth of randomness as the eager step: on a fixed batch and with
+    the optimiser's learning rate 0 the loss then varies from replay to replay exactly as it does from eager step to eager step."""
+    from mi355seg.engine import GraphedTrainStep, train_step
+    from mi355seg.models.three_d.unetr import UNETR
+    F = seg.functional
+    torch.manual_seed(0)
+    m = UNETR(img_shape=(32, 32, 32), input_dim=1, output_dim=2, embed_dim=96, patch_size=16, num_heads=12, dropout=0.3).cuda().train()
+    opt = torch.optim.Adam(m.parameters(), lr=0.0, capturable=True)
+    x = torch.randn(1, 1, 32, 32, 32, device="cuda")
+    gt = (torch.rand(1, 1, 32, 32, 32, device="cuda") > 0.7).float()
+    eager = [float(train_step(m, opt, x, gt, sync_metric=False, dtype=torch.bfloat16)["loss"]) for _ in range(4)]
+    pool = F._MASKS.pools
+    assert any(st[0] is not None for st in pool.values())                  # the pooled draw is active from the second step on
+    assert len(set(eager)) >= 3                                            # lr = 0: only the masks move the loss
+    g = GraphedTrainStep(m, opt, x, gt, warmup=1, dtype=torch.bfloat16)
+    replay = [float(g(x, gt, sync_metric=False)["loss"]) for _ in range(4)]
+    assert all(torch.isfinite(torch.tensor(replay))) and len(set(replay)) >= 3
+    lo, hi = min(eager) - 0.1, max(eager) + 0.1
+    assert all(lo <= v <= hi for v in replay)
