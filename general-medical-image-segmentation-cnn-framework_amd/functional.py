@@ -626,7 +626,9 @@ def conv_transpose3d_k2s2(x, weight, bias=None):
 # ----------------------------------------------------------------------------- norm + activation
 class _NormAct(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, res, running_mean, running_var, training, momentum, eps, act, slope, instance):
+    def forward(ctx, x, gamma, beta, res, running_mean, running_var, training, momentum, eps, act, slope, instance, left_pad=0):
+        # left_pad > 0: the result is the RIGHT channel slice of a buffer with left_pad free channels on its left, which a later node
+        # fills (conv_in_act(..., cat_right=)): the skip concatenation of residual_unet3d.py:174-209 without the copies
         x, ldx = cl_view(x, "norm input")
         N, D, H, W, C = x.shape
         groups = N if instance else 1
@@ -649,9 +651,13 @@ class _NormAct(Function):
             mean = running_mean
             rstd = torch.empty(C, dtype=torch.float32, device=dev)
             L.call("mi355seg_rstd_from_var_f32", _p(running_var), eps, _p(rstd), C, _stream())
-        y = torch.empty((N, D, H, W, C), dtype=x.dtype, device=dev)
+        if left_pad:
+            full = torch.empty((N, D, H, W, left_pad + C), dtype=x.dtype, device=dev)
+            y = full[..., left_pad:]
+        else:
+            y = torch.empty((N, D, H, W, C), dtype=x.dtype, device=dev)
         L.call("mi355seg_norm_act_fwd_" + _sfx(x), _p(x), ldx, _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), ldres,
-               _p(y), C, rows, groups, C, act, slope, _stream())
+               y.data_ptr(), left_pad + C, rows, groups, C, act, slope, _stream())
         ctx.save_for_backward(x, mean, rstd, gamma, beta, res)
         ctx.cfg = (ldx, ldres, rows, groups, C, act, slope, bool(training or instance))
         return y
@@ -672,19 +678,20 @@ class _NormAct(Function):
         dres = torch.empty(x.shape, dtype=x.dtype, device=dev) if res is not None else None
         L.call("mi355seg_norm_act_bwd_" + _sfx(x), _p(dy), lddy, _p(x), ldx, _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), ldres,
                _p(dx), C, _p(dgamma), _p(dbeta), _p(dres), C, rows, groups, C, act, slope, _p(ws), ws.numel(), _stream())
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5,
                    act=ACT_NONE, slope=0.01, residual=None):
     """act(BatchNorm3d(x) [+ residual]); training mode updates running stats in place."""
     return _NormAct.apply(x, gamma, beta, residual, running_mean, running_var, bool(training), float(momentum),
-                          float(eps), int(act), float(slope), False)
+                          float(eps), int(act), float(slope), False, 0)
 
 
-def instance_norm_act(x, eps=1e-5, act=ACT_NONE, slope=0.01):
-    """act(InstanceNorm3d(x)) with affine=False, track_running_stats=False."""
-    return _NormAct.apply(x, None, None, None, None, None, True, 0.0, float(eps), int(act), float(slope), True)
+def instance_norm_act(x, eps=1e-5, act=ACT_NONE, slope=0.01, left_pad=0):
+    """act(InstanceNorm3d(x)) with affine=False, track_running_stats=False.  ``left_pad``: see _NormAct (the result is the right channel
+    slice of a concat buffer)."""
+    return _NormAct.apply(x, None, None, None, None, None, True, 0.0, float(eps), int(act), float(slope), True, int(left_pad))
 
 
 class _ConvBnAct(Function):
@@ -693,7 +700,10 @@ class _ConvBnAct(Function):
     pass (no separate pass over dy).  Training mode only updates running stats exactly as nn.BatchNorm3d."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, rmean, rvar, stride, pad, training, momentum, eps, act, slope, left_pad, inference=False, fork=False):
+    def forward(ctx, x, w, b, gamma, beta, rmean, rvar, stride, pad, training, momentum, eps, act, slope, left_pad, inference=False, fork=False, cat_right=None):
+        # cat_right (training): a tensor that IS the right channel slice of a concat buffer with exactly Cout free channels on its left
+        # (instance_norm_act / activation_fork(..., left_pad=Cout)): the activation is written into those channels and the whole buffer
+        # is returned -- cat((act(norm(conv(x))), cat_right), channels) without the two copies
         # fork (training): the result is (act(bn(conv(x))), x) -- x also continues unchanged (a residual block's input, vnet3d.py:61-104), and
         # the backward sums the pass-through's gradient into the input gradient it computes (bf16: in that kernel's epilogue)
         xa_in = _get_amax(x)
@@ -754,7 +764,17 @@ class _ConvBnAct(Function):
             mean = rmean
             rstd = torch.empty(Cout, dtype=torch.float32, device=dev)
             L.call("mi355seg_rstd_from_var_f32", _p(rvar), eps, _p(rstd), Cout, _stream())
-        if left_pad:
+        lda = left_pad + Cout
+        ctx.cat = 0
+        if cat_right is not None:
+            base = cat_right._base
+            Cs = cat_right.shape[-1]
+            if not (base is not None and base.dim() == 5 and base.is_contiguous() and tuple(base.shape) == (N, Do, Ho, Wo, Cout + Cs) and base.dtype == x.dtype
+                    and cat_right.data_ptr() == base.data_ptr() + base.element_size() * Cout and cat_right.stride() == base.stride() and not left_pad):
+                raise Mi355SegError("conv_bn_act: `cat_right` is not the right channel slice of a matching concat buffer")
+            full, a, lda = base, base[..., :Cout], Cout + Cs
+            ctx.cat = Cs
+        elif left_pad:
             # the activation lands in the RIGHT channel slice of a wider buffer whose left `left_pad` channels a later
             # up-convolution fills (conv_transpose3d_k2s2_cat): the skip concatenation then costs no copy
             full = torch.empty((N, Do, Ho, Wo, left_pad + Cout), dtype=x.dtype, device=dev)
@@ -764,16 +784,19 @@ class _ConvBnAct(Function):
         if ax:
             aa = _amax_slot(dev)
             L.call("mi355seg_norm_act_fwd_ax_f32", _p(y), Cout, _p(mean), _p(rstd), _p(gamma), _p(beta), None, 0,
-                   a.data_ptr(), left_pad + Cout, rows, 1, Cout, act, slope, _p(aa), _stream())
-            _set_amax(a, aa)
+                   a.data_ptr(), lda, rows, 1, Cout, act, slope, _p(aa), _stream())
+            if not ctx.cat:
+                _set_amax(a, aa)
         else:
             L.call("mi355seg_norm_act_fwd_" + _sfx(x), _p(y), Cout, _p(mean), _p(rstd), _p(gamma), _p(beta), None, 0,
-                   a.data_ptr(), left_pad + Cout, rows, 1, Cout, act, slope, _stream())
+                   a.data_ptr(), lda, rows, 1, Cout, act, slope, _stream())
         ctx.save_for_backward(x, w, y, mean, rstd, gamma, beta)
         ctx.cfg = (N, D, H, W, Cin, Cout, k, stride, pad, ldx, b is not None, rows, act, slope, bool(training))
         if fork:
             ctx.set_materialize_grads(False)
             return a, x_arg.view_as(x_arg)
+        if ctx.cat:
+            return full
         return a
 
     @staticmethod
@@ -783,9 +806,13 @@ class _ConvBnAct(Function):
         if not training:
             raise Mi355SegError("backward through eval-mode BatchNorm (running statistics) is not supported")
         if da is None:                       # (fork, only the pass-through was used)
-            return (dpass,) + (None,) * 16
+            return (dpass,) + (None,) * 17
         if dpass is not None:
             dpass, lddp = cl_view(_like(dpass, x), "pass-through grad")
+        dcat = None
+        if ctx.cat:                          # da is the gradient of the whole concat buffer: ours is its left slice, the right one goes back to cat_right
+            da = _like(da, x)
+            dcat, da = da[..., Cout:], da[..., :Cout]
         da, ldda = cl_view(_like(da, x), "conv+norm grad")
         L = lib()
         dev = x.device
@@ -813,7 +840,7 @@ class _ConvBnAct(Function):
                 dw = torch.empty_like(w)
                 L.call("mi355seg_conv3d_wgrad_ax_f32", _p(dy), Cout, _p(x), ldx, _p(dw), None, N, D, H, W, Cin, Cout, k, stride, pad,
                        0, _p(dya), _p(xa), _p(ws), ws.numel(), _stream())
-            return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None, None
+            return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None, None, dcat
         L.call("mi355seg_norm_act_bwd_colsum_" + _sfx(x), _p(da), ldda, _p(y), Cout, _p(mean), _p(rstd), _p(gamma), _p(beta), None, 0,
                _p(dy), Cout, _p(dgamma), _p(dbeta), None, 0, _p(db), rows, 1, Cout, act, slope, _p(ws), ws.numel(), _stream())
         dx = dw = None
@@ -833,21 +860,29 @@ class _ConvBnAct(Function):
             dw = torch.empty_like(w)
             L.call("mi355seg_conv3d_wgrad_" + _sfx(x), _p(dy), Cout, _p(x), ldx, _p(dw), None, N, D, H, W, Cin, Cout, k, stride, pad,
                    0, _p(ws), ws.numel(), _stream())
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None, None, dcat
 
 
-def conv_in_act(x, conv, norm, act=ACT_NONE, slope=0.01):
+def conv_in_act(x, conv, norm, act=ACT_NONE, slope=0.01, cat_right=None):
     """act(InstanceNorm3d(conv(x))) (residual_unet3d.py:82-107: conv_norm_lrelu and the tail of norm_lrelu_upscale_conv_norm_lrelu;
     affine=False, no running statistics).  With ONE sample per batch -- cfg 4 -- the per-(sample, channel) statistics are per-channel
     statistics over the whole tensor, i.e. exactly what the convolution's epilogue already reduces for BatchNorm: the node of
     conv_bn_act without affine parameters and buffers (no separate statistics pass over y).  N > 1: convolution, then the
     instance-norm node."""
     if x.shape[0] != 1 or norm.affine or norm.track_running_stats or not torch.is_grad_enabled():
-        return norm.forward_act(conv(x), act, slope)
+        a = norm.forward_act(conv(x), act, slope)
+        return a if cat_right is None else cat_channels(a, cat_right)
     stride = conv.stride[0] if isinstance(conv.stride, (tuple, list)) else conv.stride
     pad = conv.padding[0] if isinstance(conv.padding, (tuple, list)) else conv.padding
-    return _ConvBnAct.apply(x, conv.weight, conv.bias, None, None, None, None, int(stride), int(pad), True, 0.0, float(norm.eps),
-                            int(act), float(slope), 0, False, False)
+    # cat_right: cat((result, cat_right), channels) -- written in place when cat_right is the right slice of a matching concat buffer
+    # (instance_norm_act / activation_fork(..., left_pad=)), by two slice copies otherwise
+    base = getattr(cat_right, "_base", None) if cat_right is not None else None
+    inplace = base is not None and base.dim() == 5 and base.is_contiguous() and base.shape[-1] == conv.out_channels + cat_right.shape[-1] and \
+        cat_right.dtype == x.dtype and cat_right.data_ptr() == base.data_ptr() + base.element_size() * conv.out_channels and \
+        cat_right.stride() == base.stride() and not os.environ.get("MI355SEG_NO_CAT_FUSION")
+    out = _ConvBnAct.apply(x, conv.weight, conv.bias, None, None, None, None, int(stride), int(pad), True, 0.0, float(norm.eps),
+                           int(act), float(slope), 0, False, False, cat_right if inplace else None)
+    return out if (cat_right is None or inplace) else cat_channels(out, cat_right)
 
 
 def conv_bn_act(x, conv, bn, act=ACT_NONE, slope=0.01, left_pad=0, fork=False):
@@ -1176,12 +1211,15 @@ class _ActFork(Function):
     add the two gradients with a kernel of its own."""
 
     @staticmethod
-    def forward(ctx, x, act, slope):
+    def forward(ctx, x, act, slope, left_pad=0):
         xv, ldx = cl_view(x, "activation input")
         N, D, H, W, C = xv.shape
-        y = torch.empty((N, D, H, W, C), dtype=xv.dtype, device=xv.device)
+        if left_pad:                         # the activation is the RIGHT channel slice of a concat buffer a later node fills on the left
+            y = torch.empty((N, D, H, W, left_pad + C), dtype=xv.dtype, device=xv.device)[..., left_pad:]
+        else:
+            y = torch.empty((N, D, H, W, C), dtype=xv.dtype, device=xv.device)
         rows = N * D * H * W
-        lib().call("mi355seg_act_fwd_" + _sfx(xv), _p(xv), ldx, None, 0, _p(y), C, rows, C, act, slope, _stream())
+        lib().call("mi355seg_act_fwd_" + _sfx(xv), _p(xv), ldx, None, 0, y.data_ptr(), left_pad + C, rows, C, act, slope, _stream())
         ctx.cfg = (ldx, rows, C, act, slope)
         ctx.save_for_backward(xv)
         ctx.set_materialize_grads(False)
@@ -1192,19 +1230,20 @@ class _ActFork(Function):
         ldx, rows, C, act, slope = ctx.cfg
         (x,) = ctx.saved_tensors
         if dy is None:
-            return dpass, None, None
+            return dpass, None, None, None
         dy, lddy = cl_view(_like(dy, x), "activation grad")
         add = ldadd = None
         if dpass is not None:
             add, ldadd = cl_view(_like(dpass, x), "pass-through grad")
         dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
         lib().call("mi355seg_act_bwd_add_" + _sfx(x), _p(dy), lddy, _p(x), ldx, None, 0, _p(add), ldadd or 0, _p(dx), C, rows, C, act, slope, _stream())
-        return dx, None, None
+        return dx, None, None, None
 
 
-def activation_fork(x, act, slope=0.01):
-    """(act(x), x) for a tensor that feeds an activation and continues unchanged; see _ActFork."""
-    return _ActFork.apply(x, int(act), float(slope))
+def activation_fork(x, act, slope=0.01, left_pad=0):
+    """(act(x), x) for a tensor that feeds an activation and continues unchanged; see _ActFork.  ``left_pad``: act(x) is the right channel
+    slice of a concat buffer with that many free channels on its left."""
+    return _ActFork.apply(x, int(act), float(slope), int(left_pad))
 
 
 class _PReLU(Function):

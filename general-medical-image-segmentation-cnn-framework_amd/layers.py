@@ -60,10 +60,10 @@ class BatchNorm3d(nn.BatchNorm3d):
 
 
 class InstanceNorm3d(nn.InstanceNorm3d):
-    def forward_act(self, x, act=F.ACT_NONE, slope=0.01):
+    def forward_act(self, x, act=F.ACT_NONE, slope=0.01, left_pad=0):
         if self.affine or self.track_running_stats:
             raise NotImplementedError("InstanceNorm3d: only affine=False, track_running_stats=False is implemented")
-        return F.instance_norm_act(x, self.eps, act, slope)
+        return F.instance_norm_act(x, self.eps, act, slope, left_pad=left_pad)
 
     def forward(self, x):
         return self.forward_act(x)

@@ -35,9 +35,11 @@ class _ConvNormLrelu(nn.Sequential):
 class _NormLreluUpConvNormLrelu(nn.Sequential):
     """[InstanceNorm3d, LeakyReLU, Upsample, Conv3d, InstanceNorm3d, LeakyReLU] (keys '.3.weight')."""
 
-    def forward(self, x):
+    def forward(self, x, cat_right=None):
+        """``cat_right``: the skip tensor the result is concatenated with (residual_unet3d.py:183-209) -- the result is then
+        cat((block(x), cat_right), channels), written in place when cat_right was produced as the right slice of a concat buffer."""
         n0, _a0, up, conv, n1, _a1 = self.children()
-        return F.conv_in_act(up(n0.forward_act(x, *_LRELU)), conv, n1, *_LRELU)
+        return F.conv_in_act(up(n0.forward_act(x, *_LRELU)), conv, n1, *_LRELU, cat_right=cat_right)
 
 
 def _conv3(cin, cout, stride=1):
@@ -115,7 +117,11 @@ class UNet(nn.Module):
         h = self.conv3d_c1_2(a)
         act1, conv1 = self.lrelu_conv_c1.children()
         h = conv1(act1(self.dropout3d(h)), residual=res)       # (:121) conv + residual in one launch
-        c1, h = F.activation_fork(h, F.ACT_LRELU, self.lrelu.negative_slope)     # context_1 = lrelu(sum); the sum itself goes on into the norm
+        # the four context tensors are born as the RIGHT channel slices of their levels' concat buffers; the localisation path's blocks
+        # write their outputs into the left slices (torch.cat of :183-209 without the copies)
+        left = [self.norm_lrelu_upscale_conv_norm_lrelu_l3[3].out_channels, self.norm_lrelu_upscale_conv_norm_lrelu_l2[3].out_channels,
+                self.norm_lrelu_upscale_conv_norm_lrelu_l1[3].out_channels, self.conv3d_l0.out_channels]
+        c1, h = F.activation_fork(h, F.ACT_LRELU, self.lrelu.negative_slope, left_pad=left[0])     # context_1 = lrelu(sum); the sum itself goes on into the norm
         ctx = [c1]
         h = self.inorm3d_c1.forward_act(h, *_LRELU)
         for lvl in (2, 3, 4, 5):                               # (:123-168)
@@ -124,18 +130,16 @@ class UNet(nn.Module):
             blk = getattr(self, f"norm_lrelu_conv_c{lvl}")     # shared weights, applied twice
             h = blk(self.dropout3d(blk(h)), residual=res)       # (:131,:141,...) the residual sum in the second convolution's epilogue
             if lvl < 5:
-                h = getattr(self, f"inorm3d_c{lvl}").forward_act(h, *_LRELU)
+                h = getattr(self, f"inorm3d_c{lvl}").forward_act(h, *_LRELU, left_pad=left[lvl - 1])
                 ctx.append(h)
         h = self.norm_lrelu_upscale_conv_norm_lrelu_l0(h)
-        h = F.conv_in_act(h, self.conv3d_l0, self.inorm3d_l0, *_LRELU)
+        h = F.conv_in_act(h, self.conv3d_l0, self.inorm3d_l0, *_LRELU, cat_right=ctx[3])      # ... and the cat with context_4 (:174-176)
         ds = {}
-        for lvl in (1, 2, 3):                                  # localisation (:174-194)
-            h = F.cat_channels(h, ctx[4 - lvl])
+        for lvl in (1, 2, 3):                                  # localisation (:174-194); h arrives concatenated with its level's context
             h = getattr(self, f"conv_norm_lrelu_l{lvl}")(h)
             ds[lvl] = h
             h = getattr(self, f"conv3d_l{lvl}")(h)
-            h = getattr(self, f"norm_lrelu_upscale_conv_norm_lrelu_l{lvl}")(h)
-        h = F.cat_channels(h, ctx[0])
+            h = getattr(self, f"norm_lrelu_upscale_conv_norm_lrelu_l{lvl}")(h, cat_right=ctx[3 - lvl])
         out_pred = self.conv3d_l4(self.conv_norm_lrelu_l4(h))
         s = F.activation(self.upsacle(self.ds2_1x1_conv3d(ds[2])), F.ACT_NONE, residual=self.ds3_1x1_conv3d(ds[3]))
         out = F.activation(out_pred, F.ACT_NONE, residual=self.upsacle(s))
