@@ -307,7 +307,11 @@ bool b16s_plan(int KS, int N, int D, int H, int W, int Cin, int Cout, const void
     if ((long long)D * H * W * ldx * 2 >= 0x7FFFFFF0LL) return false;       // one sample is addressed through a 32-bit buffer offset
     if (g_b16_tiles == 1) return true;
     const double waste = (double)p->ntx * SBX * p->nty * STY * p->ntz * p->TZ / ((double)W * H * D);
-    return waste <= 1.35 && (long long)p->nM * p->nN * p->ksplit >= 192;
+    if (waste <= 1.35 && (long long)p->nM * p->nN * p->ksplit >= 192) return true;
+    // r5: the deep levels (20^3 ... 4^3 voxels, 64-512 channels) pad these tiles by up to 4.7x and cut few of them -- and still run 1.2-2.8x
+    // faster here than on the generic 32x32x16 tiles (profiles/r05_b16s_small_volumes_ab.log: every shape with >= 1,728 products per output
+    // value, i.e. Cin >= 64 at k3 or any k5 layer; the two shapes that lost have Cin = 32 at k3: two K chunks per tile and no tap split)
+    return (long long)Cin * KS * KS * KS >= 1728;
 }
 size_t b16s_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k) {
     B16sPlan p;
