@@ -361,6 +361,7 @@ static int pick_ck(int math, int KS, int Kc) {
 }
 
 // Kc = GEMM K channels per input tap (multiple of CK), Nc = GEMM N per output tap (multiple of 32)
+static bool x3s_enabled();
 static bool igemm_plan(int math, int KS, int N, int D, int H, int W, int Kc, int Nc, int ntaps_out, IgemmPlan* p) {
     if (KS != 1 && KS != 3 && KS != 5) return false;
     // the split-precision igemm serves the k3 layers.  (k5 was measured: three planes of the 5^3 halo are 86-110 KB, one workgroup
@@ -375,6 +376,9 @@ static bool igemm_plan(int math, int KS, int N, int D, int H, int W, int Kc, int
     int BX = 0; long long best = -1;
     for (int bx : {32, 16, 8}) {
         if (math == MATH_X3 && bx == 32) continue;
+        // f16x3 (r5): the 16-wide tiles carry the conv_x3s kernels (three fp16 MFMAs per product); an 8-wide volume on the generic tiles
+        // runs bf16x6 (six) on a slower loop -- half-empty 16-wide tiles are the cheaper choice (profiles/r05_x3s_small_volumes_ab.log)
+        if (math == MATH_X3 && bx == 8 && x3s_enabled() && x3_f16() && KS == 3 && Kc % 16 == 0 && W >= 8) continue;
         // bf16 k5: the 5^3 halo of a two-block tile fits twice per CU only for the 16- and 8-wide tiles (61 / 55 KB vs 83 KB),
         // and two M-blocks per wave halve both the halo overfetch (11x -> 5x) and the weight-fragment loads per MFMA
         if (math == MATH_B16 && KS == 5 && bx == 32 && W % 16 == 0) continue;
