@@ -62,6 +62,8 @@ def main():
     L = mi355seg.lib()
     if a.conv_math:
         mi355seg.set_conv_math(a.conv_math)
+    if os.environ.get("MI355SEG_WGRAD_WIDE"):          # A/B knob: 0 never, 1 where it pays (default), 2 wherever the geometry allows
+        mi355seg.set_wgrad_wide(int(os.environ["MI355SEG_WGRAD_WIDE"]))
     if os.environ.get("MI355SEG_B16_TILES"):           # A/B knob: 0 auto, 1 the 16x16x32 bf16 tiles wherever the geometry allows, 2 never
         mi355seg.set_b16_tiles(int(os.environ["MI355SEG_B16_TILES"]))
     math = "bf16" if a.dtype == "bf16" else mi355seg.get_conv_math()
