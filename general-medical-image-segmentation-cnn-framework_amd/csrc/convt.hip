@@ -152,6 +152,8 @@ size_t mi355seg_convt3d_k2s2_ws_bytes(int N, int D, int H, int W, int Cin, int C
     if (pw > part) part = pw;
     const size_t lw = convt_wgrad_lowp_ws_bytes((long long)N * D * H * W, Cin, Cout);
     if (lw > part) part = lw;
+    const size_t slab = convt_direct_slab_bytes((long long)N * D * H * W, Cin, Cout);
+    if (slab > part) part = slab;
     return wb + (part > red ? part : red) + 1024;
 }
 

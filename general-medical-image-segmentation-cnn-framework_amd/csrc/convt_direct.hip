@@ -37,6 +37,8 @@ struct CtArgs {
     int nchunk;             // K / 64
     int ntn;                // N-tiles
     unsigned* amax_out;     // SCATTER, optional: max |y| of what this launch writes, max-combined (the f16x3 scale of the convolution that reads the concat buffer)
+    int ksplit, cps;        // GEMM form, GATHER on fp32 tensors (r5): K-splits and chunks per split; ksplit > 1: y is an fp32 slab array
+    long long slab_stride;  // floats between the slabs of consecutive splits
 };
 
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h2, unsigned& m2, unsigned& l2) {
@@ -70,8 +72,12 @@ __global__ __launch_bounds__(256, 2) void convt_gemm_kernel(CtArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
     const int wm = wave & 1, wn = wave >> 1;
-    const int ntile = blockIdx.x % a.ntn;
-    const long long vox0 = (long long)(blockIdx.x / a.ntn) * BM;
+    // (r5) K-splits of a tile are adjacent workgroups: the deep levels' input gradients cut 64-256 tiles of a long K (8 Cout = 1024-2048)
+    const int ks = a.ksplit > 1 ? (int)(blockIdx.x % a.ksplit) : 0;
+    const unsigned bid = a.ksplit > 1 ? blockIdx.x / a.ksplit : blockIdx.x;
+    const int ntile = bid % a.ntn;
+    const long long vox0 = (long long)(bid / a.ntn) * BM;
+    const int c0 = a.ksplit > 1 ? ks * a.cps : 0, c1 = a.ksplit > 1 ? c0 + a.cps : a.nchunk;
     const TT* const xg = static_cast<const TT*>(a.x);
     const int fH = 2 * a.H, fW = 2 * a.W;
 
@@ -141,12 +147,12 @@ __global__ __launch_bounds__(256, 2) void convt_gemm_kernel(CtArgs a) {
     const unsigned char* const xrd = xl + (g * XS + wm * WM + r) * 16;
     const unsigned char* const wrd = wl + (g * WS + wn * WN + r) * 16;
 
-    load_global(0);
-    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+    load_global(c0);
+    for (int chunk = c0; chunk < c1; ++chunk) {
         __syncthreads();
         write_lds();
         __syncthreads();
-        if (chunk + 1 < a.nchunk) load_global(chunk + 1);
+        if (chunk + 1 < c1) load_global(chunk + 1);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8_t wf[TN][NP], xf[TM][NP];
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void convt_gemm_kernel(CtArgs a) {
     }
 
     // ---- epilogue: lane holds rows n = 4g .. 4g+3 of column (voxel) r of every 16 x 16 tile
-    TT* const yg = static_cast<TT*>(a.y);
+    TT* const yg = static_cast<TT*>(a.y) + (GATHER && F32 ? (long long)ks * a.slab_stride : 0);      // (ksplit > 1: this split's slab, pitch ldy = the GEMM width)
     float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -426,7 +432,21 @@ void launch_ct(const CtArgs& a, int mtiles, hipStream_t st) {
     constexpr int NP = sizeof(TT) == 4 ? 3 : 1;
     constexpr size_t lds = (size_t)NP * 8 * ((BM + 8) + (BN + 8)) * 16;
     SEG_SET_LDS((convt_gemm_kernel<TT, GATHER, BM, BN>), lds);
-    hipLaunchKernelGGL((convt_gemm_kernel<TT, GATHER, BM, BN>), dim3((unsigned)(mtiles * a.ntn)), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((convt_gemm_kernel<TT, GATHER, BM, BN>), dim3((unsigned)(mtiles * a.ntn * (a.ksplit > 1 ? a.ksplit : 1))), dim3(256), lds, st, a);
+}
+
+// dx[v][c] = sum over the K-splits' slabs (fixed order)
+__global__ __launch_bounds__(256) void convt_splitk_reduce_kernel(const float* __restrict__ slabs, int ksplit, long long stride, float* __restrict__ dx, int lddx,
+                                                                  long long nvox, int C) {
+    const int cw = C / 4;
+    const long long total = nvox * cw;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long v = i / cw;
+        const int c = (int)(i - v * cw) * 4;
+        f32x4 s = *reinterpret_cast<const f32x4*>(slabs + v * C + c);
+        for (int k = 1; k < ksplit; ++k) s += *reinterpret_cast<const f32x4*>(slabs + k * stride + v * C + c);
+        *reinterpret_cast<f32x4*>(dx + v * lddx + c) = s;
+    }
 }
 
 }  // namespace
@@ -455,7 +475,23 @@ bool convt_direct_supported(int elem_bytes, bool gather, int N, int D, int H, in
     return nvox < (1ll << 31) - 4096 && 8ll * H * W * (ld_fine > ld_coarse ? ld_fine : ld_coarse) < (1ll << 31) && nvox / 64 * (p.Nc / p.BN) < (1ll << 31) - 65536;
 }
 
+// K-splits of the GEMM-form input gradient on fp32 tensors: few tiles (the deep levels) and a long K
+static int ct_ksplit(bool gather, int elem_bytes, const CtPlan& p, long long nvox) {
+    if (!gather || elem_bytes != 4 || p.stream) return 1;
+    const long long tiles = ((nvox + (p.BN == 128 ? 63 : 127)) / (p.BN == 128 ? 64 : 128)) * (p.Nc / p.BN);
+    const int nchunk = p.K / 64;
+    int ks = 1;
+    while (tiles * ks < 512 && ks < 8 && nchunk % (ks * 2) == 0 && nchunk / (ks * 2) >= 2) ks *= 2;
+    return ks;
+}
 size_t convt_direct_ws_bytes(int Cin, int Cout) { return align_up((size_t)8 * Cin * Cout * 6, 256); }
+// (+ the split-K slabs of the deep levels' input gradient: at most 8 x 512 tiles' worth of fp32 results)
+size_t convt_direct_slab_bytes(long long nvox, int Cin, int Cout) {
+    CtPlan p;
+    if (!ct_plan(4, true, nvox, Cin, Cout, &p)) return 0;
+    const int ks = ct_ksplit(true, 4, p, nvox);
+    return ks > 1 ? align_up((size_t)ks * nvox * Cin * sizeof(float), 256) : 0;
+}
 
 template <typename TT, bool GATHER>
 static void launch_any(const CtPlan& p, const CtArgs& a, hipStream_t st) {
@@ -489,11 +525,24 @@ int convt_direct(bool gather, const TT* x, int ldx, const float* w, const float*
     const long long slots = (long long)p.K * p.Nc / 8;
     hipLaunchKernelGGL(convt_pack_planes_kernel<NP>, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, w, wq, Cin, Cout, gather ? 1 : 0, p.BN, p.K, p.Nc);
     SEG_CHECK_LAUNCH();
-    CtArgs a{x, wq, gather ? nullptr : bias, y, ldx, ldy, D, H, W, Cout, (long long)N * D * H * W, p.K / 64, p.Nc / p.BN, gather ? nullptr : reinterpret_cast<unsigned*>(y_amax)};
+    CtArgs a{x, wq, gather ? nullptr : bias, y, ldx, ldy, D, H, W, Cout, (long long)N * D * H * W, p.K / 64, p.Nc / p.BN, gather ? nullptr : reinterpret_cast<unsigned*>(y_amax),
+             1, p.K / 64, 0};
     const double vox = (double)a.nvox;
     ProfScope ps(PF_CONVT, 2.0 * vox * 8 * Cin * Cout, sizeof(TT) * vox * (Cin + 8.0 * Cout) + 4.0 * 8 * Cin * Cout, st);
+    const int ks = ct_ksplit(gather, (int)sizeof(TT), p, a.nvox);
+    float* slabs = nullptr;
+    if (ks > 1) {
+        slabs = cv.take<float>((size_t)ks * a.nvox * Cin);
+        if (cv.used() <= ws_bytes) { a.ksplit = ks; a.cps = a.nchunk / ks; a.slab_stride = a.nvox * Cin; a.y = slabs; a.ldy = Cin; }     // (no room: unsplit)
+    }
     if (gather) launch_any<TT, true>(p, a, st); else launch_any<TT, false>(p, a, st);
     SEG_CHECK_LAUNCH();
+    if (a.ksplit > 1) {
+        const long long tot = a.nvox * (Cin / 4);
+        hipLaunchKernelGGL(convt_splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256 > 2048 ? 2048 : (tot + 255) / 256)), dim3(256), 0, st, slabs, a.ksplit, a.slab_stride,
+                           reinterpret_cast<float*>(y), ldy, a.nvox, Cin);
+        SEG_CHECK_LAUNCH();
+    }
     return MI355SEG_OK;
 }
 

@@ -151,6 +151,7 @@ template <typename T> int conv_gwgrad(const T* dy, int lddy, const T* x, int ldx
 // cores (fp32 tensors: bf16x6 planes); coarse = the low-resolution tensor, fine = the 2x one
 bool convt_direct_supported(int elem_bytes, bool gather, int N, int D, int H, int W, int Cin, int Cout, int ld_coarse, int ld_fine);
 size_t convt_direct_ws_bytes(int Cin, int Cout);
+size_t convt_direct_slab_bytes(long long nvox, int Cin, int Cout);      // split-K slabs of the GEMM-form input gradient (fp32, deep levels), 0 when unsplit
 template <typename TT> int convt_direct(bool gather, const TT* x, int ldx, const float* w, const float* bias, TT* y, int ldy, int N, int D, int H, int W,
                                         int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t st, float* y_amax = nullptr);
 // convt_wgrad_lowp.hip: ConvTranspose3d k2 s2 weight gradient on the bf16 matrix cores (fp32 tensors: bf16x6 planes)
