@@ -55,14 +55,17 @@ __device__ __forceinline__ float row16_sum_b(float v) {
     return v;
 }
 
+#ifndef B16S_K3_OCC
+#define B16S_K3_OCC 2
+#endif
 template <int KS, int WMG>
-__global__ __launch_bounds__(256, 2) void conv_b16s_kernel(IgemmArgs a) {
+__global__ __launch_bounds__(256, KS == 3 ? B16S_K3_OCC : 2) void conv_b16s_kernel(IgemmArgs a) {
     using G = SGeo<KS, WMG>;
     constexpr int NT = G::NT, WNG = G::WNG, NSTEP = G::NSTEP, PS = G::PS;
     constexpr int UNIT = (NT / 16) * 512;                        // bf16 elements of one K-step of packed weights: [tile][lane][8]
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int wm = wave / WNG, wn = wave % WNG;
 
@@ -98,17 +101,9 @@ __global__ __launch_bounds__(256, 2) void conv_b16s_kernel(IgemmArgs a) {
     const bf16* __restrict__ xin = reinterpret_cast<const bf16*>(a.x);
 
     // ---- halo staging: buffer loads at per-tile offsets (zero fill by the range check) -> registers -> LDS
+    // (r6: formed incrementally -- additions and selects, no per-piece divisions or multiplies: halo_piece_offsets, igemm_kernel.h)
     int voff[G::NITER];
-#pragma unroll
-    for (int it = 0; it < G::NITER; ++it) {
-        const int p = it * 256 + tid;
-        const int vox = p >> 1, part = p & 1;
-        const int hz = vox / (G::HY * G::HX), rem = vox % (G::HY * G::HX);
-        const int hy = rem / G::HX, hx = rem % G::HX;
-        const int gz = z0 - G::HALO + hz, gy = y0 - G::HALO + hy, gx = x0 - G::HALO + hx;
-        const bool ok = (p < G::NPIECE) && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        voff[it] = ok ? (((gz * a.H + gy) * a.W + gx) * a.ldx + part * 8) * 2 : 0x7FFFFFF0;
-    }
+    halo_piece_offsets<G::NITER, G::NPIECE, 2, G::HX, G::HY, G::HZ>(voff, tid, x0 - G::HALO, y0 - G::HALO, z0 - G::HALO, a.D, a.H, a.W, a.ldx * 2);
     const bf16* xsample = xin + (long long)n * a.D * a.H * a.W * a.ldx;
     const int sample_bytes = a.D * a.H * a.W * a.ldx * 2;        // < 2^31: checked on the host
     bf16x8_t stage[G::NITER];
@@ -202,27 +197,44 @@ __global__ __launch_bounds__(256, 2) void conv_b16s_kernel(IgemmArgs a) {
     float ssum[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) ssum[c] = 0.f;
+    // r6: a line's address = this lane's voxel of the tile's first line + a wave-uniform line offset (line0 is wave-uniform: scalar
+    // arithmetic instead of three 64-bit vector multiplies per line), and the residual's eight fragments are requested up front,
+    // unconditionally at clamped coordinates -- under the per-line `if (inside)` each was a load -> s_waitcnt vmcnt(0) -> store round
+    // trip that also waited for the previous line's store (the conv_x3s epilogue's r5 finding)
+    const long long tile_row = (((long long)n * a.D + z0) * a.H + y0) * a.W;
+    const long long ylane = (tile_row + gx) * a.ldy + cbase;
+    bf16x8_t rs[SRV] = {};
+    if (a.res && !slab) {
+        const bf16* rlane = reinterpret_cast<const bf16*>(a.res) + (long long)min(gx, a.W - 1) * a.ldres + cbase;
+#pragma unroll
+        for (int j = 0; j < SRV; ++j) {
+            const int line = line0 + j;
+            const int cz = min(z0 + line / STY, a.D - 1), cy = min(y0 + line % STY, a.H - 1);
+            rs[j] = *reinterpret_cast<const bf16x8_t*>(rlane + (((long long)n * a.D + cz) * a.H + cy) * a.W * a.ldres);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < SRV; ++j) {
         const int line = line0 + j;
         const int gz = z0 + line / STY, gy = y0 + line % STY;
-        if (gz < a.D && gy < a.H && gx < a.W) {
-            const long long off = ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.ldy + cbase;
-            if (slab) {                                          // bias and statistics belong to the reduce pass
+        const bool inside = gz < a.D && gy < a.H && gx < a.W;
+        const long long off = ylane + (long long)(((line / STY) * a.H + line % STY) * a.W) * a.ldy;
+        if (slab) {                                              // bias and statistics belong to the reduce pass
+            if (inside) {
                 *reinterpret_cast<f32x4*>(yslab + off) = acc[j][0];
                 *reinterpret_cast<f32x4*>(yslab + off + 4) = acc[j][1];
-            } else {
-                bf16x8_t o, rs = {};
-                if (a.res) rs = *reinterpret_cast<const bf16x8_t*>(reinterpret_cast<const bf16*>(a.res) + ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.ldres + cbase);
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    float v = acc[j][c >> 2][c & 3] + bv[c];
-                    if (a.act) v = act_apply(v, a.act, a.slope);
-                    if (a.res) v = (float)(bf16)v + (float)rs[c];       // the convolution's own bf16 rounding, then the sum's
-                    o[c] = (bf16)v; ssum[c] += v;
-                }
-                *reinterpret_cast<bf16x8_t*>(yout + off) = o;
             }
+        } else {
+            bf16x8_t o;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float v = acc[j][c >> 2][c & 3] + bv[c];
+                if (a.act) v = act_apply(v, a.act, a.slope);
+                if (a.res) v = (float)(bf16)v + (float)rs[j][c];       // the convolution's own bf16 rounding, then the sum's
+                o[c] = (bf16)v;
+                if (inside) ssum[c] += v;
+            }
+            if (inside) *reinterpret_cast<bf16x8_t*>(yout + off) = o;
         }
     }
     if (a.spart) {

@@ -355,6 +355,13 @@ __global__ __launch_bounds__(256) void stem1_wgrad_kernel(const T* __restrict__ 
 // xhat s2 / n) has ONE consumer, this weight gradient.  It is formed here from d(activation) and the pre-norm tensor (norm_act_bwd_apply_kernel's
 // expression, operation for operation) instead of being written (537 MB at 2 x 128^3) and read back; its column sums (conv1's bias gradient)
 // come out of the same pass.  part[blk][tap][co] as stem1_wgrad_kernel, cpart[blk][co].
+// floats ahead of the constant table: the staged halo tile and the end-of-kernel reduction scratch share this region, so it holds the larger
+// of the two (for Cout <= 8 the tile -- 130 or 258 voxels wide -- is the larger one)
+__host__ __device__ static inline int stem_bn_scratch_floats(int Cout) {
+    const int TX = 256 / (Cout / 4);
+    const int tile = (TX + 2) * (S1_TY + 2) * (S1_TZ + 2), red = 4 * 28 * Cout;
+    return ((tile > red ? tile : red) + 3) & ~3;
+}
 struct StemBn { const float* da; int ldda; const float* y; int ldy; const float* mean; const float* rstd; const float* gamma; const float* beta;
                 const float* s1; const float* s2; int act; float slope; float invM; };
 
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void stem1_wgrad_bn_kernel(const float* __r
     const int cq = threadIdx.x % LPV, xs = threadIdx.x / LPV;
     // per-channel constants in LDS behind the reduction scratch (six quads per thread and tile, live only while d is formed: held in
     // registers across the 27-tap loop they spill)
-    float* const ctab = sm + 4 * 28 * Cout;
+    float* const ctab = sm + stem_bn_scratch_floats(Cout);
     float* const dtab = ctab + 6 * Cout;              // [8 lines][256 threads] quads of d(conv output)
     for (int c = threadIdx.x; c < Cout; c += 256) {
         ctab[c] = b.mean[c]; ctab[Cout + c] = b.rstd[c]; ctab[2 * Cout + c] = b.gamma ? b.gamma[c] : 1.f; ctab[3 * Cout + c] = b.beta ? b.beta[c] : 0.f;
@@ -603,7 +610,7 @@ static size_t stem1_lds(int Cout) {
 bool stem_wgrad_bn_supported(int N, int D, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
     if (!(k == 3 && stride == 1 && pad == 1 && Cin == 1 && Cout % 4 == 0 && Cout >= 4 && Cout <= 64 && ((Cout / 4) & (Cout / 4 - 1)) == 0)) return false;
     SmallGeom g{N, D, H, W, Cin, Cout, 1, Cout};
-    return stem1_tiled_ok(g) && (size_t)4 * 28 * Cout * 4 <= 64 * 1024;
+    return stem1_tiled_ok(g) && ((size_t)stem_bn_scratch_floats(Cout) + 6 * Cout) * 4 + (size_t)S1_TZ * S1_TY * 256 * 16 <= 80 * 1024;
 }
 
 int stem_wgrad_bn(const float* da, int ldda, const float* y, int ldy, const float* mean, const float* rstd, const float* gamma, const float* beta,
@@ -618,9 +625,7 @@ int stem_wgrad_bn(const float* da, int ldda, const float* y, int ldy, const floa
     float* cpart = cv.take<float>((size_t)nb * Cout);
     SEG_CHECK_WS(cv.used(), ws_bytes);
     StemBn b{da, ldda, y, ldy, mean, rstd, gamma, beta, s1, s2, act, slope, 1.f / (float)nvox};
-    size_t lds = stem1_lds(Cout);
-    if (lds < (size_t)4 * 28 * Cout * 4) lds = (size_t)4 * 28 * Cout * 4;
-    lds = (size_t)4 * 28 * Cout * 4 + (size_t)6 * Cout * 4 + (size_t)S1_TZ * S1_TY * 256 * 16;       // reduction scratch | constants | parked d (32 KB)
+    const size_t lds = ((size_t)stem_bn_scratch_floats(Cout) + 6 * Cout) * 4 + (size_t)S1_TZ * S1_TY * 256 * 16;   // tile / reduction scratch | constants | parked d (32 KB)
     {
         ProfScope ps(PF_DIRECT, 2.0 * nvox * 27.0 * Cout, 4.0 * nvox * (1 + 2.0 * Cout), st);
         hipLaunchKernelGGL(stem1_wgrad_bn_kernel, dim3(nb), dim3(256), lds, st, x, b, part, cpart, g, ntiles);

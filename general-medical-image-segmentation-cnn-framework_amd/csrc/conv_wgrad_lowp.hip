@@ -776,6 +776,14 @@ size_t wgrad_lowp_ws_bytes_geom(int N, int D, int H, int W, int Cin, int Cout, i
             if (need > best) best = need;
         }
     }
+    // the swapped-role wide form (conv_wgrad_lowp: Cin % 64 == 0, Cout % 64 != 0) plans its strips with the channel counts exchanged
+    if (k == 3 && stride == 1 && Cin % 64 == 0 && Cout % 64 != 0) {
+        LWgradPlan p;
+        if (lwgrad_plan(MATH_X3, k, stride, N, lw_out(D, k, stride, pad), lw_out(H, k, stride, pad), lw_out(W, k, stride, pad), Cout, Cin, &p, true)) {
+            const size_t need = align_up((size_t)p.nstrips * p.taps * Cin * Cout * sizeof(float), 256) + 1024;
+            if (need > best) best = need;
+        }
+    }
     return best;
 }
 
@@ -785,6 +793,13 @@ size_t wgrad_lowp_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int k)
         for (bool wide : {false, true}) {
             LWgradPlan p;
             if (!lwgrad_plan(math, k, 1, N, D, H, W, Cin, Cout, &p, wide)) continue;
+            const size_t need = align_up((size_t)p.nstrips * p.taps * Cin * Cout * sizeof(float), 256) + 1024;
+            if (need > best) best = need;
+        }
+    }
+    if (k == 3 && Cin % 64 == 0 && Cout % 64 != 0) {              // the swapped-role wide form
+        LWgradPlan p;
+        if (lwgrad_plan(MATH_X3, k, 1, N, D, H, W, Cout, Cin, &p, true)) {
             const size_t need = align_up((size_t)p.nstrips * p.taps * Cin * Cout * sizeof(float), 256) + 1024;
             if (need > best) best = need;
         }

@@ -47,6 +47,9 @@ namespace {
 #ifndef X3S_HALO_AUX
 #define X3S_HALO_AUX 0          // cache policy of the halo loads (A/B knob: 2 = nt, 16 = sc1)
 #endif
+#ifndef X3S_BNX_EARLY
+#define X3S_BNX_EARLY 1
+#endif
 constexpr int XBX = 16, XTY = 4, XHX = XBX + 2, XHY = XTY + 2;
 constexpr int X3S_PRO_MAX_CIN = 512;             // the prologue table (8 bytes per input channel) must fit beside two halo tiles per CU
 
@@ -60,6 +63,7 @@ struct Geo {
     static constexpr int NPIECE = NVOX * 4;                     // staged 16-byte pieces (4 fp32 channels) per chunk
     static constexpr int NITER = (NPIECE + 255) / 256;
 };
+
 
 __device__ __forceinline__ constexpr int tap_slot(int t) { return ((t / 9) * XHY + (t / 3) % 3) * XHX + t % 3; }
 // which per-lane base a K-step uses: the second tap of the pair is +1 slot (x), +HX (y), +HY*HX (z) or the same voxel (zero weights)
@@ -101,17 +105,21 @@ __device__ __forceinline__ void x3_epilogue(const IgemmArgs& a, f32x4 (&acc)[LW]
     constexpr int NG = (LW + LH - 1) / LH;
     constexpr bool DB = NG > 1 && NTW <= 2;          // (the 64-channel-per-wave forms have no registers for a second group)
     f32x4 bxv[DB ? 2 : 1][LH][NTW];
+    const int bnx_lane = min(gx, a.W - 1) * a.ldbnx + n0 + 4 * g;
     auto load_bnx = [&](int j0, int buf) {
 #pragma unroll
         for (int j = 0; j < LH; ++j) {
             const int line = line0 + min(j0 + j, LW - 1);
-            const int cz = min(z0 + line / XTY, a.D - 1), cy = min(y0 + line % XTY, a.H - 1), cx = min(gx, a.W - 1);
-            const float* src = a.bnx + ((((long long)n * a.D + cz) * a.H + cy) * a.W + cx) * a.ldbnx + n0 + 4 * g;
+            const int cz = min(z0 + line / XTY, a.D - 1), cy = min(y0 + line % XTY, a.H - 1);
+            // (line0 is wave-uniform: the row's first voxel is scalar arithmetic, the lane adds its clamped x)
+            const float* src = a.bnx + (((long long)n * a.D + cz) * a.H + cy) * a.W * a.ldbnx + bnx_lane;
 #pragma unroll
             for (int t = 0; t < NTW; ++t) bxv[buf][j][t] = *reinterpret_cast<const f32x4*>(src + 16 * t);
         }
     };
-    if (a.bnpart) load_bnx(0, 0);
+    // (r6) BOTH buffers are requested ahead of the stores: vmcnt retires in order, so a group requested behind the tile's sixteen stores per
+    // lane is only reduced once every one of those stores has been acknowledged
+    if (a.bnpart) { load_bnx(0, 0); if (DB && X3S_BNX_EARLY) load_bnx(LH, 1); }
     if (scale_exp != 0) {
 #pragma unroll
         for (int j = 0; j < LW; ++j)
@@ -121,6 +129,7 @@ __device__ __forceinline__ void x3_epilogue(const IgemmArgs& a, f32x4 (&acc)[LW]
                 for (int e = 0; e < 4; ++e) acc[j][t][e] = __builtin_ldexpf(acc[j][t][e], scale_exp);
     }
     float* yslab = reinterpret_cast<float*>(a.y) + (long long)ks * a.split_stride;     // ksplit > 1: raw partial sums of this split (split_stride 0 otherwise)
+    float* const ylane = yslab + ((((long long)n * a.D + z0) * a.H + y0) * a.W + gx) * a.ldy + n0 + 4 * g;      // line 0 of the TILE, this lane's voxel and channels
     float ssum[NTW][4];
 #pragma unroll
     for (int t = 0; t < NTW; ++t)
@@ -135,7 +144,7 @@ __device__ __forceinline__ void x3_epilogue(const IgemmArgs& a, f32x4 (&acc)[LW]
         const int line = line0 + j;
         const int gz = z0 + line / XTY, gy = y0 + line % XTY;
         const bool inside = gz < a.D && gy < a.H && gx < a.W;
-        float* dst = yslab + ((((long long)n * a.D + gz) * a.H + gy) * a.W + gx) * a.ldy + n0 + 4 * g;
+        float* dst = ylane + (long long)(((line / XTY) * a.H + line % XTY) * a.W) * a.ldy;     // (wave-uniform offset of the line)
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
             f32x4 v = acc[j][t] + bv[t];
@@ -182,9 +191,10 @@ __device__ __forceinline__ void x3_epilogue(const IgemmArgs& a, f32x4 (&acc)[LW]
         auto any_grad = [&](float z) { return act_grad(z, bact, bslope); };
 #pragma unroll
         for (int k = 0; k < NG; ++k) {
-            if (DB && k + 1 < NG) load_bnx((k + 1) * LH, (k + 1) & 1);
+            if (DB && !X3S_BNX_EARLY && k + 1 < NG) load_bnx((k + 1) * LH, (k + 1) & 1);
             if (!DB && k > 0) load_bnx(k * LH, 0);
             if (bact == MI355SEG_ACT_RELU) reduce(k * LH, DB ? (k & 1) : 0, relu_grad); else reduce(k * LH, DB ? (k & 1) : 0, any_grad);
+            if (DB && X3S_BNX_EARLY && k + 2 < NG) load_bnx((k + 2) * LH, k & 1);
         }
         float* lds = reinterpret_cast<float*>(lds_raw);
         __syncthreads();                 // LDS halo no longer needed
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
     constexpr int PS = G::PS;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
 
     // ---- block -> tile map: identical to conv_igemm_kernel (XCD-contiguous ranges, (y, z) bricks of M-tiles)
@@ -336,17 +346,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
     // same for every chunk, so it is computed once per tile; the loads are buffer loads on a per-chunk descriptor
     // (base = sample + 16 * chunk channels) whose range check returns zeros for the pieces outside the volume (offset
     // 0x7FFFFFF0 >= num_records): no address arithmetic and no select in the K loop.
+    // (r6: formed incrementally -- additions and selects, no per-piece divisions or multiplies: halo_piece_offsets, igemm_kernel.h)
     int voff[G::NITER];
-#pragma unroll
-    for (int it = 0; it < G::NITER; ++it) {
-        const int p = it * 256 + tid;
-        const int vox = p >> 2, part = p & 3;
-        const int hz = vox / (XHY * XHX), rem = vox % (XHY * XHX);
-        const int hy = rem / XHX, hx = rem % XHX;
-        const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-        const bool ok = (p < G::NPIECE) && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        voff[it] = ok ? (((gz * a.H + gy) * a.W + gx) * a.ldx + part * 4) * 4 : 0x7FFFFFF0;
-    }
+    halo_piece_offsets<G::NITER, G::NPIECE, 4, XHX, XHY, G::HZ>(voff, tid, x0 - 1, y0 - 1, z0 - 1, a.D, a.H, a.W, a.ldx * 4);
     const float* xsample = xin + (long long)n * a.D * a.H * a.W * a.ldx;
     const int sample_bytes = a.D * a.H * a.W * a.ldx * 4;        // < 2^31: checked on the host (x3s_plan_ok)
     f32x4 stage[G::NITER];

@@ -657,6 +657,47 @@ inline int pick_ksplit(int tiles, int nchunks) {
 }
 
 // conv_x3s.hip: the bf16x6 k3 kernel on v_mfma_f32_16x16x32_bf16 (fp32 tensors, BX = 16 tiles of the plan above).
+// ---- per-tile byte offsets of a thread's halo pieces, formed incrementally (r6; conv_x3s.hip, conv_b16s.hip).
+// Piece p = it * 256 + tid is (halo voxel p / PPV, 16-byte part p % PPV) of a HZ x HY x HX halo box; consecutive pieces of a thread are
+// STEP = 256 / PPV halo voxels apart = (DZ planes + DY rows + DX voxels), so (hx, hy, hz) and the byte offset advance by constants with two
+// carries -- additions and selects only.  The direct form (two divisions by constants and a three-level multiply per piece) compiled to
+// 34 v_mad_u64_u32 + 17 v_mul_lo_u32 + 80 16-/24-bit multiplies per thread ahead of the tile's first load: ~1.2 us of a 17-us tile.
+// voff[it] = byte offset inside the sample (bytes_x per voxel step), or 0x7FFFFFF0 (past the descriptor's range: reads as zeros) for a
+// piece outside the volume / past the tile's last piece.  (ox, oy, oz) = the box's first voxel, may be -HALO.
+template <int NITER, int NPIECE, int PPV, int HX, int HY, int HZ>
+__device__ __forceinline__ void halo_piece_offsets(int (&voff)[NITER], int tid, int ox, int oy, int oz, int D, int H, int W, int bytes_x) {
+    constexpr int STEP = 256 / PPV, DZ = STEP / (HY * HX), DY = (STEP % (HY * HX)) / HX, DX = STEP % HX;
+    static_assert(256 % PPV == 0 && STEP < 2 * HY * HX, "piece walk: one carry per axis");
+    const int sx = bytes_x, sy = W * sx, sz = H * sy;                             // wave-uniform
+    const int c1 = DX * sx + DY * sy + DZ * sz, c2 = sy - HX * sx, c3 = sz - HY * sy;
+    // valid halo coordinates of this tile: [l, l + n) per axis (wave-uniform)
+    const int lz = oz < 0 ? -oz : 0, ly = oy < 0 ? -oy : 0, lx = ox < 0 ? -ox : 0;
+    const unsigned nz = (unsigned)(min(HZ, D - oz) - lz), ny = (unsigned)(min(HY, H - oy) - ly), nx = (unsigned)(min(HX, W - ox) - lx);
+    const int v0 = tid / PPV;                                                    // < 256 / PPV <= HY * HX * 2
+    int hz = v0 / (HY * HX);
+    const int rem = v0 - hz * (HY * HX);
+    int hy = rem / HX, hx = rem - hy * HX;
+    int off = ((oz * H + oy) * W + ox) * sx + hz * sz + hy * sy + hx * sx + (tid % PPV) * 16;
+    auto walk = [&](auto BORDER) {
+#pragma unroll
+        for (int it = 0; it < NITER; ++it) {
+            bool ok = true;
+            if constexpr (decltype(BORDER)::value) ok = (unsigned)(hz - lz) < nz && (unsigned)(hy - ly) < ny && (unsigned)(hx - lx) < nx;
+            if ((it + 1) * 256 > NPIECE) ok = ok && (it * 256 + tid < NPIECE);
+            voff[it] = ok ? off : 0x7FFFFFF0;
+            hx += DX; off += c1;
+            const bool cx = hx >= HX;
+            hx -= cx ? HX : 0; hy += cx ? DY + 1 : DY; off += cx ? c2 : 0;
+            const bool cy = hy >= HY;
+            hy -= cy ? HY : 0; off += cy ? c3 : 0;
+            if constexpr (decltype(BORDER)::value) hz += cy ? DZ + 1 : DZ;
+        }
+    };
+    // (wave-uniform) the whole halo box lies inside the volume: no piece of this tile is zero-filled, no bounds to test
+    if (ox >= 0 && oy >= 0 && oz >= 0 && ox + HX <= W && oy + HY <= H && oz + HZ <= D) walk(std::false_type{});
+    else walk(std::true_type{});
+}
+
 // K-step s of a 16-channel chunk contracts the tap pair (x3s_pair_tap(s, 0), x3s_pair_tap(s, 1)); tap 27 = zero weights.
 constexpr int X3S_NPAIR = 14;
 __host__ __device__ constexpr int x3s_pair_tap(int s, int which) {

@@ -1961,6 +1961,9 @@ class _MaskPool(threading.local):
 
 
 _MASKS = _MaskPool()
+# (values, device) -> the tensor of ones the pooled draw reads.  Entries are never dropped: a captured GraphedTrainStep has the buffer's
+# address baked into its dropout node, so freeing it on a later request of another size (another model or patch shape in the same process)
+# would let replays draw their masks from recycled memory.  One float per mask value and distinct size: a few MB per model.
 _POOL_ONES = {}
 
 
@@ -1971,8 +1974,7 @@ def dropout_pool_begin_step():
         if need > 0 and not os.environ.get("MI355SEG_NO_MASK_POOL"):
             ones = _POOL_ONES.get((need, dev))
             if ones is None:
-                _POOL_ONES.clear()
-                ones = _POOL_ONES[(need, dev)] = torch.ones(need, device=dev)
+                ones = _POOL_ONES.setdefault((need, dev), torch.ones(need, device=dev))
             st[0] = torch.nn.functional.dropout(ones, p, True)       # keep / (1 - p), one launch for the whole step
 
 

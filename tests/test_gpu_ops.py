@@ -998,7 +998,8 @@ def test_double_conv_with_norm_prologue_matches_the_unfused_block(seg, shape, ch
         assert (a - b).abs().max() < 1e-6 * max(1.0, sc(b))
 
 
-@pytest.mark.parametrize("shape,C,act", [((2, 8, 8, 32), 32, "relu"), ((1, 4, 8, 64), 16, "relu"), ((1, 6, 12, 32), 32, "lrelu"), ((2, 16, 16, 64), 32, "relu")])
+@pytest.mark.parametrize("shape,C,act", [((2, 8, 8, 32), 32, "relu"), ((1, 4, 8, 64), 16, "relu"), ((1, 6, 12, 32), 32, "lrelu"), ((2, 16, 16, 64), 32, "relu"),
+                                         ((1, 4, 8, 128), 8, "relu"), ((1, 2, 8, 256), 4, "relu"), ((1, 4, 4, 16), 64, "lrelu")])
 def test_stem_weight_gradient_with_norm_backward_prologue(seg, shape, C, act):
     """r5, mi355seg_stem_wgrad_bnbwd_f32: the 1-channel stem's weight + bias gradient formed straight from d(activation) and the pre-norm tensor
     (the norm backward's apply half inside the kernel; /root/reference/models/three_d/unet3d.py:80-89) against the library's own two-step chain
