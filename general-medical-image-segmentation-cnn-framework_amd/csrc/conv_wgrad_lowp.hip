@@ -222,8 +222,13 @@ __global__ __launch_bounds__(LW_THREADS, 2) void conv_wgrad_lowp_kernel(LWgradAr
         if constexpr (EPP == 4) {
             if constexpr (NP == 2) {                  // two fp16 planes h | l of the scaled voxel row
                 f16x4_t qh, ql;
+                if (LW_DBG(a, 256)) {                 // timing probe: the operand arrives already split -- staging is a copy
+                    using f32x2p = __attribute__((ext_vector_type(2))) float;
+                    qh = __builtin_bit_cast(f16x4_t, f32x2p{v[0], v[1]}); ql = __builtin_bit_cast(f16x4_t, f32x2p{v[2], v[3]});
+                } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { _Float16 bh, bl; split2h(v[e] * scale, bh, bl); qh[e] = bh; ql[e] = bl; }
+                }
                 *reinterpret_cast<f16x4_t*>(dst) = qh;
                 *reinterpret_cast<f16x4_t*>(dst + 64) = ql;
             } else if constexpr (NP == 3) {                  // split once per staged value: planes h | m | l of the voxel row
@@ -569,6 +574,11 @@ __global__ __launch_bounds__(FW_THREADS, 1) void conv_wgrad_wide_kernel(LWgradAr
             f32x4 v;
             if (j < XITER) v = stx[j]; else v = std_[j - XITER];
             if (j < XITER && pro) { v = pro_x(j, v); sc = 1.f; }
+            if (LW_DBG(a, 256) && !(j < XITER && pro)) {      // timing probe: the operand arrives already split -- staging is a copy
+                using f32x2p = __attribute__((ext_vector_type(2))) float;
+                cvh[j] = __builtin_bit_cast(f16x4_t, f32x2p{v[0], v[1]}); cvl[j] = __builtin_bit_cast(f16x4_t, f32x2p{v[2], v[3]});
+                return;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) { _Float16 bh, bl; split2h(v[e] * sc, bh, bl); cvh[j][e] = bh; cvl[j][e] = bl; }
         }
@@ -879,6 +889,9 @@ int conv_wgrad_lowp(int math, const void* dy, int lddy, const void* x, int ldx, 
             SEG_CHECK_LAUNCH();
         }
         a.amax_x = dy_amax; a.amax_dy = x_amax;                    // (roles swapped)
+#ifdef MI355SEG_TUNE
+        { static const char* e = getenv("MI355SEG_DBG"); a.dbg = e ? atoi(e) : 0; }
+#endif
         const int nwg = psw.nstrips * psw.npairs * psw.planes;
         const double vox = (double)N * Do * Ho * Wo;
         {

@@ -47,6 +47,9 @@ namespace {
 #ifndef X3S_HALO_AUX
 #define X3S_HALO_AUX 0          // cache policy of the halo loads (A/B knob: 2 = nt, 16 = sc1)
 #endif
+#ifndef X3S_SPLIT_MIX
+#define X3S_SPLIT_MIX 0          // 1: h / l of the scaled split as one v_fma_mix{lo,hi}_f16 each (10 instead of 12 VALU per staged quad; measured 0.99x: kept off)
+#endif
 #ifndef X3S_BNX_EARLY
 #define X3S_BNX_EARLY 1
 #endif
@@ -374,6 +377,16 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
         l2 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{q0, q1}, bf16x2_t));
     };
     // f16x3: v 2^s = h + l, two packed conversions; the remainder is one v_fma_mix per value (f16 operand read in place)
+    // (r6) scaled form: h = fp16(x sc) and l = fp16(x sc - h) are ONE v_fma_mix{lo,hi}_f16 each (the product with the power of two is exact, the
+    // difference is exact in fp32: the same bits as scale -> convert -> subtract -> convert), four VALU per pair instead of six and no packing
+#if X3S_SPLIT_MIX
+    auto split_pair_h = [&](float x0_, float x1_, unsigned& h2, unsigned& l2, float sc) {
+        f16x2_t hh, ll;
+        hh[0] = (_Float16)__builtin_fmaf(x0_, sc, 0.f); hh[1] = (_Float16)__builtin_fmaf(x1_, sc, 0.f);
+        ll[0] = (_Float16)__builtin_fmaf(x0_, sc, -(float)hh[0]); ll[1] = (_Float16)__builtin_fmaf(x1_, sc, -(float)hh[1]);
+        h2 = __builtin_bit_cast(unsigned, hh); l2 = __builtin_bit_cast(unsigned, ll);
+    };
+#else
     auto split_pair_h = [&](float x0_, float x1_, unsigned& h2, unsigned& l2, float sc) {
         const float s0 = x0_ * sc, s1 = x1_ * sc;
         const f16x2_t hh = __builtin_convertvector(f32x2_t{s0, s1}, f16x2_t);
@@ -381,6 +394,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
         const float r0 = __builtin_fmaf((float)hh[0], -1.f, s0), r1 = __builtin_fmaf((float)hh[1], -1.f, s1);
         l2 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r0, r1}, f16x2_t));
     };
+#endif
     // piece p = it * 256 + tid sits at LDS byte  ((part >> 1) * PS + tid / 4) * 16 + (part & 1) * 8  +  it * 1024
     unsigned char* const wdst = lds_raw + (((tid & 3) >> 1) * PS + (tid >> 2)) * 16 + (tid & 1) * 8;
     // PRO: the norm + activation prologue on the staged values (this thread's four channels of the chunk: part = tid & 3 for every
@@ -409,6 +423,11 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
                         if constexpr (decltype(MASK)::value) { if (voff[it] == 0x7FFFFFF0) v = f32x4{0.f, 0.f, 0.f, 0.f}; }
                         split_pair_h(v[0], v[1], h0, l0, 1.f);
                         split_pair_h(v[2], v[3], h1, l1, 1.f);
+                    } else if (SEG_DBG(a, 256)) {
+                        // timing probe: the operand arrives ALREADY split (a piece = four fp16 h | four fp16 l): staging is a copy
+                        using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+                        const u32x4 u = __builtin_bit_cast(u32x4, stage[it]);
+                        h0 = u[0]; h1 = u[1]; l0 = u[2]; l1 = u[3];
                     } else {
                         split_pair_h(stage[it][0], stage[it][1], h0, l0, xscale);
                         split_pair_h(stage[it][2], stage[it][3], h1, l1, xscale);

@@ -1020,6 +1020,9 @@ class _DoubleConvBnAct(Function):
                               pro1[0] if fuse1 else None, pro1[1] if fuse1 else None)
         ctx.cfg = (cfg1, cfg2, act, slope)
         ctx.amax = (am1, am2)
+        # the prologue form exists under one conv math only: its backward must meet the policy the forward chose (a set_conv_math between
+        # the two would otherwise make the weight gradient's entry point refuse -- the activation it would need was never written)
+        ctx.math = L.query("mi355seg_get_conv_math") if fuse1 else None
         ctx.head_bias = head is not None and bh is not None
         if pool:                             # max |max_pool(a)| <= max |a| (equal for the non-negative outputs of a ReLU)
             return _set_amax(pd, am2[2]), _set_amax(a2, am2[2])
@@ -1084,8 +1087,15 @@ class _DoubleConvBnAct(Function):
                _p(dya2), _p(wa2), _p(ws), ws.numel(), _stream())
         dw2 = torch.empty_like(w2)
         if al1 is not None:                  # conv2 read conv1's raw output through the norm + activation prologue: so does its weight gradient
-            L.call("mi355seg_conv3d_wgrad_pro_ax_f32", _p(dy2), C2, _p(y1), C1, _p(al1), _p(bl1), act, slope, _p(dw2), None,
-                   N, D2, H2, W2, C1, C2, k2, st2, pd2, 0, _p(dya2), _p(xa2), _p(ws), ws.numel(), _stream())
+            now = L.query("mi355seg_get_conv_math")
+            if now != ctx.math:
+                L.call("mi355seg_set_conv_math", ctx.math)
+            try:
+                L.call("mi355seg_conv3d_wgrad_pro_ax_f32", _p(dy2), C2, _p(y1), C1, _p(al1), _p(bl1), act, slope, _p(dw2), None,
+                       N, D2, H2, W2, C1, C2, k2, st2, pd2, 0, _p(dya2), _p(xa2), _p(ws), ws.numel(), _stream())
+            finally:
+                if now != ctx.math:
+                    L.call("mi355seg_set_conv_math", now)
         else:
             L.call("mi355seg_conv3d_wgrad_ax_f32", _p(dy2), C2, _p(a1), lda1, _p(dw2), None, N, D2, H2, W2, C1, C2, k2, st2, pd2,
                    0, _p(dya2), _p(xa2), _p(ws), ws.numel(), _stream())
@@ -1160,7 +1170,9 @@ def double_conv_bn_act(x, conv1, bn1, conv2, bn2, act=ACT_NONE, slope=0.01, left
         k2, (s2_, p2_) = conv2.weight.shape[2], geo(conv2)
         k1, (s1_, p1_) = conv1.weight.shape[2], geo(conv1)
         ext = [((e + 2 * p1_ - k1) // s1_ + 1 + 2 * p2_ - k2) // s2_ + 1 for e in (D, H, W)]
-        if not os.environ.get("MI355SEG_NO_POOL_FUSION") and \
+        # (the fused kernels address the skip slice -- full[..., left_pad:] -- and its gradient by 16-byte quads: left_pad and the buffer's
+        # channel pitch must be multiples of four, else the separate pool node below takes the shape)
+        if not os.environ.get("MI355SEG_NO_POOL_FUSION") and left_pad % 4 == 0 and (left_pad + conv2.out_channels) % 4 == 0 and \
                 lib().query("mi355seg_bn_act_pool_supported_f32", int(x.shape[0]), ext[0], ext[1], ext[2], conv2.out_channels, conv2.out_channels) != 0:
             return _DoubleConvBnAct.apply(*args, None, None, True)
         return max_pool3d_2x_and_skip(_DoubleConvBnAct.apply(*args))

@@ -185,6 +185,42 @@ def test_conv_transpose3d_k2s2(seg, case):
     assert rel_err(bg.grad.cpu(), br.grad) < TOL
 
 
+@pytest.mark.parametrize("case", [
+    # (N, D, H, W, Cin, Cout, lddx, expected K-splits): K = 8 Cout in 64-wide chunks, split while a half still holds two chunks
+    (1, 5, 5, 4, 64, 32, 64, 2), (1, 5, 5, 4, 64, 64, 64, 4), (1, 4, 4, 4, 128, 128, 128, 8), (2, 8, 8, 8, 512, 256, 512, 8),
+    (1, 3, 7, 5, 64, 64, 96, 4),        # ragged voxel count, dx written into a wider buffer
+])
+def test_conv_transpose3d_input_gradient_split_k(seg, case):
+    """convt_direct.hip, GEMM-form input gradient of ConvTranspose3d k2 s2 on fp32 tensors (unet3d.py:47-53 backward): the deep levels
+    split K over adjacent workgroups into slabs + a reduce.  Each split launch against the SAME entry point handed a workspace too small
+    for the slabs (the library then runs the unsplit launch: identical products, another summation order) and against ATen-CPU."""
+    N, D, H, W, Cin, Cout, lddx, ks = case
+    F = seg.functional
+    L = seg.lib()
+    dev = "cuda"
+    nvox = N * D * H * W
+    dy = rnd(N, 2 * D, 2 * H, 2 * W, Cout, seed=1).to(dev)
+    w = rnd(Cin, Cout, 2, 2, 2, seed=2, scale=(2.0 / (Cout * 8)) ** 0.5).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    full = L.query("mi355seg_convt3d_k2s2_ws_bytes", N, D, H, W, Cin, Cout)
+    slab = ks * nvox * Cin * 4
+    assert full >= slab + 8 * Cin * Cout * 6, "the workspace query must cover the slabs"
+    out = []
+    packed = (8 * Cin * Cout * 6 + 255) // 256 * 256          # the bf16x6 planes of the packed weights: all the unsplit launch needs
+    for nbytes in (full, packed + slab // 2):     # with room for the slabs / without: split / unsplit
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        dx = torch.full((nvox, lddx), 7.0, device=dev)
+        L.call("mi355seg_convt3d_k2s2_dgrad_f32", dy.data_ptr(), Cout, w.data_ptr(), dx.data_ptr(), lddx, N, D, H, W, Cin, Cout, ws.data_ptr(), nbytes, st)
+        torch.cuda.synchronize()
+        assert bool((dx[:, Cin:] == 7.0).all()), "columns beyond Cin must stay untouched"
+        out.append(dx[:, :Cin].clone())
+    want = TF.conv3d(dy.permute(0, 4, 1, 2, 3).cpu(), w.cpu(), stride=2).permute(0, 2, 3, 4, 1).reshape(nvox, Cin)
+    sc = float(want.abs().max())
+    assert (out[0].cpu() - want).abs().max() < 2e-5 * sc
+    assert (out[1].cpu() - want).abs().max() < 2e-5 * sc
+    assert (out[0] - out[1]).abs().max() < 4e-6 * sc and not torch.equal(out[0], out[1]), "the two launches must differ in summation order only"
+
+
 @pytest.mark.parametrize("case", [(1, 4, 4, 8, 64, 32, 4), (2, 3, 2, 5, 8, 4, 4), (1, 3, 4, 5, 16, 32, 3), (1, 2, 2, 4, 512, 128, 4)])
 def test_conv_transpose3d_kernel_equals_stride(seg, case):
     """nn.ConvTranspose3d(k, stride=k) (csrnet.py:121-137, k = 4) as the adjoint of the matching Conv3d: MFMA gather

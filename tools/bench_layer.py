@@ -11,6 +11,9 @@ argv = sys.argv[1:]
 dtype, math = "f32", None
 if "--dtype" in argv:
     i = argv.index("--dtype"); dtype = argv[i + 1]; del argv[i:i + 2]
+presplit_mode = "--presplit" in argv
+if presplit_mode:
+    argv.remove("--presplit")
 if "--conv-math" in argv:
     i = argv.index("--conv-math"); math = argv[i + 1]; del argv[i:i + 2]
 if math:
@@ -50,6 +53,38 @@ if dtype == "f32" and L.query("mi355seg_conv_math_takes_amax") and "--measure-am
     L.call("mi355seg_amax_f32", w.data_ptr(), w.numel(), 1, w.numel(), am.data_ptr() + 4, st)
     L.call("mi355seg_amax_f32", y.data_ptr(), Cout, N * Do * Ho * Wo, Cout, am.data_ptr() + 8, st)
     ax, aw, ay = am.data_ptr(), am.data_ptr() + 4, am.data_ptr() + 8
+    if presplit_mode:
+        # TUNE build + MI355SEG_DBG=256 (staging = copy): hand the kernels tensors that ARE split -- per channel quad four fp16 h | four fp16 l
+        # of v 2^s in the quad's 16 bytes -- so the timing runs on real operand bits and the results can be compared with the plain run's
+        def presplit(t, amax):
+            e = (int(amax.view(torch.int32).item()) >> 23) & 0xff
+            sc = min(141 - e, 126) if e else 0
+            v = t * (2.0 ** sc)
+            h = v.half(); l = (v - h.float()).half()
+            q = torch.stack((h.reshape(-1, t.shape[-1] // 4, 4), l.reshape(-1, t.shape[-1] // 4, 4)), dim=2).contiguous()
+            return q.view(torch.float32).reshape(t.shape)
+        # reference: the exact-fp32 MFMA kernels (another code path, untouched by the probe switch)
+        mi355seg.set_conv_math("fp32")
+        ref = {}
+        L.call("mi355seg_conv3d_fwd_f32", x.data_ptr(), Cin, w.data_ptr(), b.data_ptr(), y.data_ptr(), Cout, N, D, H, W, Cin, Cout, k, stride, pad, None, None, ws.data_ptr(), ws.numel(), st)
+        ref["fwd"] = y.clone()
+        dyt = torch.randn_like(y)
+        L.call("mi355seg_amax_f32", dyt.data_ptr(), Cout, N * Do * Ho * Wo, Cout, am.data_ptr() + 8, st)
+        L.call("mi355seg_conv3d_dgrad_f32", dyt.data_ptr(), Cout, w.data_ptr(), dx.data_ptr(), Cin, N, D, H, W, Cin, Cout, k, stride, pad, ws.data_ptr(), ws.numel(), st)
+        ref["dgrad"] = dx.clone()
+        L.call("mi355seg_conv3d_wgrad_f32", dyt.data_ptr(), Cout, x.data_ptr(), Cin, dw.data_ptr(), None, N, D, H, W, Cin, Cout, k, stride, pad, 0, ws.data_ptr(), ws.numel(), st)
+        ref["wgrad"] = dw.clone()
+        mi355seg.set_conv_math(math or "f16x3")
+        xs, ds = presplit(x, am[0]), presplit(dyt, am[2])
+        torch.cuda.synchronize()
+        assert os.environ.get("MI355SEG_DBG") == "256", "--presplit needs the TUNE build and MI355SEG_DBG=256"
+        run("fwd", lambda: L.call("mi355seg_conv3d_fwd_ax_f32", xs.data_ptr(), Cin, w.data_ptr(), b.data_ptr(), y.data_ptr(), Cout, N, D, H, W, Cin, Cout, k, stride, pad, None, None, ax, aw, ws.data_ptr(), ws.numel(), st))
+        print("   fwd   max |presplit - plain| =", float((y - ref["fwd"]).abs().max()), " of", float(ref["fwd"].abs().max()))
+        run("dgrad", lambda: L.call("mi355seg_conv3d_dgrad_ax_f32", ds.data_ptr(), Cout, w.data_ptr(), dx.data_ptr(), Cin, N, D, H, W, Cin, Cout, k, stride, pad, ay, aw, ws.data_ptr(), ws.numel(), st))
+        print("   dgrad max |presplit - plain| =", float((dx - ref["dgrad"]).abs().max()), " of", float(ref["dgrad"].abs().max()))
+        run("wgrad", lambda: L.call("mi355seg_conv3d_wgrad_ax_f32", ds.data_ptr(), Cout, xs.data_ptr(), Cin, dw.data_ptr(), None, N, D, H, W, Cin, Cout, k, stride, pad, 0, ay, ax, ws.data_ptr(), ws.numel(), st))
+        print("   wgrad max |presplit - plain| =", float((dw - ref["wgrad"]).abs().max()), " of", float(ref["wgrad"].abs().max()))
+        sys.exit(0)
     run("fwd", lambda: L.call("mi355seg_conv3d_fwd_ax_f32", x.data_ptr(), Cin, w.data_ptr(), b.data_ptr(), y.data_ptr(), Cout, N, D, H, W, Cin, Cout, k, stride, pad, None, None, ax, aw, ws.data_ptr(), ws.numel(), st))
     L.call("mi355seg_amax_f32", y.data_ptr(), Cout, N * Do * Ho * Wo, Cout, am.data_ptr() + 8, st)
     run("dgrad", lambda: L.call("mi355seg_conv3d_dgrad_ax_f32", y.data_ptr(), Cout, w.data_ptr(), dx.data_ptr(), Cin, N, D, H, W, Cin, Cout, k, stride, pad, ay, aw, ws.data_ptr(), ws.numel(), st))
