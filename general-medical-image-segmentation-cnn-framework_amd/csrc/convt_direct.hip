@@ -62,7 +62,14 @@ template <typename TT, bool GATHER, int BM, int BN>
 __global__ __launch_bounds__(256, 2) void convt_gemm_kernel(CtArgs a) {
     constexpr bool F32 = sizeof(TT) == 4;
     constexpr int NP = F32 ? 3 : 1;
-    constexpr int XS = BM + 8, WS = BN + 8;                        // slots per k-group
+    // slots per k-group.  The voxel tile is WRITTEN by lanes (k-group tid & 7, row tid >> 3): the 16 lanes of a write phase hold 8 k-groups x 2
+    // rows, so the k-group pitch must be == 2 mod 16 slots for them to fall on 16 distinct slot positions (r6; with BM + 8 == 8 mod 16 the even
+    // k-groups shared one position and the odd ones another: four-way conflicts, LDS conflict share 0.625 in r05_pmc_sq_unetr.csv); the weight
+    // tile is written row-contiguously, any pitch does
+#ifndef CT_XPAD
+#define CT_XPAD 2
+#endif
+    constexpr int XS = BM + CT_XPAD, WS = BN + 8;
     constexpr int XPL = 8 * XS, WPL = 8 * WS;                      // slots per plane
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
     constexpr int XIT = BM * 8 / 256, WIT = NP * 8 * BN / 256;
@@ -430,7 +437,7 @@ void launch_stream(const CtArgs& a, hipStream_t st) {
 template <typename TT, bool GATHER, int BM, int BN>
 void launch_ct(const CtArgs& a, int mtiles, hipStream_t st) {
     constexpr int NP = sizeof(TT) == 4 ? 3 : 1;
-    constexpr size_t lds = (size_t)NP * 8 * ((BM + 8) + (BN + 8)) * 16;
+    constexpr size_t lds = (size_t)NP * 8 * ((BM + 8) + (BN + 8)) * 16;      // (the voxel pitch is BM + 2 now: within this)
     SEG_SET_LDS((convt_gemm_kernel<TT, GATHER, BM, BN>), lds);
     hipLaunchKernelGGL((convt_gemm_kernel<TT, GATHER, BM, BN>), dim3((unsigned)(mtiles * a.ntn * (a.ksplit > 1 ? a.ksplit : 1))), dim3(256), lds, st, a);
 }

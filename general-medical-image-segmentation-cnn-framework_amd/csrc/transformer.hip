@@ -5,6 +5,7 @@
 // along whichever operand index is contiguous, deterministic split-K when the tile count cannot fill the chip; a wavefront per row for LayerNorm / softmax (DPP shuffles).
 #include "common.h"
 #include "internal.h"
+#include <algorithm>
 
 namespace seg {
 
@@ -252,15 +253,17 @@ __global__ __launch_bounds__(GD_WAVES * 64) void gemm_direct_kernel(GemmArgs g) 
 // v_mfma_f32_32x32x16_bf16 with fp32 accumulation, fp32 result.  A lane holds EIGHT consecutive k of its row / column per MFMA
 // (k = 16 j + 8 h + e): two float4 loads where the operand is contiguous along k, eight coalesced dword loads otherwise; one MFMA
 // does the work of eight fp32 ones.  K % 8 == 0 (host): a lane's group of eight is inside K or wholly past it (zeros).
-template <bool AK, bool BK>
-__global__ __launch_bounds__(GD_WAVES * 64) void gemm_direct_lowp_kernel(GemmArgs g) {
-    __shared__ float red[GD_WAVES * 1024];
+// MUL (r6): the A operand is A * amul * [agate > 0] (same indexing as A; either may be null) -- a dropout layer's factors and the ReLU
+// backward's gate folded into the loads of the gradient a Linear layer's two backward GEMMs read (an element-wise launch each before)
+template <bool AK, bool BK, bool MUL>
+__device__ __forceinline__ void gemm_direct_lowp_body(const GemmArgs& g, int zb, const float* __restrict__ amul, const float* __restrict__ agate, float* red) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, i = lane & 31;
-    const int b0 = blockIdx.z / g.nb1, b1 = blockIdx.z % g.nb1;
+    const int b0 = zb / g.nb1, b1 = zb % g.nb1;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     const int arow = min(m0 + i, g.M - 1), bcol = min(n0 + i, g.N - 1);
-    const float* __restrict__ ap = g.A + b0 * g.a_b0 + b1 * g.a_b1 + (long long)arow * g.a_rs;
+    const long long aoff = b0 * g.a_b0 + b1 * g.a_b1 + (long long)arow * g.a_rs;
+    const float* __restrict__ ap = g.A + aoff;
     const float* __restrict__ bp = g.B + b0 * g.b_b0 + b1 * g.b_b1 + (long long)bcol * g.b_cs;
     const int nblk = (g.K + 15) / 16;
     f32x16 acc;
@@ -291,6 +294,19 @@ __global__ __launch_bounds__(GD_WAVES * 64) void gemm_direct_lowp_kernel(GemmArg
         for (int u = 0; u < U; ++u) {
             const int j = min(wave + GD_WAVES * (jt * U + u), nblk - 1);
             ld8(ap, g.a_cs, AK, j, xa[u]); ld8(bp, g.b_rs, BK, j, xb[u]);
+            if constexpr (MUL) {
+                float f[8];
+                if (amul) {
+                    ld8(amul + aoff, g.a_cs, AK, j, f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xa[u][e] *= f[e];
+                }
+                if (agate) {
+                    ld8(agate + aoff, g.a_cs, AK, j, f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xa[u][e] = f[e] > 0.f ? xa[u][e] : 0.f;
+                }
+            }
         }
     };
     const bool rowsum = g.arowsum != nullptr && blockIdx.x == 0;                  // (workgroup-uniform) the first column of tiles also sums A's rows
@@ -402,12 +418,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     if (lane == 0) { mean[row] = m; rstd[row] = rs; }
 }
 
-__global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__device__ __forceinline__ void layernorm_bwd_dx_part(int blk, const float* __restrict__ dy, const float* __restrict__ x,
         const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
         float* __restrict__ dx, long long rows, int E, const float* __restrict__ addend) {
     // addend (optional): a second gradient of x (the residual stream that bypasses the norm, unetr.py:160,166): dx = addend + LN backward
     const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long row = (long long)blk * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float m = mean[row], rs = rstd[row];
     float g[LN_MAXJ], xh[LN_MAXJ];
@@ -429,12 +445,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __re
 
 // dgamma[c] = sum_rows dy * xhat, dbeta[c] = sum_rows dy.  Block = 32 columns x 8 row groups (rows r = g, g+8, ...);
 // the eight partial sums of a column are added in group order through LDS (fixed order -> reproducible).
-__global__ __launch_bounds__(256) void layernorm_bwd_affine_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__device__ __forceinline__ void layernorm_bwd_affine_part(int blk, const float* __restrict__ dy, const float* __restrict__ x,
         const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
         long long rows, int E) {
     __shared__ double sa[8][32], sb[8][32];
     const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    const int c = blk * 32 + cl;
     double a = 0.0, b = 0.0;
     if (c < E) {
         for (long long r = g; r < rows; r += 8) {
@@ -451,6 +467,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_affine_kernel(const float* 
         for (int k = 0; k < 8; ++k) { ta += sa[k][cl]; tb += sb[k][cl]; }
         dgamma[c] = (float)ta; dbeta[c] = (float)tb;
     }
+}
+
+// (r6) both halves of the LayerNorm backward in ONE launch: they read the same tensors and do not depend on each other -- workgroups
+// [0, ndx) write dx (a wavefront per row), the rest reduce dgamma / dbeta (32 columns each); 48 launches per UNETR step fewer
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+        const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+        long long rows, int E, const float* __restrict__ addend, int ndx) {
+    if ((int)blockIdx.x < ndx) layernorm_bwd_dx_part(blockIdx.x, dy, x, gamma, mean, rstd, dx, rows, E, addend);
+    else layernorm_bwd_affine_part((int)blockIdx.x - ndx, dy, x, mean, rstd, dgamma, dbeta, rows, E);
 }
 
 // ---------------------------------------------------------------- row softmax (one wavefront per row)
@@ -513,6 +538,67 @@ __global__ __launch_bounds__(256) void softmax_rows_keep_bwd_kernel(const float*
     for (int c = lane; c < L; c += 64) dot += y[row * L + c] * (dyk[row * L + c] * keep[row * L + c]);
     dot = wave_sum(dot);
     for (int c = lane; c < L; c += 64) dx[row * L + c] = y[row * L + c] * (dyk[row * L + c] * keep[row * L + c] - dot);
+}
+
+template <bool AK, bool BK>
+__global__ __launch_bounds__(GD_WAVES * 64) void gemm_direct_lowp_kernel(GemmArgs g) {
+    __shared__ float red[GD_WAVES * 1024];
+    gemm_direct_lowp_body<AK, BK, false>(g, blockIdx.z, nullptr, nullptr, red);
+}
+
+// ---- (r6) TWO independent small GEMMs in ONE launch.  The token encoder's backward is pairs of few-hundred-row GEMMs that read the same
+// gradient and do not depend on each other -- a Linear layer's dX = dY W and dW = dY^T X (unetr.py:61-66,120-121), attention's dP = dO V^T and
+// dV = Pd^T dO, dQ = dS K and dK = dS^T Q (unetr.py:74-98) -- each a 12-us launch at MFMA busy 0.01: latency, not work.  blockIdx.z picks the
+// problem (z < nz0: problem 0, batch z; else problem 1, batch z - nz0), the x / y grid is the larger of the two tilings and a workgroup
+// outside its problem's tiling leaves at once.  The body is gemm_direct_lowp_kernel's own, instantiated per problem: each result is
+// bit-identical to its own launch's.
+struct GemmPair { GemmArgs g[2]; const float* amul; const float* agate; int nz0; };
+
+template <bool AK0, bool BK0, bool AK1, bool BK1, bool MUL>
+__global__ __launch_bounds__(GD_WAVES * 64) void gemm_direct_lowp_pair_kernel(GemmPair gp) {
+    __shared__ float red[GD_WAVES * 1024];
+    if ((int)blockIdx.z < gp.nz0) {
+        if ((int)blockIdx.y * 32 >= gp.g[0].M || (int)blockIdx.x * 32 >= gp.g[0].N) return;                 // (workgroup-uniform)
+        gemm_direct_lowp_body<AK0, BK0, MUL>(gp.g[0], blockIdx.z, gp.amul, gp.agate, red);
+    } else {
+        if ((int)blockIdx.y * 32 >= gp.g[1].M || (int)blockIdx.x * 32 >= gp.g[1].N) return;
+        gemm_direct_lowp_body<AK1, BK1, MUL>(gp.g[1], (int)blockIdx.z - gp.nz0, gp.amul, gp.agate, red);
+    }
+}
+
+// an operand of a small-GEMM problem: contiguous along k (16-byte aligned rows) or along its outer index
+static bool pair_operand_ok(const float* p, long long kfast_other, long long kstride, long long b0s, long long b1s, bool* kcontig) {
+    *kcontig = kstride == 1;
+    if (*kcontig) return kfast_other % 4 == 0 && b0s % 4 == 0 && b1s % 4 == 0 && (uintptr_t)p % 16 == 0;
+    return kfast_other == 1;
+}
+static bool pair_problem_ok(const GemmArgs& g, int nb0, bool* ak, bool* bk) {
+    if (!(g.A && g.B && g.C && g.M > 0 && g.N > 0 && g.K > 0 && g.K % 8 == 0)) return false;
+    if (!pair_operand_ok(g.A, g.a_rs, g.a_cs, g.a_b0, g.a_b1, ak) || !pair_operand_ok(g.B, g.b_cs, g.b_rs, g.b_b0, g.b_b1, bk)) return false;
+    return (long long)cdiv(g.M, 32) * cdiv(g.N, 32) * nb0 * g.nb1 <= 4096;
+}
+static int launch_pair(GemmPair& gp, int nb0a, int nb0b, void* stream) {
+    bool ak0, bk0, ak1, bk1;
+    SEG_CHECK_ARG(pair_problem_ok(gp.g[0], nb0a, &ak0, &bk0), "gemm pair: problem 0 is outside the small-GEMM kernel's range");
+    SEG_CHECK_ARG(pair_problem_ok(gp.g[1], nb0b, &ak1, &bk1), "gemm pair: problem 1 is outside the small-GEMM kernel's range");
+    gp.nz0 = nb0a * gp.g[0].nb1;
+    const int nz1 = nb0b * gp.g[1].nb1;
+    SEG_CHECK_ARG(gp.nz0 + nz1 < 65536, "gemm pair: too many batches");
+    const int tx = (int)std::max(cdiv(gp.g[0].N, 32), cdiv(gp.g[1].N, 32)), ty = (int)std::max(cdiv(gp.g[0].M, 32), cdiv(gp.g[1].M, 32));
+    const dim3 grid(tx, ty, gp.nz0 + nz1), block(GD_WAVES * 64);
+    const bool mul = gp.amul || gp.agate;
+    // the operand layouts of the pairs this is built for: (row-major A, row-major B^T or B) with (A^T, row-major B)
+    if (ak0 && !bk0 && !ak1 && !bk1) {
+        if (mul) hipLaunchKernelGGL((gemm_direct_lowp_pair_kernel<true, false, false, false, true>), grid, block, 0, (hipStream_t)stream, gp);
+        else hipLaunchKernelGGL((gemm_direct_lowp_pair_kernel<true, false, false, false, false>), grid, block, 0, (hipStream_t)stream, gp);
+    } else if (ak0 && bk0 && !ak1 && !bk1 && !mul) {
+        hipLaunchKernelGGL((gemm_direct_lowp_pair_kernel<true, true, false, false, false>), grid, block, 0, (hipStream_t)stream, gp);
+    } else {
+        set_error("gemm pair: operand layouts (%d %d | %d %d) are not among the built instantiations", (int)ak0, (int)bk0, (int)ak1, (int)bk1);
+        return MI355SEG_EINVAL;
+    }
+    SEG_CHECK_LAUNCH();
+    return MI355SEG_OK;
 }
 
 }  // namespace seg
@@ -643,6 +729,45 @@ int mi355seg_linear_fwd_f32(int lowp, const float* x, int ldx, const float* w, c
     return rc;
 }
 
+// The backward of nn.Linear as ONE launch (r6): dyf = dy * dmul * [dgate > 0] (either may be NULL), dx[M][K] = dyf W, dw[N][K] = dyf^T x,
+// db[n] = sum_m dyf[m][n].  bf16 products (the token path under autocast) on the few-hundred-row shapes; mi355seg_linear_bwd_supported_f32
+// says whether a shape is taken (the caller runs the separate GEMMs otherwise).
+int mi355seg_linear_bwd_supported_f32(int lowp, int M, int N, int K) {
+    if (!lowp || M <= 0 || N <= 0 || K <= 0 || N % 8 || M % 8 || K % 4) return 0;
+    return ((long long)cdiv(M, 32) * cdiv(K, 32) <= 4096 && (long long)cdiv(N, 32) * cdiv(K, 32) <= 4096) ? 1 : 0;
+}
+int mi355seg_linear_bwd_f32(int lowp, const float* dy, int lddy, const float* dmul, const float* dgate, const float* x, int ldx, const float* w,
+                            float* dx, float* dw, float* db, int M, int N, int K, void* stream) {
+    SEG_CHECK_ARG(dy && x && w && dx && dw && lddy >= N && ldx >= K && mi355seg_linear_bwd_supported_f32(lowp, M, N, K), "linear_bwd: unsupported arguments (see mi355seg_linear_bwd_supported_f32)");
+    GemmPair gp{};
+    // dx = dyf W: A(m, n) = dyf[m][n] (k = n contiguous), B(n, k) = w[n][k] (outer index k contiguous)
+    gp.g[0] = GemmArgs{dy, w, dx, nullptr, lddy, 1, 0, 0, K, 1, 0, 0, K, 0, 0, M, K, N, 1, 1.f, 0, 0, 1, N, 0, 0, nullptr, nullptr, nullptr, nullptr, 0};
+    // dw = dyf^T x: A(n, m) = dyf[m][n] (outer index n contiguous), B(m, k) = x[m][k] (outer index k contiguous); db = A's row sums
+    gp.g[1] = GemmArgs{dy, x, dw, nullptr, 1, lddy, 0, 0, ldx, 1, 0, 0, K, 0, 0, N, K, M, 1, 1.f, 0, 0, 1, M, 0, 0, nullptr, db, nullptr, nullptr, 0};
+    gp.amul = dmul; gp.agate = dgate;
+    return launch_pair(gp, 1, 1, stream);
+}
+
+// Two independent batched small GEMMs C_p[b0][b1] = alpha_p A_p B_p in one launch (r6: attention's backward pairs, unetr.py:74-98), bf16
+// products, fp32 accumulation; both problems on nb0 x nb1 batches with their own strides.
+int mi355seg_gemm_pair_supported_f32(int M0, int N0, int K0, int M1, int N1, int K1, int nb0, int nb1) {
+    if (M0 <= 0 || N0 <= 0 || K0 <= 0 || M1 <= 0 || N1 <= 0 || K1 <= 0 || nb0 <= 0 || nb1 <= 0 || K0 % 8 || K1 % 8) return 0;
+    return ((long long)cdiv(M0, 32) * cdiv(N0, 32) * nb0 * nb1 <= 4096 && (long long)cdiv(M1, 32) * cdiv(N1, 32) * nb0 * nb1 <= 4096 && 2ll * nb0 * nb1 < 65536) ? 1 : 0;
+}
+int mi355seg_gemm_pair_lowp_f32(const float* A0, long long a0_rs, long long a0_cs, long long a0_b0, long long a0_b1,
+                                const float* B0, long long b0_rs, long long b0_cs, long long b0_b0, long long b0_b1,
+                                float* C0, long long c0_rs, long long c0_b0, long long c0_b1, int M0, int N0, int K0, float alpha0,
+                                const float* A1, long long a1_rs, long long a1_cs, long long a1_b0, long long a1_b1,
+                                const float* B1, long long b1_rs, long long b1_cs, long long b1_b0, long long b1_b1,
+                                float* C1, long long c1_rs, long long c1_b0, long long c1_b1, int M1, int N1, int K1, float alpha1,
+                                int nb0, int nb1, void* stream) {
+    SEG_CHECK_ARG(nb0 > 0 && nb1 > 0, "gemm_pair: bad batch counts");
+    GemmPair gp{};
+    gp.g[0] = GemmArgs{A0, B0, C0, nullptr, a0_rs, a0_cs, a0_b0, a0_b1, b0_rs, b0_cs, b0_b0, b0_b1, c0_rs, c0_b0, c0_b1, M0, N0, K0, nb1, alpha0, 0, 0, 1, K0, 0, 0, nullptr, nullptr, nullptr, nullptr, 0};
+    gp.g[1] = GemmArgs{A1, B1, C1, nullptr, a1_rs, a1_cs, a1_b0, a1_b1, b1_rs, b1_cs, b1_b0, b1_b1, c1_rs, c1_b0, c1_b1, M1, N1, K1, nb1, alpha1, 0, 0, 1, K1, 0, 0, nullptr, nullptr, nullptr, nullptr, 0};
+    return launch_pair(gp, nb0, nb0, stream);
+}
+
 int mi355seg_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                                long long rows, int E, float eps, void* stream) {
     SEG_CHECK_ARG(x && gamma && beta && y && mean && rstd && rows > 0 && E > 0 && E <= 64 * LN_MAXJ, "layernorm_fwd: bad arguments (E <= %d)", 64 * LN_MAXJ);
@@ -653,18 +778,16 @@ int mi355seg_layernorm_fwd_f32(const float* x, const float* gamma, const float* 
 int mi355seg_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                                float* dx, float* dgamma, float* dbeta, long long rows, int E, void* stream) {
     SEG_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0 && E > 0 && E <= 64 * LN_MAXJ, "layernorm_bwd: bad arguments");
-    hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd, dx, rows, E, (const float*)nullptr);
-    SEG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(layernorm_bwd_affine_kernel, dim3(cdiv(E, 32)), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, dgamma, dbeta, rows, E);
+    const int ndx = (int)cdiv(rows, 4);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(ndx + (int)cdiv(E, 32)), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, E, (const float*)nullptr, ndx);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }
 int mi355seg_layernorm_bwd_add_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, const float* addend,
                                    float* dx, float* dgamma, float* dbeta, long long rows, int E, void* stream) {
     SEG_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0 && E > 0 && E <= 64 * LN_MAXJ, "layernorm_bwd_add: bad arguments");
-    hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd, dx, rows, E, addend);
-    SEG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(layernorm_bwd_affine_kernel, dim3(cdiv(E, 32)), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, dgamma, dbeta, rows, E);
+    const int ndx = (int)cdiv(rows, 4);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(ndx + (int)cdiv(E, 32)), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, E, addend, ndx);
     SEG_CHECK_LAUNCH();
     return MI355SEG_OK;
 }

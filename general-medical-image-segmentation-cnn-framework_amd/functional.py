@@ -2064,6 +2064,17 @@ class _Linear(Function):
         shp, M, N, K, relu, has_b, has_res = ctx.cfg
         dy2 = dy.contiguous().view(M, N)
         dres = dy if has_res else None                       # d(... + residual) / d residual = dy itself: no kernel
+        L = lib()
+        # r6: the whole backward as ONE launch -- dx = dyf W and dw = dyf^T x (+ db) are independent, latency-bound GEMMs at the token
+        # encoder's sizes and run as two problems of one grid; the dropout factors and the ReLU gate (dyf = dy * mask * [y > 0]) are folded
+        # into their loads of dy (mi355seg_linear_bwd_f32; bit-identical to the separate launches)
+        if lowp and not os.environ.get("MI355SEG_NO_GEMM_PAIRS") and L.query("mi355seg_linear_bwd_supported_f32", 1, M, N, K) != 0 and \
+                all(t is None or (t.is_contiguous() and t.data_ptr() % 16 == 0) for t in (dy2, mask, yrelu if relu else None, x2, w)):
+            dx = torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
+            dw = torch.empty_like(w)
+            db = torch.empty(N, dtype=dy2.dtype, device=dy2.device) if has_b else None
+            L.call("mi355seg_linear_bwd_f32", 1, _p(dy2), N, _p(mask), _p(yrelu) if relu else None, _p(x2), K, _p(w), _p(dx), _p(dw), _p(db), M, N, K, _stream())
+            return dx.view(*shp), dw, db, None, None, dres
         if mask is not None:
             dy2 = _mul(dy2, mask.view(M, N))
         if relu:                                            # dy * 1[y > 0]: the ReLU backward kernel, keyed on the saved output (mask 0 => y 0 and dy 0)
@@ -2075,7 +2086,6 @@ class _Linear(Function):
         # weight gradient; the bias gradient (column sums of dy) rides in the same launch on the token encoder's shapes
         dw = torch.empty_like(w)
         db = torch.empty(N, dtype=dy2.dtype, device=dy2.device) if has_b else None
-        L = lib()
         ws = workspace(max(L.query("mi355seg_gemm_ws_bytes", N, K, M, 1, 1), L.query("mi355seg_norm_ws_bytes", M, 1, N)), dy2.device)
         L.call("mi355seg_linear_wgrad_f32", int(lowp), _p(dy2), N, _p(x2), K, _p(dw), _p(db), M, N, K, _p(ws), ws.numel(), _stream())
         return dx.view(*shp), dw, db, None, None, dres
@@ -2084,6 +2094,48 @@ class _Linear(Function):
 def linear(x, weight, bias=None, relu=False, mask=None, residual=None):
     """nn.Linear; ``mask`` / ``residual``: see _Linear (y = relu?(x W^T + b) * mask + residual in one launch)."""
     return _Linear.apply(x, weight, bias, relu, mask, residual)
+
+
+def qkv_params_are_fused(wq, wk, wv, bq, bk, bv):
+    """The three projections' parameters are consecutive slices of ONE buffer (models.three_d.unetr.SelfAttention seats them so): the
+    [3E, K] weight and the [3E] bias of the fused projection exist in place."""
+    if bq is None or bk is None or bv is None or wq.dim() != 2 or wq.shape != wk.shape or wq.shape != wv.shape:
+        return False
+    E, K = wq.shape
+    ts = (wq, wk, wv, bq, bk, bv)
+    if not all(t.is_contiguous() and t.dtype == torch.float32 and t.is_cuda for t in ts) or bq.numel() != E or bk.numel() != E or bv.numel() != E:
+        return False
+    if wk.data_ptr() != wq.data_ptr() + 4 * E * K or wv.data_ptr() != wq.data_ptr() + 8 * E * K:
+        return False
+    if bk.data_ptr() != bq.data_ptr() + 4 * E or bv.data_ptr() != bq.data_ptr() + 8 * E:
+        return False
+    room = lambda t, n: t.untyped_storage().nbytes() >= 4 * (t.storage_offset() + n)
+    return room(wq, 3 * E * K) and room(bq, 3 * E)
+
+
+class _LinearQKV(Function):
+    """The query / key / value projections of unetr.py:60-75 as ONE GEMM on parameters that are slices of one buffer
+    (qkv_params_are_fused): no concatenation of the weights in the forward, and the backward hands each parameter its rows of the fused
+    weight / bias gradient as views (r6; the concatenated form cost two copy launches per layer and step)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv, bq, bk, bv):
+        E, K = wq.shape
+        wf = torch.as_strided(wq.detach(), (3 * E, K), (K, 1))
+        bf = torch.as_strided(bq.detach(), (3 * E,), (1,))
+        ctx.E = E
+        return _Linear.forward(ctx, x, wf, bf, False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx, dw, db = _Linear.backward(ctx, dy)[:3]
+        E = ctx.E
+        return dx, dw[:E], dw[E:2 * E], dw[2 * E:], db[:E], db[E:2 * E], db[2 * E:]
+
+
+def linear_qkv(x, wq, wk, wv, bq, bk, bv):
+    """[x Wq^T + bq | x Wk^T + bk | x Wv^T + bv] for parameters seated as slices of one buffer; see _LinearQKV."""
+    return _LinearQKV.apply(x, wq, wk, wv, bq, bk, bv)
 
 
 class _LayerNorm(Function):
@@ -2239,11 +2291,23 @@ class _AttentionQKV(Function):
         dqkv = torch.empty_like(qkv)
         dq, dk, dv = _p(dqkv), _p(dqkv) + 4 * E, _p(dqkv) + 8 * E
         dpd = torch.empty_like(probs)                                   # dP = dO V^T
-        _gemm(_p(do), E, 1, P * E, d, v, 1, E3, P * E3, d, _p(dpd), P, HPP, PP, None, P, P, d, B, heads, lowp=lowp)
-        _gemm(_p(pd), 1, P, HPP, PP, _p(do), E, 1, P * E, d, dv, E3, P * E3, d, None, P, d, P, B, heads, lowp=lowp)             # dV = Pd^T dO
+        L = lib()
+        # r6: the two pairs of independent GEMMs (dP with dV: both read dO; dQ with dK: both read dS) as one launch each
+        pairs = lowp and not os.environ.get("MI355SEG_NO_GEMM_PAIRS") and \
+            L.query("mi355seg_gemm_pair_supported_f32", P, P, d, P, d, P, B, heads) != 0 and L.query("mi355seg_gemm_pair_supported_f32", P, d, P, P, d, P, B, heads) != 0
+        if pairs:
+            L.call("mi355seg_gemm_pair_lowp_f32", _p(do), E, 1, P * E, d, v, 1, E3, P * E3, d, _p(dpd), P, HPP, PP, P, P, d, 1.0,
+                   _p(pd), 1, P, HPP, PP, _p(do), E, 1, P * E, d, dv, E3, P * E3, d, P, d, P, 1.0, B, heads, _stream())
+        else:
+            _gemm(_p(do), E, 1, P * E, d, v, 1, E3, P * E3, d, _p(dpd), P, HPP, PP, None, P, P, d, B, heads, lowp=lowp)
+            _gemm(_p(pd), 1, P, HPP, PP, _p(do), E, 1, P * E, d, dv, E3, P * E3, d, None, P, d, P, B, heads, lowp=lowp)         # dV = Pd^T dO
         ds = _softmax_keep_bwd(probs, dpd, keep, B * heads * P, P)
-        _gemm(_p(ds), P, 1, HPP, PP, k, E3, 1, P * E3, d, dq, E3, P * E3, d, None, P, d, P, B, heads, alpha, lowp=lowp)          # dQ = alpha dS K
-        _gemm(_p(ds), 1, P, HPP, PP, q, E3, 1, P * E3, d, dk, E3, P * E3, d, None, P, d, P, B, heads, alpha, lowp=lowp)          # dK = alpha dS^T Q
+        if pairs:
+            L.call("mi355seg_gemm_pair_lowp_f32", _p(ds), P, 1, HPP, PP, k, E3, 1, P * E3, d, dq, E3, P * E3, d, P, d, P, alpha,
+                   _p(ds), 1, P, HPP, PP, q, E3, 1, P * E3, d, dk, E3, P * E3, d, P, d, P, alpha, B, heads, _stream())
+        else:
+            _gemm(_p(ds), P, 1, HPP, PP, k, E3, 1, P * E3, d, dq, E3, P * E3, d, None, P, d, P, B, heads, alpha, lowp=lowp)      # dQ = alpha dS K
+            _gemm(_p(ds), 1, P, HPP, PP, q, E3, 1, P * E3, d, dk, E3, P * E3, d, None, P, d, P, B, heads, alpha, lowp=lowp)      # dK = alpha dS^T Q
         return dqkv, None, None
 
 

@@ -119,15 +119,37 @@ class SelfAttention(nn.Module):
         self.attn_dropout, self.proj_dropout = Dropout(dropout), Dropout(dropout)
         self.softmax = nn.Softmax(dim=-1)            # kept for interface parity; the fused kernel does the work
         self.vis = False
+        self._seat_qkv()
+
+    def _seat_qkv(self):
+        """Seat query / key / value .weight and .bias as consecutive slices of one buffer each: the fused [3E, E] projection then exists
+        in place (no torch.cat per step) while the module keeps the reference's six parameters and state_dict keys (unetr.py:66-68).
+        load_state_dict copies into the slices; Module.to() / .cuda() re-seats them (``_apply`` below)."""
+        ws = [self.query.weight, self.key.weight, self.value.weight]
+        bs = [self.query.bias, self.key.bias, self.value.bias]
+        with torch.no_grad():
+            fw, fb = torch.cat([w.detach() for w in ws], dim=0), torch.cat([b.detach() for b in bs], dim=0)
+            rows = ws[0].shape[0]
+            for i, (w, b) in enumerate(zip(ws, bs)):
+                w.data, b.data = fw[i * rows:(i + 1) * rows], fb[i * rows:(i + 1) * rows]
+
+    def _apply(self, fn, *args, **kwargs):
+        super()._apply(fn, *args, **kwargs)
+        self._seat_qkv()
+        return self
 
     def forward(self, hidden_states, residual=None):
         """``residual``: the block's residual stream -- the result is then residual + proj_dropout(out(attention)) (unetr.py:98-100,160),
         the dropout product and the sum in the out-projection's GEMM epilogue."""
         # the three projections as ONE GEMM on the concatenated weights (the parameters stay separate: state_dict keys query / key /
         # value of unetr.py:66-68; the concat's backward hands each its rows of the fused weight gradient)
-        w = torch.cat((self.query.weight, self.key.weight, self.value.weight), dim=0)
-        b = torch.cat((self.query.bias, self.key.bias, self.value.bias), dim=0)
-        qkv = F.linear(hidden_states, w, b)
+        params = (self.query.weight, self.key.weight, self.value.weight, self.query.bias, self.key.bias, self.value.bias)
+        if F.qkv_params_are_fused(*params):          # the parameters ARE the rows of the fused weight (``_seat_qkv``)
+            qkv = F.linear_qkv(hidden_states, *params)
+        else:
+            w = torch.cat(params[:3], dim=0)
+            b = torch.cat(params[3:], dim=0)
+            qkv = F.linear(hidden_states, w, b)
         mask = None
         if self.training and self.attn_dropout.p > 0.0:
             n, p = qkv.shape[0], qkv.shape[1]

@@ -501,6 +501,26 @@ int mi355seg_linear_fwd_f32(int lowp, const float* x, int ldx, const float* w, c
  * (mi355seg_gemm_lowp_f32).  db may be NULL.  ws: max(mi355seg_gemm_ws_bytes(N, K, M, 1, 1), mi355seg_norm_ws_bytes(M, 1, N)). */
 int mi355seg_linear_wgrad_f32(int lowp, const float* dy, int lddy, const float* x, int ldx, float* dw, float* db, int M, int N, int K,
                               void* ws, size_t ws_bytes, void* stream);
+/* The backward of nn.Linear as ONE launch (r6; /root/reference/models/three_d/unetr.py:61-66,98-100,120-138 backward): with
+ * dyf = dy * dmul * [dgate > 0] (dmul: the keep / (1 - p) factors of the dropout layer behind the Linear, dgate: the ReLU's saved output; either
+ * may be NULL) it writes dx[M][K] = dyf W, dw[N][K] = dyf^T x and db[n] = sum_m dyf[m][n] (db may be NULL).  The two GEMMs are independent and
+ * latency-bound at the token encoder's sizes (216 rows): they run as two problems of one grid, the element-wise factors folded into their loads
+ * of dy (they were an element-wise launch each), every result bit-identical to the separate launches'.  bf16 products (lowp != 0) on shapes
+ * mi355seg_linear_bwd_supported_f32 accepts; the caller runs mi355seg_gemm_lowp_f32 + mi355seg_linear_wgrad_f32 otherwise. */
+int mi355seg_linear_bwd_supported_f32(int lowp, int M, int N, int K);
+int mi355seg_linear_bwd_f32(int lowp, const float* dy, int lddy, const float* dmul, const float* dgate, const float* x, int ldx, const float* w,
+                            float* dx, float* dw, float* db, int M, int N, int K, void* stream);
+/* Two independent batched small GEMMs C_p[b0][b1] = alpha_p A_p B_p (p = 0, 1; nb0 x nb1 batches each, own strides) in one launch (r6:
+ * the pairs of attention's backward, dP = dO V^T with dV = Pd^T dO and dQ = dS K with dK = dS^T Q, unetr.py:74-98 backward).  bf16 products,
+ * fp32 accumulation; each result bit-identical to mi355seg_gemm_lowp_f32's.  Shapes: mi355seg_gemm_pair_supported_f32. */
+int mi355seg_gemm_pair_supported_f32(int M0, int N0, int K0, int M1, int N1, int K1, int nb0, int nb1);
+int mi355seg_gemm_pair_lowp_f32(const float* A0, long long a0_rs, long long a0_cs, long long a0_b0, long long a0_b1,
+                                const float* B0, long long b0_rs, long long b0_cs, long long b0_b0, long long b0_b1,
+                                float* C0, long long c0_rs, long long c0_b0, long long c0_b1, int M0, int N0, int K0, float alpha0,
+                                const float* A1, long long a1_rs, long long a1_cs, long long a1_b0, long long a1_b1,
+                                const float* B1, long long b1_rs, long long b1_cs, long long b1_b0, long long b1_b1,
+                                float* C1, long long c1_rs, long long c1_b0, long long c1_b1, int M1, int N1, int K1, float alpha1,
+                                int nb0, int nb1, void* stream);
 /* Scratch for the deterministic split-K path (single-batch GEMMs with too few 64x64 tiles to fill 256 CUs); 0 when
  * the shape is not split.  With a smaller / NULL workspace the GEMM runs unsplit. */
 size_t mi355seg_gemm_ws_bytes(int M, int N, int K, int nb0, int nb1);

@@ -1108,6 +1108,78 @@ def test_linear_weight_and_bias_gradient_in_one_call(seg, shape, lowp):
     assert torch.equal(dw3, dw2)
 
 
+@pytest.mark.parametrize("mask,gate", [(False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("shape", [(216, 768, 768), (216, 2048, 768), (216, 768, 2048), (216, 2304, 768), (64, 40, 96)])
+def test_linear_backward_as_one_launch(seg, shape, mask, gate):
+    """r6, mi355seg_linear_bwd_f32: the backward of nn.Linear (unetr.py:61-66,98-100,120-138) as one launch -- dx = dyf W and dw = dyf^T x
+    (+ db) as two problems of one grid, dyf = dy * mask * [y > 0] formed in the loads.  Every output must be BIT-identical to the chain it
+    replaces (element-wise kernels, mi355seg_gemm_lowp_f32, mi355seg_linear_wgrad_f32)."""
+    F, L = seg.functional, seg.lib()
+    M, N, K = shape
+    dev = "cuda"
+    assert L.query("mi355seg_linear_bwd_supported_f32", 1, M, N, K) == 1
+    dy = rnd(M, N, seed=61).to(dev)
+    x = rnd(M, K, seed=62).to(dev)
+    w = (rnd(N, K, seed=63) * 0.05).to(dev)
+    mk = ((rnd(M, N, seed=64) > -0.8).float() / 0.9).to(dev) if mask else None
+    y = (rnd(M, N, seed=65).clamp_min(0.0).to(dev) * (mk if mk is not None else 1.0)) if gate else None
+    st = torch.cuda.current_stream().cuda_stream
+    dx1, dw1, db1 = torch.empty(M, K, device=dev), torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+    L.call("mi355seg_linear_bwd_f32", 1, dy.data_ptr(), N, mk.data_ptr() if mask else None, y.data_ptr() if gate else None, x.data_ptr(), K, w.data_ptr(),
+           dx1.data_ptr(), dw1.data_ptr(), db1.data_ptr(), M, N, K, st)
+    dyf = dy.clone()
+    if mask:
+        L.call("mi355seg_mul_f32", dyf.data_ptr(), mk.data_ptr(), dyf.data_ptr(), M * N, st)
+    if gate:
+        g = torch.empty_like(dyf)
+        L.call("mi355seg_act_bwd_f32", dyf.data_ptr(), N, y.data_ptr(), N, None, 0, g.data_ptr(), N, M, N, F.ACT_RELU, 0.0, st)
+        dyf = g
+    ws = F.workspace(max(L.query("mi355seg_gemm_ws_bytes", N, K, M, 1, 1), L.query("mi355seg_norm_ws_bytes", M, 1, N)), torch.device(dev))
+    dx2, dw2, db2 = torch.empty(M, K, device=dev), torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+    L.call("mi355seg_gemm_lowp_f32", dyf.data_ptr(), N, 1, 0, 0, w.data_ptr(), K, 1, 0, 0, dx2.data_ptr(), K, 0, 0, None, M, K, N, 1, 1, 1.0, 0, 0, ws.data_ptr(), ws.numel(), st)
+    L.call("mi355seg_linear_wgrad_f32", 1, dyf.data_ptr(), N, x.data_ptr(), K, dw2.data_ptr(), db2.data_ptr(), M, N, K, ws.data_ptr(), ws.numel(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(dx1, dx2) and torch.equal(dw1, dw2) and torch.equal(db1, db2)
+    # and against fp64 on the bf16-rounded operands (fp32 accumulation)
+    want = dyf.bfloat16().double() @ w.bfloat16().double()
+    assert (dx1.double() - want).abs().max() < 2e-5 * float(want.abs().max()) + 1e-6
+
+
+def test_two_batched_gemms_in_one_launch(seg):
+    """r6, mi355seg_gemm_pair_lowp_f32: attention's backward pairs (unetr.py:74-98) -- dP = dO V^T with dV = Pd^T dO, dQ = a dS K with
+    dK = a dS^T Q -- on the fused [B, P, 3E] layout, each bit-identical to its own mi355seg_gemm_lowp_f32 launch."""
+    F, L = seg.functional, seg.lib()
+    dev = "cuda"
+    B, P, heads, d = 2, 216, 12, 64
+    E, E3 = heads * d, 3 * heads * d
+    qkv = rnd(B, P, E3, seed=71).to(dev)
+    do = rnd(B, P, E, seed=72).to(dev)
+    pd = rnd(B, heads, P, P, seed=73).to(dev)
+    HPP, PP = heads * P * P, P * P
+    q, k, v = qkv.data_ptr(), qkv.data_ptr() + 4 * E, qkv.data_ptr() + 8 * E
+    st = torch.cuda.current_stream().cuda_stream
+    alpha = 0.125
+    assert L.query("mi355seg_gemm_pair_supported_f32", P, P, d, P, d, P, B, heads) == 1
+    dpd1, dqkv1 = torch.empty_like(pd), torch.zeros_like(qkv)
+    dq1, dk1, dv1 = dqkv1.data_ptr(), dqkv1.data_ptr() + 4 * E, dqkv1.data_ptr() + 8 * E
+    L.call("mi355seg_gemm_pair_lowp_f32", do.data_ptr(), E, 1, P * E, d, v, 1, E3, P * E3, d, dpd1.data_ptr(), P, HPP, PP, P, P, d, 1.0,
+           pd.data_ptr(), 1, P, HPP, PP, do.data_ptr(), E, 1, P * E, d, dv1, E3, P * E3, d, P, d, P, 1.0, B, heads, st)
+    L.call("mi355seg_gemm_pair_lowp_f32", pd.data_ptr(), P, 1, HPP, PP, k, E3, 1, P * E3, d, dq1, E3, P * E3, d, P, d, P, alpha,
+           pd.data_ptr(), 1, P, HPP, PP, q, E3, 1, P * E3, d, dk1, E3, P * E3, d, P, d, P, alpha, B, heads, st)
+    dpd2, dqkv2 = torch.empty_like(pd), torch.zeros_like(qkv)
+    dq2, dk2, dv2 = dqkv2.data_ptr(), dqkv2.data_ptr() + 4 * E, dqkv2.data_ptr() + 8 * E
+
+    def gemm(*a):
+        L.call("mi355seg_gemm_lowp_f32", *a, None, 0, st)
+    gemm(do.data_ptr(), E, 1, P * E, d, v, 1, E3, P * E3, d, dpd2.data_ptr(), P, HPP, PP, None, P, P, d, B, heads, 1.0, 0, 0)
+    gemm(pd.data_ptr(), 1, P, HPP, PP, do.data_ptr(), E, 1, P * E, d, dv2, E3, P * E3, d, None, P, d, P, B, heads, 1.0, 0, 0)
+    gemm(pd.data_ptr(), P, 1, HPP, PP, k, E3, 1, P * E3, d, dq2, E3, P * E3, d, None, P, d, P, B, heads, alpha, 0, 0)
+    gemm(pd.data_ptr(), 1, P, HPP, PP, q, E3, 1, P * E3, d, dk2, E3, P * E3, d, None, P, d, P, B, heads, alpha, 0, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(dpd1, dpd2) and torch.equal(dqkv1, dqkv2)
+    assert float(dqkv1.abs().max()) > 0
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(1, 8, 12, 16, 16), (2, 5, 6, 7, 12), (1, 4, 4, 8, 64)])
 def test_activation_fork_sums_both_gradients_in_one_pass(seg, shape, dtype):
