@@ -77,11 +77,15 @@ def main():
     lab = torch.randint(0, a.classes, (N, 1, D, H, W), device="cuda")
     tgt = torch.cat([(lab == i).float() for i in range(a.classes)], dim=1)
 
+    bns = [b for b in m.modules() if isinstance(b, torch.nn.modules.batchnorm._BatchNorm) and b.training and b.num_batches_tracked is not None]
+
     def step():
         opt.zero_grad(set_to_none=True)
         F.dropout_pool_begin_step()                  # (as engine.train_step: the step's element-wise dropout masks from one draw)
-        with mi355seg.autocast(dtype):
+        with mi355seg.autocast(dtype), F.counters_batched(bns):      # (the BatchNorm counters by one multi-tensor launch, as engine.train_step)
             pred = m(x)
+        if bns:
+            torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
         loss = F.bce_with_logits(pred, tgt)
         loss.backward()
         opt.step()
