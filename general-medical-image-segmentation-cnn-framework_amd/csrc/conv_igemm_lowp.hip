@@ -51,4 +51,21 @@ void dispatch_igemm_lowp(int math, const IgemmPlan& p, const IgemmArgs& a, int n
     }
 }
 
+// the output phases of a strided input gradient in ONE launch (bf16 tensors, k1 gather plans; conv_gather_dgrad_mfma)
+template <int CK>
+static bool dispatch_phases_ck(const IgemmPlan& p, const IgemmArgs& a, const IgemmPhases& pt, int nwg, hipStream_t st) {
+#define PHASE_CASE(bx, mb, nbw) \
+    if (p.BX == bx && p.MB == mb && p.NBW == nbw) { launch_igemm_phases<MATH_B16, 1, bx, mb, nbw, CK>(a, pt, nwg, st); return true; }
+    PHASE_CASE(32, 2, 2) PHASE_CASE(32, 2, 1) PHASE_CASE(32, 1, 2) PHASE_CASE(32, 1, 1)
+    PHASE_CASE(16, 2, 2) PHASE_CASE(16, 2, 1) PHASE_CASE(8, 2, 2) PHASE_CASE(8, 2, 1)
+    PHASE_CASE(16, 1, 2) PHASE_CASE(16, 1, 1) PHASE_CASE(8, 1, 2) PHASE_CASE(8, 1, 1)
+#undef PHASE_CASE
+    return false;
+}
+
+bool dispatch_igemm_phases_lowp(int math, const IgemmPlan& p, const IgemmArgs& a, const IgemmPhases& pt, int nwg, hipStream_t st) {
+    if (math != MATH_B16 || p.KS != 1 || p.WN != 1) return false;
+    return p.CK == 64 ? dispatch_phases_ck<64>(p, a, pt, nwg, st) : (p.CK == 16 ? dispatch_phases_ck<16>(p, a, pt, nwg, st) : false);
+}
+
 }  // namespace seg

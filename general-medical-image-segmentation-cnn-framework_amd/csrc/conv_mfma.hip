@@ -779,6 +779,10 @@ int conv_gather_fwd_mfma(int math, const void* x, int ldx, const float* w, const
 }
 
 // dx[N,D,H,W,Cin] from dy[N,Do,Ho,Wo,Cout]:  dx[u] = sum over taps t with (u + pad - t) % stride == 0 of dy[(u + pad - t) / stride] W[.,.,t]
+// One GEMM per output phase (u mod stride).  bf16 tensors (r6): all phases in ONE launch over ONE packing of the weights -- the taps
+// partition over the phases, so the packing is the phases' tap lists back to back -- instead of eight pack + eight convolution launches
+// (the deep Residual U-Net levels: eight launches of ~60 workgroups, 14-94 us each, now one of ~480); other maths, or phases whose
+// plans differ, keep the per-phase launches.
 int conv_gather_dgrad_mfma(int math, const void* dy, int lddy, const float* w, void* dx, int lddx, int N, int D, int H, int W,
                            int Cin, int Cout, int k, int stride, int pad, void* ws, size_t ws_bytes, hipStream_t st) {
     const int Do = out_extent(D, k, stride, pad), Ho = out_extent(H, k, stride, pad), Wo = out_extent(W, k, stride, pad);
@@ -787,9 +791,11 @@ int conv_gather_dgrad_mfma(int math, const void* dy, int lddy, const float* w, v
     Carver cv(ws);
     char* wq_all = cv.take<char>(wq_bytes(math, (size_t)T * Cin * Cout));
     SEG_CHECK_WS(cv.used(), ws_bytes);
-    size_t wq_used = 0;
     ProfScope ps(PF_IGEMM, 2.0 * (double)N * Do * Ho * Wo * T * Cin * Cout,
                  matrix_bytes(math, (double)N * D * H * W * Cin + (double)N * Do * Ho * Wo * Cout, (double)T * Cin * Cout), st);
+    struct Phase { IgemmPlan p; IgemmArgs a; TapList tl; int nt; };
+    Phase phs[64];
+    int nph = 0;
     for (int ph = 0; ph < stride * stride * stride; ++ph) {
         const int pz = ph / (stride * stride), py = (ph / stride) % stride, px = ph % stride;
         const int Bz = (D - pz + stride - 1) / stride, By = (H - py + stride - 1) / stride, Bx = (W - px + stride - 1) / stride;
@@ -802,25 +808,73 @@ int conv_gather_dgrad_mfma(int math, const void* dy, int lddy, const float* w, v
         }
         const int nt = nz * ny * nx;
         SEG_CHECK_ARG(nt > 0, "conv_gather_dgrad_mfma: a phase without taps (k < stride)");
-        IgemmPlan p;
+        Phase& q = phs[nph++];
+        q.nt = nt;
+        IgemmPlan& p = q.p;
         SEG_CHECK_ARG(igemm_plan(math, 1, N, Bz, By, Bx, Cout, Cin, 1, &p), "conv_gather_dgrad_mfma: unsupported shape");
         const int cpt = Cout / p.CK, nchunks = nt * cpt;
-        void* wq = wq_all + wq_used;
-        wq_used += align_up(wq_bytes(math, (size_t)nt * Cin * Cout), 16);
-        IgemmArgs a{dy, wq, nullptr, dx, nullptr, lddy, lddx, N, Bz, By, Bx, Cin, p.ntx, p.nty, p.ntz, p.nN, nchunks, cpt, p.nN, 1, stride,
-                    p.nM, 1, nchunks, 0, 0};
+        q.a = IgemmArgs{dy, nullptr, nullptr, dx, nullptr, lddy, lddx, N, Bz, By, Bx, Cin, p.ntx, p.nty, p.ntz, p.nN, nchunks, cpt, p.nN, 1, stride,
+                        p.nM, 1, nchunks, 0, 0};
+        IgemmArgs& a = q.a;
         a.Di = Do; a.Hi = Ho; a.Wi = Wo; a.Do = D; a.Ho = H; a.Wo = W; a.cz = pz; a.cy = py; a.cx = px;
-        TapList tl{};
+        q.tl = TapList{};
         int slot = 0;
         for (int iz = 0; iz < nz; ++iz)
             for (int iy = 0; iy < ny; ++iy)
                 for (int ix = 0; ix < nx; ++ix, ++slot) {
-                    tl.t[slot] = (unsigned char)((lz[iz] * k + ly[iy]) * k + lx[ix]);
+                    q.tl.t[slot] = (unsigned char)((lz[iz] * k + ly[iy]) * k + lx[ix]);
                     a.toff[slot][0] = (signed char)dz[iz]; a.toff[slot][1] = (signed char)dyo[iy]; a.toff[slot][2] = (signed char)dxo[ix];
                 }
-        launch_pack(math, w, wq, nt * Cout, Cin, 1, p.NT, 6, Cout, p.CK, T, tl, st);
+    }
+    // ---- one launch: the same tile shape in every phase, at most eight phases of at most eight taps, every tap in exactly one phase
+    bool multi = math == MATH_B16 && nph >= 2 && nph <= 8;
+    int taps_total = 0;
+    for (int i = 0; i < nph && multi; ++i) {
+        const IgemmPlan &p = phs[i].p, &p0 = phs[0].p;
+        multi = phs[i].nt <= 8 && p.KS == p0.KS && p.CK == p0.CK && p.BX == p0.BX && p.MB == p0.MB && p.NBW == p0.NBW && p.WN == 1 && p.nN == p0.nN && !p.flat;
+        taps_total += phs[i].nt;
+    }
+    multi = multi && taps_total == T;
+    if (multi) {
+        const IgemmPlan& p0 = phs[0].p;
+        const int cpt = Cout / p0.CK;
+        const size_t chunk_bytes = (size_t)p0.CK * p0.NT * esize(math);          // one (N-tile, chunk) of the packing (bf16: one plane)
+        IgemmArgs a = phs[0].a;
+        IgemmPhases pt{};
+        TapList tl{};
+        int slot0 = 0, first = 0;
+        for (int i = 0; i < nph; ++i) {
+            const Phase& q = phs[i];
+            for (int sl = 0; sl < q.nt; ++sl) {
+                tl.t[slot0 + sl] = q.tl.t[sl];
+                for (int c = 0; c < 4; ++c) a.toff[8 * i + sl][c] = q.a.toff[sl][c];
+            }
+            IgemmPhase& f = pt.ph[i];
+            f.wq = wq_all + (size_t)slot0 * cpt * chunk_bytes;
+            f.D = q.a.D; f.H = q.a.H; f.W = q.a.W; f.ntx = q.p.ntx; f.nty = q.p.nty; f.ntz = q.p.ntz;
+            f.by = tile_block(f.nty); f.bz = f.ntz >= 4 ? 4 : tile_block(f.ntz);
+            f.nchunks = q.nt * cpt; f.wstride = T * cpt; f.cz = q.a.cz; f.cy = q.a.cy; f.cx = q.a.cx; f.first = first;
+            first += (q.p.nM * q.p.nN + 7) / 8 * 8;
+            slot0 += q.nt;
+        }
+        pt.n = nph;
+        launch_pack(math, w, wq_all, T * Cout, Cin, 1, p0.NT, 6, Cout, p0.CK, T, tl, st);
         SEG_CHECK_LAUNCH();
-        dispatch_igemm(math, p, a, p.nM * p.nN, st);
+        a.wq = wq_all; a.total = first;
+        if (dispatch_igemm_phases_lowp(math, p0, a, pt, first, st)) {
+            SEG_CHECK_LAUNCH();
+            return MI355SEG_OK;
+        }
+    }
+    size_t wq_used = 0;
+    for (int i = 0; i < nph; ++i) {
+        Phase& q = phs[i];
+        void* wq = wq_all + wq_used;
+        wq_used += align_up(wq_bytes(math, (size_t)q.nt * Cin * Cout), 16);
+        q.a.wq = wq;
+        launch_pack(math, w, wq, q.nt * Cout, Cin, 1, q.p.NT, 6, Cout, q.p.CK, T, q.tl, st);
+        SEG_CHECK_LAUNCH();
+        dispatch_igemm(math, q.p, q.a, q.p.nM * q.p.nN, st);
         SEG_CHECK_LAUNCH();
     }
     return MI355SEG_OK;

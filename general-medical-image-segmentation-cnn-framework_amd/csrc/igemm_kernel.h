@@ -130,6 +130,14 @@ struct IgemmArgs {
 };
 
 
+// One launch over the (up to 8) output PHASES of a strided input gradient (r6; conv_gather_dgrad_mfma): phase p = the dx voxels with
+// (u mod stride) = (cz, cy, cx) is a GEMM of its own -- base grid (D, H, W), its taps (toff rows 8 p .. of the launch's IgemmArgs), its
+// K range -- that used to be a launch of its own (eight launches of 60 workgroups each on the deep levels).  Blocks first .. of the
+// grid belong to the phase (first is a multiple of 8: the XCD map of a phase starts on XCD 0); wq = the phase's first chunk inside the
+// ONE packing of all taps, wstride = chunks per N-tile of that packing.
+struct IgemmPhase { const void* wq; int D, H, W, ntx, nty, ntz, by, bz, nchunks, wstride, cz, cy, cx, first; };
+struct IgemmPhases { IgemmPhase ph[8]; int n; };
+
 struct TapList { unsigned char t[64]; };
 struct IgemmPlan { int KS, CK, BX, MB, NBW, TZ, nM, nN, ntx, nty, ntz, flat, WN, NT, TY; };     // NT = 32 * NBW * WN: tile width in channels
 
@@ -143,8 +151,10 @@ struct IgemmPlan { int KS, CK, BX, MB, NBW, TZ, nM, nN, ntx, nty, ntz, flat, WN,
 // 2 (M) x 2 (N) grid, a wave owns MB M-blocks and its own NBW N-blocks (tile = 64*MB voxels x 64*NBW channels): each weight
 // fragment a wave loads then feeds MB MFMAs and is loaded by two waves instead of four -- the layout of the bf16 tiles,
 // whose single MFMA per k-step would otherwise leave the L1 path saturated by the four waves' re-loads of the same weights.
-template <int MATH, int KS, int BX, int MB, int NBW, int CK, int WN = 1>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
+// MULTI: the launch runs several phases (IgemmPhases); `ph` then overrides the per-phase fields of `a`, `bid` / `total` are the block's
+// index inside its phase and the phase's tile count, `tap0` its first row of a.toff
+template <int MATH, int KS, int BX, int MB, int NBW, int CK, int WN, bool MULTI>
+__device__ __forceinline__ void conv_igemm_body(const IgemmArgs& a, const IgemmPhase& ph, const int bid_in, const int total_in, const int tap0_in) {
     using T = Tile<MATH, KS, BX, MB, CK, WN>;
     using MT = MathTraits<MATH>;
     using in_t = typename MT::in_t;
@@ -167,6 +177,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
     // M-tiles are walked in (y, z) blocks of by x bz tiles (x fastest inside a block) so that the ~64 tiles an XCD works
     // on at any moment form a compact brick whose shared halo planes stay in that XCD's L2 (by divides nty; the last
     // z-row of bricks may be shorter than bz)
+    // the fields a phase of a MULTI launch overrides (all wave-uniform)
+    const void* const awq = MULTI ? ph.wq : a.wq;
+    const int aD = MULTI ? ph.D : a.D, aH = MULTI ? ph.H : a.H, aW = MULTI ? ph.W : a.W;
+    const int antx = MULTI ? ph.ntx : a.ntx, anty = MULTI ? ph.nty : a.nty, antz = MULTI ? ph.ntz : a.ntz, aby = MULTI ? ph.by : a.by, abz = MULTI ? ph.bz : a.bz;
+    const int anchunks = MULTI ? ph.wstride : a.nchunks, acps = MULTI ? ph.nchunks : a.cps;     // (N-tile pitch of the packing | chunks this block runs)
+    const int acz = MULTI ? ph.cz : a.cz, acy = MULTI ? ph.cy : a.cy, acx = MULTI ? ph.cx : a.cx;
+    const int tap0 = MULTI ? tap0_in : 0;
     struct TC { int ks, ntile, mtile, n, x0, y0, z0; };
     auto decode = [&](int t) {
         TC c;
@@ -174,18 +191,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
         c.ntile = t % a.nN;
         c.mtile = t / a.nN;
         int mt = c.mtile;
-        const int per_n = a.ntx * a.nty * a.ntz;
+        const int per_n = antx * anty * antz;
         c.n = mt / per_n; mt -= c.n * per_n;
-        const int zfull = a.ntz / a.bz;                       // full z-rows of bricks; a ragged last row holds the remaining slabs
-        const int rowtiles = a.ntx * a.nty * a.bz;            // tiles per full z-row
-        int zrow = mt / rowtiles, bzz = a.bz;
-        if (zrow >= zfull) { zrow = zfull; bzz = a.ntz - zfull * a.bz; }
+        const int zfull = antz / abz;                         // full z-rows of bricks; a ragged last row holds the remaining slabs
+        const int rowtiles = antx * anty * abz;               // tiles per full z-row
+        int zrow = mt / rowtiles, bzz = abz;
+        if (zrow >= zfull) { zrow = zfull; bzz = antz - zfull * abz; }
         mt -= zrow * rowtiles;
-        const int blk = a.ntx * a.by * bzz;
+        const int blk = antx * aby * bzz;
         const int b = mt / blk; mt -= b * blk;
-        const int txi = mt % a.ntx; mt /= a.ntx;
-        const int tyi = b * a.by + mt % a.by;
-        const int tzi = zrow * a.bz + mt / a.by;
+        const int txi = mt % antx; mt /= antx;
+        const int tyi = b * aby + mt % aby;
+        const int tzi = zrow * abz + mt / aby;
         c.x0 = txi * BX; c.y0 = tyi * T::TY; c.z0 = tzi * T::TZ;
         return c;
     };
@@ -194,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
     // layer (Cin = 32: two chunks, 3.5 us of MFMAs per tile) otherwise spends most of a tile's life waiting for the first
     // loads of a freshly launched workgroup.  Not PERSIST: one tile per workgroup, grid = tiles.
     constexpr bool PERSIST = T::PERSIST;
-    const int total = PERSIST ? a.total : (int)gridDim.x, bid = blockIdx.x;
+    const int total = PERSIST ? a.total : total_in, bid = bid_in;
     const int q8 = total >> 3, r8 = total & 7, xcd = bid & 7;
     const int xstart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, xcnt = q8 + (xcd < r8 ? 1 : 0);
     const int xslots = ((int)gridDim.x + 7) >> 3;             // workgroups per XCD
@@ -205,8 +222,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
     // plans): their multipliers, tap offsets and child logic fold away at compile time
     constexpr bool PLAIN = KS != 1;
     const int in_mul = PLAIN ? 1 : a.in_mul, out_mul = PLAIN ? 1 : a.out_mul;
-    const int Di = PLAIN ? a.D : a.Di, Hi = PLAIN ? a.H : a.Hi, Wi = PLAIN ? a.W : a.Wi;
-    const int Do = PLAIN ? a.D : a.Do, Ho = PLAIN ? a.H : a.Ho, Wo = PLAIN ? a.W : a.Wo;
+    const int Di = PLAIN ? aD : a.Di, Hi = PLAIN ? aH : a.Hi, Wi = PLAIN ? aW : a.Wi;
+    const int Do = PLAIN ? aD : a.Do, Ho = PLAIN ? aH : a.Ho, Wo = PLAIN ? aW : a.Wo;
     const in_t* __restrict__ xin = reinterpret_cast<const in_t*>(a.x);
 
     // per-lane LDS base (LDS elements) of the A fragment for each M-block: lane (i, h) reads voxel i of the block and the
@@ -231,9 +248,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
             const int hz = vox / (T::HY * T::HX), rem = vox % (T::HY * T::HX);
             const int hy = rem / T::HX, hx = rem % T::HX;
             const int tapk = PLAIN ? 0 : chunk / a.cpt, cch = PLAIN ? chunk : chunk - tapk * a.cpt;     // input child (ConvT dgrad), else 0
-            const int gz = (c.z0 - T::HALO + hz) * in_mul + (PLAIN ? 0 : a.toff[tapk][0]);
-            const int gy = (c.y0 - T::HALO + hy) * in_mul + (PLAIN ? 0 : a.toff[tapk][1]);
-            const int gx = (c.x0 - T::HALO + hx) * in_mul + (PLAIN ? 0 : a.toff[tapk][2]);
+            const int gz = (c.z0 - T::HALO + hz) * in_mul + (PLAIN ? 0 : a.toff[tap0 + tapk][0]);
+            const int gy = (c.y0 - T::HALO + hy) * in_mul + (PLAIN ? 0 : a.toff[tap0 + tapk][1]);
+            const int gx = (c.x0 - T::HALO + hx) * in_mul + (PLAIN ? 0 : a.toff[tap0 + tapk][2]);
             const bool ok = (p < T::NPIECE) && (unsigned)gz < (unsigned)Di && (unsigned)gy < (unsigned)Hi && (unsigned)gx < (unsigned)Wi;
             stage_t v = {};
             if (ok) {
@@ -266,12 +283,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
         }
     };
 
-    load_stage(tc, tc.ks * a.cps);
+    load_stage(tc, tc.ks * acps);
     for (;;) {
     const int ks = tc.ks, ntile = tc.ntile, mtile = tc.mtile, n = tc.n, x0 = tc.x0, y0 = tc.y0, z0 = tc.z0;
     const int tapn = PLAIN ? 0 : ntile / a.nNpt;              // output child (ConvT fwd), else 0
     const int n0 = (PLAIN ? ntile : ntile % a.nNpt) * NT;
-    const int c0 = ks * a.cps, c1 = c0 + a.cps;             // this split's chunk range
+    const int c0 = ks * acps, c1 = c0 + acps;               // this split's chunk range
     bool has_next = false;
     if constexpr (PERSIST) {
         local += xslots;
@@ -281,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
     // the chunk after `chunk`: the next one of this tile, else the first one of this workgroup's next tile
     auto prefetch = [&](int chunk) {
         if (chunk + 1 < c1) load_stage(tc, chunk + 1);
-        else if (PERSIST && has_next) load_stage(tn, tn.ks * a.cps);
+        else if (PERSIST && has_next) load_stage(tn, tn.ks * acps);
     };
     f32x16 acc[MB][NBW];
 #pragma unroll
@@ -294,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
         constexpr int STEP_FLOATS = 2 * NT * 4;                 // packed weights consumed per (tap, kk) step
         constexpr int CHUNK_FLOATS = NTAP * (CK / 8) * STEP_FLOATS;
         const float* lds = reinterpret_cast<const float*>(lds_raw);
-        const float* wlane = reinterpret_cast<const float*>(a.wq) + (long long)ntile * a.nchunks * CHUNK_FLOATS + (h * NT + i) * 4;
+        const float* wlane = reinterpret_cast<const float*>(awq) + (long long)ntile * anchunks * CHUNK_FLOATS + (h * NT + i) * 4;
         for (int chunk = c0; chunk < c1; ++chunk) {
             const float* wp = wlane + (long long)chunk * CHUNK_FLOATS;
             // B fragments run PFD steps ahead of the MFMAs that consume them (register ring, static indices).
@@ -348,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
         constexpr int NSTEP = NTAP * KSTEPS;
         constexpr int CHUNK = NSTEP * STEP;
         const bf16* lds = reinterpret_cast<const bf16*>(lds_raw);
-        const bf16* wlane = reinterpret_cast<const bf16*>(a.wq) + (long long)ntile * a.nchunks * CHUNK + (h * NT + i) * 8;
+        const bf16* wlane = reinterpret_cast<const bf16*>(awq) + (long long)ntile * anchunks * CHUNK + (h * NT + i) * 8;
         if constexpr (T::SLIDE) {
             // bf16 k3, sliding window along y.  At one MFMA per (voxel fragment, weight fragment) pair the plain loop reads a
             // 1 KB fragment from LDS per MFMA -- exactly the LDS bandwidth of a CU at full MFMA rate, so LDS, not the matrix
@@ -539,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
     for (int nb = 0; nb < NBW; ++nb) {
         int col = n0 + (nbase + nb) * 32 + i, child = tapn;
         if (!PLAIN && a.flatn) { const int nf = ntile * NT + (nbase + nb) * 32 + i; child = nf / a.Cout; col = nf - child * a.Cout; }   // per-lane child
-        const int oz = PLAIN ? 0 : ((child >> 2) & 1) + a.cz, oy = PLAIN ? 0 : ((child >> 1) & 1) + a.cy, ox = PLAIN ? 0 : (child & 1) + a.cx;
+        const int oz = PLAIN ? 0 : ((child >> 2) & 1) + acz, oy = PLAIN ? 0 : ((child >> 1) & 1) + acy, ox = PLAIN ? 0 : (child & 1) + acx;
         const float bv = a.bias ? a.bias[col] : 0.f;
         float s1 = 0.f;
 #pragma unroll
@@ -555,7 +572,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
                 float val = acc[mb][nb][v] + bv;
                 if (a.act) val = act_apply(val, a.act, a.slope);
                 // partial tiles (extents that are not tile multiples): rows outside the volume are dropped
-                const bool inside = (z0 + line / T::TY) < a.D && (y0 + line % T::TY) < a.H && (x0 + xx) < a.W &&
+                const bool inside = (z0 + line / T::TY) < aD && (y0 + line % T::TY) < aH && (x0 + xx) < aW &&
                                     gz < Do && gy < Ho && gx < Wo;
 #ifdef MI355SEG_TUNE
                 if (inside && (!(a.dbg & 4) || val == 12345.678f))
@@ -588,7 +605,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
             if (h == 0) lds[wave_m * NT + (nbase + nb) * 32 + i] = s1;
         }
         {   // valid rows of this tile (same for every channel)
-            const int vz = min(T::TZ, a.D - z0), vy = min(T::TY, a.H - y0), vx = min(BX, a.W - x0);
+            const int vz = min(T::TZ, aD - z0), vy = min(T::TY, aH - y0), vx = min(BX, aW - x0);
             cnt = (float)(vz * vy * vx);
         }
         __syncthreads();
@@ -613,7 +630,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
                 for (int v = 0; v < 16; ++v) {
                     const int r = (v & 3) + 8 * (v >> 2) + 4 * h;
                     const int line = m * T::LPB + r / BX, xx = r % BX;
-                    const bool inside = (z0 + line / T::TY) < a.D && (y0 + line % T::TY) < a.H && (x0 + xx) < a.W;
+                    const bool inside = (z0 + line / T::TY) < aD && (y0 + line % T::TY) < aH && (x0 + xx) < aW;
                     const float d = acc[mb][nb][v] + bv - tmean[nb];
                     if (inside) m2 += d * d;
                 }
@@ -633,6 +650,32 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
     if (!has_next) break;
     tc = tn;
     }
+}
+
+template <int MATH, int KS, int BX, int MB, int NBW, int CK, int WN = 1>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmArgs a) {
+    conv_igemm_body<MATH, KS, BX, MB, NBW, CK, WN, false>(a, IgemmPhase{}, (int)blockIdx.x, (int)gridDim.x, 0);
+}
+
+// the phases of a strided input gradient in one launch (k1 gather plans only): block -> phase by the phases' first blocks
+template <int MATH, int KS, int BX, int MB, int NBW, int CK>
+__global__ __launch_bounds__(256, 2) void conv_igemm_phases_kernel(IgemmArgs a, IgemmPhases pt) {
+    const int bid = (int)blockIdx.x;
+    int p = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) if (k < pt.n && bid >= pt.ph[k].first) p = k;
+    const int end = p + 1 < pt.n ? pt.ph[p + 1].first : (int)gridDim.x;
+    const int tiles = pt.ph[p].ntx * pt.ph[p].nty * pt.ph[p].ntz * a.N * a.nN;      // (the phase's blocks past its tiles leave in the XCD map)
+    conv_igemm_body<MATH, KS, BX, MB, NBW, CK, 1, true>(a, pt.ph[p], bid - pt.ph[p].first, min(tiles, end - pt.ph[p].first), 8 * p);
+}
+
+template <int MATH, int KS, int BX, int MB, int NBW, int CK>
+static void launch_igemm_phases(const IgemmArgs& a, const IgemmPhases& pt, int nwg, hipStream_t st) {
+    using T = Tile<MATH, KS, BX, MB, CK, 1>;
+    static_assert(KS == 1 && !T::PERSIST, "phase launches are gather plans");
+    constexpr int LDSB = T::LDS_BYTES < 8 * 64 * 4 ? 8 * 64 * 4 : T::LDS_BYTES;
+    SEG_SET_LDS((conv_igemm_phases_kernel<MATH, KS, BX, MB, NBW, CK>), LDSB);
+    hipLaunchKernelGGL((conv_igemm_phases_kernel<MATH, KS, BX, MB, NBW, CK>), dim3(nwg), dim3(256), LDSB, st, a, pt);
 }
 
 template <int MATH, int KS, int BX, int MB, int NBW, int CK, int WN = 1>
@@ -724,6 +767,7 @@ int get_b16_tiles();
 
 // conv_igemm_lowp.hip: the MATH_X3 / MATH_B16 instantiations (their own translation unit: they compile in parallel)
 void dispatch_igemm_lowp(int math, const IgemmPlan& p, const IgemmArgs& a, int nwg, hipStream_t st);
+bool dispatch_igemm_phases_lowp(int math, const IgemmPlan& p, const IgemmArgs& a, const IgemmPhases& pt, int nwg, hipStream_t st);     // false: no such instantiation
 bool igemm_lowp_has(int math, int KS, int CK, int BX, int MB);
 
 }  // namespace seg
