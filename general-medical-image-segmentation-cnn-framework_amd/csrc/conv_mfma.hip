@@ -21,6 +21,7 @@
 #include "common.h"
 #include "internal.h"
 #include "igemm_kernel.h"
+#include "pack.h"
 #include <stdlib.h>
 #include <initializer_list>
 
@@ -36,16 +37,6 @@ namespace seg {
 //   mode 3 (convT dgrad):  chunk = (tapk, cc): B = Wt[ci = n][co = cc*CK + ..][tapk]     Wt: (Cin_f, Cout_f, 8), T = 1
 //   mode 5 (gather fwd):   chunk = (tap, cc):  B = W[co = n][ci = cc*CK + ..][tap]      W: (Cout, Cin, TW), aux = Cin, T = 1
 //   mode 6 (gather dgrad): chunk = (slot, cc): B = W[co = cc*CK + ..][ci = n][taps.t[slot]]   aux = Cout, T = 1
-__device__ __forceinline__ float pack_src(const float* __restrict__ w, int mode, int n, int k, int tap, int K, int Nn, int T, int aux, int TW,
-                                          const TapList& taps) {
-    if (mode == 0) return w[((long long)n * K + k) * T + tap];
-    if (mode == 1) return w[((long long)k * Nn + n) * T + (T - 1 - tap)];
-    if (mode == 2) { const int cout = aux; const int tapn = n / cout, co = n % cout; return w[((long long)k * cout + co) * 8 + tapn]; }
-    if (mode == 3 || mode == 5) { const int cout = aux; const int tapk = k / cout, co = k % cout; return w[((long long)n * cout + co) * TW + tapk]; }
-    const int cout = aux; const int slot = k / cout, co = k % cout;
-    return w[((long long)co * Nn + n) * TW + taps.t[slot]];
-}
-
 // oscale (optional): per-output-channel factor folded into the packed weights -- eval-mode BatchNorm (gamma / sqrt(var + eps))
 // for the fused inference forward; n is the GEMM column = output channel in the modes that use it (0: conv forward)
 __global__ void pack_wq_kernel(const float* __restrict__ w, float* __restrict__ wq, int K, int Nn, int T, int NT, int mode, int aux, int CK,
@@ -64,34 +55,7 @@ __global__ void pack_wq_kernel(const float* __restrict__ w, float* __restrict__ 
     }
 }
 
-// (IDX: the element index type -- every packing of the networks here has fewer than 2^31 elements, and seven 64-bit divisions per
-//  element were most of this kernel's time: 44 us for the 3.5 M weights of a 256 -> 512 k3 layer, 10 us for a 1 x 1 x 1 one)
-template <int NP, typename IDX>
-__global__ void pack_wq_lowp_kernel(const float* __restrict__ w, bf16* __restrict__ wq, int K, int Nn, int T, int NT, int mode, int aux, int CK,
-                                    int TW, TapList taps, const float* __restrict__ oscale) {
-    const IDX total = (IDX)K * Nn * T;
-    const int plane = 2 * NT * 8;
-    for (IDX idx = (IDX)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (IDX)gridDim.x * blockDim.x) {
-        IDX r = idx;
-        const int e = (int)(r % 8); r /= 8;
-        const int j = (int)(r % NT); r /= NT;
-        const int h = (int)(r % 2); r /= 2;
-        const int kst = (int)(r % (CK / 16)); r /= (CK / 16);
-        const int tap = (int)(r % T); r /= T;
-        const int chunk = (int)(r % (K / CK)); r /= (K / CK);
-        const int nt = (int)r;
-        const float v = pack_src(w, mode, nt * NT + j, chunk * CK + kst * 16 + 8 * h + e, tap, K, Nn, T, aux, TW, taps) * (oscale ? oscale[nt * NT + j] : 1.f);
-        const long long base = ((((long long)nt * (K / CK) + chunk) * T + tap) * (CK / 16) + kst) * (NP * plane) + ((long long)h * NT + j) * 8 + e;
-        if (NP == 3) {
-            bf16 bh, bm, bl;
-            split3(v, bh, bm, bl);
-            wq[base] = bh; wq[base + plane] = bm; wq[base + 2 * plane] = bl;
-        } else {
-            wq[base] = (bf16)v;
-        }
-    }
-}
-
+// (the low-precision form of this layout: pack_wq_lowp_body, prepack.hip)
 // conv_x3s.hip layout: wq[nt][chunk][unit = (K-step s, 32-channel half nh)][plane][16-channel tile t2][lane][8]; lane = (c, g):
 // element e = plane of W[co = nt*NT + nh*32 + t2*16 + c][ci = chunk*16 + 8*(g&1) + e][tap = x3s_pair_tap(s, g>>1)]  (tap 27: zero)
 __global__ void pack_wq_x3s_kernel(const float* __restrict__ w, bf16* __restrict__ wq, int K, int Nn, int NBW, int mode, const float* __restrict__ oscale) {
@@ -200,102 +164,41 @@ __global__ void pack_wq_b16s_kernel(const float* __restrict__ w, bf16* __restric
     }
 }
 
-// The two hot packings above, tiled: a workgroup owns NB (8; 4 for k5 and for narrow layers) GEMM columns x one 16-channel K chunk x all taps, reads that block of W
-// with full-width coalesced loads (the per-element kernels read W at a stride of T floats -- one 64-byte sector per 4 bytes used;
-// 10-16 us per layer, 0.4-0.8 ms of a V-Net / Res-U-Net step) into LDS and emits whole 16-byte fragment slots.
-// LAYOUT 0: conv_b16s.hip (P = NT), 1: conv_x3s.hip (P = NBW), 2: conv_x3s.hip f16x3 (two fp16 planes of w * 2^sw, sw from *amax_w).
-// mode 0 / 1 as pack_src.
-template <int LAYOUT, int NB>
-__global__ __launch_bounds__(256) void pack_tiled_kernel(const float* __restrict__ w, bf16* __restrict__ wq, int K, int Nn, int T, int P, int mode,
-                                                         const float* __restrict__ oscale, const float* __restrict__ amax_w) {
-    extern __shared__ float tile[];
-    const int nnb = Nn / NB;
-    const int n0 = (blockIdx.x % nnb) * NB, chunk = blockIdx.x / nnb, k0 = chunk * 16;
-    const int tid = threadIdx.x;
-    // phase 1: mode 0: NB runs (n) of 16 T floats at W[n][k0 ..][.]; mode 1: 16 runs (k) of NB T floats at W[k][n0 ..][.]
-    const int nrun = mode == 0 ? NB : 16, rlen = (mode == 0 ? 16 : NB) * T;
-    for (int i = tid * 4; i < nrun * rlen; i += 1024) {
-        const int run = i / rlen, off = i - run * rlen;
-        const float* src = mode == 0 ? w + ((long long)(n0 + run) * K + k0) * T : w + ((long long)(k0 + run) * Nn + n0) * T;
-        *reinterpret_cast<f32x4*>(tile + i) = *reinterpret_cast<const f32x4*>(src + off);
-    }
-    __syncthreads();
-    const int nstep = LAYOUT == 0 ? (T + 1) / 2 : X3S_NPAIR, nch = K / 16;
-    constexpr int LB = NB == 8 ? 3 : (NB == 4 ? 2 : 1);
-    for (int q = tid; q < nstep * 4 * NB; q += 256) {
-        const int half = q & 1, nl = (q >> 1) & (NB - 1), gh = (q >> (1 + LB)) & 1, s = q >> (2 + LB);
-        const int tap = LAYOUT == 0 ? 2 * s + gh : x3s_pair_tap(s, gh);
-        const int n = n0 + nl, g = 2 * gh + half;
-        float v[8];
-        if (tap < T) {
-            float sc = (oscale && mode == 0) ? oscale[n] : 1.f;
-            if (LAYOUT == 2) sc *= pow2f(f16x_scale_exp(*amax_w));
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int kl = 8 * half + e;
-                v[e] = (mode == 0 ? tile[(nl * 16 + kl) * T + tap] : tile[(kl * NB + nl) * T + (T - 1 - tap)]) * sc;
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.f;
-        }
-        if (LAYOUT == 0) {
-            const int NT = P, ntt = NT / 16, nt = n / NT, nin = n - nt * NT;
-            const int tt = 2 * (nin / 32) + ((nin >> 2) & 1), c = 4 * ((nin & 31) >> 3) + (nin & 3);
-            bf16x8_t o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-            reinterpret_cast<bf16x8_t*>(wq)[((((long long)nt * nch + chunk) * nstep + s) * ntt + tt) * 64 + c + 16 * g] = o;
-        } else if (LAYOUT == 2) {
-            const int NBW = P, NT = 32 * NBW, nt = n / NT, nin = n - nt * NT;
-            const int nh = nin / 32, t2 = (nin & 31) >> 4, c = nin & 15;
-            f16x8_t oh, ol;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { _Float16 a, b; split2h(v[e], a, b); oh[e] = a; ol[e] = b; }
-            _Float16* dst = reinterpret_cast<_Float16*>(wq) + (((long long)nt * nch + chunk) * (X3S_NPAIR * NBW) + s * NBW + nh) * 2048 + t2 * 512 + (c + 16 * g) * 8;
-            *reinterpret_cast<f16x8_t*>(dst) = oh;
-            *reinterpret_cast<f16x8_t*>(dst + 1024) = ol;
-        } else {
-            const int NBW = P, NT = 32 * NBW, nt = n / NT, nin = n - nt * NT;
-            const int nh = nin / 32, t2 = (nin & 31) >> 4, c = nin & 15;
-            bf16x8_t oh, om, ol;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { bf16 a, b, d; split3(v[e], a, b, d); oh[e] = a; om[e] = b; ol[e] = d; }
-            bf16* dst = wq + (((long long)nt * nch + chunk) * (X3S_NPAIR * NBW) + s * NBW + nh) * 3072 + t2 * 512 + (c + 16 * g) * 8;
-            *reinterpret_cast<bf16x8_t*>(dst) = oh;
-            *reinterpret_cast<bf16x8_t*>(dst + 1024) = om;
-            *reinterpret_cast<bf16x8_t*>(dst + 2048) = ol;
-        }
-    }
+// The two hot packings above, tiled (pack_tiled_body, prepack.hip): the descriptor of one
+static PackDesc tiled_desc(int layout, const float* w, void* wq, int K, int Nn, int T, int P, int mode, const float* oscale, const float* amax_w) {
+    PackDesc d{};
+    d.kind = PD_TILED; d.layout = layout;
+    // enough workgroups for the narrow layers, short serial work per workgroup for the 125-tap ones (runs of 4 T floats keep the 16-byte alignment)
+    d.nb = (T > 27 || (long long)(Nn / 8) * (K / 16) < 256) ? 4 : 8;
+    d.w = w; d.dst = wq; d.amax = amax_w; d.oscale = oscale;
+    d.K = K; d.Nn = Nn; d.T = T; d.P = P; d.mode = mode;
+    d.amax_elems = layout == 2 ? (long long)K * Nn * T : 0;
+    return d;
 }
-
-template <int LAYOUT, int NB>
-static void launch_pack_tiled_nb(const float* w, bf16* wq, int K, int Nn, int T, int P, int mode, const float* oscale, const float* amax_w, hipStream_t st) {
-    const size_t lds = (size_t)16 * NB * T * sizeof(float);
-    SEG_SET_LDS((pack_tiled_kernel<LAYOUT, NB>), lds);
-    hipLaunchKernelGGL((pack_tiled_kernel<LAYOUT, NB>), dim3((unsigned)((Nn / NB) * (K / 16))), dim3(256), lds, st, w, wq, K, Nn, T, P, mode, oscale, amax_w);
-}
-template <int LAYOUT>
-static void launch_pack_tiled(const float* w, bf16* wq, int K, int Nn, int T, int P, int mode, const float* oscale, hipStream_t st, const float* amax_w = nullptr) {
-    // enough workgroups for the narrow layers, short serial work per workgroup for the 125-tap ones
-    if (T > 27 || (long long)(Nn / 8) * (K / 16) < 256) launch_pack_tiled_nb<LAYOUT, 4>(w, wq, K, Nn, T, P, mode, oscale, amax_w, st);   // (runs of 4 T floats keep the 16-byte alignment)
-    else launch_pack_tiled_nb<LAYOUT, 8>(w, wq, K, Nn, T, P, mode, oscale, amax_w, st);
+static PackDesc lowp_desc(int np, const float* w, void* wq, int K, int Nn, int T, int NT, int mode, int aux, int CK, int TW, const TapList& taps, const float* oscale) {
+    PackDesc d{};
+    d.kind = PD_LOWP; d.np = np; d.w = w; d.dst = wq; d.oscale = oscale;
+    d.K = K; d.Nn = Nn; d.T = T; d.P = NT; d.mode = mode; d.aux = aux; d.CK = CK; d.TW = TW; d.taps = taps;
+    return d;
 }
 
 static int pack_grid(long long total) { return (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256); }
 // MATH_X3: sized for the 28-tap layout of conv_x3s.hip (27 taps + one zero tap), which is the larger of its two packings
 // MATH_B16 likewise for conv_b16s.hip (taps paired: one zero tap when the tap count is odd)
 static size_t wq_bytes(int math, size_t nelem) { return math == MATH_F32 ? nelem * 4 : (math == MATH_X3 ? (nelem + nelem / 27 + 64) * 6 : (nelem + nelem / 27 + 64) * 2); }
+// the generic layouts; the low-precision ones with fewer than 2^31 elements through a descriptor (*desc, when asked for, tells the caller
+// what was launched so that a recorded step can replay it: kind 0 = not replayable)
 static void launch_pack(int math, const float* w, void* wq, int K, int Nn, int T, int NT, int mode, int aux, int CK, int TW, const TapList& taps,
-                        hipStream_t st, const float* oscale = nullptr) {
+                        hipStream_t st, const float* oscale = nullptr, PackDesc* desc = nullptr) {
     const int grid = pack_grid((long long)K * Nn * T);
+    if (desc) desc->kind = 0;
     if (math == MATH_F32) hipLaunchKernelGGL(pack_wq_kernel, dim3(grid), dim3(256), 0, st, w, (float*)wq, K, Nn, T, NT, mode, aux, CK, TW, taps, oscale);
-    else if ((long long)K * Nn * T < 0x7F000000LL) {
-        if (math == MATH_X3) hipLaunchKernelGGL((pack_wq_lowp_kernel<3, unsigned>), dim3(grid), dim3(256), 0, st, w, (bf16*)wq, K, Nn, T, NT, mode, aux, CK, TW, taps, oscale);
-        else hipLaunchKernelGGL((pack_wq_lowp_kernel<1, unsigned>), dim3(grid), dim3(256), 0, st, w, (bf16*)wq, K, Nn, T, NT, mode, aux, CK, TW, taps, oscale);
+    else {
+        PackDesc d = lowp_desc(math == MATH_X3 ? 3 : 1, w, wq, K, Nn, T, NT, mode, aux, CK, TW, taps, oscale);
+        d.layout = (long long)K * Nn * T < 0x7F000000LL ? 0 : 1;          // (1: 64-bit element indices)
+        pack_launch(d, st);
+        if (desc) *desc = d;
     }
-    else if (math == MATH_X3) hipLaunchKernelGGL((pack_wq_lowp_kernel<3, long long>), dim3(grid), dim3(256), 0, st, w, (bf16*)wq, K, Nn, T, NT, mode, aux, CK, TW, taps, oscale);
-    else hipLaunchKernelGGL((pack_wq_lowp_kernel<1, long long>), dim3(grid), dim3(256), 0, st, w, (bf16*)wq, K, Nn, T, NT, mode, aux, CK, TW, taps, oscale);
 }
 
 // y[r][c] = bias[c] + sum_k part[k][r][c]   (split-K second stage; fixed order)
@@ -571,6 +474,10 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
     size_t tail = cv.used();
     SEG_CHECK_WS(tail + ((ssum && ksplit > 1) ? colsum_ws_bytes(Cout) : 0), ws_bytes);
     const bool w16 = ((uintptr_t)w % 16) == 0;                     // the tiled packings read W in 16-byte pieces
+    // the step's prepacked copy (prepack.hip) where there is one; the key holds everything the packing below depends on
+    const int pk_form = f16 ? (w16 ? 1 : 2) : (b16s ? (w16 ? 3 : 4) : (x3s ? (w16 ? 5 : 6) : 7));
+    const PackKey pkey = make_pack_key(w, PK_CONV, pk_form, Cin, Cout, T, dgrad ? 1 : 0, b16s ? bp.NT : (pk_form == 7 ? p.NT * 64 + p.CK + 4096 * math : p.NBW));
+    const bool pk_hit = !oscale && prepack_find(pkey, &wq, f16 ? &w_amax : nullptr);
     if (f16) {
         if (!x_amax || !w_amax) {
             if (hipMemsetAsync(amax, 0, 2 * sizeof(float), st) != hipSuccess) { set_error("conv_fwd_mfma: hipMemsetAsync failed"); return MI355SEG_EHIP; }
@@ -582,15 +489,21 @@ int conv_fwd_mfma(int math, const void* x, int ldx, const float* w, const float*
                 w_amax = amax + 1;
             }
         }
-        if (w16) launch_pack_tiled<2>(w, (bf16*)wq, Cin, Cout, 27, p.NBW, dgrad ? 1 : 0, oscale, st, w_amax);
-        else hipLaunchKernelGGL(pack_wq_x3s_f16_kernel, dim3(pack_grid((long long)28 * Cin * Cout)), dim3(256), 0, st, w, (_Float16*)wq, Cin, Cout, p.NBW, dgrad ? 1 : 0, oscale, w_amax);
     }
-    else if (b16s && w16) launch_pack_tiled<0>(w, (bf16*)wq, Cin, Cout, T, bp.NT, dgrad ? 1 : 0, oscale, st);
-    else if (b16s) hipLaunchKernelGGL(pack_wq_b16s_kernel, dim3(pack_grid((long long)(T + 1) * Cin * Cout)), dim3(256), 0, st, w, (bf16*)wq, Cin, Cout, T, bp.NT, dgrad ? 1 : 0, oscale);
-    else if (x3s && w16) launch_pack_tiled<1>(w, (bf16*)wq, Cin, Cout, 27, p.NBW, dgrad ? 1 : 0, oscale, st);
-    else if (x3s) hipLaunchKernelGGL(pack_wq_x3s_kernel, dim3(pack_grid((long long)28 * Cin * Cout)), dim3(256), 0, st, w, (bf16*)wq, Cin, Cout, p.NBW, dgrad ? 1 : 0, oscale);
-    else launch_pack(math, w, wq, Cin, Cout, T, p.NT, dgrad ? 1 : 0, 0, p.CK, T, TapList{}, st, oscale);
-    SEG_CHECK_LAUNCH();
+    if (!pk_hit) {
+        PackDesc pd{};
+        const int dg = dgrad ? 1 : 0;
+        if (pk_form == 1) pd = tiled_desc(2, w, wq, Cin, Cout, 27, p.NBW, dg, oscale, w_amax);
+        else if (pk_form == 3) pd = tiled_desc(0, w, wq, Cin, Cout, T, bp.NT, dg, oscale, nullptr);
+        else if (pk_form == 5) pd = tiled_desc(1, w, wq, Cin, Cout, 27, p.NBW, dg, oscale, nullptr);
+        if (pd.kind) pack_launch(pd, st);
+        else if (pk_form == 2) hipLaunchKernelGGL(pack_wq_x3s_f16_kernel, dim3(pack_grid((long long)28 * Cin * Cout)), dim3(256), 0, st, w, (_Float16*)wq, Cin, Cout, p.NBW, dg, oscale, w_amax);
+        else if (pk_form == 4) hipLaunchKernelGGL(pack_wq_b16s_kernel, dim3(pack_grid((long long)(T + 1) * Cin * Cout)), dim3(256), 0, st, w, (bf16*)wq, Cin, Cout, T, bp.NT, dg, oscale);
+        else if (pk_form == 6) hipLaunchKernelGGL(pack_wq_x3s_kernel, dim3(pack_grid((long long)28 * Cin * Cout)), dim3(256), 0, st, w, (bf16*)wq, Cin, Cout, p.NBW, dg, oscale);
+        else launch_pack(math, w, wq, Cin, Cout, T, p.NT, dg, 0, p.CK, T, TapList{}, st, oscale, &pd);
+        SEG_CHECK_LAUNCH();
+        if (pd.kind) prepack_note(pkey, wq_bytes(math, (size_t)T * Cin * Cout), pd);
+    }
     IgemmArgs a{x, wq, ksplit > 1 ? nullptr : bias, ksplit > 1 ? (void*)slabs : y, spart, ldx, ksplit > 1 ? Cout : ldy, N, D, H, W, Cout,
                 p.ntx, p.nty, p.ntz, p.nN, nchunks, nchunks, p.nN, 1, 1, p.nM, ksplit, nchunks / ksplit, nvox * Cout, dbg_flags()};
     a.Di = a.Do = D; a.Hi = a.Ho = H; a.Wi = a.Wo = W;
@@ -660,8 +573,15 @@ int convt_fwd_mfma(int math, const void* x, int ldx, const float* w, const float
     Carver cv(ws);
     void* wq = cv.take<char>(wq_bytes(math, (size_t)8 * Cin * Cout));
     SEG_CHECK_WS(cv.used(), ws_bytes);
-    launch_pack(math, w, wq, Cin, 8 * Cout, 1, p.NT, 2, Cout, p.CK, 8, TapList{}, st);
-    SEG_CHECK_LAUNCH();
+    {
+        const PackKey pkey = make_pack_key(w, PK_CONVT_FWD, math, Cin, Cout, p.NT, p.CK);
+        if (!prepack_find(pkey, &wq, nullptr)) {
+            PackDesc pd{};
+            launch_pack(math, w, wq, Cin, 8 * Cout, 1, p.NT, 2, Cout, p.CK, 8, TapList{}, st, nullptr, &pd);
+            SEG_CHECK_LAUNCH();
+            if (pd.kind) prepack_note(pkey, wq_bytes(math, (size_t)8 * Cin * Cout), pd);
+        }
+    }
     IgemmArgs a{x, wq, bias, y, nullptr, ldx, ldy, N, D, H, W, Cout, p.ntx, p.nty, p.ntz, p.nN, Cin / p.CK, Cin / p.CK,
                 p.flat ? p.nN : p.nN / 8, 1, 2, p.nM, 1, Cin / p.CK, 0, 0};
     a.Di = D; a.Hi = H; a.Wi = W; a.Do = 2 * D; a.Ho = 2 * H; a.Wo = 2 * W; a.flatn = p.flat;
@@ -680,8 +600,15 @@ int convt_dgrad_mfma(int math, const void* dy, int lddy, const float* w, void* d
     Carver cv(ws);
     void* wq = cv.take<char>(wq_bytes(math, (size_t)8 * Cin * Cout));
     SEG_CHECK_WS(cv.used(), ws_bytes);
-    launch_pack(math, w, wq, 8 * Cout, Cin, 1, p.NT, 3, Cout, p.CK, 8, TapList{}, st);
-    SEG_CHECK_LAUNCH();
+    {
+        const PackKey pkey = make_pack_key(w, PK_CONVT_DGRAD, math, Cin, Cout, p.NT, p.CK);
+        if (!prepack_find(pkey, &wq, nullptr)) {
+            PackDesc pd{};
+            launch_pack(math, w, wq, 8 * Cout, Cin, 1, p.NT, 3, Cout, p.CK, 8, TapList{}, st, nullptr, &pd);
+            SEG_CHECK_LAUNCH();
+            if (pd.kind) prepack_note(pkey, wq_bytes(math, (size_t)8 * Cin * Cout), pd);
+        }
+    }
     IgemmArgs a{dy, wq, nullptr, dx, nullptr, lddy, lddx, N, D, H, W, Cin, p.ntx, p.nty, p.ntz, p.nN, 8 * Cout / p.CK, Cout / p.CK, p.nN, 2, 1,
                 p.nM, 1, 8 * Cout / p.CK, 0, 0};
     a.Di = 2 * D; a.Hi = 2 * H; a.Wi = 2 * W; a.Do = D; a.Ho = H; a.Wo = W;
@@ -748,8 +675,15 @@ int conv_gather_fwd_mfma(int math, const void* x, int ldx, const float* w, const
     float* slabs = ksplit > 1 ? cv.take<float>((size_t)ksplit * nvo * Cout) : nullptr;
     const size_t tail = cv.used();
     SEG_CHECK_WS(tail + ((ssum && ksplit > 1) ? colsum_ws_bytes(Cout) : 0), ws_bytes);
-    launch_pack(math, w, wq, T * Cin, Cout, 1, p.NT, 5, Cin, p.CK, T, TapList{}, st);
-    SEG_CHECK_LAUNCH();
+    {
+        const PackKey pkey = make_pack_key(w, PK_GATHER_FWD, math, Cin, Cout, T, p.NT, p.CK);
+        if (!prepack_find(pkey, &wq, nullptr)) {
+            PackDesc pd{};
+            launch_pack(math, w, wq, T * Cin, Cout, 1, p.NT, 5, Cin, p.CK, T, TapList{}, st, nullptr, &pd);
+            SEG_CHECK_LAUNCH();
+            if (pd.kind) prepack_note(pkey, wq_bytes(math, (size_t)T * Cin * Cout), pd);
+        }
+    }
     IgemmArgs a{x, wq, ksplit > 1 ? nullptr : bias, ksplit > 1 ? (void*)slabs : y, spart, ldx, ksplit > 1 ? Cout : ldy, N, Do, Ho, Wo, Cout, p.ntx, p.nty, p.ntz, p.nN, nchunks, cpt, p.nN, stride, 1,
                 p.nM, ksplit, nchunks / ksplit, nvo * Cout, 0};
     a.Di = D; a.Hi = H; a.Wi = W; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
@@ -858,8 +792,19 @@ int conv_gather_dgrad_mfma(int math, const void* dy, int lddy, const float* w, v
             slot0 += q.nt;
         }
         pt.n = nph;
-        launch_pack(math, w, wq_all, T * Cout, Cin, 1, p0.NT, 6, Cout, p0.CK, T, tl, st);
-        SEG_CHECK_LAUNCH();
+        {
+            const PackKey pkey = make_pack_key(w, PK_GATHER_DGRAD, math, Cin, Cout, k * 256 + stride * 16 + pad, p0.NT, p0.CK);
+            void* hit = nullptr;
+            if (prepack_find(pkey, &hit, nullptr)) {
+                for (int i = 0; i < nph; ++i) pt.ph[i].wq = (const char*)hit + ((const char*)pt.ph[i].wq - wq_all);
+                wq_all = (char*)hit;
+            } else {
+                PackDesc pd{};
+                launch_pack(math, w, wq_all, T * Cout, Cin, 1, p0.NT, 6, Cout, p0.CK, T, tl, st, nullptr, &pd);
+                SEG_CHECK_LAUNCH();
+                if (pd.kind) prepack_note(pkey, wq_bytes(math, (size_t)T * Cin * Cout), pd);
+            }
+        }
         a.wq = wq_all; a.total = first;
         if (dispatch_igemm_phases_lowp(math, p0, a, pt, first, st)) {
             SEG_CHECK_LAUNCH();

@@ -18,6 +18,7 @@
 // instruction spread over all 64 banks; the 16 rows a fragment read touches are consecutive).
 #include "common.h"
 #include "internal.h"
+#include "pack.h"
 
 namespace seg {
 namespace {
@@ -390,36 +391,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void convt_stream_kernel(CtArgs a) {
     }
 }
 
-// packed planes of w (Cin, Cout, 8): slot (ntile, chunk, plane, kgroup, row) holds k = chunk * 64 + kgroup * 8 .. + 7 of GEMM
-// column n = ntile * BN + row.   SCATTER: n = (t, co), k = ci.   GATHER: n = ci, k = (t, co).
-template <int NP>
-__global__ __launch_bounds__(256) void convt_pack_planes_kernel(const float* __restrict__ w, bf16x8_t* __restrict__ wq, int Cin, int Cout,
-                                                                 int gather, int BN, int K, int Ncols) {
-    const int nchunk = K / 64;
-    const long long total = (long long)(Ncols / BN) * nchunk * 8 * BN;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int row = (int)(i % BN); long long q = i / BN;
-        const int kgp = (int)(q % 8); q /= 8;
-        const int chunk = (int)(q % nchunk); const int ntile = (int)(q / nchunk);
-        const int n = ntile * BN + row, k0 = chunk * 64 + kgp * 8;
-        bf16x8_t ph, pm, pl;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            // three planes (fp32 tensors): k-group g of a 32-wide k-step holds channels {4g .. 4g+3, 16 + 4g .. 16 + 4g+3}
-            const int k = NP == 3 ? (k0 & ~31) + 4 * ((k0 >> 3) & 3) + (e < 4 ? e : 12 + e) : k0 + e;
-            int ci, co, t;
-            if (gather) { ci = n; t = k / Cout; co = k - t * Cout; }
-            else { ci = k; t = n / Cout; co = n - t * Cout; }
-            const float v = w[((long long)ci * Cout + co) * 8 + t];
-            bf16 h, m, l;
-            split3(v, h, m, l);
-            ph[e] = h; pm[e] = m; pl[e] = l;
-        }
-        bf16x8_t* dst = wq + (((long long)ntile * nchunk + chunk) * NP * 8 + kgp) * BN + row;
-        dst[0] = ph;
-        if (NP == 3) { dst[8 * BN] = pm; dst[16 * BN] = pl; }
-    }
-}
+// (the packed planes of w (Cin, Cout, 8) -- slot (ntile, chunk, plane, kgroup, row) holds k = chunk * 64 + kgroup * 8 .. + 7 of GEMM column
+// n = ntile * BN + row; SCATTER: n = (t, co), k = ci; GATHER: n = ci, k = (t, co) -- are formed by convt_pack_planes_body, prepack.hip)
 
 template <typename TT, bool GATHER, int KK, int BN, int TM, int NW, int OCC>
 void launch_stream(const CtArgs& a, hipStream_t st) {
@@ -530,8 +503,18 @@ int convt_direct(bool gather, const TT* x, int ldx, const float* w, const float*
     bf16x8_t* wq = reinterpret_cast<bf16x8_t*>(cv.take<char>((size_t)p.K * p.Nc * 2 * NP));
     SEG_CHECK_WS(cv.used(), ws_bytes);
     const long long slots = (long long)p.K * p.Nc / 8;
-    hipLaunchKernelGGL(convt_pack_planes_kernel<NP>, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, w, wq, Cin, Cout, gather ? 1 : 0, p.BN, p.K, p.Nc);
-    SEG_CHECK_LAUNCH();
+    {
+        const PackKey pkey = make_pack_key(w, PK_CONVT_DIRECT, NP, Cin, Cout, gather ? 1 : 0, p.BN, p.K, p.Nc);
+        void* hit = nullptr;
+        if (prepack_find(pkey, &hit, nullptr)) wq = reinterpret_cast<bf16x8_t*>(hit);
+        else {
+            PackDesc pd{};
+            pd.kind = PD_CONVT; pd.np = NP; pd.w = w; pd.dst = wq; pd.K = Cin; pd.Nn = Cout; pd.mode = gather ? 1 : 0; pd.P = p.BN; pd.aux = p.K; pd.TW = p.Nc;
+            pack_launch(pd, st);
+            SEG_CHECK_LAUNCH();
+            prepack_note(pkey, (size_t)p.K * p.Nc * 2 * NP, pd);
+        }
+    }
     CtArgs a{x, wq, gather ? nullptr : bias, y, ldx, ldy, D, H, W, Cout, (long long)N * D * H * W, p.K / 64, p.Nc / p.BN, gather ? nullptr : reinterpret_cast<unsigned*>(y_amax),
              1, p.K / 64, 0};
     const double vox = (double)a.nvox;

@@ -70,31 +70,33 @@ def train_step(model, optimizer, x, gt, criterion=None, sync_metric=True, grad_h
     bns = [m for m in model.modules()
            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training and m.num_batches_tracked is not None]
     F.dropout_pool_begin_step()              # the element-wise dropout masks of the step from one draw (once their total is known)
-    if (dtype or F.compute_dtype()) == torch.float32:
-        F.prefetch_weight_amax(model)        # f16x3: the k3 weights' maxima by one multi-tensor launch (valid for this step only)
-    try:
-        with F.autocast(dtype or F.compute_dtype()), F.counters_batched(bns):
-            if getattr(model, "takes_frequency_bands", False):      # the IS network, train.py:198-201: second output discarded
-                from .models.three_d.IS import frequency_bands
-                low_x, high_x = frequency_bands(x)
-                pred, _ = _forward(model, _leaves, x, low_x, high_x)
-            else:
-                pred = _forward(model, _leaves, x)
-    finally:
-        F.clear_weight_amax()                # (the backward reuses the scalars the forward handed to each layer, not the table)
-    F.flush_deferred_waits()                                     # (a model without norm layers)
-    if bns:
-        torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
-    if criterion is None:
-        # nn.BCEWithLogitsLoss + pred.argmax + gt.argmax + the Dice counters in one pass over the logits
-        loss, mask, counts = F.bce_argmax_dice(pred, gt2)
-    else:
-        loss = criterion(pred, gt2)
-        with torch.no_grad():
-            mask = F.argmax_channels(pred)
-            gt_lab = F.argmax_channels(gt2)
-            counts = F.dice_counts(gt_lab, mask)
-    loss.backward()
+    # the step's weight packings by one launch at its top (recorded during the model's first step at this signature)
+    with F.prepacked_weights(model, (str(dtype or F.compute_dtype()), F.conv_math_signature(), tuple(x.shape))) as pp:
+        if (dtype or F.compute_dtype()) == torch.float32 and not pp.replaying:
+            F.prefetch_weight_amax(model)        # f16x3: the k3 weights' maxima by one multi-tensor launch (valid for this step only; a replayed plan measured them)
+        try:
+            with F.autocast(dtype or F.compute_dtype()), F.counters_batched(bns):
+                if getattr(model, "takes_frequency_bands", False):      # the IS network, train.py:198-201: second output discarded
+                    from .models.three_d.IS import frequency_bands
+                    low_x, high_x = frequency_bands(x)
+                    pred, _ = _forward(model, _leaves, x, low_x, high_x)
+                else:
+                    pred = _forward(model, _leaves, x)
+        finally:
+            F.clear_weight_amax()                # (the backward reuses the scalars the forward handed to each layer, not the table)
+        F.flush_deferred_waits()                                     # (a model without norm layers)
+        if bns:
+            torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
+        if criterion is None:
+            # nn.BCEWithLogitsLoss + pred.argmax + gt.argmax + the Dice counters in one pass over the logits
+            loss, mask, counts = F.bce_argmax_dice(pred, gt2)
+        else:
+            loss = criterion(pred, gt2)
+            with torch.no_grad():
+                mask = F.argmax_channels(pred)
+                gt_lab = F.argmax_channels(gt2)
+                counts = F.dice_counts(gt_lab, mask)
+        loss.backward()
     if _leaves is not None:                  # the capture's stand-in leaves: their gradients ARE the parameters' (static tensors of the graph pool)
         for name, p in model.named_parameters():
             p.grad = _leaves[name].grad

@@ -132,6 +132,89 @@ def workspace(nbytes, device):
     return buf
 
 
+# ----------------------------------------------------------------------------- a step's weight packings in one launch (csrc/prepack.hip)
+_PREPACK_OFF = bool(os.environ.get("MI355SEG_NO_PREPACK"))
+_PREPACK_ACTIVE = [False]       # a recorded plan is being replayed for the running step (prepacked_weights)
+
+
+def conv_math_signature():
+    """The process-wide kernel policies that decide which packings a step's convolutions read (part of a prepack plan's key)."""
+    L = lib()
+    return (L.query("mi355seg_get_conv_math"), L.query("mi355seg_get_x3_shape"), L.query("mi355seg_get_b16_tiles"))
+
+
+def _prepack_free(plans):
+    try:
+        L = lib()
+        for rec in plans.values():
+            L.call("mi355seg_prepack_free", rec["plan"])
+    except Exception:            # interpreter shutdown
+        pass
+
+
+class prepacked_weights:
+    """Context manager around ONE training iteration of ``model`` (forward AND backward inside it; engine.train_step).  The first
+    iteration at a signature (``key`` = whatever fixes the kernels' plans: dtype, conv math, input shape; plus the parameters' storage
+    addresses) runs as always while the library records every weight packing its convolutions launch; each later one starts with
+    ALL of those packings formed by one launch into an arena this object owns (include/mi355seg.h, mi355seg_prepack_run) and its
+    convolutions read them there -- 44 small launches off the cfg-2 step's stream, ~50 off UNETR's.  Bit-identical results.
+    MI355SEG_NO_PREPACK=1 turns it off."""
+
+    def __init__(self, model, key):
+        self.model, self.key, self.mode = model, key, None
+
+    @property
+    def replaying(self):
+        return self.mode == "run" and _PREPACK_ACTIVE[0]
+
+    def __enter__(self):
+        if _PREPACK_OFF:
+            return self
+        params = [p for p in self.model.parameters()]
+        if not params or not params[0].is_cuda:
+            return self
+        sig = (self.key, tuple(p.data_ptr() for p in params))
+        plans = self.model.__dict__.get("_seg_prepack")
+        if plans is None:
+            import weakref
+            plans = self.model.__dict__["_seg_prepack"] = {}
+            weakref.finalize(self.model, _prepack_free, plans)
+        rec = plans.get(sig)
+        L = lib()
+        if rec is None:
+            if torch.cuda.is_current_stream_capturing():     # (a capture without eager warm-up: nothing recorded, the packings stay in place)
+                return self
+            if len(plans) >= 4:                              # shapes keep changing: forget the oldest
+                old = next(iter(plans))
+                L.call("mi355seg_prepack_free", plans.pop(old)["plan"])
+            L.call("mi355seg_prepack_record_begin")
+            self.mode, self.sig, self.plans = "record", sig, plans
+        elif rec["plan"]:
+            L.call("mi355seg_prepack_run", rec["plan"], _p(rec["arena"]), rec["arena"].numel(), _stream())
+            self.mode = "run"
+            _PREPACK_ACTIVE[0] = L.query("mi355seg_prepack_active") != 0
+        return self
+
+    def __exit__(self, *exc):
+        L = lib()
+        if self.mode == "record":
+            import ctypes
+            plan, nbytes = ctypes.c_int(0), ctypes.c_size_t(0)
+            L.call("mi355seg_prepack_record_end", ctypes.byref(plan), ctypes.byref(nbytes))
+            if exc[0] is not None:
+                if plan.value:
+                    L.call("mi355seg_prepack_free", plan.value)
+            else:
+                dev = next(self.model.parameters()).device
+                arena = torch.empty(max(int(nbytes.value), 256), dtype=torch.uint8, device=dev) if plan.value else None
+                self.plans[self.sig] = {"plan": plan.value, "arena": arena}
+        elif self.mode == "run":
+            _PREPACK_ACTIVE[0] = False
+            L.call("mi355seg_prepack_done", _stream())
+        self.mode = None
+        return False
+
+
 def _require_cuda(t, what, allow_bf16=False):
     if not t.is_cuda:
         raise Mi355SegError(f"{what}: expected a tensor on an MI355X (cuda/HIP) device, got {t.device}; "
@@ -379,6 +462,8 @@ def clear_weight_amax():
 
 
 def _weight_amax(w):
+    if _PREPACK_ACTIVE[0]:       # the step's packings (and max |w| with them) were formed up front: the library hands the kernels its own scalars
+        return None              # (a weight tensor the plan does not hold is measured by the entry point: NULL = measure)
     rec = _WEIGHT_AMAX.get(w.data_ptr())
     if rec is not None and rec[1] == w.numel() and rec[0].device == w.device:
         return rec[0]

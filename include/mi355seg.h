@@ -662,6 +662,25 @@ int mi355seg_conv3d_wgrad_bf16(const mi355seg_bf16* dy, int lddy, const mi355seg
 int mi355seg_cast_f32_to_bf16(const float* src, int ldsrc, mi355seg_bf16* dst, int lddst, long long rows, int C, void* stream);
 int mi355seg_cast_bf16_to_f32(const mi355seg_bf16* src, int ldsrc, float* dst, int lddst, long long rows, int C, void* stream);
 
+/* ---- every weight packing of a training step in ONE launch (r6; csrc/prepack.hip).  Every matrix-core convolution reads its fp32 master
+ * weights (the reference's nn.Conv3d / nn.ConvTranspose3d parameters, /root/reference/models/three_d/unet3d.py:29-43,80-101) in a
+ * packed form that its entry point builds right in front of the launch: 44 small launches per cfg-2 step.  A training step can have
+ * them built all at once instead:
+ *   record_begin ... one full step through the ordinary entry points ... record_end  -> plan id + arena size (once per model and shape);
+ *   each later step: prepack_run(plan, arena, bytes, stream) at its top -- one memset, one launch measuring max |w| where a packing scales
+ *   by it (f16x3) and ONE launch that forms every recorded packing in the caller's arena, all on `stream`; until prepack_done an entry
+ *   point that finds its (weight pointer, layout) in the plan reads the arena copy and launches no packing of its own.
+ * Anything not found packs as before; results are bit-identical either way.  The caller guarantees that the recorded weight
+ * pointers are alive and that the weights do not change between prepack_run and their last use in the step.  (The first prepack_run
+ * with an arena writes the job table into it with a blocking copy; called first inside a stream capture it leaves the plan inactive.) */
+int mi355seg_prepack_record_begin(void);
+int mi355seg_prepack_record_end(int* plan, size_t* arena_bytes);
+int mi355seg_prepack_jobs(int plan);
+int mi355seg_prepack_run(int plan, void* arena, size_t arena_bytes, void* stream);
+int mi355seg_prepack_done(void* stream);
+int mi355seg_prepack_active(void);      /* != 0 between a prepack_run that activated its plan and prepack_done */
+int mi355seg_prepack_free(int plan);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,12 +82,13 @@ def main():
     def step():
         opt.zero_grad(set_to_none=True)
         F.dropout_pool_begin_step()                  # (as engine.train_step: the step's element-wise dropout masks from one draw)
-        with mi355seg.autocast(dtype), F.counters_batched(bns):      # (the BatchNorm counters by one multi-tensor launch, as engine.train_step)
-            pred = m(x)
-        if bns:
-            torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
-        loss = F.bce_with_logits(pred, tgt)
-        loss.backward()
+        with F.prepacked_weights(m, (a.dtype, F.conv_math_signature(), tuple(x.shape))):     # (every weight packing of the step by one launch, as engine.train_step)
+            with mi355seg.autocast(dtype), F.counters_batched(bns):      # (the BatchNorm counters by one multi-tensor launch, as engine.train_step)
+                pred = m(x)
+            if bns:
+                torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
+            loss = F.bce_with_logits(pred, tgt)
+            loss.backward()
         opt.step()
         return loss
 
