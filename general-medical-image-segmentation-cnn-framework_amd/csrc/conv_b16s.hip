@@ -19,6 +19,7 @@
 #include "common.h"
 #include "internal.h"
 #include "igemm_kernel.h"
+#include <type_traits>
 
 namespace seg {
 
@@ -57,6 +58,12 @@ __device__ __forceinline__ float row16_sum_b(float v) {
 
 #ifndef B16S_K3_OCC
 #define B16S_K3_OCC 2
+#endif
+#ifndef B16S_WD
+#define B16S_WD 2
+#endif
+#ifndef B16S_XD
+#define B16S_XD 1               // regions (half K-steps) the voxel fragments are requested ahead of their MFMAs
 #endif
 template <int KS, int WMG>
 __global__ __launch_bounds__(256, KS == 3 ? B16S_K3_OCC : 2) void conv_b16s_kernel(IgemmArgs a) {
@@ -136,11 +143,14 @@ __global__ __launch_bounds__(256, KS == 3 ? B16S_K3_OCC : 2) void conv_b16s_kern
     for (int j = 0; j < SRV; ++j) { acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     const bf16* wlane = reinterpret_cast<const bf16*>(a.wq) + (long long)ntile * a.nchunks * (NSTEP * UNIT) + wn * 1024 + lane * 8;
-    load_stage(c0);
-    for (int chunk = c0; chunk < c1; ++chunk) {
+    // (-DMI355SEG_TUNE timing probes, MI355SEG_DBG; same launch, garbage results: 1 = the halo is staged for a tile's first chunk only,
+    //  64 = no halo loads at all (the first chunk stages stale registers), 128 = no MFMAs, 32 = no output stores, 256 = no K loop)
+    if (!SEG_DBG(a, 64)) load_stage(c0);
+    for (int chunk = c0; chunk < (SEG_DBG(a, 256) ? c0 : c1); ++chunk) {     // (probe 256: no K loop at all -- a tile's prologue and epilogue alone)
         const bf16* wp = wlane + (long long)chunk * (NSTEP * UNIT);
-        constexpr int WD = 2;                                    // K-steps of weights in flight ahead of the MFMAs
-        bf16x8_t wf[WD + 1][2], xf[2][4];
+        constexpr int WD = B16S_WD;                              // K-steps of weights in flight ahead of the MFMAs
+        constexpr int XD = B16S_XD;
+        bf16x8_t wf[WD + 1][2], xf[XD + 1][4];
         auto load_w = [&](int s) {
             wf[s % (WD + 1)][0] = *reinterpret_cast<const bf16x8_t*>(wp + s * UNIT);
             wf[s % (WD + 1)][1] = *reinterpret_cast<const bf16x8_t*>(wp + s * UNIT + 512);
@@ -148,26 +158,31 @@ __global__ __launch_bounds__(256, KS == 3 ? B16S_K3_OCC : 2) void conv_b16s_kern
         // the first weight fragments are requested BEFORE the next chunk's halo: vmcnt retires in order
 #pragma unroll
         for (int s = 0; s < WD; ++s) load_w(s);
+        if (!SEG_DBG(a, 1) || chunk == c0) {
         __syncthreads();                                         // every wave is done reading the previous chunk
         write_stage();
         __syncthreads();
-        if (chunk + 1 < c1) load_stage(chunk + 1);
+        }
+        if (chunk + 1 < c1 && !SEG_DBG(a, 1) && !SEG_DBG(a, 64)) load_stage(chunk + 1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xf[0][j] = *reinterpret_cast<const bf16x8_t*>(lds_raw + xaddr(0, j));
+        for (int q0 = 0; q0 < XD; ++q0)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xf[q0][j] = *reinterpret_cast<const bf16x8_t*>(lds_raw + xaddr(q0 >> 1, (q0 & 1) * 4 + j));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 2 * NSTEP; ++q) {                    // region = (K-step, half of the wave's lines)
-            const int s = q >> 1, hf = q & 1, cur = q & 1, nxt = cur ^ 1;
+            const int s = q >> 1, hf = q & 1, cur = q % (XD + 1), nxt = (q + XD) % (XD + 1);
             if (hf == 0 && s + WD < NSTEP) load_w(s + WD);
-            if (q + 1 < 2 * NSTEP) {
+            if (q + XD < 2 * NSTEP) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xf[nxt][j] = *reinterpret_cast<const bf16x8_t*>(lds_raw + xaddr((q + 1) >> 1, ((q + 1) & 1) * 4 + j));
+                for (int j = 0; j < 4; ++j) xf[nxt][j] = *reinterpret_cast<const bf16x8_t*>(lds_raw + xaddr((q + XD) >> 1, ((q + XD) & 1) * 4 + j));
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
-                    acc[hf * 4 + j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s % (WD + 1)][t], xf[cur][j], acc[hf * 4 + j][t], 0, 0, 0);
+                    if (!SEG_DBG(a, 128)) acc[hf * 4 + j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s % (WD + 1)][t], xf[cur][j], acc[hf * 4 + j][t], 0, 0, 0);
+                    else acc[hf * 4 + j][t][0] += (float)wf[s % (WD + 1)][t][0] + (float)xf[cur][j][0];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -213,30 +228,37 @@ __global__ __launch_bounds__(256, KS == 3 ? B16S_K3_OCC : 2) void conv_b16s_kern
             rs[j] = *reinterpret_cast<const bf16x8_t*>(rlane + (((long long)n * a.D + cz) * a.H + cy) * a.W * a.ldres);
         }
     }
+    // (r6) the store loop in two instantiations -- ACT: the fused inference forward's activation (a per-element switch with exp / division
+    // branches: 64 inlined copies of it were 60 KB of the training launches' 70-KB instruction stream, all of it jumped over) -- so that the
+    // training path's epilogue is a few hundred contiguous instructions
+    auto store_lines = [&](auto ACTc) {
+        constexpr bool ACT = decltype(ACTc)::value;
 #pragma unroll
-    for (int j = 0; j < SRV; ++j) {
-        const int line = line0 + j;
-        const int gz = z0 + line / STY, gy = y0 + line % STY;
-        const bool inside = gz < a.D && gy < a.H && gx < a.W;
-        const long long off = ylane + (long long)(((line / STY) * a.H + line % STY) * a.W) * a.ldy;
-        if (slab) {                                              // bias and statistics belong to the reduce pass
-            if (inside) {
-                *reinterpret_cast<f32x4*>(yslab + off) = acc[j][0];
-                *reinterpret_cast<f32x4*>(yslab + off + 4) = acc[j][1];
-            }
-        } else {
-            bf16x8_t o;
+        for (int j = 0; j < SRV; ++j) {
+            const int line = line0 + j;
+            const int gz = z0 + line / STY, gy = y0 + line % STY;
+            const bool inside = gz < a.D && gy < a.H && gx < a.W;
+            const long long off = ylane + (long long)(((line / STY) * a.H + line % STY) * a.W) * a.ldy;
+            if (slab) {                                              // bias and statistics belong to the reduce pass
+                if (inside) {
+                    *reinterpret_cast<f32x4*>(yslab + off) = acc[j][0];
+                    *reinterpret_cast<f32x4*>(yslab + off + 4) = acc[j][1];
+                }
+            } else {
+                bf16x8_t o;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                float v = acc[j][c >> 2][c & 3] + bv[c];
-                if (a.act) v = act_apply(v, a.act, a.slope);
-                if (a.res) v = (float)(bf16)v + (float)rs[j][c];       // the convolution's own bf16 rounding, then the sum's
-                o[c] = (bf16)v;
-                if (inside) ssum[c] += v;
+                for (int c = 0; c < 8; ++c) {
+                    float v = acc[j][c >> 2][c & 3] + bv[c];
+                    if constexpr (ACT) v = act_apply(v, a.act, a.slope);
+                    if (a.res) v = (float)(bf16)v + (float)rs[j][c];       // the convolution's own bf16 rounding, then the sum's
+                    o[c] = (bf16)v;
+                    if (inside) ssum[c] += v;
+                }
+                if (inside && (!SEG_DBG(a, 32) || o[0] == (bf16)12345.f)) *reinterpret_cast<bf16x8_t*>(yout + off) = o;
             }
-            if (inside) *reinterpret_cast<bf16x8_t*>(yout + off) = o;
         }
-    }
+    };
+    if (a.act) store_lines(std::true_type{}); else store_lines(std::false_type{});
     if (a.spart) {
         // per channel (sum, M2 about the tile mean, n) of this tile, as conv_igemm_kernel: spart[mtile][c] = {sum, M2, n}
         float* lds = reinterpret_cast<float*>(lds_raw);

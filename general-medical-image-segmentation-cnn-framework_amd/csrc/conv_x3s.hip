@@ -142,24 +142,31 @@ __device__ __forceinline__ void x3_epilogue(const IgemmArgs& a, f32x4 (&acc)[LW]
     f32x4 bv[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) bv[t] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n0 + 16 * t + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // (r6) the store loop in two instantiations -- ACT: the fused inference forward's activation, a per-element switch with exp / division
+    // branches whose 4 LW NTW inlined copies were most of a training launch's instruction stream (108 of 130 KB on the <8, 1, F16> tile), all
+    // of it jumped over -- so that the training path's epilogue is short and contiguous
+    auto store_lines = [&](auto ACTc) {
+        constexpr bool ACT = decltype(ACTc)::value;
 #pragma unroll
-    for (int j = 0; j < LW; ++j) {
-        const int line = line0 + j;
-        const int gz = z0 + line / XTY, gy = y0 + line % XTY;
-        const bool inside = gz < a.D && gy < a.H && gx < a.W;
-        float* dst = ylane + (long long)(((line / XTY) * a.H + line % XTY) * a.W) * a.ldy;     // (wave-uniform offset of the line)
+        for (int j = 0; j < LW; ++j) {
+            const int line = line0 + j;
+            const int gz = z0 + line / XTY, gy = y0 + line % XTY;
+            const bool inside = gz < a.D && gy < a.H && gx < a.W;
+            float* dst = ylane + (long long)(((line / XTY) * a.H + line % XTY) * a.W) * a.ldy;     // (wave-uniform offset of the line)
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            f32x4 v = acc[j][t] + bv[t];
-            if (a.act) { v[0] = act_apply(v[0], a.act, a.slope); v[1] = act_apply(v[1], a.act, a.slope); v[2] = act_apply(v[2], a.act, a.slope); v[3] = act_apply(v[3], a.act, a.slope); }
-            if (inside) {
-                *reinterpret_cast<f32x4*>(dst + 16 * t) = v;
+            for (int t = 0; t < NTW; ++t) {
+                f32x4 v = acc[j][t] + bv[t];
+                if constexpr (ACT) { v[0] = act_apply(v[0], a.act, a.slope); v[1] = act_apply(v[1], a.act, a.slope); v[2] = act_apply(v[2], a.act, a.slope); v[3] = act_apply(v[3], a.act, a.slope); }
+                if (inside) {
+                    *reinterpret_cast<f32x4*>(dst + 16 * t) = v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ssum[t][e] += v[e];
-                if (a.amax_y) ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                    for (int e = 0; e < 4; ++e) ssum[t][e] += v[e];
+                    if (a.amax_y) ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                }
             }
         }
-    }
+    };
+    if (a.act) store_lines(std::true_type{}); else store_lines(std::false_type{});
     if (a.amax_y) { __syncthreads(); block_amax_commit(ymax, a.amax_y); }
     if (a.bnpart) {
         // reduce dz and dz * xhat per channel over the tile (dz = d(activation) * act'(gamma xhat + beta))
