@@ -552,46 +552,52 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmArgs& a, const IgemmP
     out_t* yout = reinterpret_cast<out_t*>(a.y);
     const bool slab = a.ksplit > 1;
     float ssum[NBW];
+    // (r6) two instantiations of the store loop -- ACT: the fused inference forward's activation (a per-element switch with exp / division
+    // branches, 16 MB NBW inlined copies of it) stays out of the training launches' instruction stream
+    auto store_tile = [&](auto ACTc) {
+        constexpr bool ACT = decltype(ACTc)::value;
 #pragma unroll
-    for (int nb = 0; nb < NBW; ++nb) {
-        int col = n0 + (nbase + nb) * 32 + i, child = tapn;
-        if (!PLAIN && a.flatn) { const int nf = ntile * NT + (nbase + nb) * 32 + i; child = nf / a.Cout; col = nf - child * a.Cout; }   // per-lane child
-        const int oz = PLAIN ? 0 : ((child >> 2) & 1) + acz, oy = PLAIN ? 0 : ((child >> 1) & 1) + acy, ox = PLAIN ? 0 : (child & 1) + acx;
-        const float bv = a.bias ? a.bias[col] : 0.f;
-        float s1 = 0.f;
+        for (int nb = 0; nb < NBW; ++nb) {
+            int col = n0 + (nbase + nb) * 32 + i, child = tapn;
+            if (!PLAIN && a.flatn) { const int nf = ntile * NT + (nbase + nb) * 32 + i; child = nf / a.Cout; col = nf - child * a.Cout; }   // per-lane child
+            const int oz = PLAIN ? 0 : ((child >> 2) & 1) + acz, oy = PLAIN ? 0 : ((child >> 1) & 1) + acy, ox = PLAIN ? 0 : (child & 1) + acx;
+            const float bv = a.bias ? a.bias[col] : 0.f;
+            float s1 = 0.f;
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            const int m = wave_m * MB + mb;
+            for (int mb = 0; mb < MB; ++mb) {
+                const int m = wave_m * MB + mb;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int r = (v & 3) + 8 * (v >> 2) + 4 * h;      // row of the 32x32 tile held in register v
-                const int line = m * T::LPB + r / BX, xx = r % BX;
-                const int gz = (z0 + line / T::TY) * out_mul + oz;
-                const int gy = (y0 + line % T::TY) * out_mul + oy;
-                const int gx = (x0 + xx) * out_mul + ox;
-                float val = acc[mb][nb][v] + bv;
-                if (a.act) val = act_apply(val, a.act, a.slope);
-                // partial tiles (extents that are not tile multiples): rows outside the volume are dropped
-                const bool inside = (z0 + line / T::TY) < aD && (y0 + line % T::TY) < aH && (x0 + xx) < aW &&
-                                    gz < Do && gy < Ho && gx < Wo;
+                for (int v = 0; v < 16; ++v) {
+                    const int r = (v & 3) + 8 * (v >> 2) + 4 * h;      // row of the 32x32 tile held in register v
+                    const int line = m * T::LPB + r / BX, xx = r % BX;
+                    const int gz = (z0 + line / T::TY) * out_mul + oz;
+                    const int gy = (y0 + line % T::TY) * out_mul + oy;
+                    const int gx = (x0 + xx) * out_mul + ox;
+                    float val = acc[mb][nb][v] + bv;
+                    if constexpr (ACT) val = act_apply(val, a.act, a.slope);
+                    // partial tiles (extents that are not tile multiples): rows outside the volume are dropped
+                    const bool inside = (z0 + line / T::TY) < aD && (y0 + line % T::TY) < aH && (x0 + xx) < aW &&
+                                        gz < Do && gy < Ho && gx < Wo;
 #ifdef MI355SEG_TUNE
-                if (inside && (!(a.dbg & 4) || val == 12345.678f))
+                    if (inside && (!(a.dbg & 4) || val == 12345.678f))
 #else
-                if (inside)
+                    if (inside)
 #endif
-                {
-                    const long long off = ((((long long)n * Do + gz) * Ho + gy) * Wo + gx) * a.ldy + col;
-                    if constexpr (MATH == MATH_B16) {
-                        if (slab) yslab[off] = val; else yout[off] = (out_t)val;
-                    } else {
-                        yslab[off] = val;                           // ks == 0 and split_stride == 0 when there is one split
+                    {
+                        const long long off = ((((long long)n * Do + gz) * Ho + gy) * Wo + gx) * a.ldy + col;
+                        if constexpr (MATH == MATH_B16) {
+                            if (slab) yslab[off] = val; else yout[off] = (out_t)val;
+                        } else {
+                            yslab[off] = val;                           // ks == 0 and split_stride == 0 when there is one split
+                        }
                     }
+                    if (inside) s1 += val;
                 }
-                if (inside) s1 += val;
             }
+            ssum[nb] = s1;
         }
-        ssum[nb] = s1;
-    }
+    };
+    if (a.act) store_tile(std::true_type{}); else store_tile(std::false_type{});
     if (a.spart) {
         // BatchNorm batch statistics of this tile, cancellation-free: per channel the tile sum, then the tile
         // mean, then M2 = sum (y - tile_mean)^2 from the accumulators still in registers; the second stage
