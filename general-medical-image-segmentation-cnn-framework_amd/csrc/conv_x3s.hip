@@ -158,7 +158,7 @@ __device__ __forceinline__ void x3_epilogue(const IgemmArgs& a, f32x4 (&acc)[LW]
                 f32x4 v = acc[j][t] + bv[t];
                 if constexpr (ACT) { v[0] = act_apply(v[0], a.act, a.slope); v[1] = act_apply(v[1], a.act, a.slope); v[2] = act_apply(v[2], a.act, a.slope); v[3] = act_apply(v[3], a.act, a.slope); }
                 if (inside) {
-                    *reinterpret_cast<f32x4*>(dst + 16 * t) = v;
+                    if (!SEG_DBG(a, 2048) || v[0] == 12345.678f) *reinterpret_cast<f32x4*>(dst + 16 * t) = v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ssum[t][e] += v[e];
                     if (a.amax_y) ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
@@ -475,8 +475,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3s_kernel(IgemmArgs a) {
     const bool interior = x0 >= 1 && y0 >= 1 && z0 >= 1 && x0 + XBX + 1 <= a.W && y0 + XTY + 1 <= a.H && z0 + G::TZ + 1 <= a.D;
 
     const bf16* wlane = reinterpret_cast<const bf16*>(a.wq) + (long long)ntile * a.nchunks * (NUP * UNIT) + lane * 8;
-    load_stage(c0);
-    for (int chunk = c0; chunk < c1; ++chunk) {
+    // (-DMI355SEG_TUNE probes of a tile's fixed part: MI355SEG_DBG 512 = no K loop, 1024 = no first halo request, 2048 = no output stores)
+    if (!SEG_DBG(a, 1024)) load_stage(c0);
+    for (int chunk = c0; chunk < (SEG_DBG(a, 512) ? c0 : c1); ++chunk) {
         const bf16* wp = wlane + (long long)chunk * (NUP * UNIT) + wn * (NBW * UNIT);       // unit u of this wave = packed unit (u / NBW) * NBW * WN + wn * NBW + u % NBW
         // weight units in flight ahead of the MFMAs (bf16x6: the 64-channel 4-line tile is register-bound) and voxel fragments
         // requested XD regions ahead.  f16x3 (r4 ablation: weights loaded once per chunk +28-41 % on <4, 2> at one unit = 384 cycles of
