@@ -839,7 +839,8 @@ def main():
             if name == args.workload and hg:             # the headline's own replay: beside the line, never instead of it
                 hg["speedup_over_eager"] = res["ms_per_step"] / hg["ms_per_step"]
                 hg["note"] = "the headline step as one hipGraphLaunch per iteration (engine.GraphedTrainStep, config.hip_graph=true), fresh model in a process " \
-                             "of its own; informational -- `value` / `ms_per_step` of this line are the eager launch loop's"
+                             "of its own; informational -- `value` / `ms_per_step` of this line are the eager launch loop's (the same at every --gpus N), although since r6 (all weight packings " \
+                             "of a step by one launch, recorded in the warm-up steps) the replay is the faster way to run this step"
                 res["hip_graph"] = hg
                 continue
             if leg is not None and hg:
