@@ -34,8 +34,8 @@ struct BhArgs {
 };
 
 // z = gamma xhat + beta from the backward's point of view (norm.hip BwdF::one), a2 from the forward's (norm_act_fwd_kernel)
-template <int K>
-__global__ __launch_bounds__(256) void bn_head_fwd_kernel(BhArgs a) {
+template <int K, int ACT>
+__device__ __forceinline__ void bn_head_fwd_body(const BhArgs& a) {
     const int LPV = a.C / 4, VPB = 256 / LPV;
     const int c4 = threadIdx.x % LPV, vl = threadIdx.x / LPV;
     f32x4_t wr[K], al, be;
@@ -58,8 +58,8 @@ __global__ __launch_bounds__(256) void bn_head_fwd_kernel(BhArgs a) {
         for (int u = 0; u < 2; ++u) {
             const float4 x = u ? x1 : x0;
             f32x4_t o;
-            o[0] = act_apply(fmaf(x.x, al[0], be[0]), a.act, a.slope); o[1] = act_apply(fmaf(x.y, al[1], be[1]), a.act, a.slope);
-            o[2] = act_apply(fmaf(x.z, al[2], be[2]), a.act, a.slope); o[3] = act_apply(fmaf(x.w, al[3], be[3]), a.act, a.slope);
+            o[0] = act_apply(fmaf(x.x, al[0], be[0]), (ACT >= 0 ? ACT : a.act), a.slope); o[1] = act_apply(fmaf(x.y, al[1], be[1]), (ACT >= 0 ? ACT : a.act), a.slope);
+            o[2] = act_apply(fmaf(x.z, al[2], be[2]), (ACT >= 0 ? ACT : a.act), a.slope); o[3] = act_apply(fmaf(x.w, al[3], be[3]), (ACT >= 0 ? ACT : a.act), a.slope);
             float r[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -74,6 +74,11 @@ __global__ __launch_bounds__(256) void bn_head_fwd_kernel(BhArgs a) {
             }
         }
     }
+}
+// (r6) the training launches of the U-Net run ReLU: that instantiation has no per-element activation switch
+template <int K>
+__global__ __launch_bounds__(256) void bn_head_fwd_kernel(BhArgs a) {
+    if (a.act == MI355SEG_ACT_RELU) bn_head_fwd_body<K, MI355SEG_ACT_RELU>(a); else bn_head_fwd_body<K, -1>(a);
 }
 
 // per-voxel backward quantities of one channel quad
@@ -92,7 +97,7 @@ struct BhBwd {
         }
     }
     // dz, xhat (and the activation value when WANT_A) of the quad at one voxel
-    template <bool WANT_A>
+    template <bool WANT_A, int ACT>
     __device__ __forceinline__ void eval(const BhArgs& a, const float4 x, const float (&dl)[K], f32x4_t& dz, f32x4_t& xh, f32x4_t& av) const {
         f32x4_t da = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -102,15 +107,15 @@ struct BhBwd {
         for (int j = 0; j < 4; ++j) {
             xh[j] = (xv[j] - m[j]) * rs[j];
             const float z = fmaf(xh[j], ga[j], be[j]);
-            dz[j] = da[j] * act_grad(z, a.act, a.slope);
-            if (WANT_A) av[j] = act_apply(fmaf(xv[j], al[j], bf[j]), a.act, a.slope);   // the forward's a2
+            dz[j] = da[j] * act_grad(z, (ACT >= 0 ? ACT : a.act), a.slope);
+            if (WANT_A) av[j] = act_apply(fmaf(xv[j], al[j], bf[j]), (ACT >= 0 ? ACT : a.act), a.slope);   // the forward's a2
         }
     }
 };
 
 // partials of one block: part[blk][ (2 + K) * C + K ] = s1[C] | s2[C] | dWh[K][C] | dbh[K]
-template <int K>
-__global__ __launch_bounds__(256) void bn_head_bwd_sums_kernel(BhArgs a) {
+template <int K, int ACT>
+__device__ __forceinline__ void bn_head_bwd_sums_body(const BhArgs& a) {
     constexpr int NS = 8 + 4 * K;                       // floats per thread: s1 quad, s2 quad, K dWh quads
     __shared__ float sred[4 * 64 * (NS + K)];
     const int LPV = a.C / 4, VPB = 256 / LPV;
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256) void bn_head_bwd_sums_kernel(BhArgs a) {
         for (int u = 0; u < 2; ++u) {
             if (u == 1 && !two) break;
             f32x4_t dz, xh, av;
-            q.template eval<true>(a, u ? x1 : x0, u ? d1 : d0, dz, xh, av);
+            q.template eval<true, ACT>(a, u ? x1 : x0, u ? d1 : d0, dz, xh, av);
             s1 += dz; s2 += dz * xh;
 #pragma unroll
             for (int k = 0; k < K; ++k) { const float d = u ? d1[k] : d0[k]; dw[k] += d * av; db[k] += d; }
@@ -178,6 +183,11 @@ __global__ __launch_bounds__(256) void bn_head_bwd_sums_kernel(BhArgs a) {
         dst[i] = s;
     }
 }
+// (r6) the training launches of the U-Net run ReLU: that instantiation has no per-element activation switch
+template <int K>
+__global__ __launch_bounds__(256) void bn_head_bwd_sums_kernel(BhArgs a) {
+    if (a.act == MI355SEG_ACT_RELU) bn_head_bwd_sums_body<K, MI355SEG_ACT_RELU>(a); else bn_head_bwd_sums_body<K, -1>(a);
+}
 
 // out[j] = sum over the blocks of part[b][j], fp64, one wavefront per column, fixed order
 __global__ __launch_bounds__(64) void bh_finalize_kernel(const float* __restrict__ part, int nblk, int ncol, float* __restrict__ o0, int n0,
@@ -196,8 +206,8 @@ __global__ __launch_bounds__(64) void bh_finalize_kernel(const float* __restrict
 }
 
 // dy2 = rstd gamma (dz - s1 / n - xhat s2 / n); per-block column sums of dy2 into part[blk][C]; max |dy2|
-template <int K>
-__global__ __launch_bounds__(256) void bn_head_bwd_apply_kernel(BhArgs a) {
+template <int K, int ACT>
+__device__ __forceinline__ void bn_head_bwd_apply_body(const BhArgs& a) {
     __shared__ float sred[4 * 64 * 4];
     const int LPV = a.C / 4, VPB = 256 / LPV;
     const int c4 = threadIdx.x % LPV, vl = threadIdx.x / LPV;
@@ -220,7 +230,7 @@ __global__ __launch_bounds__(256) void bn_head_bwd_apply_kernel(BhArgs a) {
         for (int u = 0; u < 2; ++u) {
             if (u == 1 && !two) break;
             f32x4_t dz, xh, av;
-            q.template eval<false>(a, u ? x1 : x0, u ? d1 : d0, dz, xh, av);
+            q.template eval<false, ACT>(a, u ? x1 : x0, u ? d1 : d0, dz, xh, av);
             f32x4_t od;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -249,6 +259,11 @@ __global__ __launch_bounds__(256) void bn_head_bwd_apply_kernel(BhArgs a) {
     }
     if (a.amax) block_amax_commit(amax, a.amax);
 }
+// (r6) the training launches of the U-Net run ReLU: that instantiation has no per-element activation switch
+template <int K>
+__global__ __launch_bounds__(256) void bn_head_bwd_apply_kernel(BhArgs a) {
+    if (a.act == MI355SEG_ACT_RELU) bn_head_bwd_apply_body<K, MI355SEG_ACT_RELU>(a); else bn_head_bwd_apply_body<K, -1>(a);
+}
 
 // ---------------------------------------------------------------- BatchNorm + activation + MaxPool3d(2, 2) of an ENCODER block
 // unet3d.py:19-25,51-58: ``pool1(enc1)`` where enc1 = relu2(norm2(.)) also feeds the skip concatenation.  Forward: thread = (pooled voxel,
@@ -273,7 +288,8 @@ __device__ __forceinline__ long long bp_child(const BpArgs& a, int n, int od, in
     return (((long long)n * a.D + 2 * od + (t >> 2)) * a.H + 2 * oh + ((t >> 1) & 1)) * a.W + 2 * ow + (t & 1);
 }
 
-__global__ __launch_bounds__(256) void bn_pool_fwd_kernel(BpArgs a) {
+template <int ACT>
+__device__ __forceinline__ void bn_pool_fwd_body(const BpArgs& a) {
     const int LPV = a.C / 4, VPB = 256 / LPV;
     const int c4 = threadIdx.x % LPV, vl = threadIdx.x / LPV;
     const int Do = a.D / 2, Ho = a.H / 2, Wo = a.W / 2;
@@ -296,8 +312,8 @@ __global__ __launch_bounds__(256) void bn_pool_fwd_kernel(BpArgs a) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             float o[4];
-            o[0] = act_apply(fmaf(x[t].x, al[0], be[0]), a.act, a.slope); o[1] = act_apply(fmaf(x[t].y, al[1], be[1]), a.act, a.slope);
-            o[2] = act_apply(fmaf(x[t].z, al[2], be[2]), a.act, a.slope); o[3] = act_apply(fmaf(x[t].w, al[3], be[3]), a.act, a.slope);
+            o[0] = act_apply(fmaf(x[t].x, al[0], be[0]), (ACT >= 0 ? ACT : a.act), a.slope); o[1] = act_apply(fmaf(x[t].y, al[1], be[1]), (ACT >= 0 ? ACT : a.act), a.slope);
+            o[2] = act_apply(fmaf(x[t].z, al[2], be[2]), (ACT >= 0 ? ACT : a.act), a.slope); o[3] = act_apply(fmaf(x[t].w, al[3], be[3]), (ACT >= 0 ? ACT : a.act), a.slope);
             stf4(a.a + bp_child(a, n, od, oh, ow, t) * a.lda + c4 * 4, make_float4(o[0], o[1], o[2], o[3]));
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -310,10 +326,14 @@ __global__ __launch_bounds__(256) void bn_pool_fwd_kernel(BpArgs a) {
     }
     if (a.amax) block_amax_commit(amax, a.amax);
 }
+// (r6) the training launches of the U-Net run ReLU: that instantiation has no per-element activation switch
+__global__ __launch_bounds__(256) void bn_pool_fwd_kernel(BpArgs a) {
+    if (a.act == MI355SEG_ACT_RELU) bn_pool_fwd_body<MI355SEG_ACT_RELU>(a); else bn_pool_fwd_body<-1>(a);
+}
 
 // APPLY = false: per-block partials part[blk][2 C] = s1 | s2;  APPLY = true: dy written, part[blk][C] = column sums of dy, max |dy|
-template <bool APPLY>
-__global__ __launch_bounds__(256) void bn_pool_bwd_kernel(BpArgs a) {
+template <bool APPLY, int ACT>
+__device__ __forceinline__ void bn_pool_bwd_body(const BpArgs& a) {
     __shared__ float sred[4 * 64 * 8];
     const int LPV = a.C / 4, VPB = 256 / LPV;
     const int c4 = threadIdx.x % LPV, vl = threadIdx.x / LPV;
@@ -354,7 +374,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(BpArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float xh = (xv[j] - m[j]) * rs[j];
-                const float dz = dv[j] * act_grad(fmaf(xh, ga[j], be[j]), a.act, a.slope);
+                const float dz = dv[j] * act_grad(fmaf(xh, ga[j], be[j]), (ACT >= 0 ? ACT : a.act), a.slope);
                 if (APPLY) {
                     od4[j] = sc[j] * (dz - k1[j] - xh * k2[j]);
                     acc1[j] += od4[j];
@@ -391,6 +411,11 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(BpArgs a) {
         }
     }
     if (APPLY && a.amax) block_amax_commit(amax, a.amax);
+}
+// (r6) the training launches of the U-Net run ReLU: that instantiation has no per-element activation switch
+template <bool APPLY>
+__global__ __launch_bounds__(256) void bn_pool_bwd_kernel(BpArgs a) {
+    if (a.act == MI355SEG_ACT_RELU) bn_pool_bwd_body<APPLY, MI355SEG_ACT_RELU>(a); else bn_pool_bwd_body<APPLY, -1>(a);
 }
 
 bool bp_ok(int N, int D, int H, int W, int C, int ldy) {

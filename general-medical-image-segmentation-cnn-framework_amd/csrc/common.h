@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <type_traits>
 #include "../../include/mi355seg.h"
 
 namespace seg {
@@ -208,6 +209,19 @@ __device__ __forceinline__ float act_apply(float z, int act, float slope) {
         case MI355SEG_ACT_LRELU: return z > 0.f ? z : z * slope;
         case MI355SEG_ACT_SIGMOID: return 1.f / (1.f + expf(-z));
         default: return z;
+    }
+}
+// host side: f(std::integral_constant<int, A>) with A = act for the activations that have kernel instantiations of their own (the streaming
+// kernels are built per activation -- the per-element run-time switch was ~100 branches of a 1,000-instruction kernel), A = -1 (the run-time
+// switch) for the rest
+template <class F>
+inline void act_host_dispatch(int act, F&& f) {
+    switch (act) {
+        case MI355SEG_ACT_NONE: f(std::integral_constant<int, MI355SEG_ACT_NONE>{}); break;
+        case MI355SEG_ACT_RELU: f(std::integral_constant<int, MI355SEG_ACT_RELU>{}); break;
+        case MI355SEG_ACT_ELU: f(std::integral_constant<int, MI355SEG_ACT_ELU>{}); break;
+        case MI355SEG_ACT_LRELU: f(std::integral_constant<int, MI355SEG_ACT_LRELU>{}); break;
+        default: f(std::integral_constant<int, -1>{}); break;
     }
 }
 __device__ __forceinline__ float act_grad(float z, int act, float slope) {

@@ -365,8 +365,9 @@ __host__ __device__ static inline int stem_bn_scratch_floats(int Cout) {
 struct StemBn { const float* da; int ldda; const float* y; int ldy; const float* mean; const float* rstd; const float* gamma; const float* beta;
                 const float* s1; const float* s2; int act; float slope; float invM; };
 
-__global__ __launch_bounds__(256, 2) void stem1_wgrad_bn_kernel(const float* __restrict__ x, StemBn b, float* __restrict__ part, float* __restrict__ cpart,
-                                                               SmallGeom g, int ntiles) {
+template <int ACT>
+__device__ __forceinline__ void stem1_wgrad_bn_body(const float* __restrict__ x, const StemBn& b, float* __restrict__ part, float* __restrict__ cpart,
+                                                    const SmallGeom& g, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Cout = g.Cout, LPV = Cout / 4, TX = 256 / LPV, HX = TX + 2, HY = S1_TY + 2;
     const int cq = threadIdx.x % LPV, xs = threadIdx.x / LPV;
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void stem1_wgrad_bn_kernel(const float* __r
                 for (int j = 0; j < 4; ++j) {
                     const float xh = (yreg[line][j] - m[j]) * rs[j];
                     const float z = fmaf(xh, ga[j], be[j]);
-                    const float dz = dreg[line][j] * act_grad(z, b.act, b.slope);
+                    const float dz = dreg[line][j] * act_grad(z, ACT >= 0 ? ACT : b.act, b.slope);
                     d[j] = ga[j] * rs[j] * (dz - k1[j] - xh * k2[j]);
                 }
                 col += d;
@@ -461,6 +462,12 @@ __global__ __launch_bounds__(256, 2) void stem1_wgrad_bn_kernel(const float* __r
         if (t < 27) part[((long long)blockIdx.x * 27 + t) * Cout + co] = s;
         else cpart[(long long)blockIdx.x * Cout + co] = s;
     }
+}
+// (r6) the U-Net's launches run ReLU: that instantiation has no per-element activation switch
+__global__ __launch_bounds__(256, 2) void stem1_wgrad_bn_kernel(const float* __restrict__ x, StemBn b, float* __restrict__ part, float* __restrict__ cpart,
+                                                               SmallGeom g, int ntiles) {
+    if (b.act == MI355SEG_ACT_RELU) stem1_wgrad_bn_body<MI355SEG_ACT_RELU>(x, b, part, cpart, g, ntiles);
+    else stem1_wgrad_bn_body<-1>(x, b, part, cpart, g, ntiles);
 }
 
 __global__ __launch_bounds__(64) void colpart_finalize_kernel(const float* __restrict__ cpart, int nblk, int C, float* __restrict__ out) {

@@ -76,7 +76,7 @@ struct StatsF {     // sum (x - pivot), sum (x - pivot)^2 ; pivots fetched once 
     }
 };
 
-template <typename T>
+template <typename T, int ACT = -1>      // ACT >= 0: the activation as a compile-time constant (else the run-time switch, per element)
 struct BwdF {       // sum dz, sum dz*xhat  with dz = dy*act'(z), z = xhat*gamma+beta (+res)
     const T* dy; int lddy; const T* x; int ldx; const float* mean; const float* rstd;
     const float* gamma; const float* beta; const T* res; int ldres; int act; float slope;
@@ -94,7 +94,7 @@ struct BwdF {       // sum dz, sum dz*xhat  with dz = dy*act'(z), z = xhat*gamma
     __device__ __forceinline__ void one(const State& st, int j, float dyv, float xv, float rv, float& a, float& b) const {
         float xh = (xv - st.m[j]) * st.rs[j];
         float z = fmaf(xh, st.ga[j], st.be[j]) + rv;
-        float dz = dyv * act_grad(z, act, slope);
+        float dz = dyv * act_grad(z, ACT >= 0 ? ACT : act, slope);
         a = dz; b = dz * xh;
     }
     __device__ __forceinline__ void eval(const State& st, long long r, int g, int c, int C, float& a, float& b) const {
@@ -291,11 +291,12 @@ struct RowMap {
     int lanes, rpi;     // threads across channels, rows per block iteration
 };
 
-template <typename T, bool VEC>
+template <typename T, bool VEC, int ACT = -1>
 __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const T* __restrict__ x, int ldx,
         const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
         const float* __restrict__ beta, const T* __restrict__ res, int ldres, T* __restrict__ y, int ldy,
         long long rows, int C, int lanes, int rpi, int act, float slope, unsigned* __restrict__ amax_out) {
+    const int ACTV = ACT >= 0 ? ACT : act;            // (a compile-time constant in the per-activation instantiations: the per-element switch folds)
     constexpr int NJ = VEC ? 4 : 1;
     const int g = blockIdx.y;
     const int cw = VEC ? C / 4 : C;
@@ -326,10 +327,10 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const T* __restrict__
                 for (int u = 0; u < 2; ++u)
                     if (u < nr) {
                         float4 o;
-                        o.x = act_apply(fmaf(v[u].x, al[0], be[0]) + rr[u].x, act, slope);
-                        o.y = act_apply(fmaf(v[u].y, al[NJ > 1 ? 1 : 0], be[NJ > 1 ? 1 : 0]) + rr[u].y, act, slope);
-                        o.z = act_apply(fmaf(v[u].z, al[NJ > 1 ? 2 : 0], be[NJ > 1 ? 2 : 0]) + rr[u].z, act, slope);
-                        o.w = act_apply(fmaf(v[u].w, al[NJ > 1 ? 3 : 0], be[NJ > 1 ? 3 : 0]) + rr[u].w, act, slope);
+                        o.x = act_apply(fmaf(v[u].x, al[0], be[0]) + rr[u].x, ACTV, slope);
+                        o.y = act_apply(fmaf(v[u].y, al[NJ > 1 ? 1 : 0], be[NJ > 1 ? 1 : 0]) + rr[u].y, ACTV, slope);
+                        o.z = act_apply(fmaf(v[u].z, al[NJ > 1 ? 2 : 0], be[NJ > 1 ? 2 : 0]) + rr[u].z, ACTV, slope);
+                        o.w = act_apply(fmaf(v[u].w, al[NJ > 1 ? 3 : 0], be[NJ > 1 ? 3 : 0]) + rr[u].w, ACTV, slope);
                         stf4(y + (rbase + r + u) * ldy + c, o);
                         amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
                     }
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const T* __restrict__
             const long long row = rbase + r;
             {
                 const float rv = res ? ld1(res + row * ldres + c) : 0.f;
-                const float o = act_apply(fmaf(ld1(x + row * ldx + c), al[0], be[0]) + rv, act, slope);
+                const float o = act_apply(fmaf(ld1(x + row * ldx + c), al[0], be[0]) + rv, ACTV, slope);
                 st1(y + row * ldy + c, o);
                 amax = fmaxf(amax, fabsf(o));
             }
@@ -350,11 +351,12 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const T* __restrict__
 }
 
 // eight channels per thread: 16-byte accesses on bf16 tensors (launched for bf16 only, see norm_api.inc)
-template <typename T>
+template <typename T, int ACT = -1>
 __global__ __launch_bounds__(256) void norm_act_fwd8_kernel(const T* __restrict__ x, int ldx,
         const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
         const float* __restrict__ beta, const T* __restrict__ res, int ldres, T* __restrict__ y, int ldy,
         long long rows, int C, int lanes, int rpi, int act, float slope) {
+    const int ACTV = ACT >= 0 ? ACT : act;            // (a compile-time constant in the per-activation instantiations: the per-element switch folds)
     const int g = blockIdx.y;
     const int cw = C / 8;
     const int rsub = threadIdx.x / lanes;
@@ -374,19 +376,20 @@ __global__ __launch_bounds__(256) void norm_act_fwd8_kernel(const T* __restrict_
             ld8(x + row * ldx + c, v);
             if (res) ld8(res + row * ldres + c, rr);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = act_apply(fmaf(v[j], al[j], be[j]) + (res ? rr[j] : 0.f), act, slope);
+            for (int j = 0; j < 8; ++j) o[j] = act_apply(fmaf(v[j], al[j], be[j]) + (res ? rr[j] : 0.f), ACTV, slope);
             st8(y + row * ldy + c, o);
         }
     }
 }
 
-template <typename T, bool VEC>
+template <typename T, bool VEC, int ACT = -1>
 __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(const T* __restrict__ dy, int lddy,
         const T* __restrict__ x, int ldx, const float* __restrict__ mean, const float* __restrict__ rstd,
         const float* __restrict__ gamma, const float* __restrict__ beta, const T* __restrict__ res, int ldres,
         const float* __restrict__ s1, const float* __restrict__ s2, T* __restrict__ dx, int lddx,
         T* __restrict__ dres, int lddres, long long rows, int C, int lanes, int rpi, int act, float slope,
         float* __restrict__ dxpart, unsigned* __restrict__ amax_out) {
+    const int ACTV = ACT >= 0 ? ACT : act;            // (a compile-time constant in the per-activation instantiations: the per-element switch folds)
     constexpr int NJ = VEC ? 4 : 1;
     __shared__ float shs[256 * 4];
     const int g = blockIdx.y;
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(const T* __rest
             for (int j = 0; j < NJ; ++j) {
                 const float xh = (xv[j] - m[j]) * rs[j];
                 const float z = fmaf(xh, ga[j], be[j]) + rv[j];
-                const float dz = dv[j] * act_grad(z, act, slope);
+                const float dz = dv[j] * act_grad(z, ACTV, slope);
                 oz[j] = dz;
                 od[j] = ga[j] * rs[j] * (dz - k1[j] - xh * k2[j]);
                 colsum[j] += od[j];
@@ -463,10 +466,11 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(const T* __rest
     if (amax_out) block_amax_commit(amax, amax_out);
 }
 
-template <typename T, bool VEC, bool BWD>
+template <typename T, bool VEC, bool BWD, int ACT = -1>
 __global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx,
         const T* __restrict__ res, int ldres, T* __restrict__ out, int ldo, long long rows, int C, int lanes, int rpi,
         int act, float slope, const float* __restrict__ slope_c) {
+    const int ACTV = ACT >= 0 ? ACT : act;            // (a compile-time constant in the per-activation instantiations: the per-element switch folds)
     // slope_c != null: PReLU -- the leaky slope of channel c is slope_c[c] (act = LRELU)
     const int cw = VEC ? C / 4 : C;
     const int rsub = threadIdx.x / lanes;
@@ -485,16 +489,16 @@ __global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ dy, int 
                 float4 o;
                 if (BWD) {
                     float4 d = ldf4(dy + r * lddy + c);
-                    o = make_float4(d.x * act_grad(v.x, act, sl.x), d.y * act_grad(v.y, act, sl.y),
-                                    d.z * act_grad(v.z, act, sl.z), d.w * act_grad(v.w, act, sl.w));
+                    o = make_float4(d.x * act_grad(v.x, ACTV, sl.x), d.y * act_grad(v.y, ACTV, sl.y),
+                                    d.z * act_grad(v.z, ACTV, sl.z), d.w * act_grad(v.w, ACTV, sl.w));
                 } else {
-                    o = make_float4(act_apply(v.x, act, sl.x), act_apply(v.y, act, sl.y),
-                                    act_apply(v.z, act, sl.z), act_apply(v.w, act, sl.w));
+                    o = make_float4(act_apply(v.x, ACTV, sl.x), act_apply(v.y, ACTV, sl.y),
+                                    act_apply(v.z, ACTV, sl.z), act_apply(v.w, ACTV, sl.w));
                 }
                 stf4(out + r * ldo + c, o);
             } else {
                 float v = ld1(x + r * ldx + c) + (res ? ld1(res + r * ldres + c) : 0.f);
-                st1(out + r * ldo + c, BWD ? ld1(dy + r * lddy + c) * act_grad(v, act, sl.x) : act_apply(v, act, sl.x));
+                st1(out + r * ldo + c, BWD ? ld1(dy + r * lddy + c) * act_grad(v, ACTV, sl.x) : act_apply(v, ACTV, sl.x));
             }
         }
     }
@@ -503,10 +507,11 @@ __global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ dy, int 
 // eight channels per thread (16-byte accesses on bf16 tensors, 32-byte on fp32), no per-channel slopes; BWD: out = addend + dy * act'(x + res)
 // -- `addend` (optional) is a second gradient of the same tensor: a residual fork's sum d(x) = d_skip + d_act * act'(x) without a separate add
 // pass (residual_unet3d.py:110-121: the level-1 tensor feeds a LeakyReLU and, unchanged, a later block sum)
-template <typename T, bool BWD>
+template <typename T, bool BWD, int ACT = -1>
 __global__ __launch_bounds__(256) void act8_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx,
         const T* __restrict__ res, int ldres, const T* __restrict__ addend, int ldadd, T* __restrict__ out, int ldo, long long rows, int C,
         int lanes, int rpi, int act, float slope) {
+    const int ACTV = ACT >= 0 ? ACT : act;            // (a compile-time constant in the per-activation instantiations: the per-element switch folds)
     const int cw = C / 8;
     const int rsub = threadIdx.x / lanes;
     if (rsub >= rpi) return;
@@ -524,10 +529,10 @@ __global__ __launch_bounds__(256) void act8_kernel(const T* __restrict__ dy, int
                 ld8(dy + r * lddy + c, d);
                 if (addend) ld8(addend + r * ldadd + c, ad);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (addend ? ad[j] : 0.f) + d[j] * act_grad(v[j], act, slope);
+                for (int j = 0; j < 8; ++j) o[j] = (addend ? ad[j] : 0.f) + d[j] * act_grad(v[j], ACTV, slope);
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = act_apply(v[j], act, slope);
+                for (int j = 0; j < 8; ++j) o[j] = act_apply(v[j], ACTV, slope);
             }
             st8(out + r * ldo + c, o);
         }

@@ -24,7 +24,7 @@ import mi355seg  # noqa: E402
 from mi355seg import functional as F  # noqa: E402
 from mi355seg.engine import make_adam, weights_init_normal  # noqa: E402
 
-PEAK = {"bf16": 2500.0, "bf16x6": 2500.0 / 6.0, "fp32": 157.3}
+PEAK = {"bf16": 2500.0, "bf16x6": 2500.0 / 6.0, "f16x3": 2500.0 / 3.0, "fp32": 157.3}
 HBM_GBS = 8000.0
 FAMILIES = ["conv_igemm_mfma", "conv_wgrad_mfma", "conv_generic", "convT_k2s2", "norm_act_stats", "pool_upsample", "loss_metric", "conv_direct_stem_head"]
 BOUND = {"conv_igemm_mfma": "mfma", "conv_wgrad_mfma": "mfma", "conv_generic": "valu", "convT_k2s2": "hbm", "norm_act_stats": "hbm",
