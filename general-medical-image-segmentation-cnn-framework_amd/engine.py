@@ -180,6 +180,9 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.opt_graph, pool=self.graph.pool()):
                 optimizer.step()
         F.amax_pool_reset()
+        # the captured step reads its weight packings (and the job table that forms them) in the arenas of the model's prepack plans: keep those
+        # tensors alive for as long as the graph is, whatever later eager steps at other shapes evict from the model's own table
+        self._prepack_arenas = [rec.get("arena") for rec in (model.__dict__.get("_seg_prepack") or {}).values()]
 
     def __call__(self, x, gt, sync_metric=True):
         self.x.copy_(x, non_blocking=True)
